@@ -1,0 +1,235 @@
+"""Configuration dictionaries of the reference training scripts, transcribed as data, and their
+flattening into the go2sim env-config arrays (include/go2sim.h enums go2sim_fcfg / go2sim_icfg).
+
+get_walk_cfgs() mirrors examples/locomotion/final/go2_train_walk.py:68-372 (env/obs/reward/command
+dicts consumed by Go2Env.__init__, go2_env_walk.py:155-525); the dict keys are the reference's own so a
+user's customised cfg dicts drop in unchanged."""
+import copy
+import math
+
+import numpy as np
+
+from .capi import C
+from .model_blob import load_model_json
+
+REWARD_IDS = {
+    "tracking_lin_vel": "GO2SIM_R_TRACKING_LIN_VEL", "tracking_ang_vel": "GO2SIM_R_TRACKING_ANG_VEL",
+    "lin_vel_z": "GO2SIM_R_LIN_VEL_Z", "base_height": "GO2SIM_R_BASE_HEIGHT", "action_rate": "GO2SIM_R_ACTION_RATE",
+    "similar_to_default": "GO2SIM_R_SIMILAR_TO_DEFAULT", "orientation_penalty": "GO2SIM_R_ORIENTATION_PENALTY",
+    "dof_acc": "GO2SIM_R_DOF_ACC", "dof_vel": "GO2SIM_R_DOF_VEL", "ang_vel_xy": "GO2SIM_R_ANG_VEL_XY",
+    "feet_air_time": "GO2SIM_R_FEET_AIR_TIME", "foot_slip": "GO2SIM_R_FOOT_SLIP", "foot_clearance": "GO2SIM_R_FOOT_CLEARANCE",
+    "joint_tracking": "GO2SIM_R_JOINT_TRACKING", "energy": "GO2SIM_R_ENERGY", "torque_load": "GO2SIM_R_TORQUE_LOAD",
+    "stand_still": "GO2SIM_R_STAND_STILL", "stand_still_vel": "GO2SIM_R_STAND_STILL_VEL", "feet_stance": "GO2SIM_R_FEET_STANCE",
+}
+
+
+def get_walk_cfgs():
+    """go2_train_walk.py:68-372 (values transcribed; comments there explain the choices)."""
+    kp_nominal, kd_nominal = 60.0, 2.0
+    curriculum_cfg = {
+        "enabled": True, "level_init": 0.10, "level_min": 0.0, "level_max": 1.0, "ema_alpha": 0.03,
+        "ready_timeout_rate": 0.80, "ready_tracking": 0.75, "ready_fall_rate": 0.15, "ready_streak": 4,
+        "hard_fall_rate": 0.25, "hard_streak": 2, "step_up": 0.01, "step_down": 0.03, "cooldown_updates": 5,
+        "update_every_episodes": 4096, "mix_prob_current": 0.80, "mix_level_low": 0.00, "mix_level_high": 0.50,
+        "friction_easy": [0.6, 0.8], "kp_easy": [0.90 * kp_nominal, 1.10 * kp_nominal],
+        "kd_easy": [0.75 * kd_nominal, 1.25 * kd_nominal], "kp_factor_easy": [0.95, 1.05], "kd_factor_easy": [0.95, 1.05],
+        "mass_shift_easy": [-0.2, 0.5], "com_shift_easy": [-0.005, 0.005], "leg_mass_shift_easy": [-0.1, 0.1],
+        "gravity_offset_easy": [-0.2, 0.2], "motor_strength_easy": [0.97, 1.03], "push_start": 0.0,
+        "push_interval_easy_s": 10.0, "delay_easy_max_steps": 0, "global_dr_update_interval": 200,
+    }
+    env_cfg = {
+        "num_actions": 16, "num_pos_actions": 12, "pls_enable": True, "pls_kp_range": [10.0, 70.0], "pls_kp_default": 40.0,
+        "pls_kp_action_scale": 20.0, "kp": kp_nominal, "kd": kd_nominal, "torque_limits": [23.7, 23.7, 45.0] * 4,
+        "simulate_action_latency": True, "foot_names": ["FR_calf", "FL_calf", "RR_calf", "RL_calf"],
+        "foot_contact_threshold": 3.0,
+        "default_joint_angles": {
+            "FL_hip_joint": 0.0, "FR_hip_joint": 0.0, "RL_hip_joint": 0.0, "RR_hip_joint": 0.0,
+            "FL_thigh_joint": 0.8, "FR_thigh_joint": 0.8, "RL_thigh_joint": 1.0, "RR_thigh_joint": 1.0,
+            "FL_calf_joint": -1.5, "FR_calf_joint": -1.5, "RL_calf_joint": -1.5, "RR_calf_joint": -1.5,
+        },
+        "joint_names": ["FR_hip_joint", "FR_thigh_joint", "FR_calf_joint", "FL_hip_joint", "FL_thigh_joint", "FL_calf_joint",
+                        "RR_hip_joint", "RR_thigh_joint", "RR_calf_joint", "RL_hip_joint", "RL_thigh_joint", "RL_calf_joint"],
+        "termination_if_roll_greater_than": 45, "termination_if_pitch_greater_than": 45,
+        "termination_if_z_vel_greater_than": 100.0, "termination_if_y_vel_greater_than": 100.0,
+        "base_init_pos": [0.0, 0.0, 0.42], "base_init_quat": [1.0, 0.0, 0.0, 0.0], "episode_length_s": 20.0,
+        "resampling_time_s": 5.0, "action_scale": 0.25, "clip_actions": 100.0, "curriculum": curriculum_cfg,
+        "friction_range": [0.3, 1.25], "kp_factor_range": [0.8, 1.2], "kd_factor_range": [0.8, 1.2],
+        "kp_range": [50.0, 70.0], "kd_range": [1.0, 5.0],
+        "obs_noise": {"ang_vel": 0.2, "gravity": 0.05, "dof_pos": 0.01, "dof_vel": 1.5}, "obs_noise_level": 1.0,
+        "action_noise_std": 0.1, "push_interval_s": 5.0, "push_force_range": [-150.0, 150.0], "push_duration_s": [0.05, 0.2],
+        "init_pos_z_range": [0.38, 0.45], "init_euler_range": [-5.0, 5.0], "mass_shift_range": [-1.0, 3.0],
+        "com_shift_range": [-0.03, 0.03], "leg_mass_shift_range": [-0.5, 0.5], "gravity_offset_range": [-1.0, 1.0],
+        "motor_strength_range": [0.9, 1.1], "min_delay_steps": 0, "max_delay_steps": 1,
+    }
+    num_obs = 3 + 3 + 3 + 12 + 12 + 16
+    obs_cfg = {"num_obs": num_obs, "num_privileged_obs": num_obs + 3 + 1 + 12 + 12 + 12 + 1 + 3 + 4 + 3 + 3 + 1,
+               "obs_scales": {"lin_vel": 2.0, "ang_vel": 0.25, "dof_pos": 1.0, "dof_vel": 0.05}}
+    reward_cfg = {
+        "tracking_sigma": 0.25, "base_height_target": 0.3, "feet_height_target": 0.075, "feet_air_time_target": 0.1,
+        "reward_scales": {
+            "tracking_lin_vel": 1.5, "tracking_ang_vel": 0.8, "lin_vel_z": -2.0, "base_height": -0.6, "action_rate": -0.01,
+            "similar_to_default": -0.1, "orientation_penalty": -5.0, "dof_acc": -2.5e-7, "dof_vel": -5e-4, "ang_vel_xy": -0.05,
+            "feet_air_time": 0.2, "foot_slip": -0.1, "foot_clearance": -0.1, "joint_tracking": -0.1, "energy": 0.0,
+            "torque_load": 0.0, "stand_still": -0.5, "stand_still_vel": -2.0, "feet_stance": -0.3,
+        },
+    }
+    command_cfg = {"num_commands": 3, "lin_vel_x_range": [-1.0, 1.0], "lin_vel_y_range": [-0.3, 0.3], "ang_vel_range": [-1.0, 1.0],
+                   "cmd_curriculum": True, "cmd_curriculum_start_frac": 0.1, "compound_commands": True, "rel_standing_envs": 0.1}
+    return env_cfg, obs_cfg, reward_cfg, command_cfg
+
+
+def _name_maps(model):
+    links = {l["name"]: i for i, l in enumerate(model["links"])}
+    joints = {j["name"]: j for j in model["joints"]}
+    return links, joints
+
+
+def flatten_walk_cfg(num_envs, env_cfg, obs_cfg, reward_cfg, command_cfg, *, model=None, per_env_global_dr=False,
+                     freeze_curriculum=False):
+    """Go2Env.__init__ (go2_env_walk.py:155-525) as data: returns (fcfg float32[FC_COUNT], icfg int32[IC_COUNT],
+    reward_names) for go2sim_env_configure."""
+    model = load_model_json() if model is None else model
+    links, joints = _name_maps(model)
+    env_cfg = copy.deepcopy(env_cfg)
+    f = np.zeros(C["GO2SIM_FC_COUNT"], dtype=np.float32)
+    i = np.zeros(C["GO2SIM_IC_COUNT"], dtype=np.int32)
+    dt = 0.02
+    F = lambda name: C["GO2SIM_FC_" + name]
+    I = lambda name: C["GO2SIM_IC_" + name]
+    curr = env_cfg.get("curriculum", {}) or {}
+
+    f[F("DT")] = dt
+    f[F("ACTION_SCALE")] = env_cfg["action_scale"]
+    f[F("CLIP_ACTIONS")] = env_cfg["clip_actions"]
+    f[F("KP")], f[F("KD")] = env_cfg["kp"], env_cfg["kd"]
+    pls = bool(env_cfg.get("pls_enable", False))
+    if pls:
+        f[F("PLS_KP_MIN")], f[F("PLS_KP_MAX")] = env_cfg["pls_kp_range"]
+        f[F("PLS_KP_DEFAULT")] = env_cfg["pls_kp_default"]
+        f[F("PLS_KP_ACTION_SCALE")] = env_cfg["pls_kp_action_scale"]
+    npos = env_cfg.get("num_pos_actions", 12)
+    assert npos == 12
+    tl = env_cfg.get("torque_limits", None) or [23.7] * 12
+    f[F("TORQUE_LIMIT0"):F("TORQUE_LIMIT0") + 12] = tl
+    f[F("DEFAULT_DOF_POS0"):F("DEFAULT_DOF_POS0") + 12] = [env_cfg["default_joint_angles"][n] for n in env_cfg["joint_names"]]
+    f[F("TERM_PITCH_DEG")] = env_cfg["termination_if_pitch_greater_than"]
+    f[F("TERM_ROLL_DEG")] = env_cfg["termination_if_roll_greater_than"]
+    f[F("TERM_ZVEL")] = env_cfg["termination_if_z_vel_greater_than"]
+    f[F("TERM_YVEL")] = env_cfg["termination_if_y_vel_greater_than"]
+    f[F("BASE_INIT_POS0"):F("BASE_INIT_POS0") + 3] = env_cfg["base_init_pos"]
+    f[F("BASE_INIT_QUAT0"):F("BASE_INIT_QUAT0") + 4] = env_cfg["base_init_quat"]
+    if "init_pos_z_range" in env_cfg:
+        i[I("HAS_INIT_Z")] = 1
+        f[F("INIT_Z_LO")], f[F("INIT_Z_HI")] = env_cfg["init_pos_z_range"]
+    if "init_euler_range" in env_cfg:
+        i[I("HAS_INIT_EULER")] = 1
+        f[F("INIT_EULER_LO_DEG")], f[F("INIT_EULER_HI_DEG")] = env_cfg["init_euler_range"]
+    sc = obs_cfg["obs_scales"]
+    f[F("OBS_SCALE_LIN_VEL")], f[F("OBS_SCALE_ANG_VEL")] = sc["lin_vel"], sc["ang_vel"]
+    f[F("OBS_SCALE_DOF_POS")], f[F("OBS_SCALE_DOF_VEL")] = sc["dof_pos"], sc["dof_vel"]
+    f[F("TRACKING_SIGMA")] = reward_cfg["tracking_sigma"]
+    f[F("BASE_HEIGHT_TARGET")] = reward_cfg["base_height_target"]
+    f[F("FEET_HEIGHT_TARGET")] = reward_cfg.get("feet_height_target", 0.075)
+    f[F("FEET_AIR_TIME_TARGET")] = reward_cfg.get("feet_air_time_target", 0.1)
+    f[F("FOOT_CONTACT_THRESHOLD")] = env_cfg.get("foot_contact_threshold", 1.0)
+    names = list(reward_cfg["reward_scales"].keys())
+    assert len(names) <= 32
+    for k, name in enumerate(names):
+        if name not in REWARD_IDS:
+            raise AttributeError(f"Reward function '_reward_{name}' not found in Go2Env.")
+        f[F("REWARD_SCALE0") + k] = reward_cfg["reward_scales"][name] * dt
+        i[I("REWARD_ID0") + k] = C[REWARD_IDS[name]]
+    i[I("N_REWARDS")] = len(names)
+    f[F("CMD_X_LO")], f[F("CMD_X_HI")] = command_cfg["lin_vel_x_range"]
+    f[F("CMD_Y_LO")], f[F("CMD_Y_HI")] = command_cfg["lin_vel_y_range"]
+    f[F("CMD_YAW_LO")], f[F("CMD_YAW_HI")] = command_cfg["ang_vel_range"]
+    f[F("CMD_START_FRAC")] = command_cfg.get("cmd_curriculum_start_frac", 0.1)
+    i[I("CMD_CURRICULUM")] = int(bool(command_cfg.get("cmd_curriculum", False)))
+    i[I("COMPOUND_COMMANDS")] = int(bool(command_cfg.get("compound_commands", True)))
+    if not i[I("COMPOUND_COMMANDS")]:
+        raise NotImplementedError("compound_commands=False is not used by the reference configs")
+    i[I("N_STANDING")] = int(float(command_cfg.get("rel_standing_envs", 0.0)) * num_envs)
+
+    kp_nom, kd_nom = float(env_cfg.get("kp", 60.0)), float(env_cfg.get("kd", 2.0))
+
+    def rng(flag, key_hard, easy_default, easy_key, base):
+        easy = curr.get(easy_key, easy_default)
+        hard = env_cfg.get(key_hard, easy)
+        f[F(base + "_EASY_LO")], f[F(base + "_EASY_HI")] = easy
+        f[F(base + "_HARD_LO")], f[F(base + "_HARD_HI")] = hard
+        if flag:
+            i[I(flag)] = int(key_hard in env_cfg)
+
+    rng("HAS_FRICTION_DR", "friction_range", [0.6, 0.9], "friction_easy", "FRICTION")
+    rng("HAS_KPF_DR", "kp_factor_range", [0.95, 1.05], "kp_factor_easy", "KPF")
+    rng("HAS_KDF_DR", "kd_factor_range", [0.85, 1.15], "kd_factor_easy", "KDF")
+    rng("HAS_KP_RANGE", "kp_range", [0.9 * kp_nom, 1.1 * kp_nom], "kp_easy", "KPR")
+    rng(None, "kd_range", [0.75 * kd_nom, 1.25 * kd_nom], "kd_easy", "KDR")
+    rng("HAS_MASS_DR", "mass_shift_range", [-0.2, 0.5], "mass_shift_easy", "MASS")
+    rng("HAS_COM_DR", "com_shift_range", [-0.005, 0.005], "com_shift_easy", "COM")
+    rng("HAS_LEGM_DR", "leg_mass_shift_range", [-0.1, 0.1], "leg_mass_shift_easy", "LEGM")
+    rng("HAS_GOFF_DR", "gravity_offset_range", [-0.2, 0.2], "gravity_offset_easy", "GOFF")
+    rng("HAS_MSTR_DR", "motor_strength_range", [0.97, 1.03], "motor_strength_easy", "MSTR")
+    if not pls and "kp_range" in env_cfg:
+        raise NotImplementedError("non-PLS per-env kp/kd ranges are not wired yet (reference configs use PLS)")
+
+    on = env_cfg.get("obs_noise", None)
+    i[I("HAS_OBS_NOISE")] = int(on is not None)
+    if on is not None:
+        f[F("OBS_NOISE_LEVEL_MAX")] = env_cfg.get("obs_noise_level", 0.0)
+        f[F("OBS_NOISE_ANG_VEL")], f[F("OBS_NOISE_GRAVITY")] = on.get("ang_vel", 0.0), on.get("gravity", 0.0)
+        f[F("OBS_NOISE_DOF_POS")], f[F("OBS_NOISE_DOF_VEL")] = on.get("dof_pos", 0.0), on.get("dof_vel", 0.0)
+    f[F("ACTION_NOISE_STD_MAX")] = env_cfg.get("action_noise_std", 0.0)
+    pfr = env_cfg.get("push_force_range", None)
+    i[I("HAS_PUSH")] = int(pfr is not None)
+    if pfr is not None:
+        f[F("PUSH_FORCE_LO")], f[F("PUSH_FORCE_HI")] = pfr
+        dur = env_cfg.get("push_duration_s", [0.05, 0.15])
+        i[I("PUSH_DUR_LO")], i[I("PUSH_DUR_HI")] = max(1, int(dur[0] / dt)), max(1, int(dur[1] / dt))
+    f[F("PUSH_INTERVAL_S_HARD")] = env_cfg.get("push_interval_s", 5.0)
+    f[F("PUSH_INTERVAL_S_EASY")] = curr.get("push_interval_easy_s", 6.0)
+    f[F("PUSH_START")] = curr.get("push_start", 0.30)
+    i[I("MIN_DELAY")] = int(env_cfg.get("min_delay_steps", 0))
+    i[I("MAX_DELAY")] = int(env_cfg.get("max_delay_steps", 2))
+    i[I("DELAY_EASY_MAX")] = int(curr.get("delay_easy_max_steps", 1))
+    if i[I("MAX_DELAY")] > 1:
+        raise NotImplementedError("max_delay_steps > 1 needs a deeper action ring (reference walk cfg uses 1)")
+
+    i[I("CURR_ENABLED")] = int(bool(curr.get("enabled", False)))
+    f[F("CURR_LEVEL_INIT")] = curr.get("level_init", 0.0)
+    f[F("CURR_LEVEL_MIN")], f[F("CURR_LEVEL_MAX")] = curr.get("level_min", 0.0), curr.get("level_max", 1.0)
+    f[F("CURR_EMA_ALPHA")] = curr.get("ema_alpha", 0.05)
+    f[F("CURR_READY_TIMEOUT_RATE")] = curr.get("ready_timeout_rate", 0.7)
+    f[F("CURR_READY_TRACKING")] = curr.get("ready_tracking", 0.6)
+    f[F("CURR_READY_FALL_RATE")] = curr.get("ready_fall_rate", 0.30)
+    f[F("CURR_HARD_FALL_RATE")] = curr.get("hard_fall_rate", 0.55)
+    f[F("CURR_STEP_UP")], f[F("CURR_STEP_DOWN")] = curr.get("step_up", 0.02), curr.get("step_down", 0.01)
+    f[F("CURR_MIX_PROB_CURRENT")] = curr.get("mix_prob_current", 0.80)
+    f[F("CURR_MIX_LEVEL_LOW")], f[F("CURR_MIX_LEVEL_HIGH")] = curr.get("mix_level_low", 0.0), curr.get("mix_level_high", 0.6)
+    i[I("CURR_READY_STREAK")], i[I("CURR_HARD_STREAK")] = curr.get("ready_streak", 3), curr.get("hard_streak", 2)
+    i[I("CURR_COOLDOWN")] = curr.get("cooldown_updates", 1)
+    i[I("CURR_UPDATE_EVERY")] = curr.get("update_every_episodes", 2048)
+    i[I("GLOBAL_DR_INTERVAL")] = curr.get("global_dr_update_interval", 200)
+
+    i[I("ENV_KIND")] = 0
+    i[I("NUM_ACTIONS")], i[I("NUM_POS_ACTIONS")] = env_cfg["num_actions"], npos
+    i[I("NUM_OBS")], i[I("NUM_PRIV_OBS")] = obs_cfg["num_obs"], obs_cfg.get("num_privileged_obs") or obs_cfg["num_obs"]
+    i[I("PLS_ENABLE")] = int(pls)
+    i[I("MANUAL_PD")] = int(pls or ("kp_factor_range" in env_cfg))
+    if not i[I("MANUAL_PD")]:
+        raise NotImplementedError("engine-PD control path (control_dofs_position) is the base env; not wired in the walk env yet")
+    i[I("SUBSTEPS")] = 2
+    i[I("MAX_EPISODE_LENGTH")] = math.ceil(env_cfg["episode_length_s"] / dt)
+    i[I("RESAMPLE_STEPS")] = int(env_cfg["resampling_time_s"] / dt)
+    for k, jn in enumerate(env_cfg["joint_names"]):
+        i[I("MOTOR_DOF0") + k] = joints[jn]["dof_start"]
+    for k, ln in enumerate(env_cfg.get("foot_names", [])):
+        i[I("FOOT_LINK0") + k] = links[ln]
+    for k, ln in enumerate(["FR_hip", "FL_hip", "RR_hip", "RL_hip"]):
+        i[I("HIP_LINK0") + k] = links[ln]
+    robot_links = [idx for idx, l in enumerate(model["links"]) if l["entity"] == 1]
+    i[I("BASE_LINK")] = robot_links[0]
+    i[I("PUSH_LINK")] = robot_links[1]  # `self.robot.links[1].idx` (go2_env_walk.py:339-342): first depth-1 link, not the base
+    i[I("PER_ENV_GLOBAL_DR")] = int(per_env_global_dr)
+    i[I("FREEZE_CURRICULUM")] = int(freeze_curriculum)
+    return f, i, names

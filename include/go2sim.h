@@ -1,0 +1,310 @@
+/* go2sim.h -- C ABI of the MI355X-native vectorised Go2 locomotion environment (libgo2sim.so)
+ * and of its CPU twin used as test oracle (oracle/libgo2sim_cpu.so, prefix go2sim_cpu_).
+ *
+ * The reference (saifahmadgit/go2-sim2real-locomotion-rl, a Genesis v0.4.0 fork) has no FFI on this
+ * path: the seam is the Python API consumed by Go2Env.  Each entry point below
+ * names the reference interface it replaces (paths relative to the reference root).
+ *
+ * Conventions
+ *  - plain C, no torch types; every pointer argument named *_dev is a DEVICE pointer for go2sim_*
+ *    (hipMalloc / torch ROCm storage) and a HOST pointer for go2sim_cpu_*.  Caller owns all buffers
+ *    it passes; the library owns its state until go2sim_destroy.
+ *  - all calls are stream-ordered on `stream` (a hipStream_t passed as void*; NULL = default stream),
+ *    never synchronise, never allocate after create; not thread-safe per handle.
+ *  - return value: 0 = ok, negative = GO2SIM_E_* ; never throws.
+ *  - batch layout at the boundary follows the reference getters: row-major [n_envs][k]
+ *    (entities/rigid_entity/rigid_entity.py getters, "tensors are [n_envs(sel), n_idx(, k)]").
+ *    Internally all per-env state is SoA [feature][n_envs] (genesis/utils/array_class.py layout).
+ *  - quaternions are (w,x,y,z).
+ */
+#ifndef GO2SIM_H
+#define GO2SIM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GO2SIM_E_OK 0
+#define GO2SIM_E_BADARG -1
+#define GO2SIM_E_BADMODEL -2
+#define GO2SIM_E_NOMEM -3
+#define GO2SIM_E_HIP -4
+#define GO2SIM_E_NODEVICE -5
+
+/* ---- model blob ("GO2M" v1), produced by go2_sim2real_locomotion_rl_amd/model_blob.py ----------
+ * int32  header[32] : 0 magic 0x4D324F47, 1 version, 2 n_links, 3 n_joints, 4 n_dofs, 5 n_qs,
+ *                     6 n_geoms, 7 n_entities, 8 n_possible_pairs, 9 max_collision_pairs,
+ *                     10 max_contact_pairs, 11 max_broad_pairs, 12 n_contacts_per_pair, 13 iterations,
+ *                     14 ls_iterations, 15 ccd_iterations, 16 support_res, 17 cyl_sections,
+ *                     18 n_floats, 19 n_ints
+ * float32 F[n_floats]:
+ *   globals[16]  : substep_dt, gravity xyz, eps, tolerance, ls_tolerance, meaninertia, mc_perturbation,
+ *                  mc_tolerance, mpr_to_gjk_overlap_ratio, ccd_eps, ccd_tolerance, 0, 0, 0
+ *   links [n][26]: pos3 quat4 inertial_pos3 inertial_quat4 inertial_i9 mass1 invweight2
+ *   joints[n][10]: pos3 sol_params7
+ *   dofs  [n][17]: motion_ang3 motion_vel3 limit2 invweight armature damping stiffness frictionloss
+ *                  kp kv force_range2
+ *   qpos0 [n_qs]
+ *   geoms [n][113]: pos3 quat4 data7 friction1 sol_params7 center3 init_aabb24 rim64(cylinder ring xy)
+ *   mass_parent_mask [n_dofs*n_dofs]
+ * int32 I[n_ints]:
+ *   links [n][13]: parent root entity is_fixed joint_start joint_end dof_start dof_end q_start q_end
+ *                  n_dofs geom_start geom_end
+ *   joints[n][5] : type link q_start dof_start dof_end
+ *   geoms [n][3] : type link is_convex
+ *   entities[n][6]: link_start link_end dof_start dof_end geom_start geom_end
+ *   collision_pair_idx [n_geoms*n_geoms]
+ *   support_theta_to_ring [support_res]
+ */
+#define GO2SIM_MODEL_MAGIC 0x4D324F47
+#define GO2SIM_MODEL_VERSION 1
+
+/* compile-time shape of the Go2+plane model the kernels are specialised for */
+#define GO2SIM_NL 14   /* links   (plane + 13)            */
+#define GO2SIM_ND 18   /* dofs    (6 free + 12 revolute)  */
+#define GO2SIM_NQ 19   /* qpos                            */
+#define GO2SIM_NG 28   /* geoms   (ground box + 27)       */
+#define GO2SIM_NJ 13   /* joints                          */
+#define GO2SIM_NPAIR_MAX 320
+#define GO2SIM_MAX_CONTACTS 150
+#define GO2SIM_MAX_BROAD 240
+#define GO2SIM_NMOTOR 12
+#define GO2SIM_NFEET 4
+
+/* ---- state fields for go2sim_get_field / go2sim_set_field ------------------------------------
+ * `k` = floats (or ints) per env.  Raw field transfers use the INTERNAL SoA layout [k][n_envs]
+ * (this is the parity-test / checkpoint interface, not the Go2Env one). */
+enum go2sim_field {
+  GO2SIM_F_QPOS = 0,          /* f32 k=19  rigid_global_info.qpos                       */
+  GO2SIM_F_VEL = 1,           /* f32 k=18  dofs_state.vel                               */
+  GO2SIM_F_ACC = 2,           /* f32 k=18  dofs_state.acc                               */
+  GO2SIM_F_QACC_WS = 3,       /* f32 k=18  constraint_state.qacc_ws                     */
+  GO2SIM_F_CTRL_FORCE = 4,    /* f32 k=18  dofs_state.ctrl_force                        */
+  GO2SIM_F_EXT_FORCE = 5,     /* f32 k=84  links cfrc_applied (ang3,vel3) x 14          */
+  GO2SIM_F_MASS_SHIFT = 6,    /* f32 k=14  links_state.mass_shift                       */
+  GO2SIM_F_COM_SHIFT = 7,     /* f32 k=42  links_state.i_pos_shift                      */
+  GO2SIM_F_FRICTION_RATIO = 8,/* f32 k=28  geoms_state.friction_ratio                   */
+  GO2SIM_F_LINK_POS = 9,      /* f32 k=42  links_state.pos                              */
+  GO2SIM_F_LINK_QUAT = 10,    /* f32 k=56  links_state.quat                             */
+  GO2SIM_F_LINK_CDVEL = 11,   /* f32 k=42  links_state.cd_vel                           */
+  GO2SIM_F_LINK_CDANG = 12,   /* f32 k=42  links_state.cd_ang                           */
+  GO2SIM_F_ROOT_COM = 13,     /* f32 k=3   links_state.root_COM of the robot            */
+  GO2SIM_F_CONTACT_FORCE = 14,/* f32 k=42  links_state.contact_force                    */
+  GO2SIM_F_MASS_MAT = 15,     /* f32 k=324 rigid_global_info.mass_mat                   */
+  GO2SIM_F_FORCE = 16,        /* f32 k=18  dofs_state.force (pre-constraint: qf_smooth) */
+  GO2SIM_F_ACC_SMOOTH = 17,   /* f32 k=18  dofs_state.acc_smooth                        */
+  GO2SIM_F_CONTACT_POS = 18,  /* f32 k=450 contact_data.pos                             */
+  GO2SIM_F_CONTACT_NORMAL = 19,/* f32 k=450 contact_data.normal                         */
+  GO2SIM_F_CONTACT_PEN = 20,  /* f32 k=150 contact_data.penetration                     */
+  GO2SIM_F_NORMAL_CACHE = 21, /* f32 k=960 contact_cache.normal (320 pairs x 3)         */
+  GO2SIM_F_SORT_VALUE = 22,   /* f32 k=56  sort_buffer.value                            */
+  GO2SIM_F_GEOM_FRICTION = 23,/* f32 k=28  geoms_info.friction (global in the reference)*/
+  GO2SIM_F_EFC_FORCE = 24,    /* f32 k=GO2SIM_MAX_ROWS constraint_state.efc_force       */
+  GO2SIM_F_QFRC_CONSTRAINT = 25, /* f32 k=18                                            */
+  /* int32 fields */
+  GO2SIM_I_N_CONTACTS = 64,   /* i32 k=1   collider_state.n_contacts                    */
+  GO2SIM_I_CONTACT_GEOMS = 65,/* i32 k=300 contact_data.geom_a, geom_b (150 + 150)      */
+  GO2SIM_I_N_CONSTRAINTS = 66,/* i32 k=1                                                */
+  GO2SIM_I_ERRNO = 67,        /* i32 k=1   errno bitmask                                */
+  GO2SIM_I_IS_WARMSTART = 68, /* i32 k=1                                                */
+  GO2SIM_I_FIRST_TIME = 69,   /* i32 k=1   collider_state.first_time                    */
+  GO2SIM_I_SORT_IG = 70,      /* i32 k=56  sort_buffer.i_g | (is_max << 8)              */
+  GO2SIM_I_N_BROAD = 71,      /* i32 k=1                                                */
+  GO2SIM_I_SOLVER_ITERS = 72, /* i32 k=1   Newton iterations used in the last solve     */
+  GO2SIM_I_CTRL_MODE = 73     /* i32 k=18  dofs_state.ctrl_mode (0 force,1 vel,2 pos)   */
+};
+#define GO2SIM_MAX_ROWS 624 /* 4*150 contact rows + 12 joint limits + 12 spare */
+
+/* errno bits (genesis/utils/array_class.py ErrorCode) */
+#define GO2SIM_ERR_OVERFLOW_CANDIDATE_CONTACTS 1
+#define GO2SIM_ERR_OVERFLOW_COLLISION_PAIRS 2
+#define GO2SIM_ERR_INVALID_FORCE_NAN 4
+#define GO2SIM_ERR_INVALID_ACC_NAN 8
+
+/* ---- Go2Env (walk) configuration: flat float / int arrays indexed by these enums --------------
+ * Mirrors the cfg dicts of examples/locomotion/final/go2_train_walk.py:68-372 as consumed by
+ * examples/locomotion/final/go2_env_walk.py:155-525. */
+enum go2sim_fcfg {
+  GO2SIM_FC_DT = 0, GO2SIM_FC_ACTION_SCALE, GO2SIM_FC_CLIP_ACTIONS,
+  GO2SIM_FC_KP, GO2SIM_FC_KD,
+  GO2SIM_FC_PLS_KP_MIN, GO2SIM_FC_PLS_KP_MAX, GO2SIM_FC_PLS_KP_DEFAULT, GO2SIM_FC_PLS_KP_ACTION_SCALE,
+  GO2SIM_FC_TORQUE_LIMIT0, /* 12 values, env joint order */
+  GO2SIM_FC_DEFAULT_DOF_POS0 = GO2SIM_FC_TORQUE_LIMIT0 + 12, /* 12 values */
+  GO2SIM_FC_TERM_PITCH_DEG = GO2SIM_FC_DEFAULT_DOF_POS0 + 12, GO2SIM_FC_TERM_ROLL_DEG,
+  GO2SIM_FC_TERM_ZVEL, GO2SIM_FC_TERM_YVEL,
+  GO2SIM_FC_BASE_INIT_POS0, GO2SIM_FC_BASE_INIT_QUAT0 = GO2SIM_FC_BASE_INIT_POS0 + 3,
+  GO2SIM_FC_INIT_Z_LO = GO2SIM_FC_BASE_INIT_QUAT0 + 4, GO2SIM_FC_INIT_Z_HI,
+  GO2SIM_FC_INIT_EULER_LO_DEG, GO2SIM_FC_INIT_EULER_HI_DEG,
+  GO2SIM_FC_OBS_SCALE_LIN_VEL, GO2SIM_FC_OBS_SCALE_ANG_VEL, GO2SIM_FC_OBS_SCALE_DOF_POS, GO2SIM_FC_OBS_SCALE_DOF_VEL,
+  GO2SIM_FC_TRACKING_SIGMA, GO2SIM_FC_BASE_HEIGHT_TARGET, GO2SIM_FC_FEET_HEIGHT_TARGET,
+  GO2SIM_FC_FEET_AIR_TIME_TARGET, GO2SIM_FC_FOOT_CONTACT_THRESHOLD,
+  GO2SIM_FC_REWARD_SCALE0, /* 32 values: reward_scales[name] * dt in evaluation order */
+  GO2SIM_FC_CMD_X_LO = GO2SIM_FC_REWARD_SCALE0 + 32, GO2SIM_FC_CMD_X_HI, GO2SIM_FC_CMD_Y_LO, GO2SIM_FC_CMD_Y_HI,
+  GO2SIM_FC_CMD_YAW_LO, GO2SIM_FC_CMD_YAW_HI, GO2SIM_FC_CMD_START_FRAC,
+  GO2SIM_FC_FRICTION_EASY_LO, GO2SIM_FC_FRICTION_EASY_HI, GO2SIM_FC_FRICTION_HARD_LO, GO2SIM_FC_FRICTION_HARD_HI,
+  GO2SIM_FC_KPF_EASY_LO, GO2SIM_FC_KPF_EASY_HI, GO2SIM_FC_KPF_HARD_LO, GO2SIM_FC_KPF_HARD_HI,
+  GO2SIM_FC_KDF_EASY_LO, GO2SIM_FC_KDF_EASY_HI, GO2SIM_FC_KDF_HARD_LO, GO2SIM_FC_KDF_HARD_HI,
+  GO2SIM_FC_KPR_EASY_LO, GO2SIM_FC_KPR_EASY_HI, GO2SIM_FC_KPR_HARD_LO, GO2SIM_FC_KPR_HARD_HI,
+  GO2SIM_FC_KDR_EASY_LO, GO2SIM_FC_KDR_EASY_HI, GO2SIM_FC_KDR_HARD_LO, GO2SIM_FC_KDR_HARD_HI,
+  GO2SIM_FC_MASS_EASY_LO, GO2SIM_FC_MASS_EASY_HI, GO2SIM_FC_MASS_HARD_LO, GO2SIM_FC_MASS_HARD_HI,
+  GO2SIM_FC_COM_EASY_LO, GO2SIM_FC_COM_EASY_HI, GO2SIM_FC_COM_HARD_LO, GO2SIM_FC_COM_HARD_HI,
+  GO2SIM_FC_LEGM_EASY_LO, GO2SIM_FC_LEGM_EASY_HI, GO2SIM_FC_LEGM_HARD_LO, GO2SIM_FC_LEGM_HARD_HI,
+  GO2SIM_FC_GOFF_EASY_LO, GO2SIM_FC_GOFF_EASY_HI, GO2SIM_FC_GOFF_HARD_LO, GO2SIM_FC_GOFF_HARD_HI,
+  GO2SIM_FC_MSTR_EASY_LO, GO2SIM_FC_MSTR_EASY_HI, GO2SIM_FC_MSTR_HARD_LO, GO2SIM_FC_MSTR_HARD_HI,
+  GO2SIM_FC_OBS_NOISE_LEVEL_MAX, GO2SIM_FC_OBS_NOISE_ANG_VEL, GO2SIM_FC_OBS_NOISE_GRAVITY,
+  GO2SIM_FC_OBS_NOISE_DOF_POS, GO2SIM_FC_OBS_NOISE_DOF_VEL, GO2SIM_FC_ACTION_NOISE_STD_MAX,
+  GO2SIM_FC_PUSH_FORCE_LO, GO2SIM_FC_PUSH_FORCE_HI, GO2SIM_FC_PUSH_INTERVAL_S_HARD,
+  GO2SIM_FC_PUSH_INTERVAL_S_EASY, GO2SIM_FC_PUSH_START,
+  GO2SIM_FC_CURR_LEVEL_INIT, GO2SIM_FC_CURR_LEVEL_MIN, GO2SIM_FC_CURR_LEVEL_MAX, GO2SIM_FC_CURR_EMA_ALPHA,
+  GO2SIM_FC_CURR_READY_TIMEOUT_RATE, GO2SIM_FC_CURR_READY_TRACKING, GO2SIM_FC_CURR_READY_FALL_RATE,
+  GO2SIM_FC_CURR_HARD_FALL_RATE, GO2SIM_FC_CURR_STEP_UP, GO2SIM_FC_CURR_STEP_DOWN,
+  GO2SIM_FC_CURR_MIX_PROB_CURRENT, GO2SIM_FC_CURR_MIX_LEVEL_LOW, GO2SIM_FC_CURR_MIX_LEVEL_HIGH,
+  GO2SIM_FC_COUNT
+};
+enum go2sim_icfg {
+  GO2SIM_IC_ENV_KIND = 0, /* 0 = walk (go2_env_walk.py) */
+  GO2SIM_IC_NUM_ACTIONS, GO2SIM_IC_NUM_POS_ACTIONS, GO2SIM_IC_NUM_OBS, GO2SIM_IC_NUM_PRIV_OBS,
+  GO2SIM_IC_PLS_ENABLE, GO2SIM_IC_MANUAL_PD, GO2SIM_IC_SUBSTEPS,
+  GO2SIM_IC_MAX_EPISODE_LENGTH, GO2SIM_IC_RESAMPLE_STEPS,
+  GO2SIM_IC_MOTOR_DOF0, /* 12 values: global dof index of env joint i */
+  GO2SIM_IC_FOOT_LINK0 = GO2SIM_IC_MOTOR_DOF0 + 12, /* 4 global link indices */
+  GO2SIM_IC_HIP_LINK0 = GO2SIM_IC_FOOT_LINK0 + 4,   /* 4 global link indices (leg mass DR) */
+  GO2SIM_IC_PUSH_LINK = GO2SIM_IC_HIP_LINK0 + 4, GO2SIM_IC_BASE_LINK,
+  GO2SIM_IC_HAS_INIT_Z, GO2SIM_IC_HAS_INIT_EULER,
+  GO2SIM_IC_N_REWARDS, GO2SIM_IC_REWARD_ID0, /* 32 values: enum go2sim_reward in evaluation order */
+  GO2SIM_IC_CMD_CURRICULUM = GO2SIM_IC_REWARD_ID0 + 32, GO2SIM_IC_COMPOUND_COMMANDS, GO2SIM_IC_N_STANDING,
+  GO2SIM_IC_HAS_FRICTION_DR, GO2SIM_IC_HAS_KPF_DR, GO2SIM_IC_HAS_KDF_DR, GO2SIM_IC_HAS_KP_RANGE,
+  GO2SIM_IC_HAS_MASS_DR, GO2SIM_IC_HAS_COM_DR, GO2SIM_IC_HAS_LEGM_DR, GO2SIM_IC_HAS_GOFF_DR, GO2SIM_IC_HAS_MSTR_DR,
+  GO2SIM_IC_HAS_OBS_NOISE, GO2SIM_IC_HAS_PUSH, GO2SIM_IC_PUSH_DUR_LO, GO2SIM_IC_PUSH_DUR_HI,
+  GO2SIM_IC_MIN_DELAY, GO2SIM_IC_MAX_DELAY, GO2SIM_IC_DELAY_EASY_MAX,
+  GO2SIM_IC_CURR_ENABLED, GO2SIM_IC_CURR_READY_STREAK, GO2SIM_IC_CURR_HARD_STREAK, GO2SIM_IC_CURR_COOLDOWN,
+  GO2SIM_IC_CURR_UPDATE_EVERY, GO2SIM_IC_GLOBAL_DR_INTERVAL,
+  GO2SIM_IC_PER_ENV_GLOBAL_DR, /* 0 = reference behaviour (one value for all envs), 1 = per-env draws */
+  GO2SIM_IC_FREEZE_CURRICULUM, /* 1 = keep the level fixed (bench protocol) */
+  GO2SIM_IC_COUNT
+};
+/* reward terms of go2_env_walk.py:1251-1366 */
+enum go2sim_reward {
+  GO2SIM_R_TRACKING_LIN_VEL = 0, GO2SIM_R_TRACKING_ANG_VEL, GO2SIM_R_LIN_VEL_Z, GO2SIM_R_BASE_HEIGHT,
+  GO2SIM_R_ACTION_RATE, GO2SIM_R_SIMILAR_TO_DEFAULT, GO2SIM_R_ORIENTATION_PENALTY, GO2SIM_R_DOF_ACC,
+  GO2SIM_R_DOF_VEL, GO2SIM_R_ANG_VEL_XY, GO2SIM_R_FEET_AIR_TIME, GO2SIM_R_FOOT_SLIP, GO2SIM_R_FOOT_CLEARANCE,
+  GO2SIM_R_JOINT_TRACKING, GO2SIM_R_ENERGY, GO2SIM_R_TORQUE_LOAD, GO2SIM_R_STAND_STILL, GO2SIM_R_STAND_STILL_VEL,
+  GO2SIM_R_FEET_STANCE, GO2SIM_R_COUNT
+};
+
+/* env-level buffers readable with go2sim_env_get (row-major [n_envs][k], device pointers) */
+enum go2sim_env_buf {
+  GO2SIM_EB_COMMANDS = 0,     /* f32 k=3  */
+  GO2SIM_EB_EPISODE_LENGTH,   /* i32 k=1  */
+  GO2SIM_EB_BASE_LIN_VEL,     /* f32 k=3  */
+  GO2SIM_EB_BASE_ANG_VEL,     /* f32 k=3  */
+  GO2SIM_EB_PROJECTED_GRAVITY,/* f32 k=3  */
+  GO2SIM_EB_DOF_POS,          /* f32 k=12 */
+  GO2SIM_EB_DOF_VEL,          /* f32 k=12 */
+  GO2SIM_EB_BASE_POS,         /* f32 k=3  */
+  GO2SIM_EB_BASE_QUAT,        /* f32 k=4  */
+  GO2SIM_EB_BASE_EULER,       /* f32 k=3  degrees */
+  GO2SIM_EB_EPISODE_SUMS,     /* f32 k=32 */
+  GO2SIM_EB_FOOT_CONTACT,     /* i32 k=4  */
+  GO2SIM_EB_FEET_AIR_TIME,    /* f32 k=4  */
+  GO2SIM_EB_REW_TERMS,        /* f32 k=32 per-term reward of the last step (already x scale) */
+  GO2SIM_EB_TORQUE,           /* f32 k=12 last commanded torque */
+  GO2SIM_EB_COUNT
+};
+
+/* device-side env globals (curriculum + "global" DR scalars), host-readable snapshot */
+typedef struct go2sim_env_globals {
+  float level;                 /* CurriculumManager.level (go2_env_walk.py:54) */
+  float timeout_rate_ema, tracking_ema, fall_rate_ema;
+  int   ema_valid, ready_streak, hard_streak, cooldown;
+  int   curr_ep_total; float curr_timeout_total, curr_tracking_sum; int curr_tracking_n;
+  float obs_noise_level_cur, action_noise_std_cur;
+  int   push_enable; float push_force_lo, push_force_hi; int push_interval, push_counter;
+  int   delay_max_cur;
+  float cmd_x_lo, cmd_x_hi, cmd_y_lo, cmd_y_hi, cmd_yaw_lo, cmd_yaw_hi;
+  int   global_dr_reset_counter;
+  float friction, mass_shift, com_shift[3], leg_mass_shift[4];
+  int   action_write_idx;
+  unsigned int step_count, reset_calls;
+  /* extras["episode"]: mean per-second reward of the envs reset in the last reset call */
+  int   last_reset_count; float last_episode_rew[32];
+  int   n_reset_now; float ep_acc[32]; /* scratch accumulators */
+  float t_sample;
+} go2sim_env_globals_t;
+
+typedef struct go2sim go2sim_t;
+
+/* gs.init + gs.Scene(...).add_entity(plane).add_entity(go2).build(n_envs)  (genesis/__init__.py:55,
+ * engine/scene.py:803; rigid_solver.py:337-523).  `device` = HIP device ordinal. */
+int go2sim_create(const void* model_blob, size_t nbytes, int n_envs, int device, uint64_t seed, go2sim_t** out);
+int go2sim_destroy(go2sim_t* h);
+int go2sim_n_envs(const go2sim_t* h);
+
+/* Scene._reset(): restore qpos0 / zero velocity, clear collider + warm start (scene.py:936,
+ * rigid_solver.py:1730-1779). */
+int go2sim_scene_reset(go2sim_t* h, void* stream);
+/* one RigidSolver.substep (rigid_solver.py:1116-1184) */
+int go2sim_substep(go2sim_t* h, void* stream);
+/* Scene.step(): `substeps` substeps + clear_external_force (scene.py:979, simulator.py:262-286) */
+int go2sim_scene_step(go2sim_t* h, int substeps, void* stream);
+/* kernel_forward_kinematics_links_geoms over the full batch (abd/forward_kinematics.py:28-66) */
+int go2sim_forward_kinematics(go2sim_t* h, void* stream);
+
+/* raw SoA field transfer (device<->device for go2sim_*, host<->host for go2sim_cpu_*), parity /
+ * checkpoint interface: buffer is [k][n_envs] of f32 or i32. */
+int go2sim_field_size(int field, int* k_out, int* is_int_out);
+int go2sim_get_field(go2sim_t* h, int field, void* dst_dev, void* stream);
+int go2sim_set_field(go2sim_t* h, int field, const void* src_dev, void* stream);
+
+/* Zero-copy access to the internal SoA state (the reference's qd_to_torch(..., copy=False) views,
+ * genesis/utils/misc.py:596): returns the DEVICE address of field `field` laid out [k][n_envs].  The
+ * Python shim wraps it as a torch tensor and implements the RigidEntity setters/getters Go2Env uses
+ * (rigid_entity.py:2173-2238,2482-2537,2707-2742,3032,3189-3240; rigid_solver.py:1314-1361) on top. */
+int go2sim_field_ptr(go2sim_t* h, int field, void** ptr_out);
+/* collider.reset(envs_idx) + constraint_solver.reset(envs_idx) + errno[envs_idx] = 0
+ * (rigid_solver.py:2403-2410): clears the contact-normal cache and the solver warm start of the given
+ * envs (int32 device index array, or NULL = all envs). */
+int go2sim_reset_caches(go2sim_t* h, const int* envs_idx_dev, int n_sel, void* stream);
+/* RigidEntity.set_friction on ground + robot: geoms_info.friction = mu for every geom
+ * (rigid_entity.py:3189, rigid_geom.py:327-336). */
+int go2sim_set_friction(go2sim_t* h, float mu, void* stream);
+/* dofs_info.kp / kv / force_range for one dof (rigid_solver.py:2270-2292); host values. */
+int go2sim_set_dof_gains(go2sim_t* h, int dof_idx, float kp, float kv, float force_lo, float force_hi);
+/* RigidSolver.check_errno (rigid_solver.py:1189-1213): OR-reduction of errno over envs, written to a
+ * host int.  This call synchronises the stream. */
+int go2sim_check_errno(go2sim_t* h, int* errno_host, void* stream);
+
+/* ---- fused Go2Env fast path (examples/locomotion/final/go2_env_walk.py) ------------------------ */
+/* Go2Env.__init__ buffers + cfg (go2_env_walk.py:155-525) */
+int go2sim_env_configure(go2sim_t* h, const float* fcfg_host, int n_f, const int* icfg_host, int n_i);
+/* Go2Env.step (go2_env_walk.py:985-1109): actions [n_envs][num_actions] -> obs [n_envs][num_obs],
+ * priv [n_envs][num_priv_obs], rew [n_envs], reset [n_envs] (u8 bool), time_outs [n_envs] f32. */
+int go2sim_env_step(go2sim_t* h, const float* actions_dev, float* obs_dev, float* priv_dev, float* rew_dev,
+                    uint8_t* reset_dev, float* timeout_dev, void* stream);
+/* Go2Env.reset (go2_env_walk.py:1242-1245): reset_idx(all envs); obs buffers are left as they are. */
+int go2sim_env_reset(go2sim_t* h, void* stream);
+/* env buffers (device pointer to [n_envs][k] row-major copy) and globals snapshot (synchronises) */
+int go2sim_env_get(go2sim_t* h, int env_buf, void* dst_dev, void* stream);
+int go2sim_env_set_episode_length(go2sim_t* h, const int* ep_len_dev, void* stream); /* rsl_rl init_at_random_ep_len */
+int go2sim_env_set_commands(go2sim_t* h, const float* cmd_dev, void* stream);
+int go2sim_env_globals(go2sim_t* h, go2sim_env_globals_t* out_host, void* stream);
+int go2sim_env_set_level(go2sim_t* h, float level, void* stream);
+
+/* hipEvent-timed duration (ms) of each kernel class accumulated since the last call with reset=1;
+ * out[0..7] = dyn, collide, solve, integrate, env_pre, env_post, misc, total ; counts in cnt[0..7].
+ * Used by bench.py for the live roofline measurement. Returns GO2SIM_E_BADARG if timing is disabled. */
+int go2sim_enable_timing(go2sim_t* h, int enable);
+int go2sim_read_timing(go2sim_t* h, float* ms_out8, int* cnt_out8, int reset);
+
+/* ---- CPU twin (test oracle; oracle/libgo2sim_cpu.so).  Same semantics, host pointers, the `stream`
+ * argument is ignored.  NOT part of the product: only tests/, __graft_entry__.smoke() and the
+ * cpu_baseline leg of bench.py may load it. */
+#define GO2SIM_CPU_DECL(name) go2sim_cpu_##name
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GO2SIM_H */
