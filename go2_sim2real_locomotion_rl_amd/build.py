@@ -1,0 +1,57 @@
+"""Build recipes.  `build_hip()` compiles the product (hipcc, gfx950); `build_oracle()` compiles the CPU
+oracle (g++) -- building the checker is not using it."""
+import os
+import shutil
+import subprocess
+import sys
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+REPO_ROOT = os.path.dirname(_HERE)
+HIP_SRC = os.path.join(_HERE, "csrc", "go2sim.hip")
+HIP_LIB = os.path.join(_HERE, "csrc", "libgo2sim.so")
+ORACLE_SRC = os.path.join(REPO_ROOT, "oracle", "go2sim_cpu.cpp")
+ORACLE_LIB = os.path.join(REPO_ROOT, "oracle", "libgo2sim_cpu.so")
+
+# -ffp-contract=off on BOTH sides is part of the numeric contract (include/go2sim_detmath.h):
+# identical IEEE binary32 operation sequences => bit-identical CPU/GPU results.
+HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-Wall", "-Wno-unused-function",
+             "-Wno-unused-const-variable"]
+CPU_FLAGS = ["-O2", "-std=c++17", "-ffp-contract=off", "-fopenmp", "-fPIC", "-shared", "-Wall", "-Wno-unused-function", "-Wno-unused-variable"]
+
+
+def _newer(target, *sources):
+    if not os.path.exists(target):
+        return False
+    t = os.path.getmtime(target)
+    return all(os.path.getmtime(s) <= t for s in sources)
+
+
+def _headers():
+    inc = os.path.join(REPO_ROOT, "include")
+    return [os.path.join(inc, f) for f in os.listdir(inc) if f.endswith(".h")]
+
+
+def build_hip(force=False, verbose=True):
+    if not force and _newer(HIP_LIB, HIP_SRC, *_headers()):
+        return HIP_LIB
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    cmd = [hipcc, *HIP_FLAGS, HIP_SRC, "-o", HIP_LIB]
+    if verbose:
+        print("[build]", " ".join(cmd), file=sys.stderr)
+    subprocess.run(cmd, check=True)
+    return HIP_LIB
+
+
+def build_oracle(force=False, verbose=True):
+    if not force and _newer(ORACLE_LIB, ORACLE_SRC, *_headers()):
+        return ORACLE_LIB
+    cmd = ["g++", *CPU_FLAGS, ORACLE_SRC, "-o", ORACLE_LIB]
+    if verbose:
+        print("[build]", " ".join(cmd), file=sys.stderr)
+    subprocess.run(cmd, check=True)
+    return ORACLE_LIB
+
+
+if __name__ == "__main__":
+    build_hip(force="--force" in sys.argv)
+    build_oracle(force="--force" in sys.argv)

@@ -1,0 +1,2866 @@
+// go2sim.hip -- MI355X (gfx950) implementation of the go2sim C ABI (include/go2sim.h).
+//
+// The vectorised Go2 locomotion environment of saifahmadgit/go2-sim2real-locomotion-rl (a Genesis
+// v0.4.0 fork) as hand-written HIP: batched rigid-body substep (articulated forward dynamics,
+// sweep-and-prune + MPR contact generation, Newton constraint solve with exact line search,
+// semi-implicit integration) and the Go2Env walk step (action latency, PLS PD torques, pushes,
+// observations, 19 reward terms, command resampling, termination, reset with domain randomisation and
+// metric-gated curriculum) with NO host synchronisation inside a step.
+//
+// Data layout: every per-env quantity lives in one HBM pool laid out SoA  [feature][n_envs]
+// (env index innermost => lane b of a wave reads word b of a 256-byte line: fully coalesced).
+// Execution model: one environment per lane, 64 environments per wavefront / workgroup.
+//
+// Reference citations use `R/` = genesis/engine/solvers/rigid/ and `E/` =
+// examples/locomotion/final/ of the reference tree.  Arithmetic follows the reference's serial
+// (`backend == gs.cpu`) evaluation order so that results are bit-identical to the CPU oracle
+// (oracle/go2sim_cpu.cpp) when both are built with -ffp-contract=off.
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+
+#include "../../include/go2sim.h"
+#include "../../include/go2sim_detmath.h"
+
+#define DEV __device__ __forceinline__
+#define DEVN __device__ __noinline__
+
+namespace {
+
+constexpr int NL = GO2SIM_NL, ND = GO2SIM_ND, NQ = GO2SIM_NQ, NG = GO2SIM_NG, NJ = GO2SIM_NJ;
+constexpr int NPAIR = GO2SIM_NPAIR_MAX, MAXC = GO2SIM_MAX_CONTACTS, MAXB = GO2SIM_MAX_BROAD, MAXR = GO2SIM_MAX_ROWS;
+constexpr int JOINT_FIXED = 0, JOINT_REVOLUTE = 1, JOINT_FREE = 4;
+constexpr int GEOM_SPHERE = 1, GEOM_CYLINDER = 3, GEOM_BOX = 5;
+constexpr int CTRL_FORCE = 0, CTRL_VELOCITY = 1, CTRL_POSITION = 2;
+constexpr int NA = 16, NM = 12, NOBS_MAX = 64, NPRIV_MAX = 128, NREW = 32;
+constexpr int WG = 64;  // one wavefront per workgroup
+
+// ---------------------------------------------------------------------------------------------
+// small vector types (registers)
+// ---------------------------------------------------------------------------------------------
+struct V3 { float x, y, z; };
+struct Q4 { float w, x, y, z; };
+struct M3 { float m[3][3]; };
+
+DEV float fmn(float a, float b) { return (b < a) ? b : a; }   // std::min semantics
+DEV float fmx(float a, float b) { return (a < b) ? b : a; }   // std::max semantics
+DEV int imn(int a, int b) { return (b < a) ? b : a; }
+DEV int imx(int a, int b) { return (a < b) ? b : a; }
+DEV V3 v3(float x, float y, float z) { V3 r = {x, y, z}; return r; }
+DEV V3 operator+(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
+DEV V3 operator-(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
+DEV V3 operator-(V3 a) { return v3(-a.x, -a.y, -a.z); }
+DEV V3 operator*(V3 a, float s) { return v3(a.x * s, a.y * s, a.z * s); }
+DEV V3 operator*(float s, V3 a) { return v3(s * a.x, s * a.y, s * a.z); }
+DEV V3 operator/(V3 a, float s) { return v3(a.x / s, a.y / s, a.z / s); }
+DEV float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+DEV V3 cross(V3 a, V3 b) { return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+DEV float norm_sqr(V3 a) { return a.x * a.x + a.y * a.y + a.z * a.z; }
+DEV float norm(V3 a) { return dm_sqrt(norm_sqr(a)); }
+DEV V3 normalized(V3 a) { float inv = 1.0f / norm(a); return inv * a; }
+DEV float vget(V3 a, int i) { return i == 0 ? a.x : (i == 1 ? a.y : a.z); }
+DEV void vset(V3& a, int i, float v) { if (i == 0) a.x = v; else if (i == 1) a.y = v; else a.z = v; }
+DEV V3 vmin(V3 a, V3 b) { return v3(fmn(a.x, b.x), fmn(a.y, b.y), fmn(a.z, b.z)); }
+DEV V3 vmax(V3 a, V3 b) { return v3(fmx(a.x, b.x), fmx(a.y, b.y), fmx(a.z, b.z)); }
+DEV float clampf(float x, float lo, float hi) { return fmn(hi, fmx(lo, x)); }
+DEV bool isnan_(float x) { return x != x; }
+DEV Q4 q4(float w, float x, float y, float z) { Q4 r = {w, x, y, z}; return r; }
+DEV float norm_sqr(Q4 q) { return q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z; }
+DEV Q4 operator*(Q4 q, float s) { return q4(q.w * s, q.x * s, q.y * s, q.z * s); }
+DEV Q4 qident() { return q4(1.0f, 0.0f, 0.0f, 0.0f); }
+DEV Q4 inv_quat(Q4 q) { return q4(q.w, -q.x, -q.y, -q.z); }
+DEV V3 mul(const M3& A, V3 v) {
+  return v3(A.m[0][0] * v.x + A.m[0][1] * v.y + A.m[0][2] * v.z, A.m[1][0] * v.x + A.m[1][1] * v.y + A.m[1][2] * v.z,
+            A.m[2][0] * v.x + A.m[2][1] * v.y + A.m[2][2] * v.z);
+}
+DEV M3 mul(const M3& A, const M3& B) {
+  M3 C;
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) C.m[i][j] = A.m[i][0] * B.m[0][j] + A.m[i][1] * B.m[1][j] + A.m[i][2] * B.m[2][j];
+  return C;
+}
+DEV M3 transpose(const M3& A) {
+  M3 C;
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) C.m[i][j] = A.m[j][i];
+  return C;
+}
+DEV M3 operator+(const M3& A, const M3& B) {
+  M3 C;
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) C.m[i][j] = A.m[i][j] + B.m[i][j];
+  return C;
+}
+DEV V3 mcol(const M3& A, int j) { return v3(j == 0 ? A.m[0][0] : (j == 1 ? A.m[0][1] : A.m[0][2]), j == 0 ? A.m[1][0] : (j == 1 ? A.m[1][1] : A.m[1][2]),
+                                          j == 0 ? A.m[2][0] : (j == 1 ? A.m[2][1] : A.m[2][2])); }
+
+// genesis/utils/geom.py:236-242
+DEV Q4 quat_mul(Q4 u, Q4 v) {
+  float w = u.w * v.w - u.x * v.x - u.y * v.y - u.z * v.z;
+  float x = u.w * v.x + u.x * v.w + u.y * v.z - u.z * v.y;
+  float y = u.w * v.y - u.x * v.z + u.y * v.w + u.z * v.x;
+  float z = u.w * v.z + u.x * v.y - u.y * v.x + u.z * v.w;
+  return q4(w, x, y, z);
+}
+// geom.py:245-252
+DEV Q4 transform_quat_by_quat(Q4 v, Q4 u) {
+  Q4 q = quat_mul(u, v);
+  float inv = 1.0f / dm_sqrt(norm_sqr(q));
+  return q4(inv * q.w, inv * q.x, inv * q.y, inv * q.z);
+}
+// geom.py:255-270
+DEV V3 transform_by_quat(V3 v, Q4 q) {
+  float q_xx = q.x * q.x, q_xy = q.x * q.y, q_xz = q.x * q.z, q_wx = q.x * q.w;
+  float q_yy = q.y * q.y, q_yz = q.y * q.z, q_wy = q.y * q.w;
+  float q_zz = q.z * q.z, q_wz = q.z * q.w;
+  float q_ww = q.w * q.w;
+  V3 r = v3(v.x * (q_xx + q_ww - q_yy - q_zz) + v.y * (2.0f * q_xy - 2.0f * q_wz) + v.z * (2.0f * q_xz + 2.0f * q_wy),
+            v.x * (2.0f * q_wz + 2.0f * q_xy) + v.y * (q_ww - q_xx + q_yy - q_zz) + v.z * (-2.0f * q_wx + 2.0f * q_yz),
+            v.x * (-2.0f * q_wy + 2.0f * q_xz) + v.y * (2.0f * q_wx + 2.0f * q_yz) + v.z * (q_ww - q_xx - q_yy + q_zz));
+  return r / (q_ww + q_xx + q_yy + q_zz);
+}
+DEV V3 inv_transform_by_quat(V3 v, Q4 q) { return transform_by_quat(v, inv_quat(q)); }
+DEV V3 transform_by_trans_quat(V3 p, V3 t, Q4 q) { return transform_by_quat(p, q) + t; }
+DEV void transform_pos_quat_by_trans_quat(V3 pos, Q4 quat, V3 t_trans, Q4 t_quat, V3& opos, Q4& oquat) {
+  opos = t_trans + transform_by_quat(pos, t_quat);
+  oquat = transform_quat_by_quat(quat, t_quat);
+}
+// geom.py:136-161
+DEV M3 quat_to_R(Q4 q, float eps) {
+  M3 R = {{{1, 0, 0}, {0, 1, 0}, {0, 0, 1}}};
+  float d = norm_sqr(q);
+  if (d > eps) {
+    float s = 2.0f / d;
+    float xs = q.x * s, ys = q.y * s, zs = q.z * s;
+    float wx = q.w * xs, wy = q.w * ys, wz = q.w * zs;
+    float xx = q.x * xs, xy = q.x * ys, xz = q.x * zs;
+    float yy = q.y * ys, yz = q.y * zs, zz = q.z * zs;
+    R.m[0][0] = 1.0f - (yy + zz); R.m[0][1] = xy - wz; R.m[0][2] = xz + wy;
+    R.m[1][0] = xy + wz; R.m[1][1] = 1.0f - (xx + zz); R.m[1][2] = yz - wx;
+    R.m[2][0] = xz - wy; R.m[2][1] = yz + wx; R.m[2][2] = 1.0f - (xx + yy);
+  }
+  return R;
+}
+// geom.py:110-133
+DEV Q4 rotvec_to_quat(V3 rv, float eps) {
+  Q4 q = q4(0, 0, 0, 0);
+  float thetasq = norm_sqr(rv);
+  if (thetasq > eps * eps) {
+    float theta = dm_sqrt(thetasq);
+    float theta_half = 0.5f * theta;
+    float s, c;
+    dm_sincos(theta_half, &s, &c);
+    q.w = c;
+    V3 xyz = (s / theta) * rv;
+    q.x = xyz.x; q.y = xyz.y; q.z = xyz.z;
+    float k = 0.5f * (3.0f - norm_sqr(q));
+    q = q * k;
+  } else {
+    q.w = 1.0f;
+  }
+  return q;
+}
+// geom.py:320-336
+DEV void transform_inertia_by_trans_quat(const M3& I, float mass, V3 t, Q4 quat, float eps, M3& oI, V3& opos) {
+  float xx = t.x * t.x, xy = t.x * t.y, xz = t.x * t.z, yy = t.y * t.y, yz = t.y * t.z, zz = t.z * t.z;
+  M3 hhT = {{{yy + zz, -xy, -xz}, {-xy, xx + zz, -yz}, {-xz, -yz, xx + yy}}};
+  M3 R = quat_to_R(quat, eps);
+  M3 RI = mul(mul(R, I), transpose(R));
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) oI.m[i][j] = RI.m[i][j] + hhT.m[i][j] * mass;
+  opos = t * mass;
+}
+// geom.py:365-383
+DEV void inertial_mul(V3 pos, const M3& I, float mass, V3 vel, V3 ang, V3& oang, V3& ovel) {
+  oang = mul(I, ang) + cross(pos, vel);
+  ovel = mass * vel - cross(pos, ang);
+}
+DEV void motion_cross_force(V3 m_ang, V3 m_vel, V3 f_ang, V3 f_vel, V3& oang, V3& ovel) {
+  ovel = cross(m_ang, f_vel);
+  oang = cross(m_ang, f_ang) + cross(m_vel, f_vel);
+}
+DEV void motion_cross_motion(V3 s_ang, V3 s_vel, V3 m_ang, V3 m_vel, V3& oang, V3& ovel) {
+  ovel = cross(s_ang, m_vel) + cross(s_vel, m_ang);
+  oang = cross(s_ang, m_ang);
+}
+// geom.py:386-401
+DEV void orthogonals(V3 a, V3& b, V3& c) {
+  if (dm_abs(a.y) < 0.5f) b = v3(-a.x * a.y, 1.0f - a.y * a.y, -a.z * a.y);
+  else b = v3(-a.x * a.z, -a.y * a.z, 1.0f - a.z * a.z);
+  b = normalized(b);
+  c = cross(a, b);
+}
+// geom.py:404-422
+DEV void imp_aref(const float* p, float neg_penetration, float vel, float pos, float& imp, float& aref) {
+  float timeconst = p[0], dampratio = p[1], dmin = p[2], dmax = p[3], width = p[4], mid = p[5], power = p[6];
+  float imp_x = dm_abs(neg_penetration) / width;
+  float imp_a = (1.0f / dm_pow(mid, power - 1.0f)) * dm_pow(imp_x, power);
+  float imp_b = 1.0f - (1.0f / dm_pow(1.0f - mid, power - 1.0f)) * dm_pow(1.0f - imp_x, power);
+  float imp_y = (imp_x < mid) ? imp_a : imp_b;
+  imp = dmin + imp_y * (dmax - dmin);
+  imp = clampf(imp, dmin, dmax);
+  imp = (imp_x > 1.0f) ? dmax : imp;
+  float b = 2.0f / (dmax * timeconst);
+  float k = 1.0f / (dmax * dmax * timeconst * timeconst * dampratio * dampratio);
+  aref = -b * vel - k * imp * pos;
+}
+
+// ---------------------------------------------------------------------------------------------
+// model tables (device global memory, read-mostly: L2 / Infinity-Cache resident)
+// ---------------------------------------------------------------------------------------------
+struct Link {
+  int parent, root, entity, is_fixed, joint_start, joint_end, dof_start, dof_end, q_start, q_end, n_dofs, geom_start, geom_end;
+  V3 pos; Q4 quat; V3 inertial_pos; Q4 inertial_quat; M3 inertial_i; float mass; float invweight[2];
+};
+struct Joint { int type, link, q_start, dof_start, dof_end; V3 pos; float sol_params[7]; };
+struct Dof { V3 motion_ang, motion_vel; float limit[2], invweight, armature, damping, stiffness, frictionloss, kp, kv, force_range[2]; };
+struct Geom { int type, link, is_convex; V3 pos; Q4 quat; float data[7], friction, sol_params[7]; V3 center; V3 aabb[8]; float rim[32][2]; };
+struct Entity { int link_start, link_end, dof_start, dof_end, geom_start, geom_end; };
+struct Model {
+  int n_links, n_joints, n_dofs, n_qs, n_geoms, n_entities, n_pairs, max_collision_pairs, max_contact_pairs, max_broad_pairs,
+      n_contacts_per_pair, iterations, ls_iterations, ccd_iterations, support_res;
+  float substep_dt; V3 gravity; float eps, tolerance, ls_tolerance, meaninertia, mc_perturbation, mc_tolerance, mpr_to_gjk_ratio, ccd_eps,
+      ccd_tolerance;
+  Link links[NL]; Joint joints[NJ]; Dof dofs[ND]; Geom geoms[NG]; Entity entities[2];
+  float qpos0[NQ]; float mass_parent_mask[ND][ND]; int pair_idx[NG][NG]; int theta_to_ring[180];
+};
+
+bool parse_model(const void* blob, size_t nbytes, Model& m) {
+  if (nbytes < 128) return false;
+  const int32_t* H = (const int32_t*)blob;
+  if (H[0] != GO2SIM_MODEL_MAGIC || H[1] != GO2SIM_MODEL_VERSION) return false;
+  m.n_links = H[2]; m.n_joints = H[3]; m.n_dofs = H[4]; m.n_qs = H[5]; m.n_geoms = H[6]; m.n_entities = H[7];
+  m.n_pairs = H[8]; m.max_collision_pairs = H[9]; m.max_contact_pairs = H[10]; m.max_broad_pairs = H[11];
+  m.n_contacts_per_pair = H[12]; m.iterations = H[13]; m.ls_iterations = H[14]; m.ccd_iterations = H[15]; m.support_res = H[16];
+  int nf = H[18], ni = H[19];
+  if (m.n_links != NL || m.n_joints != NJ || m.n_dofs != ND || m.n_qs != NQ || m.n_geoms != NG || m.n_entities != 2) return false;
+  if (m.n_pairs > NPAIR || m.max_contact_pairs > MAXC || m.max_broad_pairs > MAXB || m.support_res != 180 || H[17] != 32) return false;
+  if (nbytes < 128 + (size_t)4 * (nf + ni)) return false;
+  const float* F = (const float*)((const char*)blob + 128);
+  const int32_t* I = (const int32_t*)(F + nf);
+  const float* f = F;
+  m.substep_dt = f[0]; m.gravity = {f[1], f[2], f[3]}; m.eps = f[4]; m.tolerance = f[5]; m.ls_tolerance = f[6]; m.meaninertia = f[7];
+  m.mc_perturbation = f[8]; m.mc_tolerance = f[9]; m.mpr_to_gjk_ratio = f[10]; m.ccd_eps = f[11]; m.ccd_tolerance = f[12];
+  f += 16;
+  for (int i = 0; i < NL; ++i, f += 26) {
+    Link& l = m.links[i];
+    l.pos = {f[0], f[1], f[2]}; l.quat = {f[3], f[4], f[5], f[6]}; l.inertial_pos = {f[7], f[8], f[9]}; l.inertial_quat = {f[10], f[11], f[12], f[13]};
+    for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) l.inertial_i.m[a][b] = f[14 + 3 * a + b];
+    l.mass = f[23]; l.invweight[0] = f[24]; l.invweight[1] = f[25];
+  }
+  for (int i = 0; i < NJ; ++i, f += 10) { m.joints[i].pos = {f[0], f[1], f[2]}; for (int a = 0; a < 7; ++a) m.joints[i].sol_params[a] = f[3 + a]; }
+  for (int i = 0; i < ND; ++i, f += 17) {
+    Dof& d = m.dofs[i];
+    d.motion_ang = {f[0], f[1], f[2]}; d.motion_vel = {f[3], f[4], f[5]}; d.limit[0] = f[6]; d.limit[1] = f[7]; d.invweight = f[8];
+    d.armature = f[9]; d.damping = f[10]; d.stiffness = f[11]; d.frictionloss = f[12]; d.kp = f[13]; d.kv = f[14]; d.force_range[0] = f[15];
+    d.force_range[1] = f[16];
+  }
+  for (int i = 0; i < NQ; ++i) m.qpos0[i] = f[i];
+  f += NQ;
+  for (int i = 0; i < NG; ++i, f += 113) {
+    Geom& g = m.geoms[i];
+    g.pos = {f[0], f[1], f[2]}; g.quat = {f[3], f[4], f[5], f[6]};
+    for (int a = 0; a < 7; ++a) g.data[a] = f[7 + a];
+    g.friction = f[14];
+    for (int a = 0; a < 7; ++a) g.sol_params[a] = f[15 + a];
+    g.center = {f[22], f[23], f[24]};
+    for (int a = 0; a < 8; ++a) g.aabb[a] = {f[25 + 3 * a], f[26 + 3 * a], f[27 + 3 * a]};
+    for (int a = 0; a < 32; ++a) { g.rim[a][0] = f[49 + 2 * a]; g.rim[a][1] = f[50 + 2 * a]; }
+  }
+  for (int i = 0; i < ND; ++i) for (int j = 0; j < ND; ++j) m.mass_parent_mask[i][j] = f[i * ND + j];
+  f += ND * ND;
+  if (f - F != nf) return false;
+  const int32_t* p = I;
+  for (int i = 0; i < NL; ++i, p += 13) {
+    Link& l = m.links[i];
+    l.parent = p[0]; l.root = p[1]; l.entity = p[2]; l.is_fixed = p[3]; l.joint_start = p[4]; l.joint_end = p[5]; l.dof_start = p[6];
+    l.dof_end = p[7]; l.q_start = p[8]; l.q_end = p[9]; l.n_dofs = p[10]; l.geom_start = p[11]; l.geom_end = p[12];
+  }
+  for (int i = 0; i < NJ; ++i, p += 5) { Joint& j = m.joints[i]; j.type = p[0]; j.link = p[1]; j.q_start = p[2]; j.dof_start = p[3]; j.dof_end = p[4]; }
+  for (int i = 0; i < NG; ++i, p += 3) { m.geoms[i].type = p[0]; m.geoms[i].link = p[1]; m.geoms[i].is_convex = p[2]; }
+  for (int i = 0; i < 2; ++i, p += 6) {
+    Entity& e = m.entities[i];
+    e.link_start = p[0]; e.link_end = p[1]; e.dof_start = p[2]; e.dof_end = p[3]; e.geom_start = p[4]; e.geom_end = p[5];
+  }
+  for (int i = 0; i < NG; ++i) for (int j = 0; j < NG; ++j) m.pair_idx[i][j] = p[i * NG + j];
+  p += NG * NG;
+  for (int i = 0; i < 180; ++i) m.theta_to_ring[i] = p[i];
+  p += 180;
+  return (p - I) == ni;
+}
+
+// ---------------------------------------------------------------------------------------------
+// SoA state pool.  X(name, floats_per_env).  Order of the first group matches enum go2sim_field so
+// that go2sim_get_field / go2sim_set_field are plain device copies.
+// ---------------------------------------------------------------------------------------------
+#define GO2SIM_FLOAT_FIELDS(X)                                                                                       \
+  X(qpos, NQ) X(vel, ND) X(acc, ND) X(qacc_ws, ND) X(ctrl_force, ND) X(ext, NL * 6) X(mass_shift, NL) X(com_shift, NL * 3) \
+  X(friction_ratio, NG) X(l_pos, NL * 3) X(l_quat, NL * 4) X(cd_vel, NL * 3) X(cd_ang, NL * 3) X(root_com, NL * 3)     \
+  X(contact_force, NL * 3) X(mass_mat, ND * ND) X(qf_smooth, ND) X(acc_smooth, ND) X(c_pos, MAXC * 3) X(c_normal, MAXC * 3) \
+  X(c_pen, MAXC) X(normal_cache, NPAIR * 3) X(sort_value, 2 * NG) X(geom_friction, NG) X(efc_force, MAXR)               \
+  X(qfrc_constraint, ND)                                                                                             \
+  X(ctrl_pos, ND) X(ctrl_vel, ND) X(i_pos, NL * 3) X(i_quat, NL * 4) X(cinr_inertial, NL * 9) X(cinr_pos, NL * 3)       \
+  X(cinr_mass, NL) X(xanchor, NJ * 3) X(xaxis, NJ * 3) X(dof_pos, ND) X(cdof_ang, ND * 3) X(cdof_vel, ND * 3)            \
+  X(cdofd_ang, ND * 3) X(cdofd_vel, ND * 3) X(g_pos, NG * 3) X(g_quat, NG * 4) X(aabb_min, NG * 3) X(aabb_max, NG * 3)  \
+  X(crb_inertial, NL * 9) X(crb_pos, NL * 3) X(crb_mass, NL) X(f_ang, ND * 3) X(f_vel, ND * 3) X(mass_L, ND * ND)      \
+  X(mass_Dinv, ND) X(qf_applied, ND) X(qf_passive, ND) X(force, ND) X(cdd_vel, NL * 3) X(cdd_ang, NL * 3)              \
+  X(cfrc_vel, NL * 3) X(cfrc_ang, NL * 3) X(c_friction, MAXC) X(c_sol, MAXC * 7) X(c_force, MAXC * 3)                  \
+  X(mpr_v, 12) X(mpr_v1, 12) X(mpr_v2, 12) X(jac, MAXR * ND) X(diag, MAXR) X(aref, MAXR) X(efc_D, MAXR) X(Jaref, MAXR) \
+  X(jv, MAXR) X(qacc, ND) X(Ma, ND) X(grad, ND) X(Mgrad, ND) X(search, ND) X(mv, ND) X(nt_vec, ND) X(H, ND * ND)        \
+  X(sv, 96) /* cost, prev_cost, gauss, quad_gauss[3], gtol, alpha, debug... */                                                      \
+  X(vel_next, ND) X(qpos_next, NQ)                                                                                   \
+  /* ---- Go2Env buffers ---- */                                                                                     \
+  X(actions, NA) X(last_actions, NA) X(applied_actions, NA) X(action_history, 2 * NA) X(target_dof_pos, NM)            \
+  X(e_dof_pos, NM) X(e_dof_vel, NM) X(last_dof_vel, NM) X(torque, NM) X(base_pos, 3) X(base_quat, 4) X(base_lin_vel, 3) \
+  X(base_ang_vel, 3) X(projected_gravity, 3) X(base_euler, 3) X(commands, 3) X(time_out, 1) X(kp_factors, NM)          \
+  X(kd_factors, NM) X(motor_strength, NM) X(gravity_offset, 3) X(current_push_force, 3) X(push_stored_force, 3)       \
+  X(feet_air_time, 4) X(episode_sums, NREW) X(rew_terms, NREW) X(rew, 1) X(obs, NOBS_MAX) X(priv, NPRIV_MAX)
+
+#define GO2SIM_INT_FIELDS(X)                                                                                         \
+  X(n_contacts, 1) X(c_geom, 2 * MAXC) X(n_con, 1) X(err, 1) X(is_warmstart, 1) X(first_time, 1) X(sort_ig, 2 * NG)      \
+  X(n_broad, 1) X(solver_iters, 1) X(ctrl_mode, ND)                                                                  \
+  X(active_buf, NG) X(broad, MAXB * 2) X(c_link, 2 * MAXC) X(active, MAXR) X(prev_active, MAXR) X(si, 4) /* ls_it, ls_result, improved, - */ \
+  X(gjk_fallback, 1) X(delay_steps, 1) X(episode_length, 1) X(reset_buf, 1) X(push_remaining, 1) X(foot_contact, 4)    \
+  X(last_foot_contact, 4)
+
+enum FOff : int {
+#define X(n, c) FO_##n##_, FO_##n##_end = FO_##n##_ + (c) - 1,
+  GO2SIM_FLOAT_FIELDS(X)
+#undef X
+  FO_TOTAL
+};
+enum IOff : int {
+#define X(n, c) IO_##n##_, IO_##n##_end = IO_##n##_ + (c) - 1,
+  GO2SIM_INT_FIELDS(X)
+#undef X
+  IO_TOTAL
+};
+#define FO(n) FO_##n##_
+#define IO(n) IO_##n##_
+
+// per-lane view of the pool
+template <typename T>
+struct Arr {
+  T* p; int B;
+  DEV T& operator[](int i) const { return p[(size_t)i * B]; }
+};
+struct V3Ref {
+  float* p; int B;
+  DEV operator V3() const { return v3(p[0], p[B], p[2 * (size_t)B]); }
+  DEV const V3Ref& operator=(V3 v) const { p[0] = v.x; p[B] = v.y; p[2 * (size_t)B] = v.z; return *this; }
+  DEV const V3Ref& operator=(const V3Ref& o) const { V3 v = o; return *this = v; }
+};
+struct Q4Ref {
+  float* p; int B;
+  DEV operator Q4() const { return q4(p[0], p[B], p[2 * (size_t)B], p[3 * (size_t)B]); }
+  DEV const Q4Ref& operator=(Q4 q) const { p[0] = q.w; p[B] = q.x; p[2 * (size_t)B] = q.y; p[3 * (size_t)B] = q.z; return *this; }
+  DEV const Q4Ref& operator=(const Q4Ref& o) const { Q4 v = o; return *this = v; }
+};
+struct M3Ref {
+  float* p; int B;
+  DEV operator M3() const { M3 r;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) r.m[i / 3][i % 3] = p[(size_t)i * B];
+    return r; }
+  DEV const M3Ref& operator=(const M3& r) const {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) p[(size_t)i * B] = r.m[i / 3][i % 3];
+    return *this; }
+  DEV const M3Ref& operator=(const M3Ref& o) const { M3 v = o; return *this = v; }
+};
+struct Arr3 { float* p; int B; DEV V3Ref operator[](int i) const { return V3Ref{p + (size_t)(3 * i) * B, B}; } };
+struct Arr4 { float* p; int B; DEV Q4Ref operator[](int i) const { return Q4Ref{p + (size_t)(4 * i) * B, B}; } };
+struct Arr9 { float* p; int B; DEV M3Ref operator[](int i) const { return M3Ref{p + (size_t)(9 * i) * B, B}; } };
+template <int W>
+struct Arr2 {
+  float* p; int B;
+  DEV Arr<float> operator[](int i) const { return Arr<float>{p + (size_t)(W * i) * B, B}; }
+};
+
+struct Pool { float* f; int* i; int B; };
+
+// Env view: field accessors of lane b
+struct E {
+  float* f; int* i; int B; int b;
+  DEV E(const Pool& P, int b_) : f(P.f + b_), i(P.i + b_), B(P.B), b(b_) {}
+#define FA(name) DEV Arr<float> name() const { return Arr<float>{f + (size_t)FO(name) * B, B}; }
+#define FA3(name) DEV Arr3 name() const { return Arr3{f + (size_t)FO(name) * B, B}; }
+#define FA4(name) DEV Arr4 name() const { return Arr4{f + (size_t)FO(name) * B, B}; }
+#define FA9(name) DEV Arr9 name() const { return Arr9{f + (size_t)FO(name) * B, B}; }
+#define FA2(name, W) DEV Arr2<W> name() const { return Arr2<W>{f + (size_t)FO(name) * B, B}; }
+#define IA(name) DEV Arr<int> name() const { return Arr<int>{i + (size_t)IO(name) * B, B}; }
+  FA(qpos) FA(vel) FA(acc) FA(qacc_ws) FA(ctrl_force) FA(ctrl_pos) FA(ctrl_vel) FA(ext) FA(mass_shift) FA3(com_shift) FA(friction_ratio)
+  FA(geom_friction) FA(sort_value) FA3(normal_cache) FA3(l_pos) FA4(l_quat) FA3(i_pos) FA4(i_quat) FA3(root_com) FA9(cinr_inertial)
+  FA3(cinr_pos) FA(cinr_mass) FA3(xanchor) FA3(xaxis) FA(dof_pos) FA3(cdof_ang) FA3(cdof_vel) FA3(cdofd_ang) FA3(cdofd_vel) FA3(cd_vel)
+  FA3(cd_ang) FA3(g_pos) FA4(g_quat) FA3(aabb_min) FA3(aabb_max) FA9(crb_inertial) FA3(crb_pos) FA(crb_mass) FA3(f_ang) FA3(f_vel)
+  FA2(mass_mat, ND) FA2(mass_L, ND) FA(mass_Dinv) FA(qf_applied) FA(qf_passive) FA(force) FA(qf_smooth) FA(acc_smooth) FA3(cdd_vel)
+  FA3(cdd_ang) FA3(cfrc_vel) FA3(cfrc_ang) FA3(c_pos) FA3(c_normal) FA(c_pen) FA(c_friction) FA2(c_sol, 7) FA3(c_force) FA3(mpr_v)
+  FA3(mpr_v1) FA3(mpr_v2) FA2(jac, ND) FA(diag) FA(aref) FA(efc_D) FA(Jaref) FA(jv) FA(efc_force) FA(qacc) FA(Ma) FA(grad) FA(Mgrad)
+  FA(search) FA(mv) FA(qfrc_constraint) FA(nt_vec) FA2(H, ND) FA(sv) FA3(contact_force) FA(vel_next) FA(qpos_next)
+  FA(actions) FA(last_actions) FA(applied_actions) FA2(action_history, NA) FA(target_dof_pos) FA(e_dof_pos) FA(e_dof_vel) FA(last_dof_vel)
+  FA(torque) FA(base_pos) FA(base_quat) FA(base_lin_vel) FA(base_ang_vel) FA(projected_gravity) FA(base_euler) FA(commands) FA(time_out)
+  FA(kp_factors) FA(kd_factors) FA(motor_strength) FA(gravity_offset) FA(current_push_force) FA(push_stored_force) FA(feet_air_time)
+  FA(episode_sums) FA(rew_terms) FA(rew) FA(obs) FA(priv)
+  IA(n_contacts) IA(c_geom) IA(n_con) IA(err) IA(is_warmstart) IA(first_time) IA(sort_ig) IA(n_broad) IA(solver_iters) IA(ctrl_mode)
+  IA(active_buf) IA(broad) IA(c_link) IA(active) IA(prev_active) IA(si) IA(gjk_fallback) IA(delay_steps) IA(episode_length) IA(reset_buf)
+  IA(push_remaining) IA(foot_contact) IA(last_foot_contact)
+#undef FA
+#undef FA3
+#undef FA4
+#undef FA9
+#undef FA2
+#undef IA
+};
+// scalar slots
+enum { SV_COST = 0, SV_PREV_COST, SV_GAUSS, SV_QG0, SV_QG1, SV_QG2, SV_GTOL };
+enum { SI_LS_IT = 0, SI_LS_RESULT, SI_IMPROVED };
+
+// ---------------------------------------------------------------------------------------------
+// kinematics  (R/abd/forward_kinematics.py)
+// ---------------------------------------------------------------------------------------------
+// func_forward_kinematics_entity, forward_kinematics.py:463-618
+DEV void forward_kinematics_entity(const Model& m, const E& e, int i_e) {
+  const Entity& en = m.entities[i_e];
+  auto l_pos = e.l_pos(); auto l_quat = e.l_quat(); auto qpos = e.qpos(); auto xanchor = e.xanchor(); auto xaxis = e.xaxis(); auto dof_pos = e.dof_pos();
+  for (int i_l = en.link_start; i_l < en.link_end; ++i_l) {
+    const Link& L = m.links[i_l];
+    V3 pos = L.pos; Q4 quat = L.quat;
+    if (L.parent != -1) {
+      Q4 pq = l_quat[L.parent];
+      pos = (V3)l_pos[L.parent] + transform_by_quat(L.pos, pq);
+      quat = transform_quat_by_quat(L.quat, pq);
+    }
+    for (int i_j = L.joint_start; i_j < L.joint_end; ++i_j) {
+      const Joint& J = m.joints[i_j];
+      int q_start = J.q_start, dof_start = J.dof_start;
+      if (J.type == JOINT_FREE) {
+        V3 pos_ = v3(qpos[q_start], qpos[q_start + 1], qpos[q_start + 2]);
+        xanchor[i_j] = pos_;
+        xaxis[i_j] = v3(0, 0, 1);
+        Q4 quat_ = q4(qpos[q_start + 3], qpos[q_start + 4], qpos[q_start + 5], qpos[q_start + 6]);
+        float n = dm_sqrt(norm_sqr(quat_));
+        quat_ = q4(quat_.w / n, quat_.x / n, quat_.y / n, quat_.z / n);
+        pos = pos_; quat = quat_;
+        dof_pos[dof_start + 0] = pos.x; dof_pos[dof_start + 1] = pos.y; dof_pos[dof_start + 2] = pos.z;
+      } else if (J.type == JOINT_REVOLUTE) {
+        V3 axis = m.dofs[dof_start].motion_ang;
+        V3 anchor = transform_by_quat(J.pos, quat) + pos;
+        xanchor[i_j] = anchor;
+        xaxis[i_j] = transform_by_quat(axis, quat);
+        float dp = qpos[q_start] - m.qpos0[q_start];
+        dof_pos[dof_start] = dp;
+        Q4 qloc = rotvec_to_quat(axis * dp, m.eps);
+        quat = transform_quat_by_quat(qloc, quat);
+        pos = anchor - transform_by_quat(J.pos, quat);
+      }
+    }
+    if (!(L.parent == -1 && L.is_fixed)) { l_pos[i_l] = pos; l_quat[i_l] = quat; }
+  }
+}
+
+// func_COM_links_entity, forward_kinematics.py:224-459
+DEV void com_links_entity(const Model& m, const E& e, int i_e) {
+  const Entity& en = m.entities[i_e];
+  auto l_pos = e.l_pos(); auto l_quat = e.l_quat(); auto i_pos = e.i_pos(); auto i_quat = e.i_quat(); auto root_com = e.root_com();
+  auto mass_shift = e.mass_shift(); auto com_shift = e.com_shift();
+  // one kinematic tree per entity: root = first link of the entity
+  V3 root_com_bw = v3(0, 0, 0); float mass_sum = 0.0f;
+  for (int i_l = en.link_start; i_l < en.link_end; ++i_l) {
+    const Link& L = m.links[i_l];
+    float mass = L.mass + mass_shift[i_l];
+    V3 ipbw; Q4 iq;
+    transform_pos_quat_by_trans_quat(L.inertial_pos + (V3)com_shift[i_l], L.inertial_quat, l_pos[i_l], l_quat[i_l], ipbw, iq);
+    i_pos[i_l] = ipbw;  // holds i_pos_bw until the root COM is known
+    i_quat[i_l] = iq;
+    mass_sum = mass_sum + mass;
+    root_com_bw = root_com_bw + mass * ipbw;
+  }
+  V3 rc = root_com_bw / mass_sum;
+  for (int i_l = en.link_start; i_l < en.link_end; ++i_l) root_com[i_l] = rc;
+  auto cinr_inertial = e.cinr_inertial(); auto cinr_pos = e.cinr_pos(); auto cinr_mass = e.cinr_mass();
+  for (int i_l = en.link_start; i_l < en.link_end; ++i_l) {
+    const Link& L = m.links[i_l];
+    V3 ip = (V3)i_pos[i_l] - rc;
+    i_pos[i_l] = ip;
+    float i_mass = L.mass + mass_shift[i_l];
+    M3 oI; V3 op;
+    transform_inertia_by_trans_quat(L.inertial_i, i_mass, ip, i_quat[i_l], m.eps, oI, op);
+    cinr_inertial[i_l] = oI; cinr_pos[i_l] = op; cinr_mass[i_l] = i_mass;
+  }
+  auto xanchor = e.xanchor(); auto xaxis = e.xaxis(); auto cdof_ang = e.cdof_ang(); auto cdof_vel = e.cdof_vel();
+  for (int i_l = en.link_start; i_l < en.link_end; ++i_l) {
+    const Link& L = m.links[i_l];
+    if (L.n_dofs == 0) continue;
+    for (int i_j = L.joint_start; i_j < L.joint_end; ++i_j) {
+      const Joint& J = m.joints[i_j];
+      V3 offset_pos = rc - (V3)xanchor[i_j];
+      int ds = J.dof_start;
+      if (J.type == JOINT_REVOLUTE) {
+        V3 ax = xaxis[i_j];
+        cdof_ang[ds] = ax;
+        cdof_vel[ds] = cross(ax, offset_pos);
+      } else if (J.type == JOINT_FREE) {
+        for (int i = 0; i < 3; ++i) {
+          cdof_ang[i + ds] = v3(0, 0, 0);
+          V3 cv = v3(0, 0, 0);
+          vset(cv, i, 1.0f);
+          cdof_vel[i + ds] = cv;
+        }
+        M3 xmat_T = transpose(quat_to_R(l_quat[i_l], m.eps));
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          V3 row = v3(xmat_T.m[i][0], xmat_T.m[i][1], xmat_T.m[i][2]);
+          cdof_ang[i + ds + 3] = row;
+          cdof_vel[i + ds + 3] = cross(row, offset_pos);
+        }
+      }
+    }
+  }
+}
+
+// func_update_geoms_entity, forward_kinematics.py:709-744
+DEV void update_geoms_entity(const Model& m, const E& e, int i_e, bool force_update_fixed) {
+  const Entity& en = m.entities[i_e];
+  auto l_pos = e.l_pos(); auto l_quat = e.l_quat(); auto g_pos = e.g_pos(); auto g_quat = e.g_quat();
+  for (int i_g = en.geom_start; i_g < en.geom_end; ++i_g) {
+    const Geom& G = m.geoms[i_g];
+    bool is_fixed = m.links[G.link].is_fixed;
+    if (force_update_fixed || !is_fixed) {
+      V3 p; Q4 q;
+      transform_pos_quat_by_trans_quat(G.pos, G.quat, l_pos[G.link], l_quat[G.link], p, q);
+      g_pos[i_g] = p; g_quat[i_g] = q;
+    }
+  }
+}
+
+// func_forward_velocity_entity, forward_kinematics.py:871-994
+DEV void forward_velocity_entity(const Model& m, const E& e, int i_e) {
+  const Entity& en = m.entities[i_e];
+  auto cd_vel = e.cd_vel(); auto cd_ang = e.cd_ang(); auto cdof_ang = e.cdof_ang(); auto cdof_vel = e.cdof_vel(); auto cdofd_ang = e.cdofd_ang();
+  auto cdofd_vel = e.cdofd_vel(); auto vel = e.vel();
+  for (int i_l = en.link_start; i_l < en.link_end; ++i_l) {
+    const Link& L = m.links[i_l];
+    V3 cvel_vel = v3(0, 0, 0), cvel_ang = v3(0, 0, 0);
+    if (L.parent != -1) { cvel_vel = cd_vel[L.parent]; cvel_ang = cd_ang[L.parent]; }
+    for (int i_j = L.joint_start; i_j < L.joint_end; ++i_j) {
+      const Joint& J = m.joints[i_j];
+      int ds = J.dof_start;
+      if (J.type == JOINT_FREE) {
+        for (int i = 0; i < 3; ++i) {
+          float v = vel[ds + i];
+          cvel_vel = cvel_vel + (V3)cdof_vel[ds + i] * v;
+          cvel_ang = cvel_ang + (V3)cdof_ang[ds + i] * v;
+        }
+        for (int i = 0; i < 3; ++i) {
+          cdofd_ang[ds + i] = v3(0, 0, 0); cdofd_vel[ds + i] = v3(0, 0, 0);
+          V3 oa, ov;
+          motion_cross_motion(cvel_ang, cvel_vel, cdof_ang[ds + i + 3], cdof_vel[ds + i + 3], oa, ov);
+          cdofd_ang[ds + i + 3] = oa; cdofd_vel[ds + i + 3] = ov;
+        }
+        for (int i = 0; i < 3; ++i) {
+          float v = vel[ds + i + 3];
+          cvel_vel = cvel_vel + (V3)cdof_vel[ds + i + 3] * v;
+          cvel_ang = cvel_ang + (V3)cdof_ang[ds + i + 3] * v;
+        }
+      } else {
+        for (int i_d = ds; i_d < J.dof_end; ++i_d) {
+          V3 oa, ov;
+          motion_cross_motion(cvel_ang, cvel_vel, cdof_ang[i_d], cdof_vel[i_d], oa, ov);
+          cdofd_ang[i_d] = oa; cdofd_vel[i_d] = ov;
+        }
+        for (int i_d = ds; i_d < J.dof_end; ++i_d) {
+          float v = vel[i_d];
+          cvel_vel = cvel_vel + (V3)cdof_vel[i_d] * v;
+          cvel_ang = cvel_ang + (V3)cdof_ang[i_d] * v;
+        }
+      }
+    }
+    cd_vel[i_l] = cvel_vel; cd_ang[i_l] = cvel_ang;
+  }
+}
+
+DEV void update_cartesian_space(const Model& m, const E& e, bool force_update_fixed) {
+  for (int i_e = 0; i_e < 2; ++i_e) {
+    forward_kinematics_entity(m, e, i_e);
+    com_links_entity(m, e, i_e);
+    update_geoms_entity(m, e, i_e, force_update_fixed);
+  }
+}
+DEV void forward_velocity(const Model& m, const E& e) {
+  for (int i_e = 0; i_e < 2; ++i_e) forward_velocity_entity(m, e, i_e);
+}
+
+// ---------------------------------------------------------------------------------------------
+// forward dynamics  (R/abd/forward_dynamics.py)
+// ---------------------------------------------------------------------------------------------
+// func_compute_mass_matrix, forward_dynamics.py:291-541
+DEV void compute_mass_matrix(const Model& m, const E& e, bool implicit_damping) {
+  auto crb_inertial = e.crb_inertial(); auto crb_pos = e.crb_pos(); auto crb_mass = e.crb_mass();
+  auto cinr_inertial = e.cinr_inertial(); auto cinr_pos = e.cinr_pos(); auto cinr_mass = e.cinr_mass();
+  for (int i_l = 0; i_l < NL; ++i_l) { crb_inertial[i_l] = cinr_inertial[i_l]; crb_pos[i_l] = cinr_pos[i_l]; crb_mass[i_l] = cinr_mass[i_l]; }
+  for (int i_e = 0; i_e < 2; ++i_e) {
+    const Entity& en = m.entities[i_e];
+    int n = en.link_end - en.link_start;
+    for (int i = 0; i < n; ++i) {
+      int i_l = en.link_end - 1 - i, i_p = m.links[i_l].parent;
+      if (i_p != -1) {
+        M3 a = crb_inertial[i_p], b2 = crb_inertial[i_l];
+        crb_inertial[i_p] = a + b2;
+        crb_mass[i_p] = crb_mass[i_p] + crb_mass[i_l];
+        crb_pos[i_p] = (V3)crb_pos[i_p] + (V3)crb_pos[i_l];
+      }
+    }
+  }
+  auto cdof_ang = e.cdof_ang(); auto cdof_vel = e.cdof_vel(); auto f_ang = e.f_ang(); auto f_vel = e.f_vel(); auto mass_mat = e.mass_mat();
+  for (int i_l = 0; i_l < NL; ++i_l) {
+    const Link& L = m.links[i_l];
+    if (L.dof_start == L.dof_end) continue;
+    M3 I = crb_inertial[i_l]; V3 cp = crb_pos[i_l]; float cm = crb_mass[i_l];
+    for (int i_d = L.dof_start; i_d < L.dof_end; ++i_d) {
+      V3 oa, ov;
+      inertial_mul(cp, I, cm, cdof_vel[i_d], cdof_ang[i_d], oa, ov);
+      f_ang[i_d] = oa; f_vel[i_d] = ov;
+    }
+  }
+  for (int i_e = 0; i_e < 2; ++i_e) {
+    const Entity& en = m.entities[i_e];
+    for (int i_d = en.dof_start; i_d < en.dof_end; ++i_d) {
+      V3 fa = f_ang[i_d], fv = f_vel[i_d];
+      auto row = mass_mat[i_d];
+      for (int j_d = en.dof_start; j_d < en.dof_end; ++j_d)
+        row[j_d] = (dot(fa, cdof_ang[j_d]) + dot(fv, cdof_vel[j_d])) * m.mass_parent_mask[i_d][j_d];
+    }
+    for (int i_d = en.dof_start; i_d < en.dof_end; ++i_d)
+      for (int j_d = i_d + 1; j_d < en.dof_end; ++j_d) mass_mat[i_d][j_d] = mass_mat[j_d][i_d];
+  }
+  auto ctrl_mode = e.ctrl_mode();
+  for (int i_d = 0; i_d < ND; ++i_d) {
+    float v = mass_mat[i_d][i_d] + m.dofs[i_d].armature;
+    if (implicit_damping) {
+      v = v + m.dofs[i_d].damping * m.substep_dt;
+      int cm = ctrl_mode[i_d];
+      if (cm == CTRL_POSITION || cm == CTRL_VELOCITY) v = v + m.dofs[i_d].kv * m.substep_dt;
+    }
+    mass_mat[i_d][i_d] = v;
+  }
+}
+
+// func_factor_mass (serial branch), forward_dynamics.py:560-604
+DEV void factor_mass(const Model& m, const E& e) {
+  auto mass_mat = e.mass_mat(); auto mass_L = e.mass_L(); auto mass_Dinv = e.mass_Dinv();
+  for (int i_e = 0; i_e < 2; ++i_e) {
+    const Entity& en = m.entities[i_e];
+    int ds = en.dof_start, de = en.dof_end, n = de - ds;
+    for (int i_d = ds; i_d < de; ++i_d)
+      for (int j_d = ds; j_d < i_d + 1; ++j_d) mass_L[i_d][j_d] = mass_mat[i_d][j_d];
+    for (int i_d_ = 0; i_d_ < n; ++i_d_) {
+      int i_d = de - i_d_ - 1;
+      float D_inv = 1.0f / mass_L[i_d][i_d];
+      mass_Dinv[i_d] = D_inv;
+      for (int j_d_ = 0; j_d_ < i_d - ds; ++j_d_) {
+        int j_d = i_d - j_d_ - 1;
+        float a = mass_L[i_d][j_d] * D_inv;
+        for (int k_d = ds; k_d < j_d + 1; ++k_d) mass_L[j_d][k_d] -= a * mass_L[i_d][k_d];
+        mass_L[i_d][j_d] = a;
+      }
+      mass_L[i_d][i_d] = 1.0f;
+    }
+  }
+}
+
+// func_solve_mass_entity, forward_dynamics.py:818-900
+DEV void solve_mass(const Model& m, const E& e, Arr<float> vec, Arr<float> out) {
+  auto mass_L = e.mass_L(); auto mass_Dinv = e.mass_Dinv();
+  for (int i_e = 0; i_e < 2; ++i_e) {
+    const Entity& en = m.entities[i_e];
+    int ds = en.dof_start, de = en.dof_end, n = de - ds;
+    for (int i_d_ = 0; i_d_ < n; ++i_d_) {
+      int i_d = de - i_d_ - 1;
+      float cur = vec[i_d];
+      for (int j_d = i_d + 1; j_d < de; ++j_d) cur = cur - mass_L[j_d][i_d] * out[j_d];
+      out[i_d] = cur;
+    }
+    for (int i_d = ds; i_d < de; ++i_d) out[i_d] = out[i_d] * mass_Dinv[i_d];
+    for (int i_d = ds; i_d < de; ++i_d) {
+      float cur = out[i_d];
+      for (int j_d = ds; j_d < i_d; ++j_d) cur = cur - mass_L[i_d][j_d] * out[j_d];
+      out[i_d] = cur;
+    }
+  }
+}
+
+// func_torque_and_passive_force, forward_dynamics.py:961-1174
+DEV void torque_and_passive_force(const Model& m, const E& e) {
+  auto ctrl_mode = e.ctrl_mode(); auto ctrl_force = e.ctrl_force(); auto ctrl_pos = e.ctrl_pos(); auto ctrl_vel = e.ctrl_vel(); auto vel = e.vel();
+  auto dof_pos = e.dof_pos(); auto qf_applied = e.qf_applied(); auto qf_passive = e.qf_passive();
+  for (int i_l = 0; i_l < NL; ++i_l) {
+    const Link& L = m.links[i_l];
+    if (L.n_dofs == 0) continue;
+    int joint_type = m.joints[L.joint_start].type;
+    for (int i_d = L.dof_start; i_d < L.dof_end; ++i_d) {
+      const Dof& D = m.dofs[i_d];
+      float force = 0.0f;
+      int cm = ctrl_mode[i_d];
+      if (cm == CTRL_FORCE) force = ctrl_force[i_d];
+      else if (cm == CTRL_VELOCITY) force = D.kv * (ctrl_vel[i_d] - vel[i_d]);
+      else if (cm == CTRL_POSITION && !(joint_type == JOINT_FREE && i_d >= L.dof_start + 3))
+        force = D.kp * (ctrl_pos[i_d] - dof_pos[i_d]) + D.kv * (ctrl_vel[i_d] - vel[i_d]);
+      qf_applied[i_d] = clampf(force, D.force_range[0], D.force_range[1]);
+    }
+  }
+  for (int i_d = 0; i_d < ND; ++i_d) qf_passive[i_d] = -m.dofs[i_d].damping * vel[i_d];
+  for (int i_l = 0; i_l < NL; ++i_l) {
+    const Link& L = m.links[i_l];
+    if (L.n_dofs == 0) continue;
+    int joint_type = m.joints[L.joint_start].type;
+    if (joint_type != JOINT_FREE && joint_type != JOINT_FIXED)
+      for (int j_d = L.dof_start; j_d < L.dof_end; ++j_d) qf_passive[j_d] = qf_passive[j_d] + (-dof_pos[j_d] * m.dofs[j_d].stiffness);
+  }
+}
+
+// func_update_acc(update_cacc=False) + func_update_force + func_bias_force, forward_dynamics.py:1177-1478
+DEV void bias_forces(const Model& m, const E& e) {
+  auto cdd_vel = e.cdd_vel(); auto cdd_ang = e.cdd_ang(); auto cdofd_vel = e.cdofd_vel(); auto cdofd_ang = e.cdofd_ang(); auto vel = e.vel();
+  for (int i_e = 0; i_e < 2; ++i_e) {
+    const Entity& en = m.entities[i_e];
+    for (int i_l = en.link_start; i_l < en.link_end; ++i_l) {
+      const Link& L = m.links[i_l];
+      V3 cv, ca;
+      if (L.parent == -1) { cv = -m.gravity * (1.0f - 0.0f); ca = v3(0, 0, 0); }
+      else { cv = cdd_vel[L.parent]; ca = cdd_ang[L.parent]; }
+      for (int i_d = L.dof_start; i_d < L.dof_end; ++i_d) {
+        float v = vel[i_d];
+        V3 local_cdd_vel = (V3)cdofd_vel[i_d] * v;
+        V3 local_cdd_ang = (V3)cdofd_ang[i_d] * v;
+        cv = cv + local_cdd_vel;
+        ca = ca + local_cdd_ang;
+      }
+      cdd_vel[i_l] = cv; cdd_ang[i_l] = ca;
+    }
+  }
+  auto cinr_inertial = e.cinr_inertial(); auto cinr_pos = e.cinr_pos(); auto cinr_mass = e.cinr_mass(); auto cd_vel = e.cd_vel(); auto cd_ang = e.cd_ang();
+  auto cfrc_vel = e.cfrc_vel(); auto cfrc_ang = e.cfrc_ang(); auto ext = e.ext();
+  for (int i_l = 0; i_l < NL; ++i_l) {
+    V3 f1_ang, f1_vel, f2_ang, f2_vel, f3_ang, f3_vel;
+    M3 I = cinr_inertial[i_l]; V3 cp = cinr_pos[i_l]; float cm = cinr_mass[i_l];
+    V3 cdv = cd_vel[i_l], cda = cd_ang[i_l];
+    inertial_mul(cp, I, cm, cdd_vel[i_l], cdd_ang[i_l], f1_ang, f1_vel);
+    inertial_mul(cp, I, cm, cdv, cda, f2_ang, f2_vel);
+    motion_cross_force(cda, cdv, f2_ang, f2_vel, f3_ang, f3_vel);
+    V3 ext_ang = v3(ext[6 * i_l + 0], ext[6 * i_l + 1], ext[6 * i_l + 2]), ext_vel = v3(ext[6 * i_l + 3], ext[6 * i_l + 4], ext[6 * i_l + 5]);
+    cfrc_vel[i_l] = f1_vel + f3_vel + ext_vel + v3(0, 0, 0);
+    cfrc_ang[i_l] = f1_ang + f3_ang + ext_ang + v3(0, 0, 0);
+  }
+  for (int i_e = 0; i_e < 2; ++i_e) {
+    const Entity& en = m.entities[i_e];
+    int n = en.link_end - en.link_start;
+    for (int i = 0; i < n; ++i) {
+      int i_l = en.link_end - 1 - i, i_p = m.links[i_l].parent;
+      if (i_p != -1) {
+        cfrc_vel[i_p] = (V3)cfrc_vel[i_p] + (V3)cfrc_vel[i_l];
+        cfrc_ang[i_p] = (V3)cfrc_ang[i_p] + (V3)cfrc_ang[i_l];
+      }
+    }
+  }
+  auto cdof_ang = e.cdof_ang(); auto cdof_vel = e.cdof_vel(); auto qf_passive = e.qf_passive(); auto qf_applied = e.qf_applied();
+  auto force = e.force(); auto qf_smooth = e.qf_smooth();
+  for (int i_l = 0; i_l < NL; ++i_l) {
+    const Link& L = m.links[i_l];
+    if (L.dof_start == L.dof_end) continue;
+    V3 fa = cfrc_ang[i_l], fv = cfrc_vel[i_l];
+    for (int i_d = L.dof_start; i_d < L.dof_end; ++i_d) {
+      float qf_bias = dot(cdof_ang[i_d], fa) + dot(cdof_vel[i_d], fv);
+      float f = qf_passive[i_d] - qf_bias + qf_applied[i_d];
+      force[i_d] = f; qf_smooth[i_d] = f;
+    }
+  }
+}
+
+// kernel_step_1 without the (already fresh) FK, rigid_solver.py:3008-3069
+__global__ __launch_bounds__(WG) void k_dynamics(Pool P, const Model* __restrict__ mp) {
+  int b = blockIdx.x * WG + threadIdx.x;
+  if (b >= P.B) return;
+  const Model& m = *mp;
+  E e(P, b);
+  compute_mass_matrix(m, e, true);
+  factor_mass(m, e);
+  torque_and_passive_force(m, e);
+  bias_forces(m, e);
+  solve_mass(m, e, e.force(), e.acc_smooth());
+  auto acc = e.acc(); auto acc_smooth = e.acc_smooth();
+  for (int i_d = 0; i_d < ND; ++i_d) acc[i_d] = acc_smooth[i_d];
+}
+
+__global__ __launch_bounds__(WG) void k_fk(Pool P, const Model* __restrict__ mp, int force_update_fixed) {
+  int b = blockIdx.x * WG + threadIdx.x;
+  if (b >= P.B) return;
+  const Model& m = *mp;
+  E e(P, b);
+  update_cartesian_space(m, e, force_update_fixed != 0);
+  forward_velocity(m, e);
+}
+
+// ---------------------------------------------------------------------------------------------
+// collision detection  (R/collider/*.py)
+// ---------------------------------------------------------------------------------------------
+// kernel_update_geom_aabbs, forward_kinematics.py:1171-1193
+DEV void update_geom_aabbs(const Model& m, const E& e) {
+  const float inf = dm_bits2f(0x7f800000u);
+  auto g_pos = e.g_pos(); auto g_quat = e.g_quat(); auto aabb_min = e.aabb_min(); auto aabb_max = e.aabb_max();
+  for (int i_g = 0; i_g < NG; ++i_g) {
+    V3 lower = v3(inf, inf, inf), upper = v3(-inf, -inf, -inf);
+    V3 gp = g_pos[i_g]; Q4 gq = g_quat[i_g];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      V3 corner = transform_by_trans_quat(m.geoms[i_g].aabb[c], gp, gq);
+      lower = vmin(lower, corner); upper = vmax(upper, corner);
+    }
+    aabb_min[i_g] = lower; aabb_max[i_g] = upper;
+  }
+}
+
+// func_is_geom_aabbs_overlap, collider/utils.py:102-107
+DEV bool aabbs_overlap(const E& e, int a, int b) {
+  V3 amax = e.aabb_max()[a], amin = e.aabb_min()[a], bmax = e.aabb_max()[b], bmin = e.aabb_min()[b];
+  bool any1 = (amax.x <= bmin.x) || (amax.y <= bmin.y) || (amax.z <= bmin.z);
+  bool any2 = (amin.x >= bmax.x) || (amin.y >= bmax.y) || (amin.z >= bmax.z);
+  return !(any1 || any2);
+}
+
+// func_collision_clear + func_broad_phase, collider/broadphase.py:73-138,141-396
+DEV void broad_phase(const Model& m, const E& e) {
+  auto n_contacts = e.n_contacts(); auto c_geom = e.c_geom(); auto c_link = e.c_link(); auto c_pen = e.c_pen(); auto c_pos = e.c_pos();
+  auto c_normal = e.c_normal(); auto c_force = e.c_force();
+  int nc = n_contacts[0];
+  for (int i_c = 0; i_c < nc; ++i_c) {
+    c_link[i_c] = -1; c_link[MAXC + i_c] = -1; c_geom[i_c] = -1; c_geom[MAXC + i_c] = -1;
+    c_pen[i_c] = 0.0f; c_pos[i_c] = v3(0, 0, 0); c_normal[i_c] = v3(0, 0, 0); c_force[i_c] = v3(0, 0, 0);
+  }
+  n_contacts[0] = 0;
+  auto sort_value = e.sort_value(); auto sort_ig = e.sort_ig(); auto aabb_min = e.aabb_min(); auto aabb_max = e.aabb_max();
+  const int n2 = 2 * NG;
+  if (e.first_time()[0]) {
+    int i_buffer = 0;
+    for (int i_l = 0; i_l < NL; ++i_l)
+      for (int i_g = m.links[i_l].geom_start; i_g < m.links[i_l].geom_end; ++i_g) {
+        V3 lo = aabb_min[i_g], hi = aabb_max[i_g];
+        sort_value[2 * i_buffer] = lo.x; sort_ig[2 * i_buffer] = i_g;
+        sort_value[2 * i_buffer + 1] = hi.x; sort_ig[2 * i_buffer + 1] = i_g | 0x100;
+        i_buffer++;
+      }
+    e.first_time()[0] = 0;
+  } else {
+    for (int i = 0; i < n2; ++i) {
+      int s = sort_ig[i];
+      V3 v = (s & 0x100) ? (V3)aabb_max[s & 0xff] : (V3)aabb_min[s & 0xff];
+      sort_value[i] = v.x;
+    }
+  }
+  for (int i = 1; i < n2; ++i) {
+    float key_value = sort_value[i]; int key_s = sort_ig[i];
+    int j = i - 1;
+    while (j >= 0 && key_value < sort_value[j]) {
+      sort_value[j + 1] = sort_value[j]; sort_ig[j + 1] = sort_ig[j];
+      j -= 1;
+    }
+    sort_value[j + 1] = key_value; sort_ig[j + 1] = key_s;
+  }
+  auto active_buf = e.active_buf(); auto broad = e.broad(); auto normal_cache = e.normal_cache();
+  int n_broad = 0, n_active = 0;
+  for (int i = 0; i < n2; ++i) {
+    int s = sort_ig[i];
+    if (!(s & 0x100)) {
+      for (int j = 0; j < n_active; ++j) {
+        int i_ga = active_buf[j], i_gb = s;
+        if (i_ga > i_gb) { int t = i_ga; i_ga = i_gb; i_gb = t; }
+        int pidx = m.pair_idx[i_ga][i_gb];
+        if (pidx == -1) continue;
+        if (!aabbs_overlap(e, i_ga, i_gb)) { normal_cache[pidx] = v3(0, 0, 0); continue; }
+        if (n_broad == m.max_broad_pairs) { e.err()[0] |= GO2SIM_ERR_OVERFLOW_CANDIDATE_CONTACTS; break; }
+        broad[2 * n_broad] = i_ga; broad[2 * n_broad + 1] = i_gb;
+        n_broad++;
+      }
+      active_buf[n_active] = s;
+      n_active++;
+    } else {
+      int rm = s & 0xff;
+      for (int j = 0; j < n_active; ++j)
+        if (active_buf[j] == rm) {
+          if (j < n_active - 1)
+            for (int k = j; k < n_active - 1; ++k) active_buf[k] = active_buf[k + 1];
+          n_active--;
+          break;
+        }
+    }
+  }
+  e.n_broad()[0] = n_broad;
+}
+
+// ---- support functions, collider/support_field.py ---------------------------------------------
+DEV int wrap180(float x) {
+  if (!(x >= 0.0f)) return 0;
+  int i = (x >= 180.0f) ? (int)(x - 180.0f) : (int)x;
+  return (i > 179) ? 179 : i;
+}
+DEV int clampidx(float x) {
+  if (!(x >= 0.0f)) return 0;
+  return (x >= 179.0f) ? 179 : (int)x;
+}
+// _func_support_mesh for a cylinder (support_field.py:138-180); the 180x180 direction-grid table is
+// reproduced analytically: vertex set = 32-gon ring x {+h/2,-h/2} (tools/compile_go2_model.py)
+DEV V3 support_cylinder_local(const Model& m, const Geom& G, V3 d_mesh) {
+  const float PI = 3.14159265358979323846f;
+  float theta = dm_atan2(d_mesh.y, d_mesh.x);
+  float phi = dm_acos(d_mesh.z);
+  const float support_res = 180.0f;
+  float ii = (theta + PI) / PI / 2.0f * support_res;
+  float jj = phi / PI * support_res;
+  float dot_max = -1e20f;
+  V3 v = v3(0, 0, 0);
+  float half = 0.5f * G.data[1];
+  for (int i4 = 0; i4 < 4; ++i4) {
+    int i, j;
+    if (i4 % 2) i = wrap180(dm_ceil(ii)); else i = wrap180(dm_floor(ii));
+    if (i4 / 2 > 0) { j = clampidx(dm_ceil(jj)); if (j == 179) j = 178; }
+    else { j = clampidx(dm_floor(jj)); if (j == 0) j = 1; }
+    int k = m.theta_to_ring[i];
+    V3 pos = v3(G.rim[k][0], G.rim[k][1], (j <= 90) ? half : -half);
+    float d = dot(pos, d_mesh);
+    if (d > dot_max) { v = pos; dot_max = d; }
+  }
+  return v;
+}
+// support_driver, collider/mpr.py:146-176
+DEV V3 support_driver(const Model& m, V3 direction, int i_g, V3 pos, Q4 quat) {
+  const Geom& G = m.geoms[i_g];
+  if (G.type == GEOM_SPHERE) {
+    return pos + direction * G.data[0];
+  } else if (G.type == GEOM_BOX) {
+    V3 d_box = inv_transform_by_quat(direction, quat);
+    V3 v_ = v3((d_box.x < 0.0f ? -1.0f : 1.0f) * G.data[0] * 0.5f, (d_box.y < 0.0f ? -1.0f : 1.0f) * G.data[1] * 0.5f,
+               (d_box.z < 0.0f ? -1.0f : 1.0f) * G.data[2] * 0.5f);
+    return transform_by_trans_quat(v_, pos, quat);
+  } else {
+    V3 d_mesh = transform_by_quat(direction, inv_quat(quat));
+    V3 v_ = support_cylinder_local(m, G, d_mesh);
+    return transform_by_trans_quat(v_, pos, quat);
+  }
+}
+struct Pair { int i_ga, i_gb; V3 pos_a; Q4 quat_a; V3 pos_b; Q4 quat_b; };
+// compute_support, collider/mpr.py:179-202
+DEVN void compute_support(const Model& m, V3 direction, const Pair& pr, V3& v, V3& v1, V3& v2) {
+  v1 = support_driver(m, direction, pr.i_ga, pr.pos_a, pr.quat_a);
+  v2 = support_driver(m, -direction, pr.i_gb, pr.pos_b, pr.quat_b);
+  v = v1 - v2;
+}
+
+// ---- MPR, collider/mpr.py: the 4-vertex portal simplex lives in registers -----------------------
+struct Simplex { V3 v[4], v1[4], v2[4]; };
+DEV V3 mpr_portal_dir(const Simplex& s) { return normalized(cross(s.v[2] - s.v[1], s.v[3] - s.v[1])); }
+DEV bool mpr_portal_reach_tolerance(const Model& m, const Simplex& s, V3 v, V3 direction) {
+  float dv1 = dot(s.v[1], direction), dv2 = dot(s.v[2], direction), dv3 = dot(s.v[3], direction), dv4 = dot(v, direction);
+  float dot1 = fmn(fmn(dv4 - dv1, dv4 - dv2), dv4 - dv3);
+  return dot1 < m.ccd_tolerance + m.ccd_eps * fmx(1.0f, dot1);
+}
+DEV void simplex_set(Simplex& s, int i, V3 v, V3 v1, V3 v2) {
+  // static indexing keeps the simplex in VGPRs
+  if (i == 1) { s.v[1] = v; s.v1[1] = v1; s.v2[1] = v2; }
+  else if (i == 2) { s.v[2] = v; s.v1[2] = v1; s.v2[2] = v2; }
+  else { s.v[3] = v; s.v1[3] = v1; s.v2[3] = v2; }
+}
+DEV void mpr_expand_portal(Simplex& s, V3 v, V3 v1, V3 v2) {
+  V3 v4v0 = cross(v, s.v[0]);
+  float d = dot(s.v[1], v4v0);
+  int i_s;
+  if (d > 0) { d = dot(s.v[2], v4v0); i_s = (d > 0) ? 1 : 3; }
+  else { d = dot(s.v[3], v4v0); i_s = (d > 0) ? 2 : 1; }
+  simplex_set(s, i_s, v, v1, v2);
+}
+// mpr_discover_portal, mpr.py:445-598
+DEV int mpr_discover_portal(const Model& m, Simplex& s, const Pair& pr, V3 center_a, V3 center_b) {
+  const float EPSC = m.ccd_eps;
+  s.v1[0] = center_a; s.v2[0] = center_b; s.v[0] = center_a - center_b;
+  int simplex_size = 1;
+  if (dm_abs(s.v[0].x) < EPSC && dm_abs(s.v[0].y) < EPSC && dm_abs(s.v[0].z) < EPSC) s.v[0].x += 10.0f * EPSC;
+  V3 direction = -normalized(s.v[0]);
+  V3 v, v1, v2;
+  compute_support(m, direction, pr, v, v1, v2);
+  s.v1[1] = v1; s.v2[1] = v2; s.v[1] = v;
+  simplex_size = 2;
+  float d = dot(v, direction);
+  int ret = 0;
+  if (d < EPSC) {
+    ret = -1;
+  } else {
+    direction = cross(s.v[0], s.v[1]);
+    if (dot(direction, direction) < EPSC) {
+      if (dm_abs(s.v[1].x) < EPSC && dm_abs(s.v[1].y) < EPSC && dm_abs(s.v[1].z) < EPSC) ret = 1; else ret = 2;
+    } else {
+      direction = normalized(direction);
+      compute_support(m, direction, pr, v, v1, v2);
+      d = dot(v, direction);
+      if (d < EPSC) {
+        ret = -1;
+      } else {
+        s.v1[2] = v1; s.v2[2] = v2; s.v[2] = v;
+        simplex_size = 3;
+        V3 va = s.v[1] - s.v[0], vb = s.v[2] - s.v[0];
+        direction = normalized(cross(va, vb));
+        d = dot(direction, s.v[0]);
+        if (d > 0) {
+          V3 t;
+          t = s.v[1]; s.v[1] = s.v[2]; s.v[2] = t; t = s.v1[1]; s.v1[1] = s.v1[2]; s.v1[2] = t; t = s.v2[1]; s.v2[1] = s.v2[2]; s.v2[2] = t;
+          direction = -direction;
+        }
+        int num_trials = 0;
+        while (simplex_size < 4) {
+          compute_support(m, direction, pr, v, v1, v2);
+          d = dot(v, direction);
+          if (d < EPSC) { ret = -1; break; }
+          bool cont = false;
+          va = cross(s.v[1], v);
+          d = dot(va, s.v[0]);
+          if (d < -EPSC) { s.v1[2] = v1; s.v2[2] = v2; s.v[2] = v; cont = true; }
+          if (!cont) {
+            va = cross(v, s.v[2]);
+            d = dot(va, s.v[0]);
+            if (d < -EPSC) { s.v1[1] = v1; s.v2[1] = v2; s.v[1] = v; cont = true; }
+          }
+          if (cont) {
+            va = s.v[1] - s.v[0]; vb = s.v[2] - s.v[0];
+            direction = normalized(cross(va, vb));
+            num_trials++;
+            if (num_trials == 15) { ret = -1; break; }
+          } else {
+            s.v1[3] = v1; s.v2[3] = v2; s.v[3] = v;
+            simplex_size = 4;
+          }
+        }
+      }
+    }
+  }
+  return ret;
+}
+// mpr_refine_portal, mpr.py:232-278
+DEV int mpr_refine_portal(const Model& m, Simplex& s, const Pair& pr) {
+  int ret = 1;
+  while (true) {
+    V3 direction = mpr_portal_dir(s);
+    if (dot(s.v[1], direction) > -m.ccd_eps) { ret = 0; break; }
+    V3 v, v1, v2;
+    compute_support(m, direction, pr, v, v1, v2);
+    if (!(dot(v, direction) > -m.ccd_eps) || mpr_portal_reach_tolerance(m, s, v, direction)) { ret = -1; break; }
+    mpr_expand_portal(s, v, v1, v2);
+  }
+  return ret;
+}
+// mpr_find_pos (non-mujoco branch), mpr.py:281-316
+DEV V3 mpr_find_pos(const Model& m, const Simplex& s) {
+  float b0 = 0.0f, b1 = 0.0f, b2 = 0.0f, b3 = 0.0f;
+  float sum_ = ((b0 + b1) + b2) + b3;
+  if (sum_ < m.ccd_eps) {
+    V3 direction = mpr_portal_dir(s);
+    b0 = 0.0f;
+    b1 = dot(cross(s.v[2], s.v[3]), direction);   // i=1: i1=2, i2=3
+    b2 = dot(cross(s.v[3], s.v[1]), direction);   // i=2: i1=3, i2=1
+    b3 = dot(cross(s.v[1], s.v[2]), direction);   // i=3: i1=1, i2=2
+    sum_ = ((b0 + b1) + b2) + b3;
+  }
+  V3 p1 = v3(0, 0, 0), p2 = v3(0, 0, 0);
+  p1 = p1 + b0 * s.v1[0]; p2 = p2 + b0 * s.v2[0];
+  p1 = p1 + b1 * s.v1[1]; p2 = p2 + b1 * s.v2[1];
+  p1 = p1 + b2 * s.v1[2]; p2 = p2 + b2 * s.v2[2];
+  p1 = p1 + b3 * s.v1[3]; p2 = p2 + b3 * s.v2[3];
+  return (0.5f / sum_) * (p1 + p2);
+}
+// mpr_find_penetration, mpr.py:338-423
+DEV void mpr_find_penetration(const Model& m, Simplex& s, const Pair& pr, bool& is_col, V3& normal, float& penetration, V3& pos) {
+  int iterations = 0;
+  while (true) {
+    V3 direction = mpr_portal_dir(s);
+    V3 v, v1, v2;
+    compute_support(m, direction, pr, v, v1, v2);
+    if (mpr_portal_reach_tolerance(m, s, v, direction) || iterations > m.ccd_iterations) {
+      penetration = dot(direction, s.v[1]);
+      normal = -direction;
+      is_col = true;
+      pos = mpr_find_pos(m, s);
+      break;
+    }
+    mpr_expand_portal(s, v, v1, v2);
+    iterations++;
+  }
+}
+// guess_geoms_center, mpr.py:601-683
+DEV void guess_geoms_center(const Model& m, const Pair& pr, V3 normal_ws, V3& center_a, V3& center_b) {
+  const Geom& A = m.geoms[pr.i_ga]; const Geom& Bg = m.geoms[pr.i_gb];
+  center_a = transform_by_trans_quat(A.center, pr.pos_a, pr.quat_a);
+  center_b = transform_by_trans_quat(Bg.center, pr.pos_b, pr.quat_b);
+  if (dm_abs(normal_ws.x) > m.ccd_eps || dm_abs(normal_ws.y) > m.ccd_eps || dm_abs(normal_ws.z) > m.ccd_eps) {
+    V3 center_a_local = 0.5f * (A.aabb[7] + A.aabb[0]);
+    center_a = transform_by_trans_quat(center_a_local, pr.pos_a, pr.quat_a);
+    V3 center_b_local = 0.5f * (Bg.aabb[7] + Bg.aabb[0]);
+    center_b = transform_by_trans_quat(center_b_local, pr.pos_b, pr.quat_b);
+    V3 delta = center_a - center_b;
+    V3 normal = normalized(delta);
+    if (norm(cross(normal_ws, normal)) > 0.01f) {
+      V3 offset = dot(delta, normal_ws) * normal_ws - delta;
+      float offset_norm = norm(offset);
+      if (offset_norm > m.eps) {
+        V3 dir_offset = offset / offset_norm;
+        V3 dla = inv_transform_by_quat(dir_offset, pr.quat_a), dlb = inv_transform_by_quat(dir_offset, pr.quat_b);
+        V3 box_size_a = A.aabb[7] - A.aabb[0], box_size_b = Bg.aabb[7] - Bg.aabb[0];
+        float length_a = dot(box_size_a, v3(dm_abs(dla.x), dm_abs(dla.y), dm_abs(dla.z)));
+        float length_b = dot(box_size_b, v3(dm_abs(dlb.x), dm_abs(dlb.y), dm_abs(dlb.z)));
+        float offset_ratio = fmn(offset_norm / (length_a + length_b), 0.5f);
+        center_a = center_a + dir_offset * length_a * offset_ratio;
+        center_b = center_b - dir_offset * length_b * offset_ratio;
+      }
+    }
+  }
+}
+// func_mpr_contact -> func_mpr_contact_from_centers, mpr.py:686-819
+DEVN void mpr_contact(const Model& m, const Pair& pr, V3 normal_ws, bool& is_col, V3& normal, float& penetration, V3& pos) {
+  Simplex s;
+  V3 center_a, center_b;
+  guess_geoms_center(m, pr, normal_ws, center_a, center_b);
+  int res = mpr_discover_portal(m, s, pr, center_a, center_b);
+  is_col = false; pos = v3(0, 0, 0); normal = v3(0, 0, 0); penetration = 0.0f;
+  if (res == 1) {
+    is_col = true; penetration = 0.0f; normal = -normalized(s.v[0]); pos = (s.v1[1] + s.v2[1]) * 0.5f;
+  } else if (res == 2) {
+    is_col = true; penetration = norm(s.v[1]); normal = -normalized(s.v[1]); pos = (s.v1[1] + s.v2[1]) * 0.5f;
+  } else if (res == 0) {
+    res = mpr_refine_portal(m, s, pr);
+    if (res >= 0) mpr_find_penetration(m, s, pr, is_col, normal, penetration, pos);
+  }
+}
+
+// func_add_contact, collider/contact.py:165-199
+DEV void add_contact(const Model& m, const E& e, int i_ga, int i_gb, V3 normal, V3 contact_pos, float penetration) {
+  int i_c = e.n_contacts()[0];
+  if (i_c < m.max_contact_pairs) {
+    float friction_a = e.geom_friction()[i_ga] * e.friction_ratio()[i_ga];
+    float friction_b = e.geom_friction()[i_gb] * e.friction_ratio()[i_gb];
+    e.c_geom()[i_c] = i_ga; e.c_geom()[MAXC + i_c] = i_gb;
+    e.c_normal()[i_c] = normal; e.c_pos()[i_c] = contact_pos; e.c_pen()[i_c] = penetration;
+    e.c_friction()[i_c] = fmx(fmx(friction_a, friction_b), 1e-2f);
+    auto sol = e.c_sol()[i_c];
+    for (int k = 0; k < 7; ++k) sol[k] = 0.5f * (m.geoms[i_ga].sol_params[k] + m.geoms[i_gb].sol_params[k]);
+    e.c_link()[i_c] = m.geoms[i_ga].link; e.c_link()[MAXC + i_c] = m.geoms[i_gb].link;
+    e.n_contacts()[0] = i_c + 1;
+  } else {
+    e.err()[0] |= GO2SIM_ERR_OVERFLOW_COLLISION_PAIRS;
+  }
+}
+// func_compute_tolerance, contact.py:264-283
+DEV float compute_tolerance(const Model& m, int i_ga, int i_gb, float tolerance) {
+  float size_b = norm(m.geoms[i_gb].aabb[7] - m.geoms[i_gb].aabb[0]);
+  float size_a = norm(m.geoms[i_ga].aabb[7] - m.geoms[i_ga].aabb[0]);
+  return 0.5f * tolerance * fmn(size_a, size_b);
+}
+// func_contact_orthogonals (non-mujoco branch), contact.py:286-345
+DEV void contact_orthogonals(const Model& m, const E& e, int i_ga, int i_gb, V3 normal, V3& axis_0, V3& axis_1) {
+  V3 size_ga = m.geoms[i_ga].aabb[7], size_gb = m.geoms[i_gb].aabb[7];
+  float volume_ga = size_ga.x * size_ga.y * size_ga.z, volume_gb = size_gb.x * size_gb.y * size_gb.z;
+  int i_g = (volume_ga < volume_gb) ? i_ga : i_gb;
+  int i_l = m.geoms[i_g].link;
+  M3 rot = quat_to_R(e.i_quat()[i_l], m.eps);
+  int axis_idx = 0; float axis_angle_max = 0.0f;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    float axis_angle = dm_abs(dot(mcol(rot, i), normal));
+    if (axis_angle > axis_angle_max) { axis_angle_max = axis_angle; axis_idx = i; }
+  }
+  axis_idx = (axis_idx + 1) % 3;
+  axis_0 = mcol(rot, axis_idx);
+  axis_0 = normalized(axis_0 - dot(normal, axis_0) * normal);
+  axis_1 = cross(normal, axis_0);
+}
+// func_rotate_frame, contact.py:348-369
+DEV void rotate_frame(V3 pos, Q4 quat, V3 contact_pos, Q4 qrot, V3& new_pos, Q4& new_quat) {
+  new_quat = transform_quat_by_quat(quat, qrot);
+  V3 rel = contact_pos - pos;
+  V3 vec = transform_by_quat(rel, qrot);
+  vec = vec - rel;
+  new_pos = pos - vec;
+}
+
+// func_convex_convex_contact (CCD_ALGORITHM_CODE.MPR branch), narrowphase.py:514-961
+DEV void convex_convex_contact(const Model& m, const E& e, int i_ga, int i_gb) {
+  const float EPS = m.eps;
+  int type_a = m.geoms[i_ga].type, type_b = m.geoms[i_gb].type;
+  bool multi_contact = (type_a != GEOM_SPHERE) && (type_b != GEOM_SPHERE);
+  float tolerance = compute_tolerance(m, i_ga, i_gb, m.mc_tolerance);
+  V3 ga_pos_o = e.g_pos()[i_ga], gb_pos_o = e.g_pos()[i_gb]; Q4 ga_quat_o = e.g_quat()[i_ga], gb_quat_o = e.g_quat()[i_gb];
+  Pair pr; pr.i_ga = i_ga; pr.i_gb = i_gb; pr.pos_a = ga_pos_o; pr.quat_a = ga_quat_o; pr.pos_b = gb_pos_o; pr.quat_b = gb_quat_o;
+  bool is_col_0 = false; V3 normal_0 = v3(0, 0, 0), contact_pos_0 = v3(0, 0, 0);
+  bool is_col = false; float penetration = 0.0f; V3 normal = v3(0, 0, 0), contact_pos = v3(0, 0, 0);
+  int n_con = 0;
+  V3 axis_0 = v3(0, 0, 0), axis_1 = v3(0, 0, 0); Q4 qrot = q4(0, 0, 0, 0);
+  int i_pair = (i_ga > i_gb) ? m.pair_idx[i_gb][i_ga] : m.pair_idx[i_ga][i_gb];
+  auto normal_cache = e.normal_cache();
+  for (int i_detection = 0; i_detection < 5; ++i_detection) {
+    bool prefer_gjk = false;
+    if (multi_contact && is_col_0) {
+      V3 axis = (float)(2 * (i_detection % 2) - 1) * axis_0 + (float)(1 - 2 * ((i_detection / 2) % 2)) * axis_1;
+      qrot = rotvec_to_quat(m.mc_perturbation * axis, EPS);
+      rotate_frame(ga_pos_o, ga_quat_o, contact_pos_0, qrot, pr.pos_a, pr.quat_a);
+      rotate_frame(gb_pos_o, gb_quat_o, contact_pos_0, inv_quat(qrot), pr.pos_b, pr.quat_b);
+    }
+    if ((multi_contact && is_col_0) || (i_detection == 0)) {
+      bool is_mpr_updated = false;
+      V3 normal_ws = normal_cache[i_pair];
+      bool guess_available = (dm_abs(normal_ws.x) > EPS) || (dm_abs(normal_ws.y) > EPS) || (dm_abs(normal_ws.z) > EPS);
+      for (int i_mpr = 0; i_mpr < 2; ++i_mpr) {
+        if (i_mpr == 1) {
+          if ((i_detection == 0) && !is_col && guess_available) { normal_ws = v3(0, 0, 0); guess_available = false; is_mpr_updated = false; }
+        }
+        if (!is_mpr_updated) {
+          mpr_contact(m, pr, normal_ws, is_col, normal, penetration, contact_pos);
+          is_mpr_updated = true;
+        }
+      }
+      if (penetration > tolerance) prefer_gjk = !guess_available || (m.mc_tolerance * penetration >= m.mpr_to_gjk_ratio * tolerance);
+      if (prefer_gjk) e.gjk_fallback()[0] += 1;  // safe GJK+EPA fallback (narrowphase.py:734-845) not implemented yet: MPR result kept
+    }
+    if (i_detection == 0) {
+      is_col_0 = is_col; normal_0 = normal; contact_pos_0 = contact_pos;
+      if (is_col_0) {
+        add_contact(m, e, i_ga, i_gb, normal, contact_pos, penetration);
+        if (multi_contact) { contact_orthogonals(m, e, i_ga, i_gb, normal, axis_0, axis_1); n_con = 1; }
+        normal_cache[i_pair] = normal;
+      } else {
+        normal_cache[i_pair] = v3(0, 0, 0);
+      }
+    } else if (multi_contact && is_col) {
+      V3 contact_point_a = transform_by_quat((contact_pos - 0.5f * penetration * normal) - contact_pos_0, inv_quat(qrot)) + contact_pos_0;
+      V3 contact_point_b = transform_by_quat((contact_pos + 0.5f * penetration * normal) - contact_pos_0, qrot) + contact_pos_0;
+      contact_pos = 0.5f * (contact_point_a + contact_point_b);
+      V3 tw = cross(normal, normal_0);
+      V3 twist_rotvec = v3(clampf(tw.x, -m.mc_perturbation, m.mc_perturbation), clampf(tw.y, -m.mc_perturbation, m.mc_perturbation),
+                           clampf(tw.z, -m.mc_perturbation, m.mc_perturbation));
+      normal = normal + cross(twist_rotvec, normal);
+      penetration = dot(normal, contact_point_b - contact_point_a);
+      bool repeated = false;
+      int nc = e.n_contacts()[0];
+      for (int i_c = 0; i_c < n_con; ++i_c)
+        if (!repeated) {
+          int idx_prev = nc - 1 - i_c;
+          if (norm(contact_pos - (V3)e.c_pos()[idx_prev]) < tolerance) repeated = true;
+        }
+      if (!repeated && penetration > -tolerance) {
+        penetration = fmx(penetration, 0.0f);
+        add_contact(m, e, i_ga, i_gb, normal, contact_pos, penetration);
+        n_con++;
+      }
+    }
+  }
+}
+
+// Collider.detection, collider.py:436-528: AABBs -> SAP broad phase -> convex narrow phase
+__global__ __launch_bounds__(WG) void k_collide(Pool P, const Model* __restrict__ mp) {
+  int b = blockIdx.x * WG + threadIdx.x;
+  if (b >= P.B) return;
+  const Model& m = *mp;
+  E e(P, b);
+  update_geom_aabbs(m, e);
+  broad_phase(m, e);
+  int n_broad = e.n_broad()[0];
+  auto broad = e.broad();
+  for (int i_pair = 0; i_pair < n_broad; ++i_pair) {                // func_narrow_phase_convex_vs_convex, narrowphase.py:964-1068
+    int i_ga = broad[2 * i_pair], i_gb = broad[2 * i_pair + 1];
+    if (m.geoms[i_ga].type > m.geoms[i_gb].type) { int t = i_ga; i_ga = i_gb; i_gb = t; }
+    convex_convex_contact(m, e, i_ga, i_gb);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// constraints + Newton solver  (R/constraint/solver.py)
+// ---------------------------------------------------------------------------------------------
+// add_collision_constraints, solver.py:498-595
+DEVN void add_collision_constraints(const Model& m, const E& e) {
+  auto jac = e.jac(); auto cdof_ang = e.cdof_ang(); auto cdof_vel = e.cdof_vel(); auto root_com = e.root_com(); auto vel = e.vel();
+  auto diag_ = e.diag(); auto aref_ = e.aref(); auto efc_D = e.efc_D();
+  int nc = e.n_contacts()[0];
+  int n_con_total = e.n_con()[0];
+  for (int i_col = 0; i_col < nc; ++i_col) {
+    int link_a = e.c_link()[i_col], link_b = e.c_link()[MAXC + i_col];
+    V3 cpos = e.c_pos()[i_col], cnormal = e.c_normal()[i_col];
+    float friction = e.c_friction()[i_col], pen = e.c_pen()[i_col];
+    float sol[7];
+    auto csol = e.c_sol()[i_col];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) sol[k] = csol[k];
+    V3 d1, d2;
+    orthogonals(cnormal, d1, d2);
+    float invweight = m.links[link_a].invweight[0];
+    if (link_b > -1) invweight = invweight + m.links[link_b].invweight[0];
+    for (int i = 0; i < 4; ++i) {
+      V3 d = (float)(2 * (i % 2) - 1) * ((i < 2) ? d1 : d2);
+      V3 n = d * friction - cnormal;
+      int n_con = n_con_total++;
+      auto row = jac[n_con];
+      for (int i_d = 0; i_d < ND; ++i_d) row[i_d] = 0.0f;
+      float jac_qvel = 0.0f;
+      for (int i_ab = 0; i_ab < 2; ++i_ab) {
+        float sign = -1.0f; int link = link_a;
+        if (i_ab == 1) { sign = 1.0f; link = link_b; }
+        while (link > -1) {
+          const Link& L = m.links[link];
+          V3 t_pos = cpos - (V3)root_com[link];
+          for (int i_d_ = 0; i_d_ < L.n_dofs; ++i_d_) {
+            int i_d = L.dof_end - 1 - i_d_;
+            V3 velv = (V3)cdof_vel[i_d] - cross(t_pos, cdof_ang[i_d]);
+            V3 diff = sign * velv;
+            float j = dot(diff, n);
+            jac_qvel = jac_qvel + j * vel[i_d];
+            row[i_d] = row[i_d] + j;
+          }
+          link = L.parent;
+        }
+      }
+      float imp, aref;
+      imp_aref(sol, -pen, jac_qvel, -pen, imp, aref);
+      float diag = invweight + friction * friction * invweight;
+      diag *= 2.0f * friction * friction * (1.0f - imp) / imp;
+      diag = fmx(diag, m.eps);
+      diag_[n_con] = diag; aref_[n_con] = aref; efc_D[n_con] = 1.0f / diag;
+    }
+  }
+  e.n_con()[0] = n_con_total;
+}
+// add_joint_limit_constraints, solver.py:1088-1143
+DEVN void add_joint_limit_constraints(const Model& m, const E& e) {
+  auto qpos = e.qpos(); auto vel = e.vel(); auto jac = e.jac();
+  int n_con_total = e.n_con()[0];
+  for (int i_l = 0; i_l < NL; ++i_l)
+    for (int i_j = m.links[i_l].joint_start; i_j < m.links[i_l].joint_end; ++i_j) {
+      const Joint& J = m.joints[i_j];
+      if (J.type != JOINT_REVOLUTE) continue;
+      int i_q = J.q_start, i_d = J.dof_start;
+      float q = qpos[i_q];
+      float pos_delta_min = q - m.dofs[i_d].limit[0];
+      float pos_delta_max = m.dofs[i_d].limit[1] - q;
+      float pos_delta = fmn(pos_delta_min, pos_delta_max);
+      if (pos_delta < 0) {
+        float j = (float)((pos_delta_min < pos_delta_max) * 2 - 1);
+        float jac_qvel = j * vel[i_d];
+        float imp, aref;
+        imp_aref(J.sol_params, pos_delta, jac_qvel, pos_delta, imp, aref);
+        float diag = fmx(m.dofs[i_d].invweight * (1.0f - imp) / imp, m.eps);
+        int n_con = n_con_total++;
+        e.diag()[n_con] = diag; e.aref()[n_con] = aref; e.efc_D()[n_con] = 1.0f / diag;
+        auto row = jac[n_con];
+        for (int i_d2 = 0; i_d2 < ND; ++i_d2) row[i_d2] = 0.0f;
+        row[i_d] = j;
+      }
+    }
+  e.n_con()[0] = n_con_total;
+}
+
+// func_hessian_direct_batch, solver.py:1285-1343
+DEVN void hessian_direct(const Model& m, const E& e, int n_con) {
+  auto H = e.H(); auto jac = e.jac(); auto efc_D = e.efc_D(); auto active = e.active(); auto mass_mat = e.mass_mat();
+  for (int i = 0; i < ND; ++i) for (int j = 0; j < i + 1; ++j) H[i][j] = 0.0f;
+  for (int i_d1 = 0; i_d1 < ND; ++i_d1) {
+    auto Hrow = H[i_d1];
+    for (int i_c = 0; i_c < n_con; ++i_c) {
+      auto row = jac[i_c];
+      float j1 = row[i_d1];
+      if (dm_abs(j1) > m.eps) {
+        float D = efc_D[i_c], act = (float)active[i_c];
+        for (int i_d2 = 0; i_d2 < i_d1 + 1; ++i_d2) Hrow[i_d2] = Hrow[i_d2] + row[i_d2] * j1 * D * act;
+      }
+    }
+  }
+  for (int i_d1 = 0; i_d1 < ND; ++i_d1)
+    for (int i_d2 = 0; i_d2 < i_d1 + 1; ++i_d2) H[i_d1][i_d2] = H[i_d1][i_d2] + mass_mat[i_d1][i_d2];
+}
+// func_cholesky_factor_direct_batch, solver.py:1467-1494
+DEVN void cholesky_factor_direct(const Model& m, const E& e) {
+  auto H = e.H();
+  for (int i_d = 0; i_d < ND; ++i_d) {
+    auto Hi = H[i_d];
+    float tmp = Hi[i_d];
+    for (int j_d = 0; j_d < i_d; ++j_d) { float h = Hi[j_d]; tmp = tmp - h * h; }
+    float dgn = dm_sqrt(fmx(tmp, m.eps));
+    Hi[i_d] = dgn;
+    tmp = 1.0f / dgn;
+    for (int j_d = i_d + 1; j_d < ND; ++j_d) {
+      auto Hj = H[j_d];
+      float dotv = 0.0f;
+      for (int k_d = 0; k_d < i_d; ++k_d) dotv = dotv + Hj[k_d] * Hi[k_d];
+      Hj[i_d] = (Hj[i_d] - dotv) * tmp;
+    }
+  }
+}
+// func_hessian_and_cholesky_factor_incremental_dense_batch, solver.py:1632-1675
+DEVN bool cholesky_incremental(const Model& m, const E& e, int n_con) {
+  auto H = e.H(); auto jac = e.jac(); auto nt_vec = e.nt_vec(); auto active = e.active(); auto prev_active = e.prev_active(); auto efc_D = e.efc_D();
+  bool is_degenerated = false;
+  for (int i_c = 0; i_c < n_con; ++i_c) {
+    bool is_active = active[i_c] != 0, is_active_prev = prev_active[i_c] != 0;
+    if (is_active ^ is_active_prev) {
+      float sign = is_active ? 1.0f : -1.0f;
+      float efc_D_sqrt = dm_sqrt(efc_D[i_c]);
+      auto row = jac[i_c];
+      for (int i_d = 0; i_d < ND; ++i_d) nt_vec[i_d] = row[i_d] * efc_D_sqrt;
+      for (int k = 0; k < ND; ++k) {
+        float vk = nt_vec[k];
+        if (dm_abs(vk) > m.eps) {
+          float Lkk = H[k][k];
+          float tmp = Lkk * Lkk + sign * (vk * vk);
+          if (tmp < m.eps) { is_degenerated = true; break; }
+          float r = dm_sqrt(tmp);
+          float c = r / Lkk;
+          float cinv = 1.0f / c;
+          float s = vk / Lkk;
+          H[k][k] = r;
+          for (int i = k + 1; i < ND; ++i) H[i][k] = (H[i][k] + s * nt_vec[i] * sign) * cinv;
+          for (int i = k + 1; i < ND; ++i) nt_vec[i] = nt_vec[i] * c - s * H[i][k];
+        }
+      }
+    }
+  }
+  return is_degenerated;
+}
+// func_cholesky_solve_batch, solver.py:1747-1765
+DEV void cholesky_solve(const E& e) {
+  auto H = e.H(); auto grad = e.grad(); auto Mgrad = e.Mgrad();
+  for (int i_d = 0; i_d < ND; ++i_d) {
+    auto Hi = H[i_d];
+    float cur = grad[i_d];
+    for (int j_d = 0; j_d < i_d; ++j_d) cur = cur - Hi[j_d] * Mgrad[j_d];
+    Mgrad[i_d] = cur / Hi[i_d];
+  }
+  for (int i_d_ = 0; i_d_ < ND; ++i_d_) {
+    int i_d = ND - 1 - i_d_;
+    float cur = Mgrad[i_d];
+    for (int j_d = i_d + 1; j_d < ND; ++j_d) cur = cur - H[j_d][i_d] * Mgrad[j_d];
+    Mgrad[i_d] = cur / H[i_d][i_d];
+  }
+}
+// func_update_constraint_batch, solver.py:2428-2503 (no equality / frictionloss rows for Go2)
+DEVN void update_constraint(const Model& m, const E& e, int n_con) {
+  auto sv = e.sv(); auto active = e.active(); auto prev_active = e.prev_active(); auto Jaref = e.Jaref(); auto efc_D = e.efc_D();
+  auto efc_force = e.efc_force(); auto jac = e.jac(); auto qfrc_constraint = e.qfrc_constraint();
+  sv[SV_PREV_COST] = sv[SV_COST];
+  float cost_i = 0.0f, gauss_i = 0.0f;
+  for (int i_c = 0; i_c < n_con; ++i_c) {
+    prev_active[i_c] = active[i_c];
+    float Ja = Jaref[i_c];
+    int act = Ja < 0.0f;
+    active[i_c] = act;
+    efc_force[i_c] = 0.0f + (-Ja * efc_D[i_c] * (float)act);
+  }
+  for (int i_d = 0; i_d < ND; ++i_d) {
+    float q = 0.0f;
+    for (int i_c = 0; i_c < n_con; ++i_c) q = q + jac[i_c][i_d] * efc_force[i_c];
+    qfrc_constraint[i_d] = q;
+  }
+  auto Ma = e.Ma(); auto force = e.force(); auto qacc = e.qacc(); auto acc_smooth = e.acc_smooth();
+  for (int i_d = 0; i_d < ND; ++i_d) {
+    float v = 0.5f * (Ma[i_d] - force[i_d]) * (qacc[i_d] - acc_smooth[i_d]);
+    gauss_i = gauss_i + v;
+    cost_i = cost_i + v;
+  }
+  for (int i_c = 0; i_c < n_con; ++i_c) { float Ja = Jaref[i_c]; cost_i = cost_i + 0.5f * (Ja * Ja * efc_D[i_c] * (float)active[i_c]); }
+  sv[SV_GAUSS] = gauss_i;
+  sv[SV_COST] = cost_i;
+}
+DEV void update_gradient(const E& e) {
+  auto grad = e.grad(); auto Ma = e.Ma(); auto force = e.force(); auto qfrc_constraint = e.qfrc_constraint();
+  for (int i_d = 0; i_d < ND; ++i_d) grad[i_d] = Ma[i_d] - force[i_d] - qfrc_constraint[i_d];
+  cholesky_solve(e);
+}
+
+// ---- exact line search, solver.py:1888-2417 -------------------------------------------------------
+struct LsPoint { float alpha, cost, grad, hess; };
+DEV LsPoint ls_init_and_eval_p0(const Model& m, const E& e, int n_con) {
+  auto mass_mat = e.mass_mat(); auto search = e.search(); auto mv_ = e.mv(); auto jac = e.jac(); auto jv_ = e.jv(); auto sv = e.sv();
+  for (int i_d1 = 0; i_d1 < ND; ++i_d1) {
+    auto Mr = mass_mat[i_d1];
+    float mv = 0.0f;
+    for (int i_d2 = 0; i_d2 < ND; ++i_d2) mv = mv + Mr[i_d2] * search[i_d2];
+    mv_[i_d1] = mv;
+  }
+  for (int i_c = 0; i_c < n_con; ++i_c) {
+    auto row = jac[i_c];
+    float jv = 0.0f;
+    for (int i_d = 0; i_d < ND; ++i_d) jv = jv + row[i_d] * search[i_d];
+    jv_[i_c] = jv;
+  }
+  auto Ma = e.Ma(); auto force = e.force();
+  float qg1 = 0.0f, qg2 = 0.0f;
+  for (int i_d = 0; i_d < ND; ++i_d) {
+    float s = search[i_d];
+    qg1 = qg1 + (s * Ma[i_d] - s * force[i_d]);
+    qg2 = qg2 + 0.5f * s * mv_[i_d];
+  }
+  float gauss = sv[SV_GAUSS];
+  sv[SV_QG0] = gauss; sv[SV_QG1] = qg1; sv[SV_QG2] = qg2;
+  float t0 = gauss, t1 = qg1, t2 = qg2;
+  auto Jaref = e.Jaref(); auto efc_D = e.efc_D();
+  for (int i_c = 0; i_c < n_con; ++i_c) {
+    float Ja = Jaref[i_c], jv = jv_[i_c], D = efc_D[i_c];
+    float qf_0 = D * (0.5f * Ja * Ja), qf_1 = D * (jv * Ja), qf_2 = D * (0.5f * jv * jv);
+    float active = (float)(Ja < 0.0f);
+    t0 = t0 + qf_0 * active; t1 = t1 + qf_1 * active; t2 = t2 + qf_2 * active;
+  }
+  LsPoint p; p.alpha = 0.0f; p.cost = t0; p.grad = t1; p.hess = 2.0f * t2;
+  if (p.hess <= 0.0f) p.hess = m.eps;
+  return p;
+}
+DEV LsPoint ls_point_fn(const Model& m, const E& e, int n_con, float alpha, float qg0, float qg1, float qg2) {
+  auto Jaref = e.Jaref(); auto efc_D = e.efc_D(); auto jv_ = e.jv();
+  float t0 = qg0 + 0.0f, t1 = qg1 + 0.0f, t2 = qg2 + 0.0f;
+  for (int i_c = 0; i_c < n_con; ++i_c) {
+    float Ja = Jaref[i_c], jv = jv_[i_c], D = efc_D[i_c];
+    float x = Ja + alpha * jv;
+    float active = (float)(x < 0.0f);
+    float qf_0 = D * (0.5f * Ja * Ja), qf_1 = D * (jv * Ja), qf_2 = D * (0.5f * jv * jv);
+    t0 = t0 + qf_0 * active; t1 = t1 + qf_1 * active; t2 = t2 + qf_2 * active;
+  }
+  LsPoint p; p.alpha = alpha;
+  p.cost = alpha * alpha * t2 + alpha * t1 + t0;
+  p.grad = 2.0f * alpha * t2 + t1;
+  p.hess = 2.0f * t2;
+  if (p.hess <= 0.0f) p.hess = m.eps;
+  return p;
+}
+DEV void ls_point_fn_3(const Model& m, const E& e, int n_con, const float a[3], float qg0, float qg1, float qg2, float costs[3], float grads[3], float hess[3]) {
+  auto Jaref = e.Jaref(); auto efc_D = e.efc_D(); auto jv_ = e.jv();
+  float b0 = qg0 + 0.0f, b1 = qg1 + 0.0f, b2 = qg2 + 0.0f;
+  float t00 = b0, t01 = b1, t02 = b2, t10 = b0, t11 = b1, t12 = b2, t20 = b0, t21 = b1, t22 = b2;
+  for (int i_c = 0; i_c < n_con; ++i_c) {
+    float Ja = Jaref[i_c], jv = jv_[i_c], D = efc_D[i_c];
+    float qf_0 = D * (0.5f * Ja * Ja), qf_1 = D * (jv * Ja), qf_2 = D * (0.5f * jv * jv);
+    float a0 = (float)((Ja + a[0] * jv) < 0.0f), a1 = (float)((Ja + a[1] * jv) < 0.0f), a2 = (float)((Ja + a[2] * jv) < 0.0f);
+    t00 = t00 + qf_0 * a0; t01 = t01 + qf_1 * a0; t02 = t02 + qf_2 * a0;
+    t10 = t10 + qf_0 * a1; t11 = t11 + qf_1 * a1; t12 = t12 + qf_2 * a1;
+    t20 = t20 + qf_0 * a2; t21 = t21 + qf_1 * a2; t22 = t22 + qf_2 * a2;
+  }
+  float t[3][3] = {{t00, t01, t02}, {t10, t11, t12}, {t20, t21, t22}};
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    costs[k] = a[k] * a[k] * t[k][2] + a[k] * t[k][1] + t[k][0];
+    grads[k] = 2.0f * a[k] * t[k][2] + t[k][1];
+    hess[k] = 2.0f * t[k][2];
+    if (hess[k] <= 0.0f) hess[k] = m.eps;
+  }
+}
+DEV int update_bracket(LsPoint& p, const float alphas[3], const float costs[3], const float grads[3], const float hess[3], float& p_next_alpha) {
+  int flag = 0;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    if (p.grad < 0 && grads[i] < 0 && p.grad < grads[i]) { p.alpha = alphas[i]; p.cost = costs[i]; p.grad = grads[i]; p.hess = hess[i]; flag = 1; }
+    else if (p.grad > 0 && grads[i] > 0 && p.grad > grads[i]) { p.alpha = alphas[i]; p.cost = costs[i]; p.grad = grads[i]; p.hess = hess[i]; flag = 2; }
+  }
+  p_next_alpha = p.alpha;
+  if (flag > 0) p_next_alpha = p.alpha - p.grad / p.hess;
+  return flag;
+}
+// func_linesearch_batch, solver.py:2246-2417
+DEVN float linesearch(const Model& m, const E& e, int n_con) {
+  auto search = e.search();
+  float snorm = 0.0f;
+  for (int jd = 0; jd < ND; ++jd) { float s = search[jd]; snorm = snorm + s * s; }
+  snorm = dm_sqrt(snorm);
+  float scale = m.meaninertia * (float)imx(1, ND);
+  float gtol = m.tolerance * m.ls_tolerance * snorm * scale;
+  e.sv()[SV_GTOL] = gtol;
+  int ls_it = 0, ls_result = 0;
+  float res_alpha = 0.0f;
+  bool done = false;
+  if (snorm < m.eps) {
+    ls_result = 1; res_alpha = 0.0f;
+  } else {
+    LsPoint p0 = ls_init_and_eval_p0(m, e, n_con);
+    ls_it = 1;
+    float qg0 = e.sv()[SV_QG0], qg1 = e.sv()[SV_QG1], qg2 = e.sv()[SV_QG2];
+    LsPoint p1 = ls_point_fn(m, e, n_con, p0.alpha - p0.grad / p0.hess, qg0, qg1, qg2);
+    ls_it += 1;
+    e.sv()[8] = p0.cost; e.sv()[9] = p0.grad; e.sv()[10] = p0.hess; e.sv()[11] = p1.alpha; e.sv()[12] = p1.cost; e.sv()[13] = p1.grad; e.sv()[14] = p1.hess;
+    if (p0.cost < p1.cost) p1 = p0;
+    if (dm_abs(p1.grad) < gtol) {
+      ls_result = (dm_abs(p1.alpha) < m.eps) ? 2 : 0;
+      res_alpha = p1.alpha;
+    } else {
+      int direction = (p1.grad < 0) * 2 - 1;
+      int p2update = 0;
+      LsPoint p2 = p1;
+      while (p1.grad * (float)direction <= -gtol && ls_it < m.ls_iterations) {
+        p2 = p1; p2update = 1;
+        p1 = ls_point_fn(m, e, n_con, p1.alpha - p1.grad / p1.hess, qg0, qg1, qg2);
+        ls_it += 1;
+        if (ls_it < 20) { e.sv()[16 + 4 * ls_it] = p1.alpha; e.sv()[17 + 4 * ls_it] = p1.cost; e.sv()[18 + 4 * ls_it] = p1.grad; e.sv()[19 + 4 * ls_it] = p1.hess; }
+        if (dm_abs(p1.grad) < gtol) { res_alpha = p1.alpha; done = true; break; }
+      }
+      if (!done) {
+        if (ls_it >= m.ls_iterations) { ls_result = 3; res_alpha = p1.alpha; done = true; }
+        if (!p2update && !done) { ls_result = 6; res_alpha = p1.alpha; done = true; }
+        if (!done) {
+          float al[3];
+          al[0] = p1.alpha - p1.grad / p1.hess; al[1] = p1.alpha; al[2] = (p1.alpha + p2.alpha) * 0.5f;
+          while (ls_it < m.ls_iterations) {
+            float costs[3], grads[3], hess[3];
+            ls_point_fn_3(m, e, n_con, al, qg0, qg1, qg2, costs, grads, hess);
+            ls_it += 3;
+            if (ls_it < 20) for (int q = 0; q < 3; ++q) { int z = ls_it - 2 + q; e.sv()[16 + 4 * z] = al[q]; e.sv()[17 + 4 * z] = costs[q]; e.sv()[18 + 4 * z] = grads[q]; e.sv()[19 + 4 * z] = hess[q]; }
+            float p1_next_alpha = al[0], p2_next_alpha = al[1];
+            float best_alpha = 0.0f, best_cost = 0.0f; bool best_found = false;
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+              if (dm_abs(grads[i]) < gtol && (!best_found || costs[i] < best_cost)) { best_alpha = al[i]; best_cost = costs[i]; best_found = true; }
+            if (best_found) {
+              res_alpha = best_alpha; done = true;
+            } else {
+              int b1 = update_bracket(p1, al, costs, grads, hess, p1_next_alpha);
+              int b2 = update_bracket(p2, al, costs, grads, hess, p2_next_alpha);
+              if (b1 == 0 && b2 == 0) { ls_result = (costs[2] < p0.cost) ? 0 : 7; res_alpha = al[2]; done = true; }
+            }
+            if (done) break;
+            al[0] = p1_next_alpha; al[1] = p2_next_alpha; al[2] = (p1.alpha + p2.alpha) * 0.5f;
+          }
+          if (!done) {
+            if (p1.cost <= p2.cost && p1.cost < p0.cost) { ls_result = 4; res_alpha = p1.alpha; }
+            else if (p2.cost <= p1.cost && p2.cost < p0.cost) { ls_result = 4; res_alpha = p2.alpha; }
+            else { ls_result = 5; res_alpha = 0.0f; }
+          }
+        }
+      }
+    }
+  }
+  e.si()[SI_LS_IT] = ls_it; e.si()[SI_LS_RESULT] = ls_result;
+  e.sv()[7] = res_alpha;
+  return res_alpha;
+}
+
+// func_solve_init (non-mujoco branch), solver.py:2739-2859
+DEVN void solve_init(const Model& m, const E& e, int n_con) {
+  auto qacc = e.qacc(); auto qacc_ws = e.qacc_ws(); auto acc_smooth = e.acc_smooth(); auto mass_mat = e.mass_mat(); auto Ma = e.Ma();
+  bool ws = (n_con > 0) && e.is_warmstart()[0];
+  for (int i_d = 0; i_d < ND; ++i_d) qacc[i_d] = ws ? qacc_ws[i_d] : acc_smooth[i_d];
+  for (int i_d1 = 0; i_d1 < ND; ++i_d1) {
+    auto Mr = mass_mat[i_d1];
+    float Ma_ = 0.0f;
+    for (int i_d2 = 0; i_d2 < ND; ++i_d2) Ma_ = Ma_ + Mr[i_d2] * qacc[i_d2];
+    Ma[i_d1] = Ma_;
+  }
+  auto jac = e.jac(); auto aref = e.aref(); auto Jaref = e.Jaref();
+  for (int i_c = 0; i_c < n_con; ++i_c) {
+    auto row = jac[i_c];
+    float J = -aref[i_c];
+    for (int i_d = 0; i_d < ND; ++i_d) J = J + row[i_d] * qacc[i_d];
+    Jaref[i_c] = J;
+  }
+  update_constraint(m, e, n_con);
+  hessian_direct(m, e, n_con);
+  cholesky_factor_direct(m, e);
+  update_gradient(e);
+  auto search = e.search(); auto Mgrad = e.Mgrad();
+  for (int i_d = 0; i_d < ND; ++i_d) search[i_d] = -Mgrad[i_d];
+}
+// func_solve_iter, solver.py:2862-2938
+DEVN bool solve_iter(const Model& m, const E& e, int n_con) {
+  float alpha = linesearch(m, e, n_con);
+  bool improved;
+  if (dm_abs(alpha) < m.eps) {
+    improved = false;
+  } else {
+    auto qacc = e.qacc(); auto search = e.search(); auto Ma = e.Ma(); auto mv = e.mv(); auto Jaref = e.Jaref(); auto jv = e.jv();
+    for (int i_d = 0; i_d < ND; ++i_d) {
+      qacc[i_d] = qacc[i_d] + search[i_d] * alpha;
+      Ma[i_d] = Ma[i_d] + mv[i_d] * alpha;
+    }
+    for (int i_c = 0; i_c < n_con; ++i_c) Jaref[i_c] = Jaref[i_c] + jv[i_c] * alpha;
+    update_constraint(m, e, n_con);
+    if (cholesky_incremental(m, e, n_con)) { hessian_direct(m, e, n_con); cholesky_factor_direct(m, e); }
+    update_gradient(e);
+    float tol_scaled = (m.meaninertia * (float)imx(1, ND)) * m.tolerance;
+    float improvement = e.sv()[SV_PREV_COST] - e.sv()[SV_COST];
+    auto grad = e.grad();
+    float grad_norm = 0.0f;
+    for (int i_d = 0; i_d < ND; ++i_d) { float g = grad[i_d]; grad_norm = grad_norm + g * g; }
+    grad_norm = dm_sqrt(grad_norm);
+    improved = (grad_norm > tol_scaled) && (improvement > tol_scaled);
+    if (improved) {
+      auto Mgrad = e.Mgrad();
+      for (int i_d = 0; i_d < ND; ++i_d) search[i_d] = -Mgrad[i_d];
+    }
+  }
+  e.si()[SI_IMPROVED] = improved;
+  return improved;
+}
+
+// _func_constraint_force without the collider (rigid_solver.py:1230-1246): rows + ConstraintSolver.resolve (solver.py:177-209)
+__global__ __launch_bounds__(WG) void k_constraint_solve(Pool P, const Model* __restrict__ mp) {
+  int b = blockIdx.x * WG + threadIdx.x;
+  if (b >= P.B) return;
+  const Model& m = *mp;
+  E e(P, b);
+  e.n_con()[0] = 0;                                                  // add_equality_constraints, solver.py:791-809
+  add_collision_constraints(m, e);
+  add_joint_limit_constraints(m, e);
+  int n_con = e.n_con()[0];
+  solve_init(m, e, n_con);
+  int iters = 0;
+  if (n_con > 0) {                                                   // func_solve_body, solver.py:2941-2966
+    for (int it = 0; it < m.iterations; ++it) {
+      bool improved = solve_iter(m, e, n_con);
+      iters++;
+      if (!improved) break;
+    }
+  } else {
+    e.si()[SI_IMPROVED] = 0;
+  }
+  e.solver_iters()[0] = iters;
+  auto acc = e.acc(); auto qacc = e.qacc(); auto force = e.force(); auto qf_smooth = e.qf_smooth(); auto qfrc_constraint = e.qfrc_constraint();
+  auto qacc_ws = e.qacc_ws();
+  int err = 0;
+  for (int i_d = 0; i_d < ND; ++i_d) {                               // func_update_qacc, solver.py:3016-3037
+    float q = qacc[i_d];
+    acc[i_d] = q;
+    force[i_d] = qf_smooth[i_d] + qfrc_constraint[i_d];
+    qacc_ws[i_d] = q;
+    if (isnan_(q)) err |= GO2SIM_ERR_INVALID_FORCE_NAN;
+  }
+  if (err) e.err()[0] |= err;
+  e.is_warmstart()[0] = 1;
+  auto contact_force = e.contact_force(); auto efc_force = e.efc_force();
+  for (int i_l = 0; i_l < NL; ++i_l) contact_force[i_l] = v3(0, 0, 0);  // func_update_contact_force, solver.py:2974-3013
+  int nc = e.n_contacts()[0];
+  for (int i_c = 0; i_c < nc; ++i_c) {
+    V3 cnormal = e.c_normal()[i_c]; float friction = e.c_friction()[i_c];
+    V3 f = v3(0, 0, 0), d1, d2;
+    orthogonals(cnormal, d1, d2);
+#pragma unroll
+    for (int i_dir = 0; i_dir < 4; ++i_dir) {
+      V3 d = (float)(2 * (i_dir % 2) - 1) * ((i_dir < 2) ? d1 : d2);
+      V3 n = d * friction - cnormal;
+      f = f + n * efc_force[i_c * 4 + i_dir];
+    }
+    e.c_force()[i_c] = f;
+    int la = e.c_link()[i_c], lb = e.c_link()[MAXC + i_c];
+    contact_force[la] = (V3)contact_force[la] - f;
+    contact_force[lb] = (V3)contact_force[lb] + f;
+  }
+}
+
+// kernel_step_2 (rigid_solver.py:3072-3180): func_integrate (forward_dynamics.py:1558-1699) + func_copy_next_to_curr
+// (abd/diff.py:25-54) + FK / forward velocity of the new state
+__global__ __launch_bounds__(WG) void k_integrate_fk(Pool P, const Model* __restrict__ mp) {
+  int b = blockIdx.x * WG + threadIdx.x;
+  if (b >= P.B) return;
+  const Model& m = *mp;
+  E e(P, b);
+  auto vel = e.vel(); auto acc = e.acc(); auto qpos = e.qpos(); auto vel_next = e.vel_next(); auto qpos_next = e.qpos_next();
+  for (int i_d = 0; i_d < ND; ++i_d) vel_next[i_d] = vel[i_d] + acc[i_d] * m.substep_dt;
+  for (int i_l = 0; i_l < NL; ++i_l) {
+    const Link& L = m.links[i_l];
+    if (L.n_dofs == 0) continue;
+    int ds = L.dof_start, qs = L.q_start;
+    int joint_type = m.joints[L.joint_start].type;
+    if (joint_type == JOINT_FREE) {
+      V3 pos = v3(qpos[qs], qpos[qs + 1], qpos[qs + 2]);
+      V3 v = v3(vel_next[ds], vel_next[ds + 1], vel_next[ds + 2]);
+      pos = pos + v * m.substep_dt;
+      qpos_next[qs] = pos.x; qpos_next[qs + 1] = pos.y; qpos_next[qs + 2] = pos.z;
+      Q4 rot0 = q4(qpos[qs + 3], qpos[qs + 4], qpos[qs + 5], qpos[qs + 6]);
+      V3 ang = v3(vel_next[ds + 3], vel_next[ds + 4], vel_next[ds + 5]) * m.substep_dt;
+      Q4 qrot = rotvec_to_quat(ang, m.eps);
+      Q4 rot = transform_quat_by_quat(qrot, rot0);
+      qpos_next[qs + 3] = rot.w; qpos_next[qs + 4] = rot.x; qpos_next[qs + 5] = rot.y; qpos_next[qs + 6] = rot.z;
+    } else {
+      for (int j_ = 0; j_ < L.q_end - qs; ++j_) qpos_next[qs + j_] = qpos[qs + j_] + vel_next[ds + j_] * m.substep_dt;
+    }
+  }
+  bool is_valid = true;
+  for (int i_d = 0; i_d < ND; ++i_d) is_valid &= !isnan_(vel_next[i_d]);
+  for (int i_q = 0; i_q < NQ; ++i_q) is_valid &= !isnan_(qpos_next[i_q]);
+  if (is_valid) {
+    for (int i_d = 0; i_d < ND; ++i_d) vel[i_d] = vel_next[i_d];
+    for (int i_q = 0; i_q < NQ; ++i_q) qpos[i_q] = qpos_next[i_q];
+  } else {
+    e.err()[0] |= GO2SIM_ERR_INVALID_ACC_NAN;
+  }
+  update_cartesian_space(m, e, false);
+  forward_velocity(m, e);
+}
+
+__global__ __launch_bounds__(WG) void k_clear_ext(Pool P) {             // kernel_clear_external_force, abd/misc.py:874
+  int b = blockIdx.x * WG + threadIdx.x;
+  if (b >= P.B) return;
+  E e(P, b);
+  auto ext = e.ext();
+  for (int i = 0; i < NL * 6; ++i) ext[i] = 0.0f;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Go2Env (walk)  -- E/go2_env_walk.py.  All of Go2Env.step runs on the device: four per-env kernels
+// around the physics plus one single-thread kernel for the quantities the reference keeps in Python
+// scalars (curriculum state machine, "global" domain-randomisation draws).
+// ---------------------------------------------------------------------------------------------
+struct DCfg { float f[GO2SIM_FC_COUNT]; int i[GO2SIM_IC_COUNT]; };
+struct Acc { double timeouts, tracking, ep[NREW]; int n_reset_now; int pad; };
+typedef go2sim_env_globals_t Glob;
+
+enum { RNG_ACTION_NOISE = 1, RNG_PUSH = 2, RNG_CMD = 3, RNG_OBS_NOISE = 4, RNG_RESET_DR = 5, RNG_GLOBAL_DR = 6, RNG_RESET_CMD = 7, RNG_RESET_POSE = 8 };
+DEV dm_u4 rng4(uint64_t seed, uint32_t purpose, uint32_t env, uint32_t step, uint32_t idx) {
+  return dm_philox(env, step, purpose, idx, (uint32_t)seed, (uint32_t)(seed >> 32));
+}
+DEV float rand_float(float lower, float upper, uint32_t r) { return (upper - lower) * dm_u01(r) + lower; }   // gs_rand_float, go2_env_walk.py:7-8
+DEV int rand_int(int lower, int upper, uint32_t r) { return lower + (int)(r % (uint32_t)(upper - lower + 1)); }   // gs_rand_int, :11-13
+__host__ __device__ inline double clamp01d(double x) { return x < 0.0 ? 0.0 : (x > 1.0 ? 1.0 : x); }
+__host__ __device__ inline double lerpd(double a, double b, double t) { t = clamp01d(t); return a + (b - a) * t; }
+DEV float lerp_lo(const DCfg& c, int easy_lo, float t) { return (float)lerpd(c.f[easy_lo], c.f[easy_lo + 2], t); }
+DEV float lerp_hi(const DCfg& c, int easy_lo, float t) { return (float)lerpd(c.f[easy_lo + 1], c.f[easy_lo + 3], t); }
+
+// torch-side helpers of genesis/utils/geom.py used by Go2Env (evaluation order of the torch code)
+DEV Q4 tc_quat_mul(Q4 u, Q4 v) {                                   // geom.py:989-1007
+  float w1 = u.w, x1 = u.x, y1 = u.y, z1 = u.z, w2 = v.w, x2 = v.x, y2 = v.y, z2 = v.z;
+  float ww = (z1 + x1) * (x2 + y2), yy = (w1 - y1) * (w2 + z2), zz = (w1 + y1) * (w2 - z2);
+  float xx = ww + yy + zz;
+  float qq = 0.5f * (xx + (z1 - x1) * (x2 - y2));
+  Q4 o = q4(qq - ww + (z1 - y1) * (y2 - z2), qq - xx + (x1 + w1) * (x2 + w2), qq - yy + (w1 - x1) * (y2 + z2), qq - zz + (z1 + y1) * (w2 - x2));
+  float n = dm_sqrt(norm_sqr(o));
+  return q4(o.w / n, o.x / n, o.y / n, o.z / n);
+}
+DEV V3 tc_transform_by_quat(V3 v, Q4 q) {                          // geom.py:1052-1070
+  float q_ww = q.w * q.w, q_wx = q.w * q.x, q_wy = q.w * q.y, q_wz = q.w * q.z;
+  float q_xx = q.x * q.x, q_xy = q.x * q.y, q_xz = q.x * q.z, q_yy = q.y * q.y, q_yz = q.y * q.z, q_zz = q.z * q.z;
+  float den = q_ww + q_xx + q_yy + q_zz;
+  float vx = v.x / den, vy = v.y / den, vz = v.z / den;
+  return v3(vx * (q_xx + q_ww - q_yy - q_zz) + vy * (2.0f * q_xy - 2.0f * q_wz) + vz * (2.0f * q_xz + 2.0f * q_wy),
+            vx * (2.0f * q_wz + 2.0f * q_xy) + vy * (q_ww - q_xx + q_yy - q_zz) + vz * (2.0f * q_yz - 2.0f * q_wx),
+            vx * (2.0f * q_xz - 2.0f * q_wy) + vy * (2.0f * q_wx + 2.0f * q_yz) + vz * (q_ww - q_xx - q_yy + q_zz));
+}
+DEV V3 tc_quat_to_xyz_rpy_deg(Q4 q, float eps) {                   // geom.py:717-762 (rpy=True) + rad2deg
+  float q_ww = q.w * q.w, q_wx = q.w * q.x, q_wy = q.w * q.y, q_wz = q.w * q.z;
+  float q_xx = q.x * q.x, q_xy = q.x * q.y, q_xz = q.x * q.z, q_yy = q.y * q.y, q_yz = q.y * q.z, q_zz = q.z * q.z;
+  float sinp = q_wy - q_xz, sinrcosp = q_wx + q_yz, sinycosp = q_wz + q_xy;
+  float cosrcosp = (q_ww - q_xx - q_yy + q_zz) / 2.0f, cosycosp = (q_ww + q_xx - q_yy - q_zz) / 2.0f;
+  float cosp = dm_sqrt(cosycosp * cosycosp + sinycosp * sinycosp);
+  float x = dm_atan2(sinrcosp, cosrcosp), y = dm_atan2(sinp, cosp), z = dm_atan2(sinycosp, cosycosp);
+  if (cosp < eps) { x = 0.0f; z = dm_atan2(q_wz - q_xy, (q_ww - q_xx + q_yy - q_zz) / 2.0f); }
+  const float R2D = 57.29577951308232f;
+  return v3(x * R2D, y * R2D, z * R2D);
+}
+
+// Go2Env._apply_curriculum_level, go2_env_walk.py:628-686 (python float64 arithmetic)
+__host__ __device__ inline void apply_curriculum_level(const DCfg& c, Glob& g) {
+  double lvl = c.i[GO2SIM_IC_CURR_ENABLED] ? (double)g.level : 1.0;
+  g.obs_noise_level_cur = (float)lerpd(0.0, c.i[GO2SIM_IC_HAS_OBS_NOISE] ? c.f[GO2SIM_FC_OBS_NOISE_LEVEL_MAX] : 0.0, lvl);
+  g.action_noise_std_cur = (float)lerpd(0.0, c.f[GO2SIM_FC_ACTION_NOISE_STD_MAX], lvl);
+  double dt = c.f[GO2SIM_FC_DT];
+  if (!c.i[GO2SIM_IC_HAS_PUSH]) {
+    g.push_enable = 0; g.push_force_lo = g.push_force_hi = 0.0f; g.push_interval = 1000000000;
+  } else {
+    double push_start = c.f[GO2SIM_FC_PUSH_START];
+    if (lvl < push_start) {
+      g.push_enable = 0; g.push_force_lo = g.push_force_hi = 0.0f;
+      g.push_interval = (int)((double)c.f[GO2SIM_FC_PUSH_INTERVAL_S_EASY] / dt);
+    } else {
+      double den = 1.0 - push_start; if (den < 1e-6) den = 1e-6;
+      double s = clamp01d((lvl - push_start) / den);
+      g.push_force_lo = (float)((double)c.f[GO2SIM_FC_PUSH_FORCE_LO] * s);
+      g.push_force_hi = (float)((double)c.f[GO2SIM_FC_PUSH_FORCE_HI] * s);
+      double interval_s = lerpd(c.f[GO2SIM_FC_PUSH_INTERVAL_S_EASY], c.f[GO2SIM_FC_PUSH_INTERVAL_S_HARD], s);
+      int iv = (int)(interval_s / dt);
+      g.push_interval = iv < 1 ? 1 : iv;
+      g.push_enable = 1;
+    }
+  }
+  g.delay_max_cur = (int)rint(lerpd((double)c.i[GO2SIM_IC_DELAY_EASY_MAX], (double)c.i[GO2SIM_IC_MAX_DELAY], lvl));
+  double frac = c.i[GO2SIM_IC_CMD_CURRICULUM] ? lerpd(c.f[GO2SIM_FC_CMD_START_FRAC], 1.0, lvl) : 1.0;
+  {
+    double lo = c.f[GO2SIM_FC_CMD_X_LO], hi = c.f[GO2SIM_FC_CMD_X_HI], center = (lo + hi) / 2.0, half = (hi - lo) / 2.0;
+    g.cmd_x_lo = (float)(center - half * frac); g.cmd_x_hi = (float)(center + half * frac);
+    lo = c.f[GO2SIM_FC_CMD_Y_LO]; hi = c.f[GO2SIM_FC_CMD_Y_HI]; center = (lo + hi) / 2.0; half = (hi - lo) / 2.0;
+    g.cmd_y_lo = (float)(center - half * frac); g.cmd_y_hi = (float)(center + half * frac);
+    lo = c.f[GO2SIM_FC_CMD_YAW_LO]; hi = c.f[GO2SIM_FC_CMD_YAW_HI]; center = (lo + hi) / 2.0; half = (hi - lo) / 2.0;
+    g.cmd_yaw_lo = (float)(center - half * frac); g.cmd_yaw_hi = (float)(center + half * frac);
+  }
+}
+
+// CurriculumManager.update, go2_env_walk.py:101-142
+DEV bool curriculum_update(const DCfg& c, Glob& g, double timeout_rate, double tracking_per_sec, double fall_rate) {
+  double a = c.f[GO2SIM_FC_CURR_EMA_ALPHA];
+  if (!g.ema_valid) { g.timeout_rate_ema = (float)timeout_rate; g.tracking_ema = (float)tracking_per_sec; g.fall_rate_ema = (float)fall_rate; g.ema_valid = 1; }
+  else {
+    g.timeout_rate_ema = (float)((1.0 - a) * g.timeout_rate_ema + a * timeout_rate);
+    g.tracking_ema = (float)((1.0 - a) * g.tracking_ema + a * tracking_per_sec);
+    g.fall_rate_ema = (float)((1.0 - a) * g.fall_rate_ema + a * fall_rate);
+  }
+  if (g.cooldown > 0) g.cooldown -= 1;
+  bool ready = g.timeout_rate_ema >= c.f[GO2SIM_FC_CURR_READY_TIMEOUT_RATE] && g.tracking_ema >= c.f[GO2SIM_FC_CURR_READY_TRACKING] &&
+               g.fall_rate_ema <= c.f[GO2SIM_FC_CURR_READY_FALL_RATE];
+  bool hard = g.fall_rate_ema >= c.f[GO2SIM_FC_CURR_HARD_FALL_RATE];
+  g.ready_streak = ready ? g.ready_streak + 1 : 0;
+  g.hard_streak = hard ? g.hard_streak + 1 : 0;
+  float old_level = g.level;
+  if (g.hard_streak >= c.i[GO2SIM_IC_CURR_HARD_STREAK]) {
+    g.level = fmx(c.f[GO2SIM_FC_CURR_LEVEL_MIN], g.level - c.f[GO2SIM_FC_CURR_STEP_DOWN]);
+    g.hard_streak = 0; g.ready_streak = 0; g.cooldown = c.i[GO2SIM_IC_CURR_COOLDOWN];
+  } else if (g.ready_streak >= c.i[GO2SIM_IC_CURR_READY_STREAK] && g.cooldown == 0) {
+    g.level = fmn(c.f[GO2SIM_FC_CURR_LEVEL_MAX], g.level + c.f[GO2SIM_FC_CURR_STEP_UP]);
+    g.ready_streak = 0; g.cooldown = c.i[GO2SIM_IC_CURR_COOLDOWN];
+  }
+  g.level = fmx(0.0f, fmn(1.0f, g.level));
+  return g.level != old_level;
+}
+
+// Go2Env.step pre-physics part: go2_env_walk.py:985-1023 (+ _apply_push :872-906)
+__global__ __launch_bounds__(WG) void k_env_pre(Pool P, const Model* __restrict__ mp, const DCfg* __restrict__ cp, const Glob* __restrict__ gp,
+                                                const float* __restrict__ actions_in, uint64_t seed, uint32_t step_count, int write_idx) {
+  int b = blockIdx.x * WG + threadIdx.x;
+  if (b >= P.B) return;
+  const DCfg& c = *cp; const Glob& g = *gp;
+  E e(P, b);
+  const int na = c.i[GO2SIM_IC_NUM_ACTIONS];
+  float clip = c.f[GO2SIM_FC_CLIP_ACTIONS];
+  auto actions = e.actions(); auto hist = e.action_history(); auto applied = e.applied_actions();
+  int delay = e.delay_steps()[0];
+  int w_after = (write_idx + 1) % 2;
+  int read_idx = (((w_after - 1 - delay) % 2) + 2) % 2;
+  float delayed[NA];
+#pragma unroll
+  for (int i = 0; i < NA; ++i) {
+    if (i < na) {
+      float a = fmn(fmx(actions_in[(size_t)b * na + i], -clip), clip);
+      actions[i] = a;
+      float h0 = (write_idx == 0) ? a : hist[0][i], h1 = (write_idx == 1) ? a : hist[1][i];
+      hist[write_idx][i] = a;
+      float d = (read_idx == 0) ? h0 : h1;
+      delayed[i] = d; applied[i] = d;
+    } else {
+      delayed[i] = 0.0f;
+    }
+  }
+  float target[NM];
+#pragma unroll
+  for (int i = 0; i < NM; ++i) target[i] = delayed[i] * c.f[GO2SIM_FC_ACTION_SCALE] + c.f[GO2SIM_FC_DEFAULT_DOF_POS0 + i];
+  if (g.action_noise_std_cur > 0.0f) {
+#pragma unroll
+    for (int blk = 0; blk < 3; ++blk) {
+      dm_u4 r = rng4(seed, RNG_ACTION_NOISE, b, step_count, blk);
+      float n0, n1, n2, n3;
+      dm_normal2(r.v[0], r.v[1], &n0, &n1); dm_normal2(r.v[2], r.v[3], &n2, &n3);
+      target[4 * blk + 0] = target[4 * blk + 0] + n0 * g.action_noise_std_cur;
+      target[4 * blk + 1] = target[4 * blk + 1] + n1 * g.action_noise_std_cur;
+      target[4 * blk + 2] = target[4 * blk + 2] + n2 * g.action_noise_std_cur;
+      target[4 * blk + 3] = target[4 * blk + 3] + n3 * g.action_noise_std_cur;
+    }
+  }
+  auto target_dof_pos = e.target_dof_pos(); auto kp_factors = e.kp_factors(); auto kd_factors = e.kd_factors(); auto motor_strength = e.motor_strength();
+  auto dof_pos = e.e_dof_pos(); auto dof_vel = e.e_dof_vel(); auto torque_ = e.torque(); auto ctrl_mode = e.ctrl_mode(); auto ctrl_force = e.ctrl_force();
+#pragma unroll
+  for (int i = 0; i < NM; ++i) {
+    target_dof_pos[i] = target[i];
+    float eff_kp, eff_kd;
+    if (c.i[GO2SIM_IC_PLS_ENABLE]) {                                 // _compute_pls_kp_kd :969-979
+      int leg = i / 3;
+      float kp_leg = c.f[GO2SIM_FC_PLS_KP_DEFAULT] + delayed[NM + leg] * c.f[GO2SIM_FC_PLS_KP_ACTION_SCALE];
+      kp_leg = fmn(fmx(kp_leg, c.f[GO2SIM_FC_PLS_KP_MIN]), c.f[GO2SIM_FC_PLS_KP_MAX]);
+      float kd_j = 0.2f * dm_sqrt(kp_leg);
+      eff_kp = kp_leg * kp_factors[i] * motor_strength[i];
+      eff_kd = kd_j * kd_factors[i];
+    } else {
+      eff_kp = c.f[GO2SIM_FC_KP] * kp_factors[i]; eff_kd = c.f[GO2SIM_FC_KD] * kd_factors[i];
+    }
+    float pos_error = target[i] - dof_pos[i];
+    float torque = eff_kp * pos_error - eff_kd * dof_vel[i];
+    float lim = c.f[GO2SIM_FC_TORQUE_LIMIT0 + i];
+    torque = fmn(fmx(torque, -lim), lim);
+    torque_[i] = torque;
+    int d = c.i[GO2SIM_IC_MOTOR_DOF0 + i];
+    ctrl_mode[d] = CTRL_FORCE; ctrl_force[d] = torque;
+  }
+  auto cpf = e.current_push_force();
+  if (!c.i[GO2SIM_IC_HAS_PUSH] || !g.push_enable) {
+    cpf[0] = 0.0f; cpf[1] = 0.0f; cpf[2] = 0.0f;
+  } else {
+    auto psf = e.push_stored_force(); auto prem = e.push_remaining();
+    if (g.push_counter % g.push_interval == 0) {
+      dm_u4 r = rng4(seed, RNG_PUSH, b, step_count, 0);
+      psf[0] = rand_float(g.push_force_lo, g.push_force_hi, r.v[0]);
+      psf[1] = rand_float(g.push_force_lo, g.push_force_hi, r.v[1]);
+      psf[2] = 0.0f;
+      prem[0] = rand_int(c.i[GO2SIM_IC_PUSH_DUR_LO], c.i[GO2SIM_IC_PUSH_DUR_HI], r.v[2]);
+    }
+    int rem = prem[0];
+    float active = (rem > 0) ? 1.0f : 0.0f;
+    V3 force = v3(psf[0] * active, psf[1] * active, psf[2] * active);
+    cpf[0] = force.x; cpf[1] = force.y; cpf[2] = force.z;
+    prem[0] = imx(rem - 1, 0);
+    int l = c.i[GO2SIM_IC_PUSH_LINK];                                  // func_apply_link_external_force ref=link_origin, abd/misc.py:695-715
+    V3 tq = cross((V3)e.l_pos()[l] - (V3)e.root_com()[l], force);
+    auto ext = e.ext();
+    ext[6 * l + 0] = ext[6 * l + 0] - tq.x; ext[6 * l + 1] = ext[6 * l + 1] - tq.y; ext[6 * l + 2] = ext[6 * l + 2] - tq.z;
+    ext[6 * l + 3] = ext[6 * l + 3] - force.x; ext[6 * l + 4] = ext[6 * l + 4] - force.y; ext[6 * l + 5] = ext[6 * l + 5] - force.z;
+  }
+}
+
+struct RewCtx { float link_vel_xy[8], foot_z[4]; };
+// reward terms, go2_env_walk.py:1251-1366
+DEV float reward_term(const Model& m, const DCfg& c, const E& e, int id, const RewCtx& rc) {
+  const float dt = c.f[GO2SIM_FC_DT];
+  auto cmd = e.commands(); auto blv = e.base_lin_vel(); auto bav = e.base_ang_vel(); auto dof_pos = e.e_dof_pos(); auto dof_vel = e.e_dof_vel();
+  float c0 = cmd[0], c1 = cmd[1], c2 = cmd[2];
+  float cmd_norm = dm_sqrt(c0 * c0 + c1 * c1 + c2 * c2);
+  float still = (cmd_norm < 0.1f) ? 1.0f : 0.0f;
+  float moving = (dm_sqrt(c0 * c0 + c1 * c1) > 0.1f) ? 1.0f : 0.0f;
+  switch (id) {
+    case GO2SIM_R_TRACKING_LIN_VEL: { float d0 = c0 - blv[0], d1 = c1 - blv[1]; return dm_exp(-(d0 * d0 + d1 * d1) / c.f[GO2SIM_FC_TRACKING_SIGMA]); }
+    case GO2SIM_R_TRACKING_ANG_VEL: { float d = c2 - bav[2]; return dm_exp(-(d * d) / c.f[GO2SIM_FC_TRACKING_SIGMA]); }
+    case GO2SIM_R_LIN_VEL_Z: { float v = blv[2]; return v * v; }
+    case GO2SIM_R_ACTION_RATE: { float s = 0.0f; auto la = e.last_actions(); auto a = e.actions(); for (int i = 0; i < c.i[GO2SIM_IC_NUM_ACTIONS]; ++i) { float d = la[i] - a[i]; s = s + d * d; } return s; }
+    case GO2SIM_R_SIMILAR_TO_DEFAULT: { float s = 0.0f; for (int i = 0; i < NM; ++i) s = s + dm_abs(dof_pos[i] - c.f[GO2SIM_FC_DEFAULT_DOF_POS0 + i]); return s; }
+    case GO2SIM_R_BASE_HEIGHT: { float d = e.base_pos()[2] - c.f[GO2SIM_FC_BASE_HEIGHT_TARGET]; return d * d; }
+    case GO2SIM_R_DOF_ACC: { float s = 0.0f; auto ldv = e.last_dof_vel(); for (int i = 0; i < NM; ++i) { float a = (dof_vel[i] - ldv[i]) / dt; s = s + a * a; } return s; }
+    case GO2SIM_R_DOF_VEL: { float s = 0.0f; for (int i = 0; i < NM; ++i) { float v = dof_vel[i]; s = s + v * v; } return s; }
+    case GO2SIM_R_ORIENTATION_PENALTY: { auto pg = e.projected_gravity(); float a = pg[0], b2 = pg[1]; return a * a + b2 * b2; }
+    case GO2SIM_R_ANG_VEL_XY: { float a = bav[0], b2 = bav[1]; return a * a + b2 * b2; }
+    case GO2SIM_R_STAND_STILL: { float s = 0.0f; for (int i = 0; i < NM; ++i) s = s + dm_abs(dof_pos[i] - c.f[GO2SIM_FC_DEFAULT_DOF_POS0 + i]); return s * still; }
+    case GO2SIM_R_STAND_STILL_VEL: { float a = blv[0], b2 = blv[1], w = bav[2]; float lin = a * a + b2 * b2; float ang = w * w; return (lin + 0.5f * ang) * still; }
+    case GO2SIM_R_FEET_STANCE: {
+      float sa = 0.0f, sn = 0.0f; auto fat = e.feet_air_time(); auto fc = e.foot_contact();
+      for (int i = 0; i < 4; ++i) { sa = sa + fat[i]; sn = sn + (fc[i] ? 0.0f : 1.0f); }
+      return (sa + sn) * still;
+    }
+    case GO2SIM_R_FEET_AIR_TIME: {                                     // mutates _feet_air_time (:1303-1314)
+      auto fat = e.feet_air_time(); auto fc = e.foot_contact();
+      float first[4], at[4];
+      for (int i = 0; i < 4; ++i) { float a = fat[i]; int ct = fc[i]; first[i] = (a > 0.0f && ct) ? 1.0f : 0.0f; a = a + dt; a = a * (ct ? 0.0f : 1.0f); fat[i] = a; at[i] = a; }
+      float s = 0.0f;
+      for (int i = 0; i < 4; ++i) s = s + (at[i] - c.f[GO2SIM_FC_FEET_AIR_TIME_TARGET]) * first[i];
+      return s * moving;
+    }
+    case GO2SIM_R_FOOT_SLIP: {
+      float slip = 0.0f; auto fc = e.foot_contact();
+      for (int i = 0; i < 4; ++i) { float vx = rc.link_vel_xy[2 * i], vy = rc.link_vel_xy[2 * i + 1]; slip = slip + (fc[i] ? 1.0f : 0.0f) * (vx * vx + vy * vy); }
+      return slip;
+    }
+    case GO2SIM_R_FOOT_CLEARANCE: {
+      float pen = 0.0f; auto fc = e.foot_contact();
+      for (int i = 0; i < 4; ++i) {
+        float vx = rc.link_vel_xy[2 * i], vy = rc.link_vel_xy[2 * i + 1];
+        float vn = dm_sqrt(vx * vx + vy * vy);
+        float he = c.f[GO2SIM_FC_FEET_HEIGHT_TARGET] - rc.foot_z[i]; he = he * he;
+        pen = pen + (fc[i] ? 0.0f : 1.0f) * he * vn;
+      }
+      return pen * moving;
+    }
+    case GO2SIM_R_JOINT_TRACKING: { float s = 0.0f; auto t = e.target_dof_pos(); for (int i = 0; i < NM; ++i) { float d = t[i] - dof_pos[i]; s = s + d * d; } return s; }
+    case GO2SIM_R_ENERGY: case GO2SIM_R_TORQUE_LOAD: {                 // get_dofs_control_force, abd/accessor.py:848-875
+      float s = 0.0f; auto cf = e.ctrl_force();
+      for (int i = 0; i < NM; ++i) {
+        int d = c.i[GO2SIM_IC_MOTOR_DOF0 + i];
+        float tau = clampf(cf[d], m.dofs[d].force_range[0], m.dofs[d].force_range[1]);
+        s = s + ((id == GO2SIM_R_ENERGY) ? dm_abs(tau * dof_vel[i]) : dm_abs(tau));
+      }
+      return s;
+    }
+  }
+  return 0.0f;
+}
+
+// Go2Env.step post-physics part A: clear_external_force, state read-back, commands, termination, rewards
+// (simulator.py:283-284, go2_env_walk.py:1026-1077) + reset-call statistics (:688-715,1228-1235)
+__global__ __launch_bounds__(WG) void k_env_post_a(Pool P, const Model* __restrict__ mp, const DCfg* __restrict__ cp, const Glob* __restrict__ gp,
+                                                   Acc* acc, uint64_t seed, uint32_t step_count) {
+  int b = blockIdx.x * WG + threadIdx.x;
+  if (b >= P.B) return;
+  const Model& m = *mp; const DCfg& c = *cp; const Glob& g = *gp;
+  E e(P, b);
+  { auto ext = e.ext(); for (int i = 0; i < NL * 6; ++i) ext[i] = 0.0f; }
+  int ep_len = e.episode_length()[0] + 1;
+  e.episode_length()[0] = ep_len;
+  int bl = c.i[GO2SIM_IC_BASE_LINK];
+  V3 bp = e.l_pos()[bl]; Q4 bq = e.l_quat()[bl];
+  auto base_pos = e.base_pos(); auto base_quat = e.base_quat();
+  base_pos[0] = bp.x; base_pos[1] = bp.y; base_pos[2] = bp.z;
+  base_quat[0] = bq.w; base_quat[1] = bq.x; base_quat[2] = bq.y; base_quat[3] = bq.z;
+  Q4 inv_init = inv_quat(q4(c.f[GO2SIM_FC_BASE_INIT_QUAT0], c.f[GO2SIM_FC_BASE_INIT_QUAT0 + 1], c.f[GO2SIM_FC_BASE_INIT_QUAT0 + 2], c.f[GO2SIM_FC_BASE_INIT_QUAT0 + 3]));
+  V3 eul = tc_quat_to_xyz_rpy_deg(tc_quat_mul(bq, inv_init), m.eps);
+  auto base_euler = e.base_euler();
+  base_euler[0] = eul.x; base_euler[1] = eul.y; base_euler[2] = eul.z;
+  Q4 inv_bq = inv_quat(bq);
+  V3 rcom = e.root_com()[bl];
+  V3 cda = e.cd_ang()[bl];
+  V3 velw = (V3)e.cd_vel()[bl] + cross(cda, bp - rcom);
+  V3 blv = tc_transform_by_quat(velw, inv_bq), bav = tc_transform_by_quat(cda, inv_bq);
+  V3 pg = tc_transform_by_quat(v3(0.0f, 0.0f, -1.0f), inv_bq);
+  auto o_blv = e.base_lin_vel(); auto o_bav = e.base_ang_vel(); auto o_pg = e.projected_gravity();
+  o_blv[0] = blv.x; o_blv[1] = blv.y; o_blv[2] = blv.z;
+  o_bav[0] = bav.x; o_bav[1] = bav.y; o_bav[2] = bav.z;
+  o_pg[0] = pg.x; o_pg[1] = pg.y; o_pg[2] = pg.z;
+  auto dof_pos = e.e_dof_pos(); auto dof_vel = e.e_dof_vel(); auto sdof_pos = e.dof_pos(); auto vel = e.vel();
+  for (int i = 0; i < NM; ++i) { int d = c.i[GO2SIM_IC_MOTOR_DOF0 + i]; dof_pos[i] = sdof_pos[d]; dof_vel[i] = vel[d]; }
+  RewCtx rc;
+  auto fc = e.foot_contact(); auto lfc = e.last_foot_contact();
+  for (int i = 0; i < 4; ++i) {
+    int l = c.i[GO2SIM_IC_FOOT_LINK0 + i];
+    lfc[i] = fc[i];
+    V3 cf = e.contact_force()[l];
+    fc[i] = dm_abs(cf.z) > c.f[GO2SIM_FC_FOOT_CONTACT_THRESHOLD];
+    V3 lp = e.l_pos()[l];
+    V3 lv = (V3)e.cd_vel()[l] + cross((V3)e.cd_ang()[l], lp - rcom);
+    rc.link_vel_xy[2 * i] = lv.x; rc.link_vel_xy[2 * i + 1] = lv.y; rc.foot_z[i] = lp.z;
+  }
+  auto cmd = e.commands();
+  if (ep_len % c.i[GO2SIM_IC_RESAMPLE_STEPS] == 0) {
+    dm_u4 r = rng4(seed, RNG_CMD, b, step_count, 0);
+    float cx = rand_float(g.cmd_x_lo, g.cmd_x_hi, r.v[0]), cy = rand_float(g.cmd_y_lo, g.cmd_y_hi, r.v[1]), cz = rand_float(g.cmd_yaw_lo, g.cmd_yaw_hi, r.v[2]);
+    if (b < c.i[GO2SIM_IC_N_STANDING]) { cx = 0.0f; cy = 0.0f; cz = 0.0f; }
+    cmd[0] = cx; cmd[1] = cy; cmd[2] = cz;
+  }
+  int maxlen = c.i[GO2SIM_IC_MAX_EPISODE_LENGTH];
+  int rst = ep_len > maxlen;
+  rst |= dm_abs(eul.y) > c.f[GO2SIM_FC_TERM_PITCH_DEG];
+  rst |= dm_abs(eul.x) > c.f[GO2SIM_FC_TERM_ROLL_DEG];
+  rst |= dm_abs(blv.z) > c.f[GO2SIM_FC_TERM_ZVEL];
+  rst |= dm_abs(blv.y) > c.f[GO2SIM_FC_TERM_YVEL];
+  e.reset_buf()[0] = rst;
+  float time_out = (ep_len > maxlen) ? 1.0f : 0.0f;
+  e.time_out()[0] = time_out;
+  float rew = 0.0f;
+  auto rew_terms = e.rew_terms(); auto episode_sums = e.episode_sums();
+  int nrew = c.i[GO2SIM_IC_N_REWARDS];
+  float tracking_int = 0.0f;
+  for (int k = 0; k < nrew; ++k) {
+    int id = c.i[GO2SIM_IC_REWARD_ID0 + k];
+    float r = reward_term(m, c, e, id, rc) * c.f[GO2SIM_FC_REWARD_SCALE0 + k];
+    rew_terms[k] = r;
+    rew = rew + r;
+    float es = episode_sums[k] + r;
+    episode_sums[k] = es;
+    if (id == GO2SIM_R_TRACKING_LIN_VEL || id == GO2SIM_R_TRACKING_ANG_VEL) tracking_int = tracking_int + es;
+  }
+  e.rew()[0] = rew;
+  if (rst) {
+    float ep_steps = fmx((float)ep_len, 1.0f);
+    float ep_seconds = ep_steps * c.f[GO2SIM_FC_DT];
+    for (int k = 0; k < nrew; ++k) atomicAdd(&acc->ep[k], (double)(episode_sums[k] / ep_seconds));
+    atomicAdd(&acc->tracking, (double)(tracking_int / ep_seconds));
+    atomicAdd(&acc->timeouts, (double)time_out);
+    atomicAdd(&acc->n_reset_now, 1);
+  }
+}
+
+// Go2Env.reset: mark every env for reset + statistics (go2_env_walk.py:1242-1245)
+__global__ __launch_bounds__(WG) void k_env_mark_all(Pool P, const DCfg* __restrict__ cp, Acc* acc) {
+  int b = blockIdx.x * WG + threadIdx.x;
+  if (b >= P.B) return;
+  const DCfg& c = *cp;
+  E e(P, b);
+  e.reset_buf()[0] = 1;
+  int ep_len = e.episode_length()[0];
+  float ep_steps = fmx((float)ep_len, 1.0f);
+  float ep_seconds = ep_steps * c.f[GO2SIM_FC_DT];
+  auto episode_sums = e.episode_sums();
+  int nrew = c.i[GO2SIM_IC_N_REWARDS];
+  float tracking_int = 0.0f;
+  for (int k = 0; k < nrew; ++k) {
+    int id = c.i[GO2SIM_IC_REWARD_ID0 + k];
+    float es = episode_sums[k];
+    if (id == GO2SIM_R_TRACKING_LIN_VEL || id == GO2SIM_R_TRACKING_ANG_VEL) tracking_int = tracking_int + es;
+    atomicAdd(&acc->ep[k], (double)(es / ep_seconds));
+  }
+  atomicAdd(&acc->tracking, (double)(tracking_int / ep_seconds));
+  atomicAdd(&acc->timeouts, (double)e.time_out()[0]);
+  atomicAdd(&acc->n_reset_now, 1);
+}
+
+// single-instance part of reset_idx: curriculum, t_sample, "global" DR (go2_env_walk.py:688-756,803-848,1160-1171)
+__global__ void k_env_globals(const DCfg* __restrict__ cp, Glob* gp, Acc* acc, uint64_t seed, int count_push) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  const DCfg& c = *cp; Glob& g = *gp;
+  if (count_push && c.i[GO2SIM_IC_HAS_PUSH] && g.push_enable) g.push_counter += 1;
+  int n = acc->n_reset_now;
+  g.n_reset_now = n;
+  if (n > 0) {
+    if (c.i[GO2SIM_IC_CURR_ENABLED] && !c.i[GO2SIM_IC_FREEZE_CURRICULUM]) {
+      g.curr_ep_total += n; g.curr_timeout_total += (float)acc->timeouts; g.curr_tracking_sum += (float)acc->tracking; g.curr_tracking_n += n;
+      if (g.curr_ep_total >= c.i[GO2SIM_IC_CURR_UPDATE_EVERY]) {
+        double timeout_rate = (double)g.curr_timeout_total / (double)imx(1, g.curr_ep_total);
+        double fall_rate = 1.0 - timeout_rate;
+        double tracking_avg = (double)g.curr_tracking_sum / (double)imx(1, g.curr_tracking_n);
+        if (curriculum_update(c, g, timeout_rate, tracking_avg, fall_rate)) apply_curriculum_level(c, g);
+        g.curr_ep_total = 0; g.curr_timeout_total = 0.0f; g.curr_tracking_sum = 0.0f; g.curr_tracking_n = 0;
+      }
+    }
+    dm_u4 r0 = rng4(seed, RNG_GLOBAL_DR, 0xffffffffu, g.reset_calls, 0);
+    dm_u4 r1 = rng4(seed, RNG_GLOBAL_DR, 0xffffffffu, g.reset_calls, 1);
+    dm_u4 r2 = rng4(seed, RNG_GLOBAL_DR, 0xffffffffu, g.reset_calls, 2);
+    double t;
+    if (!c.i[GO2SIM_IC_CURR_ENABLED]) t = 1.0;
+    else if (dm_u01(r0.v[0]) < c.f[GO2SIM_FC_CURR_MIX_PROB_CURRENT]) t = clamp01d(g.level);
+    else {
+      double hi = (double)g.level < (double)c.f[GO2SIM_FC_CURR_MIX_LEVEL_HIGH] ? (double)g.level : (double)c.f[GO2SIM_FC_CURR_MIX_LEVEL_HIGH];
+      double lo = (double)c.f[GO2SIM_FC_CURR_MIX_LEVEL_LOW] < hi ? (double)c.f[GO2SIM_FC_CURR_MIX_LEVEL_LOW] : hi;
+      t = clamp01d(lo + (hi - lo) * (double)dm_u01(r0.v[1]));
+    }
+    g.t_sample = (float)t;
+    float ts = g.t_sample;
+    if (c.i[GO2SIM_IC_HAS_FRICTION_DR]) {
+      g.global_dr_reset_counter += n;
+      if (g.global_dr_reset_counter >= c.i[GO2SIM_IC_GLOBAL_DR_INTERVAL]) {
+        g.global_dr_reset_counter = 0;
+        g.friction = rand_float(lerp_lo(c, GO2SIM_FC_FRICTION_EASY_LO, ts), lerp_hi(c, GO2SIM_FC_FRICTION_EASY_LO, ts), r0.v[2]);
+      }
+    }
+    if (c.i[GO2SIM_IC_HAS_MASS_DR]) g.mass_shift = rand_float(lerp_lo(c, GO2SIM_FC_MASS_EASY_LO, ts), lerp_hi(c, GO2SIM_FC_MASS_EASY_LO, ts), r0.v[3]);
+    if (c.i[GO2SIM_IC_HAS_COM_DR])
+      for (int k = 0; k < 3; ++k) g.com_shift[k] = rand_float(lerp_lo(c, GO2SIM_FC_COM_EASY_LO, ts), lerp_hi(c, GO2SIM_FC_COM_EASY_LO, ts), r1.v[k]);
+    if (c.i[GO2SIM_IC_HAS_LEGM_DR])
+      for (int k = 0; k < 4; ++k) g.leg_mass_shift[k] = rand_float(lerp_lo(c, GO2SIM_FC_LEGM_EASY_LO, ts), lerp_hi(c, GO2SIM_FC_LEGM_EASY_LO, ts), r2.v[k]);
+    g.last_reset_count = n;
+    for (int k = 0; k < NREW; ++k) g.last_episode_rew[k] = (float)(acc->ep[k] / (double)n);
+    g.reset_calls += 1;
+  }
+}
+
+// per-env part of reset_idx (go2_env_walk.py:1156-1240)
+DEV void env_reset_one(const Model& m, const DCfg& c, const Glob& g, const E& e, int b, uint64_t seed) {
+  uint32_t rc = g.reset_calls - 1;
+  float ts = g.t_sample;
+  auto kp_factors = e.kp_factors(); auto kd_factors = e.kd_factors(); auto motor_strength = e.motor_strength(); auto gravity_offset = e.gravity_offset();
+  if (c.i[GO2SIM_IC_HAS_KPF_DR])
+    for (int blk = 0; blk < 3; ++blk) { dm_u4 r = rng4(seed, RNG_RESET_DR, b, rc, blk); for (int k = 0; k < 4; ++k) kp_factors[4 * blk + k] = rand_float(lerp_lo(c, GO2SIM_FC_KPF_EASY_LO, ts), lerp_hi(c, GO2SIM_FC_KPF_EASY_LO, ts), r.v[k]); }
+  if (c.i[GO2SIM_IC_HAS_KDF_DR])
+    for (int blk = 0; blk < 3; ++blk) { dm_u4 r = rng4(seed, RNG_RESET_DR, b, rc, 3 + blk); for (int k = 0; k < 4; ++k) kd_factors[4 * blk + k] = rand_float(lerp_lo(c, GO2SIM_FC_KDF_EASY_LO, ts), lerp_hi(c, GO2SIM_FC_KDF_EASY_LO, ts), r.v[k]); }
+  if (c.i[GO2SIM_IC_HAS_GOFF_DR]) {
+    dm_u4 r = rng4(seed, RNG_RESET_DR, b, rc, 6);
+    for (int k = 0; k < 3; ++k) gravity_offset[k] = rand_float(lerp_lo(c, GO2SIM_FC_GOFF_EASY_LO, ts), lerp_hi(c, GO2SIM_FC_GOFF_EASY_LO, ts), r.v[k]);
+  }
+  if (c.i[GO2SIM_IC_HAS_MSTR_DR])
+    for (int blk = 0; blk < 3; ++blk) { dm_u4 r = rng4(seed, RNG_RESET_DR, b, rc, 7 + blk); for (int k = 0; k < 4; ++k) motor_strength[4 * blk + k] = rand_float(lerp_lo(c, GO2SIM_FC_MSTR_EASY_LO, ts), lerp_hi(c, GO2SIM_FC_MSTR_EASY_LO, ts), r.v[k]); }
+  dm_u4 rp = rng4(seed, RNG_RESET_POSE, b, rc, 0);
+  {
+    int max_d = imx(c.i[GO2SIM_IC_MIN_DELAY], imn(g.delay_max_cur, c.i[GO2SIM_IC_MAX_DELAY]));
+    e.delay_steps()[0] = rand_int(c.i[GO2SIM_IC_MIN_DELAY], max_d, rp.v[3]);
+  }
+  auto dof_pos = e.e_dof_pos(); auto dof_vel = e.e_dof_vel(); auto qpos = e.qpos(); auto vel = e.vel();
+  for (int i = 0; i < NM; ++i) {
+    float dp = c.f[GO2SIM_FC_DEFAULT_DOF_POS0 + i];
+    dof_pos[i] = dp; dof_vel[i] = 0.0f;
+    int d = c.i[GO2SIM_IC_MOTOR_DOF0 + i];
+    int q = d + 1;
+    qpos[q] = m.qpos0[q] + dp;
+  }
+  for (int d = 0; d < ND; ++d) vel[d] = 0.0f;
+  e.err()[0] = 0; e.is_warmstart()[0] = 0;
+  { auto qacc_ws = e.qacc_ws(); for (int d = 0; d < ND; ++d) qacc_ws[d] = 0.0f; }
+  { auto ncache = e.normal_cache(); for (int p = 0; p < NPAIR; ++p) ncache[p] = v3(0, 0, 0); }
+  float bpx = c.f[GO2SIM_FC_BASE_INIT_POS0], bpy = c.f[GO2SIM_FC_BASE_INIT_POS0 + 1], bpz = c.f[GO2SIM_FC_BASE_INIT_POS0 + 2];
+  float bq[4] = {c.f[GO2SIM_FC_BASE_INIT_QUAT0], c.f[GO2SIM_FC_BASE_INIT_QUAT0 + 1], c.f[GO2SIM_FC_BASE_INIT_QUAT0 + 2], c.f[GO2SIM_FC_BASE_INIT_QUAT0 + 3]};
+  if (c.i[GO2SIM_IC_HAS_INIT_Z]) bpz = rand_float(c.f[GO2SIM_FC_INIT_Z_LO], c.f[GO2SIM_FC_INIT_Z_HI], rp.v[0]);
+  if (c.i[GO2SIM_IC_HAS_INIT_EULER]) {                                 // euler_to_quat_wxyz, go2_env_walk.py:16-25
+    const float D2R = 0.017453292519943295f;
+    float lo = c.f[GO2SIM_FC_INIT_EULER_LO_DEG] * D2R, hi = c.f[GO2SIM_FC_INIT_EULER_HI_DEG] * D2R;
+    float roll = rand_float(lo, hi, rp.v[1]), pitch = rand_float(lo, hi, rp.v[2]), yaw = 0.0f;
+    float sr, cr, sp, cpp, sy, cy;
+    dm_sincos(roll / 2.0f, &sr, &cr); dm_sincos(pitch / 2.0f, &sp, &cpp); dm_sincos(yaw / 2.0f, &sy, &cy);
+    bq[0] = cr * cpp * cy + sr * sp * sy; bq[1] = sr * cpp * cy - cr * sp * sy;
+    bq[2] = cr * sp * cy + sr * cpp * sy; bq[3] = cr * cpp * sy - sr * sp * cy;
+  }
+  auto base_pos = e.base_pos(); auto base_quat = e.base_quat();
+  base_pos[0] = bpx; base_pos[1] = bpy; base_pos[2] = bpz;
+  qpos[0] = bpx; qpos[1] = bpy; qpos[2] = bpz;
+  for (int k = 0; k < 4; ++k) { base_quat[k] = bq[k]; qpos[3 + k] = bq[k]; }
+  auto blv = e.base_lin_vel(); auto bav = e.base_ang_vel();
+  for (int k = 0; k < 3; ++k) { blv[k] = 0.0f; bav[k] = 0.0f; }
+  auto la = e.last_actions(); auto aa = e.applied_actions(); auto hist = e.action_history();
+  for (int i = 0; i < NA; ++i) { la[i] = 0.0f; aa[i] = 0.0f; hist[0][i] = 0.0f; hist[1][i] = 0.0f; }
+  { auto ldv = e.last_dof_vel(); for (int i = 0; i < NM; ++i) ldv[i] = 0.0f; }
+  { auto psf = e.push_stored_force(); for (int k = 0; k < 3; ++k) psf[k] = 0.0f; }
+  e.push_remaining()[0] = 0;
+  { auto fat = e.feet_air_time(); auto fc = e.foot_contact(); auto lfc = e.last_foot_contact(); for (int i = 0; i < 4; ++i) { fat[i] = 0.0f; fc[i] = 0; lfc[i] = 0; } }
+  { auto es = e.episode_sums(); for (int k = 0; k < NREW; ++k) es[k] = 0.0f; }
+  e.episode_length()[0] = 0; e.reset_buf()[0] = 1;
+  dm_u4 r = rng4(seed, RNG_RESET_CMD, b, rc, 0);
+  float cx = rand_float(g.cmd_x_lo, g.cmd_x_hi, r.v[0]), cy = rand_float(g.cmd_y_lo, g.cmd_y_hi, r.v[1]), cz = rand_float(g.cmd_yaw_lo, g.cmd_yaw_hi, r.v[2]);
+  if (b < c.i[GO2SIM_IC_N_STANDING]) { cx = 0.0f; cy = 0.0f; cz = 0.0f; }
+  auto cmd = e.commands();
+  cmd[0] = cx; cmd[1] = cy; cmd[2] = cz;
+}
+
+// per-env tail of a reset call: reset flagged envs, broadcast the "global" DR scalars, refresh FK for the
+// full batch (the reference's set_dofs_position/set_pos/set_quat/zero_all_dofs_velocity each run a
+// full-batch FK: rigid_solver.py:1928-1943,2412-2427)
+DEV void reset_tail(const Model& m, const DCfg& c, const Glob& g, const E& e, int b, uint64_t seed) {
+  if (g.n_reset_now <= 0) return;
+  if (e.reset_buf()[0]) env_reset_one(m, c, g, e, b, seed);
+  if (c.i[GO2SIM_IC_HAS_FRICTION_DR]) { auto gf = e.geom_friction(); for (int i = 0; i < NG; ++i) gf[i] = g.friction; }
+  int bl = c.i[GO2SIM_IC_BASE_LINK];
+  if (c.i[GO2SIM_IC_HAS_MASS_DR]) e.mass_shift()[bl] = g.mass_shift;
+  if (c.i[GO2SIM_IC_HAS_COM_DR]) e.com_shift()[bl] = v3(g.com_shift[0], g.com_shift[1], g.com_shift[2]);
+  if (c.i[GO2SIM_IC_HAS_LEGM_DR]) for (int k = 0; k < 4; ++k) e.mass_shift()[c.i[GO2SIM_IC_HIP_LINK0 + k]] = g.leg_mass_shift[k];
+  update_cartesian_space(m, e, true);
+  forward_velocity(m, e);
+}
+
+__global__ __launch_bounds__(WG) void k_env_reset_tail(Pool P, const Model* __restrict__ mp, const DCfg* __restrict__ cp, const Glob* __restrict__ gp, uint64_t seed) {
+  int b = blockIdx.x * WG + threadIdx.x;
+  if (b >= P.B) return;
+  E e(P, b);
+  reset_tail(*mp, *cp, *gp, e, b, seed);
+}
+
+// Go2Env.step post-physics part B: reset_idx tail + observations (go2_env_walk.py:1080-1141)
+__global__ __launch_bounds__(WG) void k_env_post_b(Pool P, const Model* __restrict__ mp, const DCfg* __restrict__ cp, const Glob* __restrict__ gp,
+                                                   uint64_t seed, uint32_t step_count, float* __restrict__ obs_out, float* __restrict__ priv_out,
+                                                   float* __restrict__ rew_out, uint8_t* __restrict__ reset_out, float* __restrict__ timeout_out) {
+  int b = blockIdx.x * WG + threadIdx.x;
+  if (b >= P.B) return;
+  const Model& m = *mp; const DCfg& c = *cp; const Glob& g = *gp;
+  E e(P, b);
+  int was_reset = e.reset_buf()[0];
+  reset_tail(m, c, g, e, b, seed);
+  const int na = c.i[GO2SIM_IC_NUM_ACTIONS], nobs = c.i[GO2SIM_IC_NUM_OBS], npriv = c.i[GO2SIM_IC_NUM_PRIV_OBS];
+  auto o = e.obs(); auto p = e.priv();
+  auto bav = e.base_ang_vel(); auto pg = e.projected_gravity(); auto goff = e.gravity_offset(); auto cmd = e.commands(); auto dof_pos = e.e_dof_pos();
+  auto dof_vel = e.e_dof_vel(); auto applied = e.applied_actions();
+  const float cs[3] = {c.f[GO2SIM_FC_OBS_SCALE_LIN_VEL], c.f[GO2SIM_FC_OBS_SCALE_LIN_VEL], c.f[GO2SIM_FC_OBS_SCALE_ANG_VEL]};
+  for (int k = 0; k < 3; ++k) o[k] = bav[k] * c.f[GO2SIM_FC_OBS_SCALE_ANG_VEL];
+  for (int k = 0; k < 3; ++k) o[3 + k] = pg[k] + goff[k];
+  for (int k = 0; k < 3; ++k) o[6 + k] = cmd[k] * cs[k];
+  for (int i = 0; i < NM; ++i) o[9 + i] = (dof_pos[i] - c.f[GO2SIM_FC_DEFAULT_DOF_POS0 + i]) * c.f[GO2SIM_FC_OBS_SCALE_DOF_POS];
+  for (int i = 0; i < NM; ++i) o[21 + i] = dof_vel[i] * c.f[GO2SIM_FC_OBS_SCALE_DOF_VEL];
+  for (int i = 0; i < na; ++i) o[33 + i] = applied[i];
+  if (c.i[GO2SIM_IC_HAS_OBS_NOISE] && c.f[GO2SIM_FC_OBS_NOISE_LEVEL_MAX] > 0.0f) {
+    float lvl = g.obs_noise_level_cur;
+    for (int blk = 0; blk * 4 < nobs; ++blk) {
+      dm_u4 r = rng4(seed, RNG_OBS_NOISE, b, step_count, blk);
+      float n[4];
+      dm_normal2(r.v[0], r.v[1], &n[0], &n[1]); dm_normal2(r.v[2], r.v[3], &n[2], &n[3]);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        int i = 4 * blk + k;
+        if (i < nobs) {
+          float nv = 0.0f;
+          if (i < 3) nv = c.f[GO2SIM_FC_OBS_NOISE_ANG_VEL] * c.f[GO2SIM_FC_OBS_SCALE_ANG_VEL] * lvl;
+          else if (i < 6) nv = c.f[GO2SIM_FC_OBS_NOISE_GRAVITY] * lvl;
+          else if (i < 9) nv = 0.0f;
+          else if (i < 21) nv = c.f[GO2SIM_FC_OBS_NOISE_DOF_POS] * c.f[GO2SIM_FC_OBS_SCALE_DOF_POS] * lvl;
+          else if (i < 33) nv = c.f[GO2SIM_FC_OBS_NOISE_DOF_VEL] * c.f[GO2SIM_FC_OBS_SCALE_DOF_VEL] * lvl;
+          o[i] = o[i] + n[k] * nv;
+        }
+      }
+    }
+  }
+  for (int i = 0; i < nobs; ++i) p[i] = o[i];
+  int idx = nobs;
+  auto blv = e.base_lin_vel(); auto kpf = e.kp_factors(); auto kdf = e.kd_factors(); auto mst = e.motor_strength(); auto cpf = e.current_push_force();
+  for (int k = 0; k < 3; ++k) p[idx + k] = blv[k] * c.f[GO2SIM_FC_OBS_SCALE_LIN_VEL];
+  idx += 3;
+  p[idx] = g.friction; idx += 1;
+  for (int i = 0; i < NM; ++i) p[idx + i] = kpf[i];
+  idx += 12;
+  for (int i = 0; i < NM; ++i) p[idx + i] = kdf[i];
+  idx += 12;
+  for (int i = 0; i < NM; ++i) p[idx + i] = mst[i];
+  idx += 12;
+  p[idx] = g.mass_shift; idx += 1;
+  for (int k = 0; k < 3; ++k) p[idx + k] = g.com_shift[k];
+  idx += 3;
+  for (int k = 0; k < 4; ++k) p[idx + k] = g.leg_mass_shift[k];
+  idx += 4;
+  for (int k = 0; k < 3; ++k) p[idx + k] = goff[k];
+  idx += 3;
+  for (int k = 0; k < 3; ++k) p[idx + k] = cpf[k];
+  idx += 3;
+  if (c.i[GO2SIM_IC_MAX_DELAY] > 0) p[idx] = (float)e.delay_steps()[0] / (float)c.i[GO2SIM_IC_MAX_DELAY];
+  idx += 1;
+  for (int i = idx; i < npriv; ++i) p[i] = 0.0f;
+  { auto la = e.last_actions(); auto a = e.actions(); for (int i = 0; i < na; ++i) la[i] = a[i]; }
+  { auto ldv = e.last_dof_vel(); for (int i = 0; i < NM; ++i) ldv[i] = dof_vel[i]; }
+  if (obs_out) for (int i = 0; i < nobs; ++i) obs_out[(size_t)b * nobs + i] = o[i];
+  if (priv_out) for (int i = 0; i < npriv; ++i) priv_out[(size_t)b * npriv + i] = p[i];
+  if (rew_out) rew_out[b] = e.rew()[0];
+  if (reset_out) reset_out[b] = (uint8_t)was_reset;
+  if (timeout_out) timeout_out[b] = e.time_out()[0];
+}
+
+// small device helpers for the host API
+__global__ __launch_bounds__(WG) void k_init_state(Pool P, const Model* __restrict__ mp, int keep_dr) {
+  int b = blockIdx.x * WG + threadIdx.x;
+  if (b >= P.B) return;
+  const Model& m = *mp;
+  E e(P, b);
+  // everything is zero (hipMemset) except what follows when keep_dr == 0
+  auto qpos = e.qpos();
+  for (int i = 0; i < NQ; ++i) qpos[i] = m.qpos0[i];
+  if (!keep_dr) {
+    auto fr = e.friction_ratio(); auto gf = e.geom_friction();
+    for (int i = 0; i < NG; ++i) { fr[i] = 1.0f; gf[i] = m.geoms[i].friction; }
+  }
+  auto l_pos = e.l_pos(); auto l_quat = e.l_quat();
+  for (int i = 0; i < NL; ++i) { l_pos[i] = m.links[i].pos; l_quat[i] = m.links[i].quat; }
+  e.first_time()[0] = 1;
+  update_cartesian_space(m, e, true);
+  forward_velocity(m, e);
+}
+__global__ __launch_bounds__(WG) void k_scene_reset_clear(Pool P) {   // RigidSolver.set_state + collider.clear + constraint_solver.clear
+  int b = blockIdx.x * WG + threadIdx.x;
+  if (b >= P.B) return;
+  E e(P, b);
+  auto vel = e.vel(); auto acc = e.acc(); auto qacc_ws = e.qacc_ws();
+  for (int d = 0; d < ND; ++d) { vel[d] = 0.0f; acc[d] = 0.0f; qacc_ws[d] = 0.0f; }
+  auto ncache = e.normal_cache();
+  for (int p = 0; p < NPAIR; ++p) ncache[p] = v3(0, 0, 0);
+  int nc = e.n_contacts()[0];
+  for (int i_c = 0; i_c < nc; ++i_c) { e.c_link()[i_c] = -1; e.c_link()[MAXC + i_c] = -1; e.c_geom()[i_c] = -1; e.c_geom()[MAXC + i_c] = -1; e.c_pen()[i_c] = 0.0f; e.c_pos()[i_c] = v3(0, 0, 0); e.c_normal()[i_c] = v3(0, 0, 0); e.c_force()[i_c] = v3(0, 0, 0); }
+  e.n_contacts()[0] = 0; e.err()[0] = 0; e.is_warmstart()[0] = 0; e.n_con()[0] = 0;
+  auto ext = e.ext();
+  for (int i = 0; i < NL * 6; ++i) ext[i] = 0.0f;
+}
+__global__ __launch_bounds__(WG) void k_reset_caches(Pool P, const int* __restrict__ envs_idx, int n_sel) {
+  int t = blockIdx.x * WG + threadIdx.x;
+  if (t >= n_sel) return;
+  int b = envs_idx ? envs_idx[t] : t;
+  if (b < 0 || b >= P.B) return;
+  E e(P, b);
+  e.err()[0] = 0; e.is_warmstart()[0] = 0;
+  auto qacc_ws = e.qacc_ws();
+  for (int d = 0; d < ND; ++d) qacc_ws[d] = 0.0f;
+  auto ncache = e.normal_cache();
+  for (int p = 0; p < NPAIR; ++p) ncache[p] = v3(0, 0, 0);
+}
+__global__ __launch_bounds__(WG) void k_set_friction(Pool P, float mu) {
+  int b = blockIdx.x * WG + threadIdx.x;
+  if (b >= P.B) return;
+  E e(P, b);
+  auto gf = e.geom_friction();
+  for (int i = 0; i < NG; ++i) gf[i] = mu;
+}
+__global__ __launch_bounds__(WG) void k_env_init_buffers(Pool P, const DCfg* __restrict__ cp) {
+  int b = blockIdx.x * WG + threadIdx.x;
+  if (b >= P.B) return;
+  const DCfg& c = *cp;
+  E e(P, b);
+  auto kpf = e.kp_factors(); auto kdf = e.kd_factors(); auto mst = e.motor_strength();
+  for (int k = 0; k < NM; ++k) { kpf[k] = 1.0f; kdf[k] = 1.0f; mst[k] = 1.0f; }
+  e.delay_steps()[0] = 1; e.reset_buf()[0] = 1;
+  if (c.i[GO2SIM_IC_MANUAL_PD]) for (int k = 0; k < NM; ++k) e.ctrl_mode()[c.i[GO2SIM_IC_MOTOR_DOF0 + k]] = CTRL_FORCE;
+}
+__global__ void k_errno_reduce(Pool P, int* out) {
+  int v = 0;
+  for (int b = blockIdx.x * blockDim.x + threadIdx.x; b < P.B; b += gridDim.x * blockDim.x) v |= P.i[(size_t)IO(err) * P.B + b];
+  if (v) atomicOr(out, v);
+}
+// [n_envs][k] row-major copy of an env buffer
+__global__ void k_gather(const void* __restrict__ src, void* __restrict__ dst, int k, int B) {
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= k * B) return;
+  int b = t / k, j = t % k;
+  ((uint32_t*)dst)[t] = ((const uint32_t*)src)[(size_t)j * B + b];
+}
+__global__ void k_scatter(const void* __restrict__ src, void* __restrict__ dst, int k, int B) {
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= k * B) return;
+  int b = t / k, j = t % k;
+  ((uint32_t*)dst)[(size_t)j * B + b] = ((const uint32_t*)src)[t];
+}
+
+}  // namespace
+
+// =============================================================================================
+// host side
+// =============================================================================================
+#define HIPCHK(x) do { hipError_t _e = (x); if (_e != hipSuccess) { fprintf(stderr, "go2sim: HIP error %s at %s:%d\n", hipGetErrorString(_e), __FILE__, __LINE__); return GO2SIM_E_HIP; } } while (0)
+
+enum { T_DYN = 0, T_COLLIDE, T_SOLVE, T_INTEGRATE, T_ENV_PRE, T_ENV_POST, T_MISC, T_TOTAL, T_N };
+constexpr int TIMING_RING = 2048;
+
+struct go2sim {
+  int B = 0, device = 0;
+  uint64_t seed = 0;
+  Model hm;                 // host copy of the model
+  Model* dm = nullptr;      // device copy
+  Pool P = {nullptr, nullptr, 0};
+  DCfg hcfg; DCfg* dcfg = nullptr; bool cfg_set = false;
+  Glob* dglob = nullptr; Acc* dacc = nullptr; int* derr = nullptr;
+  uint32_t step_count = 0; int action_write_idx = 0;
+  // timing
+  bool timing = false;
+  hipEvent_t ev0[TIMING_RING], ev1[TIMING_RING]; int ev_cat[TIMING_RING]; int ev_n = 0; bool ev_created = false;
+  float t_ms[T_N] = {0}; int t_cnt[T_N] = {0};
+};
+
+static inline dim3 grid_for(int B) { return dim3((B + WG - 1) / WG); }
+
+static void timing_flush(go2sim* h) {
+  for (int i = 0; i < h->ev_n; ++i) {
+    float ms = 0.0f;
+    (void)hipEventSynchronize(h->ev1[i]);
+    if (hipEventElapsedTime(&ms, h->ev0[i], h->ev1[i]) == hipSuccess) { h->t_ms[h->ev_cat[i]] += ms; h->t_cnt[h->ev_cat[i]] += 1; }
+  }
+  h->ev_n = 0;
+}
+struct ScopedTimer {
+  go2sim* h; hipStream_t s; int idx;
+  ScopedTimer(go2sim* h_, hipStream_t s_, int cat) : h(h_), s(s_), idx(-1) {
+    if (!h->timing) return;
+    if (h->ev_n == TIMING_RING) timing_flush(h);
+    idx = h->ev_n++;
+    h->ev_cat[idx] = cat;
+    (void)hipEventRecord(h->ev0[idx], s);
+  }
+  ~ScopedTimer() { if (idx >= 0) (void)hipEventRecord(h->ev1[idx], s); }
+};
+
+static int launch_substep(go2sim* h, hipStream_t s) {
+  dim3 g = grid_for(h->B), b(WG);
+  { ScopedTimer t(h, s, T_DYN); hipLaunchKernelGGL(k_dynamics, g, b, 0, s, h->P, h->dm); }
+  { ScopedTimer t(h, s, T_COLLIDE); hipLaunchKernelGGL(k_collide, g, b, 0, s, h->P, h->dm); }
+  { ScopedTimer t(h, s, T_SOLVE); hipLaunchKernelGGL(k_constraint_solve, g, b, 0, s, h->P, h->dm); }
+  { ScopedTimer t(h, s, T_INTEGRATE); hipLaunchKernelGGL(k_integrate_fk, g, b, 0, s, h->P, h->dm); }
+  return GO2SIM_E_OK;
+}
+
+extern "C" {
+
+int go2sim_create(const void* blob, size_t nbytes, int n_envs, int device, uint64_t seed, go2sim_t** out) {
+  if (!blob || !out || n_envs <= 0) return GO2SIM_E_BADARG;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { fprintf(stderr, "go2sim: no HIP device available (the product has no CPU fallback)\n"); return GO2SIM_E_NODEVICE; }
+  if (device < 0 || device >= ndev) return GO2SIM_E_BADARG;
+  go2sim* h = new (std::nothrow) go2sim();
+  if (!h) return GO2SIM_E_NOMEM;
+  if (!parse_model(blob, nbytes, h->hm)) { delete h; return GO2SIM_E_BADMODEL; }
+  h->B = n_envs; h->device = device; h->seed = seed;
+  HIPCHK(hipSetDevice(device));
+  size_t nf = (size_t)FO_TOTAL * n_envs, ni = (size_t)IO_TOTAL * n_envs;
+  HIPCHK(hipMalloc((void**)&h->P.f, nf * sizeof(float)));
+  HIPCHK(hipMalloc((void**)&h->P.i, ni * sizeof(int)));
+  h->P.B = n_envs;
+  HIPCHK(hipMemset(h->P.f, 0, nf * sizeof(float)));
+  HIPCHK(hipMemset(h->P.i, 0, ni * sizeof(int)));
+  HIPCHK(hipMalloc((void**)&h->dm, sizeof(Model)));
+  HIPCHK(hipMemcpy(h->dm, &h->hm, sizeof(Model), hipMemcpyHostToDevice));
+  HIPCHK(hipMalloc((void**)&h->dcfg, sizeof(DCfg)));
+  HIPCHK(hipMalloc((void**)&h->dglob, sizeof(Glob)));
+  HIPCHK(hipMalloc((void**)&h->dacc, sizeof(Acc)));
+  HIPCHK(hipMalloc((void**)&h->derr, sizeof(int)));
+  Glob g0; memset(&g0, 0, sizeof(g0)); g0.friction = 1.0f;
+  HIPCHK(hipMemcpy(h->dglob, &g0, sizeof(Glob), hipMemcpyHostToDevice));
+  HIPCHK(hipMemset(h->dacc, 0, sizeof(Acc)));
+  memset(&h->hcfg, 0, sizeof(DCfg));
+  hipLaunchKernelGGL(k_init_state, grid_for(n_envs), dim3(WG), 0, 0, h->P, h->dm, 0);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipDeviceSynchronize());
+  *out = h;
+  return GO2SIM_E_OK;
+}
+
+int go2sim_destroy(go2sim_t* h) {
+  if (!h) return GO2SIM_E_BADARG;
+  (void)hipSetDevice(h->device);
+  (void)hipDeviceSynchronize();
+  if (h->ev_created) for (int i = 0; i < TIMING_RING; ++i) { (void)hipEventDestroy(h->ev0[i]); (void)hipEventDestroy(h->ev1[i]); }
+  (void)hipFree(h->P.f); (void)hipFree(h->P.i); (void)hipFree(h->dm); (void)hipFree(h->dcfg); (void)hipFree(h->dglob); (void)hipFree(h->dacc); (void)hipFree(h->derr);
+  delete h;
+  return GO2SIM_E_OK;
+}
+int go2sim_n_envs(const go2sim_t* h) { return h ? h->B : GO2SIM_E_BADARG; }
+
+int go2sim_scene_reset(go2sim_t* h, void* stream) {
+  if (!h) return GO2SIM_E_BADARG;
+  hipStream_t s = (hipStream_t)stream;
+  ScopedTimer t(h, s, T_MISC);
+  hipLaunchKernelGGL(k_scene_reset_clear, grid_for(h->B), dim3(WG), 0, s, h->P);
+  hipLaunchKernelGGL(k_init_state, grid_for(h->B), dim3(WG), 0, s, h->P, h->dm, 1);
+  HIPCHK(hipGetLastError());
+  return GO2SIM_E_OK;
+}
+int go2sim_substep(go2sim_t* h, void* stream) {
+  if (!h) return GO2SIM_E_BADARG;
+  launch_substep(h, (hipStream_t)stream);
+  HIPCHK(hipGetLastError());
+  return GO2SIM_E_OK;
+}
+int go2sim_scene_step(go2sim_t* h, int substeps, void* stream) {
+  if (!h || substeps <= 0) return GO2SIM_E_BADARG;
+  hipStream_t s = (hipStream_t)stream;
+  for (int i = 0; i < substeps; ++i) launch_substep(h, s);
+  { ScopedTimer t(h, s, T_MISC); hipLaunchKernelGGL(k_clear_ext, grid_for(h->B), dim3(WG), 0, s, h->P); }
+  HIPCHK(hipGetLastError());
+  return GO2SIM_E_OK;
+}
+int go2sim_forward_kinematics(go2sim_t* h, void* stream) {
+  if (!h) return GO2SIM_E_BADARG;
+  hipStream_t s = (hipStream_t)stream;
+  ScopedTimer t(h, s, T_MISC);
+  hipLaunchKernelGGL(k_fk, grid_for(h->B), dim3(WG), 0, s, h->P, h->dm, 1);
+  HIPCHK(hipGetLastError());
+  return GO2SIM_E_OK;
+}
+
+static int field_lookup(int field, int* k, int* is_int, int* off) {
+  int kk = -1, ii = 0, oo = 0;
+  switch (field) {
+    case GO2SIM_F_QPOS: kk = NQ; oo = FO(qpos); break;
+    case GO2SIM_F_VEL: kk = ND; oo = FO(vel); break;
+    case GO2SIM_F_ACC: kk = ND; oo = FO(acc); break;
+    case GO2SIM_F_QACC_WS: kk = ND; oo = FO(qacc_ws); break;
+    case GO2SIM_F_CTRL_FORCE: kk = ND; oo = FO(ctrl_force); break;
+    case GO2SIM_F_EXT_FORCE: kk = NL * 6; oo = FO(ext); break;
+    case GO2SIM_F_MASS_SHIFT: kk = NL; oo = FO(mass_shift); break;
+    case GO2SIM_F_COM_SHIFT: kk = NL * 3; oo = FO(com_shift); break;
+    case GO2SIM_F_FRICTION_RATIO: kk = NG; oo = FO(friction_ratio); break;
+    case GO2SIM_F_LINK_POS: kk = NL * 3; oo = FO(l_pos); break;
+    case GO2SIM_F_LINK_QUAT: kk = NL * 4; oo = FO(l_quat); break;
+    case GO2SIM_F_LINK_CDVEL: kk = NL * 3; oo = FO(cd_vel); break;
+    case GO2SIM_F_LINK_CDANG: kk = NL * 3; oo = FO(cd_ang); break;
+    case GO2SIM_F_ROOT_COM: kk = 3; oo = FO(root_com) + 3; break;
+    case GO2SIM_F_CONTACT_FORCE: kk = NL * 3; oo = FO(contact_force); break;
+    case GO2SIM_F_MASS_MAT: kk = ND * ND; oo = FO(mass_mat); break;
+    case GO2SIM_F_FORCE: kk = ND; oo = FO(qf_smooth); break;
+    case GO2SIM_F_ACC_SMOOTH: kk = ND; oo = FO(acc_smooth); break;
+    case GO2SIM_F_CONTACT_POS: kk = MAXC * 3; oo = FO(c_pos); break;
+    case GO2SIM_F_CONTACT_NORMAL: kk = MAXC * 3; oo = FO(c_normal); break;
+    case GO2SIM_F_CONTACT_PEN: kk = MAXC; oo = FO(c_pen); break;
+    case GO2SIM_F_NORMAL_CACHE: kk = NPAIR * 3; oo = FO(normal_cache); break;
+    case GO2SIM_F_SORT_VALUE: kk = 2 * NG; oo = FO(sort_value); break;
+    case GO2SIM_F_GEOM_FRICTION: kk = NG; oo = FO(geom_friction); break;
+    case GO2SIM_F_EFC_FORCE: kk = MAXR; oo = FO(efc_force); break;
+    case GO2SIM_F_QFRC_CONSTRAINT: kk = ND; oo = FO(qfrc_constraint); break;
+    case GO2SIM_I_N_CONTACTS: kk = 1; ii = 1; oo = IO(n_contacts); break;
+    case GO2SIM_I_CONTACT_GEOMS: kk = 2 * MAXC; ii = 1; oo = IO(c_geom); break;
+    case GO2SIM_I_N_CONSTRAINTS: kk = 1; ii = 1; oo = IO(n_con); break;
+    case GO2SIM_I_ERRNO: kk = 1; ii = 1; oo = IO(err); break;
+    case GO2SIM_I_IS_WARMSTART: kk = 1; ii = 1; oo = IO(is_warmstart); break;
+    case GO2SIM_I_FIRST_TIME: kk = 1; ii = 1; oo = IO(first_time); break;
+    case GO2SIM_I_SORT_IG: kk = 2 * NG; ii = 1; oo = IO(sort_ig); break;
+    case GO2SIM_I_N_BROAD: kk = 1; ii = 1; oo = IO(n_broad); break;
+    case GO2SIM_I_SOLVER_ITERS: kk = 1; ii = 1; oo = IO(solver_iters); break;
+    case GO2SIM_I_CTRL_MODE: kk = ND; ii = 1; oo = IO(ctrl_mode); break;
+    default: return GO2SIM_E_BADARG;
+  }
+  if (k) *k = kk;
+  if (is_int) *is_int = ii;
+  if (off) *off = oo;
+  return GO2SIM_E_OK;
+}
+int go2sim_field_size(int field, int* k, int* is_int) { return field_lookup(field, k, is_int, nullptr); }
+int go2sim_field_ptr(go2sim_t* h, int field, void** ptr_out) {
+  int k, ii, off;
+  if (!h || !ptr_out || field_lookup(field, &k, &ii, &off)) return GO2SIM_E_BADARG;
+  *ptr_out = ii ? (void*)(h->P.i + (size_t)off * h->B) : (void*)(h->P.f + (size_t)off * h->B);
+  return GO2SIM_E_OK;
+}
+int go2sim_get_field(go2sim_t* h, int field, void* dst, void* stream) {
+  int k, ii, off; void* p;
+  if (!h || !dst || field_lookup(field, &k, &ii, &off) || go2sim_field_ptr(h, field, &p)) return GO2SIM_E_BADARG;
+  HIPCHK(hipMemcpyAsync(dst, p, (size_t)k * h->B * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return GO2SIM_E_OK;
+}
+int go2sim_set_field(go2sim_t* h, int field, const void* src, void* stream) {
+  int k, ii, off; void* p;
+  if (!h || !src || field_lookup(field, &k, &ii, &off) || go2sim_field_ptr(h, field, &p)) return GO2SIM_E_BADARG;
+  HIPCHK(hipMemcpyAsync(p, src, (size_t)k * h->B * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return GO2SIM_E_OK;
+}
+int go2sim_reset_caches(go2sim_t* h, const int* envs_idx, int n_sel, void* stream) {
+  if (!h) return GO2SIM_E_BADARG;
+  int n = envs_idx ? n_sel : h->B;
+  if (n <= 0) return GO2SIM_E_OK;
+  hipLaunchKernelGGL(k_reset_caches, grid_for(n), dim3(WG), 0, (hipStream_t)stream, h->P, envs_idx, n);
+  HIPCHK(hipGetLastError());
+  return GO2SIM_E_OK;
+}
+int go2sim_set_friction(go2sim_t* h, float mu, void* stream) {
+  if (!h) return GO2SIM_E_BADARG;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_set_friction, grid_for(h->B), dim3(WG), 0, s, h->P, mu);
+  HIPCHK(hipMemcpyAsync((char*)h->dglob + offsetof(Glob, friction), &mu, sizeof(float), hipMemcpyHostToDevice, s));
+  HIPCHK(hipStreamSynchronize(s));  // `mu` lives on the caller's stack
+  return GO2SIM_E_OK;
+}
+int go2sim_set_dof_gains(go2sim_t* h, int d, float kp, float kv, float flo, float fhi) {
+  if (!h || d < 0 || d >= ND) return GO2SIM_E_BADARG;
+  h->hm.dofs[d].kp = kp; h->hm.dofs[d].kv = kv; h->hm.dofs[d].force_range[0] = flo; h->hm.dofs[d].force_range[1] = fhi;
+  HIPCHK(hipMemcpy(&h->dm->dofs[d], &h->hm.dofs[d], sizeof(Dof), hipMemcpyHostToDevice));
+  return GO2SIM_E_OK;
+}
+int go2sim_check_errno(go2sim_t* h, int* out, void* stream) {
+  if (!h || !out) return GO2SIM_E_BADARG;
+  hipStream_t s = (hipStream_t)stream;
+  HIPCHK(hipMemsetAsync(h->derr, 0, sizeof(int), s));
+  hipLaunchKernelGGL(k_errno_reduce, dim3(64), dim3(256), 0, s, h->P, h->derr);
+  HIPCHK(hipMemcpyAsync(out, h->derr, sizeof(int), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  return GO2SIM_E_OK;
+}
+
+int go2sim_env_configure(go2sim_t* h, const float* f, int nf, const int* i, int ni) {
+  if (!h || !f || !i || nf != GO2SIM_FC_COUNT || ni != GO2SIM_IC_COUNT) return GO2SIM_E_BADARG;
+  memcpy(h->hcfg.f, f, sizeof(float) * nf); memcpy(h->hcfg.i, i, sizeof(int) * ni);
+  const DCfg& c = h->hcfg;
+  if (c.i[GO2SIM_IC_NUM_ACTIONS] > NA || c.i[GO2SIM_IC_NUM_OBS] > NOBS_MAX || c.i[GO2SIM_IC_NUM_PRIV_OBS] > NPRIV_MAX || c.i[GO2SIM_IC_N_REWARDS] > NREW ||
+      c.i[GO2SIM_IC_MAX_DELAY] > 1 || c.i[GO2SIM_IC_NUM_OBS] < 33 + c.i[GO2SIM_IC_NUM_ACTIONS])
+    return GO2SIM_E_BADARG;
+  for (int k = 0; k < NM; ++k) { int d = c.i[GO2SIM_IC_MOTOR_DOF0 + k]; if (d < 6 || d >= ND) return GO2SIM_E_BADARG; }
+  for (int k = 0; k < 4; ++k) { int l = c.i[GO2SIM_IC_FOOT_LINK0 + k], l2 = c.i[GO2SIM_IC_HIP_LINK0 + k]; if (l < 0 || l >= NL || l2 < 0 || l2 >= NL) return GO2SIM_E_BADARG; }
+  if (c.i[GO2SIM_IC_PUSH_LINK] < 0 || c.i[GO2SIM_IC_PUSH_LINK] >= NL || c.i[GO2SIM_IC_BASE_LINK] < 0 || c.i[GO2SIM_IC_BASE_LINK] >= NL) return GO2SIM_E_BADARG;
+  HIPCHK(hipSetDevice(h->device));
+  HIPCHK(hipMemcpy(h->dcfg, &h->hcfg, sizeof(DCfg), hipMemcpyHostToDevice));
+  Glob g; memset(&g, 0, sizeof(g));
+  g.level = c.f[GO2SIM_FC_CURR_LEVEL_INIT]; g.friction = 1.0f;
+  apply_curriculum_level(c, g);
+  HIPCHK(hipMemcpy(h->dglob, &g, sizeof(Glob), hipMemcpyHostToDevice));
+  // zero the env buffers
+  size_t f0 = (size_t)FO(actions) * h->B, f1 = (size_t)FO_TOTAL * h->B;
+  HIPCHK(hipMemset(h->P.f + f0, 0, (f1 - f0) * sizeof(float)));
+  size_t i0 = (size_t)IO(delay_steps) * h->B, i1 = (size_t)IO_TOTAL * h->B;
+  HIPCHK(hipMemset(h->P.i + i0, 0, (i1 - i0) * sizeof(int)));
+  hipLaunchKernelGGL(k_env_init_buffers, grid_for(h->B), dim3(WG), 0, 0, h->P, h->dcfg);
+  HIPCHK(hipGetLastError());
+  for (int k = 0; k < NM; ++k) {
+    int d = c.i[GO2SIM_IC_MOTOR_DOF0 + k];
+    if (c.i[GO2SIM_IC_MANUAL_PD]) { h->hm.dofs[d].kp = 0.0f; h->hm.dofs[d].kv = 0.0f; } else { h->hm.dofs[d].kp = c.f[GO2SIM_FC_KP]; h->hm.dofs[d].kv = c.f[GO2SIM_FC_KD]; }
+  }
+  HIPCHK(hipMemcpy(h->dm, &h->hm, sizeof(Model), hipMemcpyHostToDevice));
+  HIPCHK(hipDeviceSynchronize());
+  h->step_count = 0; h->action_write_idx = 0; h->cfg_set = true;
+  return GO2SIM_E_OK;
+}
+
+int go2sim_env_step(go2sim_t* h, const float* actions, float* obs, float* priv, float* rew, uint8_t* reset, float* timeout, void* stream) {
+  if (!h || !h->cfg_set || !actions) return GO2SIM_E_BADARG;
+  hipStream_t s = (hipStream_t)stream;
+  dim3 g = grid_for(h->B), b(WG);
+  ScopedTimer total(h, s, T_TOTAL);
+  { ScopedTimer t(h, s, T_ENV_PRE); hipLaunchKernelGGL(k_env_pre, g, b, 0, s, h->P, h->dm, h->dcfg, h->dglob, actions, h->seed, h->step_count, h->action_write_idx); }
+  int substeps = h->hcfg.i[GO2SIM_IC_SUBSTEPS];
+  for (int i = 0; i < substeps; ++i) launch_substep(h, s);
+  {
+    ScopedTimer t(h, s, T_ENV_POST);
+    HIPCHK(hipMemsetAsync(h->dacc, 0, sizeof(Acc), s));
+    hipLaunchKernelGGL(k_env_post_a, g, b, 0, s, h->P, h->dm, h->dcfg, h->dglob, h->dacc, h->seed, h->step_count);
+    hipLaunchKernelGGL(k_env_globals, dim3(1), dim3(1), 0, s, h->dcfg, h->dglob, h->dacc, h->seed, 1);
+    hipLaunchKernelGGL(k_env_post_b, g, b, 0, s, h->P, h->dm, h->dcfg, h->dglob, h->seed, h->step_count, obs, priv, rew, reset, timeout);
+  }
+  HIPCHK(hipGetLastError());
+  h->action_write_idx = (h->action_write_idx + 1) % 2;
+  h->step_count += 1;
+  return GO2SIM_E_OK;
+}
+int go2sim_env_reset(go2sim_t* h, void* stream) {
+  if (!h || !h->cfg_set) return GO2SIM_E_BADARG;
+  hipStream_t s = (hipStream_t)stream;
+  dim3 g = grid_for(h->B), b(WG);
+  ScopedTimer t(h, s, T_MISC);
+  HIPCHK(hipMemsetAsync(h->dacc, 0, sizeof(Acc), s));
+  hipLaunchKernelGGL(k_env_mark_all, g, b, 0, s, h->P, h->dcfg, h->dacc);
+  hipLaunchKernelGGL(k_env_globals, dim3(1), dim3(1), 0, s, h->dcfg, h->dglob, h->dacc, h->seed, 0);
+  hipLaunchKernelGGL(k_env_reset_tail, g, b, 0, s, h->P, h->dm, h->dcfg, h->dglob, h->seed);
+  HIPCHK(hipGetLastError());
+  return GO2SIM_E_OK;
+}
+int go2sim_env_get(go2sim_t* h, int buf, void* dst, void* stream) {
+  if (!h || !dst) return GO2SIM_E_BADARG;
+  int k = 0; const void* src = nullptr;
+  const float* F = h->P.f; const int* I = h->P.i; size_t B = h->B;
+  switch (buf) {
+    case GO2SIM_EB_COMMANDS: k = 3; src = F + FO(commands) * B; break;
+    case GO2SIM_EB_EPISODE_LENGTH: k = 1; src = I + IO(episode_length) * B; break;
+    case GO2SIM_EB_BASE_LIN_VEL: k = 3; src = F + FO(base_lin_vel) * B; break;
+    case GO2SIM_EB_BASE_ANG_VEL: k = 3; src = F + FO(base_ang_vel) * B; break;
+    case GO2SIM_EB_PROJECTED_GRAVITY: k = 3; src = F + FO(projected_gravity) * B; break;
+    case GO2SIM_EB_DOF_POS: k = 12; src = F + FO(e_dof_pos) * B; break;
+    case GO2SIM_EB_DOF_VEL: k = 12; src = F + FO(e_dof_vel) * B; break;
+    case GO2SIM_EB_BASE_POS: k = 3; src = F + FO(base_pos) * B; break;
+    case GO2SIM_EB_BASE_QUAT: k = 4; src = F + FO(base_quat) * B; break;
+    case GO2SIM_EB_BASE_EULER: k = 3; src = F + FO(base_euler) * B; break;
+    case GO2SIM_EB_EPISODE_SUMS: k = NREW; src = F + FO(episode_sums) * B; break;
+    case GO2SIM_EB_FOOT_CONTACT: k = 4; src = I + IO(foot_contact) * B; break;
+    case GO2SIM_EB_FEET_AIR_TIME: k = 4; src = F + FO(feet_air_time) * B; break;
+    case GO2SIM_EB_REW_TERMS: k = NREW; src = F + FO(rew_terms) * B; break;
+    case GO2SIM_EB_TORQUE: k = 12; src = F + FO(torque) * B; break;
+    default: return GO2SIM_E_BADARG;
+  }
+  int n = k * h->B;
+  hipLaunchKernelGGL(k_gather, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, src, dst, k, h->B);
+  HIPCHK(hipGetLastError());
+  return GO2SIM_E_OK;
+}
+int go2sim_env_set_episode_length(go2sim_t* h, const int* ep, void* stream) {
+  if (!h || !ep) return GO2SIM_E_BADARG;
+  HIPCHK(hipMemcpyAsync(h->P.i + (size_t)IO(episode_length) * h->B, ep, (size_t)h->B * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return GO2SIM_E_OK;
+}
+int go2sim_env_set_commands(go2sim_t* h, const float* cmd, void* stream) {
+  if (!h || !cmd) return GO2SIM_E_BADARG;
+  int n = 3 * h->B;
+  hipLaunchKernelGGL(k_scatter, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const void*)cmd, (void*)(h->P.f + (size_t)FO(commands) * h->B), 3, h->B);
+  HIPCHK(hipGetLastError());
+  return GO2SIM_E_OK;
+}
+int go2sim_env_globals(go2sim_t* h, go2sim_env_globals_t* out, void* stream) {
+  if (!h || !out) return GO2SIM_E_BADARG;
+  hipStream_t s = (hipStream_t)stream;
+  HIPCHK(hipMemcpyAsync(out, h->dglob, sizeof(Glob), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  out->step_count = h->step_count; out->action_write_idx = h->action_write_idx;
+  return GO2SIM_E_OK;
+}
+int go2sim_env_set_level(go2sim_t* h, float level, void* stream) {
+  if (!h || !h->cfg_set) return GO2SIM_E_BADARG;
+  hipStream_t s = (hipStream_t)stream;
+  Glob g;
+  HIPCHK(hipMemcpyAsync(&g, h->dglob, sizeof(Glob), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  g.level = level;
+  apply_curriculum_level(h->hcfg, g);
+  HIPCHK(hipMemcpyAsync(h->dglob, &g, sizeof(Glob), hipMemcpyHostToDevice, s));
+  HIPCHK(hipStreamSynchronize(s));
+  return GO2SIM_E_OK;
+}
+int go2sim_enable_timing(go2sim_t* h, int enable) {
+  if (!h) return GO2SIM_E_BADARG;
+  if (enable && !h->ev_created) {
+    for (int i = 0; i < TIMING_RING; ++i) { HIPCHK(hipEventCreate(&h->ev0[i])); HIPCHK(hipEventCreate(&h->ev1[i])); }
+    h->ev_created = true;
+  }
+  if (!enable && h->timing) timing_flush(h);
+  h->timing = enable != 0;
+  return GO2SIM_E_OK;
+}
+int go2sim_read_timing(go2sim_t* h, float* ms_out8, int* cnt_out8, int reset) {
+  if (!h || !h->ev_created) return GO2SIM_E_BADARG;
+  timing_flush(h);
+  for (int i = 0; i < T_N; ++i) { if (ms_out8) ms_out8[i] = h->t_ms[i]; if (cnt_out8) cnt_out8[i] = h->t_cnt[i]; }
+  if (reset) for (int i = 0; i < T_N; ++i) { h->t_ms[i] = 0.0f; h->t_cnt[i] = 0; }
+  return GO2SIM_E_OK;
+}
+
+/* development/test aid (not declared in include/go2sim.h): device address of ANY pool field by name */
+int go2sim_debug_field(go2sim_t* h, const char* name, void** ptr, int* k, int* is_int) {
+  if (!h || !name || !ptr) return GO2SIM_E_BADARG;
+#define X(n, c) if (!strcmp(name, #n)) { *ptr = h->P.f + (size_t)FO(n) * h->B; if (k) *k = (c); if (is_int) *is_int = 0; return GO2SIM_E_OK; }
+  GO2SIM_FLOAT_FIELDS(X)
+#undef X
+#define X(n, c) if (!strcmp(name, #n)) { *ptr = h->P.i + (size_t)IO(n) * h->B; if (k) *k = (c); if (is_int) *is_int = 1; return GO2SIM_E_OK; }
+  GO2SIM_INT_FIELDS(X)
+#undef X
+  return GO2SIM_E_BADARG;
+}
+
+}  // extern "C"

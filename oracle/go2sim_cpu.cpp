@@ -343,6 +343,7 @@ struct Env {
   real qacc[ND], Ma[ND], grad[ND], Mgrad[ND], search[ND], mv[ND], qfrc_constraint[ND], nt_vec[ND];
   real H[ND][ND];
   real cost, prev_cost, gauss, quad_gauss[3], gtol; int ls_it, ls_result, improved, solver_iters;
+  real dbg[96];
   V3 contact_force[NL];
   real vel_next[ND], qpos_next[NQ];
 };
@@ -1410,6 +1411,7 @@ real linesearch(const Model& m, Env& e) {
   } else {
     LsPoint p0 = ls_init_and_eval_p0(m, e);
     LsPoint p1 = ls_point_fn(m, e, p0.alpha - p0.grad / p0.hess);
+    e.dbg[8] = p0.cost; e.dbg[9] = p0.grad; e.dbg[10] = p0.hess; e.dbg[11] = p1.alpha; e.dbg[12] = p1.cost; e.dbg[13] = p1.grad; e.dbg[14] = p1.hess;
     if (p0.cost < p1.cost) p1 = p0;
     if (dm_abs(p1.grad) < gtol) {
       e.ls_result = (dm_abs(p1.alpha) < m.eps) ? 2 : 0;
@@ -1421,6 +1423,7 @@ real linesearch(const Model& m, Env& e) {
       while (p1.grad * (real)direction <= -gtol && e.ls_it < m.ls_iterations) {
         p2 = p1; p2update = 1;
         p1 = ls_point_fn(m, e, p1.alpha - p1.grad / p1.hess);
+        if (e.ls_it < 20) { e.dbg[16 + 4 * e.ls_it] = p1.alpha; e.dbg[17 + 4 * e.ls_it] = p1.cost; e.dbg[18 + 4 * e.ls_it] = p1.grad; e.dbg[19 + 4 * e.ls_it] = p1.hess; }
         if (dm_abs(p1.grad) < gtol) { res_alpha = p1.alpha; done = true; break; }
       }
       if (!done) {
@@ -1432,6 +1435,7 @@ real linesearch(const Model& m, Env& e) {
           while (e.ls_it < m.ls_iterations) {
             real costs[3], grads[3], hess[3];
             ls_point_fn_3(m, e, al, costs, grads, hess);
+            if (e.ls_it < 20) for (int q = 0; q < 3; ++q) { int z = e.ls_it - 2 + q; e.dbg[16 + 4 * z] = al[q]; e.dbg[17 + 4 * z] = costs[q]; e.dbg[18 + 4 * z] = grads[q]; e.dbg[19 + 4 * z] = hess[q]; }
             real p1_next_alpha = al[0], p2_next_alpha = al[1];
             real best_alpha = 0.0f, best_cost = 0.0f; bool best_found = false;
             for (int i = 0; i < 3; ++i)
@@ -1458,6 +1462,7 @@ real linesearch(const Model& m, Env& e) {
       }
     }
   }
+  e.dbg[7] = res_alpha; e.dbg[0] = e.cost; e.dbg[1] = e.prev_cost; e.dbg[2] = e.gauss; e.dbg[3] = e.quad_gauss[0]; e.dbg[4] = e.quad_gauss[1]; e.dbg[5] = e.quad_gauss[2]; e.dbg[6] = e.gtol;
   return res_alpha;
 }
 
@@ -2458,6 +2463,37 @@ int go2sim_cpu_gjk_fallback_count(go2sim* h, long long* out) {
   long long s = 0;
   for (int b = 0; b < h->B; ++b) s += h->envs[b].gjk_fallback_count;
   *out = s;
+  return GO2SIM_E_OK;
+}
+
+// development/test aid: copy a solver-internal array of every env into dst laid out [k][n_envs]
+int go2sim_cpu_debug_get(go2sim* h, const char* name, float* dst, int* k_out) {
+  if (!h || !name) return GO2SIM_E_BADARG;
+  int k = 0;
+  for (int b = 0; b < h->B; ++b) {
+    Env& e = h->envs[b];
+    const float* src = nullptr;
+    if (!strcmp(name, "jac")) { src = &e.jac[0][0]; k = MAXR * ND; }
+    else if (!strcmp(name, "diag")) { src = e.diag; k = MAXR; }
+    else if (!strcmp(name, "aref")) { src = e.aref; k = MAXR; }
+    else if (!strcmp(name, "efc_D")) { src = e.efc_D; k = MAXR; }
+    else if (!strcmp(name, "Jaref")) { src = e.Jaref; k = MAXR; }
+    else if (!strcmp(name, "jv")) { src = e.jv; k = MAXR; }
+    else if (!strcmp(name, "H")) { src = &e.H[0][0]; k = ND * ND; }
+    else if (!strcmp(name, "grad")) { src = e.grad; k = ND; }
+    else if (!strcmp(name, "Mgrad")) { src = e.Mgrad; k = ND; }
+    else if (!strcmp(name, "search")) { src = e.search; k = ND; }
+    else if (!strcmp(name, "qacc")) { src = e.qacc; k = ND; }
+    else if (!strcmp(name, "Ma")) { src = e.Ma; k = ND; }
+    else if (!strcmp(name, "mv")) { src = e.mv; k = ND; }
+    else if (!strcmp(name, "sv")) { src = e.dbg; k = 96; }
+    else if (!strcmp(name, "mass_L")) { src = &e.mass_L[0][0]; k = ND * ND; }
+    else if (!strcmp(name, "cdof_ang")) { src = (const float*)e.cdof_ang; k = ND * 3; }
+    else if (!strcmp(name, "cdof_vel")) { src = (const float*)e.cdof_vel; k = ND * 3; }
+    else return GO2SIM_E_BADARG;
+    if (dst) for (int j = 0; j < k; ++j) dst[(size_t)j * h->B + b] = src[j];
+  }
+  if (k_out) *k_out = k;
   return GO2SIM_E_OK;
 }
 
