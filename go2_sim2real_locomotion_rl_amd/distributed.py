@@ -1,0 +1,45 @@
+"""Multi-GPU sharding helpers.
+
+Environments are fully independent, so the hot path shards as contiguous blocks of envs per GPU with NO
+physics traffic.  The only collective the path needs is the rollout advantage-normalisation statistics:
+an all-gather of [sum, sum of squares, count] (3 floats per rank) over RCCL/xGMI (backend "nccl" on ROCm,
+"gloo" in the CPU tests).  The reference has no distributed code on this path (its only multi-GPU artefact
+is examples/ddp_multi_gpu.py:36-90, one independent scene per rank with seed=local_rank)."""
+import torch
+import torch.distributed as dist
+
+
+def shard_seed(seed: int, rank: int) -> int:
+    """Per-rank RNG stream (examples/ddp_multi_gpu.py:58 uses seed=local_rank)."""
+    return int(seed) + int(rank)
+
+
+def shard_envs(total_envs: int, world_size: int, rank: int):
+    """Contiguous block of envs owned by `rank` -> (start, count)."""
+    base, rem = divmod(total_envs, world_size)
+    count = base + (1 if rank < rem else 0)
+    start = rank * base + min(rank, rem)
+    return start, count
+
+
+def local_moments(x: torch.Tensor) -> torch.Tensor:
+    x = x.reshape(-1).to(torch.float32)
+    return torch.stack([x.sum(), (x * x).sum(), torch.tensor(float(x.numel()), device=x.device)])
+
+
+def global_mean_std(x: torch.Tensor, group=None, eps: float = 1e-8):
+    """Mean / std of `x` over all ranks (unbiased=False), via ONE all-gather of 3 floats per rank."""
+    m = local_moments(x)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        world = dist.get_world_size(group)
+        out = torch.empty(3 * world, device=m.device, dtype=m.dtype)
+        dist.all_gather_into_tensor(out, m, group=group)
+        m = out.view(world, 3).sum(0)
+    mean = m[0] / m[2]
+    var = torch.clamp(m[1] / m[2] - mean * mean, min=0.0)
+    return mean, torch.sqrt(var + eps)
+
+
+def normalize_advantages(adv: torch.Tensor, group=None, eps: float = 1e-8) -> torch.Tensor:
+    mean, std = global_mean_std(adv, group, eps)
+    return (adv - mean) / std

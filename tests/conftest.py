@@ -1,0 +1,45 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a ROCm GPU (MI355X); run with -m gpu on the GPU box")
+
+
+@pytest.fixture(scope="session")
+def libs_built():
+    """Both native libraries exist (built in-tree; they travel to the GPU box as .so files)."""
+    from go2_sim2real_locomotion_rl_amd import build
+
+    if not os.path.exists(build.ORACLE_LIB) or os.path.exists("/usr/bin/g++"):
+        build.build_oracle(verbose=False)
+    if not os.path.exists(build.HIP_LIB):
+        build.build_hip(verbose=False)
+    return True
+
+
+@pytest.fixture(scope="session")
+def blob():
+    from go2_sim2real_locomotion_rl_amd.model_blob import pack_model
+
+    return pack_model()
+
+
+@pytest.fixture(scope="session")
+def oracle_lib(libs_built):
+    from go2_sim2real_locomotion_rl_amd.capi import load_cpu_oracle_lib
+
+    return load_cpu_oracle_lib()
+
+
+@pytest.fixture(scope="session")
+def hip_lib(libs_built):
+    from go2_sim2real_locomotion_rl_amd.capi import load_hip_lib
+
+    return load_hip_lib()

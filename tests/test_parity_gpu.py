@@ -1,0 +1,155 @@
+"""Parity tests proper: the HIP path vs the CPU oracle through the C ABI, same seeds / actions.
+
+Bar (BASELINE.json north_star): observations and per-term rewards within fp32 tolerance, contact counts and done
+masks bit-exact.  Because both sides evaluate identical IEEE binary32 operation sequences
+(include/go2sim_detmath.h, -ffp-contract=off) the tests demand BIT-EXACT equality of everything (tolerance 0);
+the only exception are the double-precision reset statistics (atomic accumulation order), compared to 1e-6."""
+import numpy as np
+import pytest
+
+from util import CpuEnv, GpuEnv, F, bits_equal, make_actions
+
+pytestmark = pytest.mark.gpu
+
+FIELDS = ["F_QPOS", "F_VEL", "F_ACC", "F_QACC_WS", "F_MASS_MAT", "F_FORCE", "F_ACC_SMOOTH", "I_N_BROAD", "I_N_CONTACTS", "I_CONTACT_GEOMS",
+          "F_CONTACT_POS", "F_CONTACT_NORMAL", "F_CONTACT_PEN", "F_NORMAL_CACHE", "I_N_CONSTRAINTS", "I_SOLVER_ITERS", "F_EFC_FORCE",
+          "F_QFRC_CONSTRAINT", "F_CONTACT_FORCE", "F_LINK_POS", "F_LINK_QUAT", "F_LINK_CDVEL", "F_LINK_CDANG", "F_SORT_VALUE", "I_SORT_IG",
+          "I_ERRNO", "I_IS_WARMSTART", "F_MASS_SHIFT", "F_COM_SHIFT", "F_GEOM_FRICTION"]
+
+
+def _compare_fields(cpu, gpu, tag):
+    for fn in FIELDS:
+        assert bits_equal(cpu.field(fn), gpu.field(fn)), f"{tag}: field {fn} differs"
+
+
+def _compare_globals(cpu, gpu):
+    a, b = cpu.sim.env_globals().as_dict(), gpu.sim.env_globals().as_dict()
+    for k in a:
+        if k in ("ep_acc", "n_reset_now"):
+            continue
+        if k in ("last_episode_rew", "curr_tracking_sum", "curr_timeout_total", "tracking_ema", "timeout_rate_ema", "fall_rate_ema"):
+            assert np.allclose(a[k], b[k], rtol=1e-6, atol=1e-7), k  # double accumulation order (atomics) differs
+        else:
+            assert a[k] == b[k], (k, a[k], b[k])
+
+
+@pytest.mark.parametrize("n_envs,steps,kind,seed", [(64, 150, "mixed", 7), (4, 80, "0.5", 1), (1, 40, "zeros", 3), (130, 60, "2.0", 11)])
+def test_env_step_bit_exact(oracle_lib, hip_lib, blob, n_envs, steps, kind, seed):
+    """Go2Env.step parity incl. resets, pushes, noise, DR; ragged batch sizes (1, 130) exercise the tail wavefront."""
+    cpu, gpu = CpuEnv(oracle_lib, blob, n_envs, seed=seed), GpuEnv(hip_lib, blob, n_envs, seed=seed)
+    cpu.reset(); gpu.reset()
+    _compare_fields(cpu, gpu, "after reset")
+    acts = make_actions(steps, n_envs, seed=seed, kind=kind)
+    n_resets = 0
+    for s, a in enumerate(acts):
+        oc, pc, rc, dc, tc = cpu.step(a)
+        og, pg, rg, dg, tg = gpu.step(a)
+        assert np.array_equal(dc, dg), f"done mask differs at step {s}"
+        assert np.array_equal(cpu.field("I_N_CONTACTS"), gpu.field("I_N_CONTACTS")), f"contact counts differ at step {s}"
+        assert bits_equal(oc, og) and bits_equal(pc, pg), f"observations differ at step {s}"
+        assert bits_equal(rc, rg) and bits_equal(tc, tg), f"reward / time_out differ at step {s}"
+        assert bits_equal(cpu.env_buf("REW_TERMS", 32), gpu.env_buf("REW_TERMS", 32)), f"per-term rewards differ at step {s}"
+        n_resets += int(dc.sum())
+        if s % 25 == 0:
+            _compare_fields(cpu, gpu, f"step {s}")
+    _compare_fields(cpu, gpu, "final")
+    _compare_globals(cpu, gpu)
+    assert gpu.sim.check_errno() == cpu.sim.check_errno() == 0
+    if kind in ("mixed", "2.0"):
+        assert n_resets > 0, "the action set was meant to provoke falls / resets"
+
+
+def test_scene_step_bit_exact_with_uploaded_state(oracle_lib, hip_lib, blob):
+    """gs.Scene.step parity: random (qpos, vel, ctrl) uploaded through set_field on both sides."""
+    B = 96
+    cpu, gpu = CpuEnv(oracle_lib, blob, B, seed=2), GpuEnv(hip_lib, blob, B, seed=2)
+    rng = np.random.default_rng(5)
+    q = cpu.field("F_QPOS")
+    q[2] = rng.uniform(0.25, 0.5, B); quat = rng.standard_normal((4, B)) * 0.15 + np.array([[1], [0], [0], [0]])
+    q[3:7] = quat / np.linalg.norm(quat, axis=0)
+    q[7:19] = np.array([0, 0, 0, 0, 0.8, 0.8, 1.0, 1.0, -1.5, -1.5, -1.5, -1.5])[:, None] + 0.2 * rng.standard_normal((12, B))
+    v = rng.standard_normal((18, B)).astype(np.float32)
+    ctrl = np.zeros((18, B), np.float32); ctrl[6:] = 8.0 * rng.standard_normal((12, B))
+    for e in (cpu, gpu):
+        setter = e.sim.set_field_np if e is cpu else None
+        for name, arr in (("F_QPOS", q.astype(np.float32)), ("F_VEL", v), ("F_CTRL_FORCE", ctrl)):
+            if e is cpu:
+                e.sim.set_field_np(F(name), arr)
+            else:
+                e.set_field(name, arr)
+        e.sim.reset_caches()
+        e.sim.forward_kinematics()
+    for s in range(30):
+        cpu.sim.scene_step(2); gpu.sim.scene_step(2)
+        _compare_fields(cpu, gpu, f"scene step {s}")
+    assert (cpu.field("I_N_CONTACTS") > 0).any()
+
+
+def test_full_size_short_run_bit_exact(oracle_lib, hip_lib, blob):
+    """BASELINE configs[1] size (4096 envs): a short run compared bit for bit."""
+    B = 4096
+    cpu, gpu = CpuEnv(oracle_lib, blob, B, seed=21), GpuEnv(hip_lib, blob, B, seed=21)
+    cpu.reset(); gpu.reset()
+    acts = make_actions(12, B, seed=4, kind="0.5")
+    for s, a in enumerate(acts):
+        oc, pc, rc, dc, tc = cpu.step(a)
+        og, pg, rg, dg, tg = gpu.step(a)
+        assert np.array_equal(dc, dg) and bits_equal(oc, og) and bits_equal(rc, rg), f"step {s}"
+    assert np.array_equal(cpu.field("I_N_CONTACTS"), gpu.field("I_N_CONTACTS"))
+    assert bits_equal(cpu.field("F_QPOS"), gpu.field("F_QPOS"))
+
+
+def test_full_size_invariants(hip_lib, blob):
+    """Size-independent properties at 4096 envs over a longer horizon: finite values, unit quaternions, contact padding,
+    weight carried by the contacts, idempotent kinematics refresh, determinism of a re-run."""
+    B, steps = 4096, 150
+    finals = []
+    for rep in range(2):
+        gpu = GpuEnv(hip_lib, blob, B, seed=31, freeze_curriculum=True)
+        gpu.reset()
+        act = np.zeros((B, 16), np.float32)
+        for s in range(steps):
+            obs, priv, rew, rst, to = gpu.step(act)
+        assert np.isfinite(obs).all() and np.isfinite(rew).all() and gpu.sim.check_errno() == 0
+        q = gpu.field("F_QPOS")
+        assert np.allclose(np.linalg.norm(q[3:7], axis=0), 1.0, atol=1e-5)
+        nc = gpu.field("I_N_CONTACTS")[0]
+        pen = gpu.field("F_CONTACT_PEN")
+        assert (nc >= 0).all() and (nc <= 150).all()
+        mask = np.arange(150)[:, None] >= nc[None, :]
+        assert (pen[mask] == 0).all()
+        cf = gpu.field("F_CONTACT_FORCE").reshape(14, 3, B)
+        standing = (rst == 0) & (nc >= 4)
+        g = gpu.sim.env_globals()
+        weight = (15.019 + g.mass_shift + sum(g.leg_mass_shift)) * 9.81
+        assert standing.mean() > 0.9
+        assert abs(np.median(cf[1:, 2, standing].sum(0)) - weight) / weight < 0.05
+        before = {f: gpu.field(f) for f in ("F_LINK_POS", "F_LINK_QUAT", "F_LINK_CDVEL")}
+        gpu.sim.forward_kinematics()
+        for f, v in before.items():
+            assert bits_equal(v, gpu.field(f)), "forward_kinematics must be idempotent"
+        finals.append((obs.copy(), q.copy()))
+    assert bits_equal(finals[0][0], finals[1][0]) and bits_equal(finals[0][1], finals[1][1])
+
+
+def test_env_get_and_setters(hip_lib, oracle_lib, blob):
+    B = 70
+    cpu, gpu = CpuEnv(oracle_lib, blob, B, seed=5), GpuEnv(hip_lib, blob, B, seed=5)
+    cpu.reset(); gpu.reset()
+    ep = np.arange(B, dtype=np.int32) * 10
+    cmd = np.random.default_rng(1).uniform(-1, 1, (B, 3)).astype(np.float32)
+    cpu.sim.env_set_episode_length(ep); cpu.sim.env_set_commands(cmd)
+    gpu.sim.env_set_episode_length(gpu.torch.from_numpy(ep).to(gpu.dev)); gpu.sim.env_set_commands(gpu.torch.from_numpy(cmd).to(gpu.dev))
+    a = make_actions(3, B, seed=2, kind="0.3")
+    for x in a:
+        cpu.step(x); gpu.step(x)
+    for name, k, dt in (("COMMANDS", 3, np.float32), ("EPISODE_LENGTH", 1, np.int32), ("BASE_EULER", 3, np.float32), ("DOF_POS", 12, np.float32),
+                        ("FOOT_CONTACT", 4, np.int32), ("FEET_AIR_TIME", 4, np.float32), ("EPISODE_SUMS", 32, np.float32), ("TORQUE", 12, np.float32)):
+        assert bits_equal(cpu.env_buf(name, k, dt), gpu.env_buf(name, k, dt)), name
+    assert np.array_equal(gpu.env_buf("EPISODE_LENGTH", 1, np.int32)[:, 0], ep + 3)
+
+
+def test_graft_entry_smoke():
+    import __graft_entry__
+
+    __graft_entry__.smoke()

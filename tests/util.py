@@ -1,0 +1,113 @@
+"""Shared helpers for the parity tests."""
+import numpy as np
+
+from go2_sim2real_locomotion_rl_amd.capi import C, Go2Sim
+from go2_sim2real_locomotion_rl_amd.configs import flatten_walk_cfg, get_walk_cfgs
+
+NOBS, NPRIV, NACT = 49, 104, 16
+
+
+def F(name):
+    return C["GO2SIM_" + name]
+
+
+def walk_cfg(n_envs, mutate=None, **kw):
+    cfgs = get_walk_cfgs()
+    if mutate is not None:
+        mutate(*cfgs)
+    return flatten_walk_cfg(n_envs, *cfgs, **kw)
+
+
+def make_actions(steps, n_envs, seed=0, kind="mixed"):
+    rng = np.random.default_rng(seed)
+    a = np.zeros((steps, n_envs, NACT), np.float32)
+    for s in range(steps):
+        if kind == "zeros":
+            scale = 0.0
+        elif kind == "mixed":
+            scale = 0.0 if s < steps // 3 else (0.5 if s < 2 * steps // 3 else 2.0)
+        else:
+            scale = float(kind)
+        a[s] = (scale * rng.standard_normal((n_envs, NACT))).astype(np.float32)
+    return a
+
+
+class CpuEnv:
+    """Go2Env on the CPU oracle with numpy buffers."""
+
+    def __init__(self, lib, blob, n_envs, seed=1, **cfg_kw):
+        self.sim = Go2Sim(lib, blob, n_envs, 0, seed)
+        f, i, self.reward_names = walk_cfg(n_envs, **cfg_kw)
+        self.sim.env_configure(f, i)
+        self.B = n_envs
+        self.obs = np.zeros((n_envs, NOBS), np.float32); self.priv = np.zeros((n_envs, NPRIV), np.float32)
+        self.rew = np.zeros(n_envs, np.float32); self.rst = np.zeros(n_envs, np.uint8); self.to = np.zeros(n_envs, np.float32)
+
+    def reset(self):
+        self.sim.env_reset()
+
+    def step(self, act):
+        self.sim.env_step(np.ascontiguousarray(act, np.float32), self.obs, self.priv, self.rew, self.rst, self.to)
+        return self.obs, self.priv, self.rew, self.rst, self.to
+
+    def field(self, name):
+        return self.sim.get_field_np(F(name))
+
+    def env_buf(self, name, k, dtype=np.float32):
+        out = np.zeros((self.B, k), dtype)
+        self.sim.env_get(C["GO2SIM_EB_" + name], out)
+        return out
+
+
+class GpuEnv:
+    """Go2Env on the HIP library with torch (ROCm) buffers; everything goes through the C ABI."""
+
+    def __init__(self, lib, blob, n_envs, seed=1, **cfg_kw):
+        import torch
+
+        self.torch = torch
+        self.dev = torch.device("cuda:0")
+        self.sim = Go2Sim(lib, blob, n_envs, 0, seed)
+        f, i, self.reward_names = walk_cfg(n_envs, **cfg_kw)
+        self.sim.env_configure(f, i)
+        self.B = n_envs
+        self.obs = torch.zeros(n_envs, NOBS, device=self.dev); self.priv = torch.zeros(n_envs, NPRIV, device=self.dev)
+        self.rew = torch.zeros(n_envs, device=self.dev); self.rst = torch.zeros(n_envs, dtype=torch.uint8, device=self.dev)
+        self.to = torch.zeros(n_envs, device=self.dev)
+
+    def reset(self):
+        self.sim.env_reset()
+
+    def step(self, act):
+        a = self.torch.from_numpy(np.ascontiguousarray(act, np.float32)).to(self.dev)
+        self.sim.env_step(a, self.obs, self.priv, self.rew, self.rst, self.to)
+        self.torch.cuda.synchronize()
+        return self.obs.cpu().numpy(), self.priv.cpu().numpy(), self.rew.cpu().numpy(), self.rst.cpu().numpy(), self.to.cpu().numpy()
+
+    def field(self, name):
+        torch = self.torch
+        k, is_int = self.sim.field_size(F(name))
+        t = torch.zeros(k, self.B, dtype=torch.int32 if is_int else torch.float32, device=self.dev)
+        self.sim.get_field(F(name), t)
+        torch.cuda.synchronize()
+        return t.cpu().numpy()
+
+    def set_field(self, name, arr):
+        torch = self.torch
+        t = torch.from_numpy(np.ascontiguousarray(arr)).to(self.dev)
+        self.sim.set_field(F(name), t)
+        torch.cuda.synchronize()
+
+    def env_buf(self, name, k, dtype=np.float32):
+        torch = self.torch
+        t = torch.zeros(self.B, k, dtype=torch.int32 if dtype == np.int32 else torch.float32, device=self.dev)
+        self.sim.env_get(C["GO2SIM_EB_" + name], t)
+        torch.cuda.synchronize()
+        return t.cpu().numpy()
+
+
+def bits_equal(a, b):
+    a = np.ascontiguousarray(a); b = np.ascontiguousarray(b)
+    if a.dtype == np.float32:
+        return np.array_equal(a.view(np.int32), b.view(np.int32))
+    return np.array_equal(a, b)
