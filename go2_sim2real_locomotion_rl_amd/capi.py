@@ -209,6 +209,11 @@ class Go2Sim:
         self._call("env_globals", ctypes.byref(g), _ptr(stream))
         return g
 
+    def env_globals_ptr(self):
+        p = ctypes.c_void_p()
+        self._call("env_globals_ptr", ctypes.byref(p))
+        return p.value
+
     def env_set_level(self, level, stream=None):
         self._call("env_set_level", ctypes.c_float(level), _ptr(stream))
 

@@ -320,7 +320,7 @@ bool parse_model(const void* blob, size_t nbytes, Model& m) {
   X(cfrc_vel, NL * 3) X(cfrc_ang, NL * 3) X(c_friction, MAXC) X(c_sol, MAXC * 7) X(c_force, MAXC * 3)                  \
   X(mpr_v, 12) X(mpr_v1, 12) X(mpr_v2, 12) X(jac, MAXR * ND) X(diag, MAXR) X(aref, MAXR) X(efc_D, MAXR) X(Jaref, MAXR) \
   X(jv, MAXR) X(qacc, ND) X(Ma, ND) X(grad, ND) X(Mgrad, ND) X(search, ND) X(mv, ND) X(nt_vec, ND) X(H, ND * ND)        \
-  X(sv, 96) /* cost, prev_cost, gauss, quad_gauss[3], gtol, alpha, debug... */                                                      \
+  X(sv, 8) /* cost, prev_cost, gauss, quad_gauss[3], gtol */                                                      \
   X(vel_next, ND) X(qpos_next, NQ)                                                                                   \
   /* ---- Go2Env buffers ---- */                                                                                     \
   X(actions, NA) X(last_actions, NA) X(applied_actions, NA) X(action_history, 2 * NA) X(target_dof_pos, NM)            \
@@ -1594,7 +1594,6 @@ DEVN float linesearch(const Model& m, const E& e, int n_con) {
     float qg0 = e.sv()[SV_QG0], qg1 = e.sv()[SV_QG1], qg2 = e.sv()[SV_QG2];
     LsPoint p1 = ls_point_fn(m, e, n_con, p0.alpha - p0.grad / p0.hess, qg0, qg1, qg2);
     ls_it += 1;
-    e.sv()[8] = p0.cost; e.sv()[9] = p0.grad; e.sv()[10] = p0.hess; e.sv()[11] = p1.alpha; e.sv()[12] = p1.cost; e.sv()[13] = p1.grad; e.sv()[14] = p1.hess;
     if (p0.cost < p1.cost) p1 = p0;
     if (dm_abs(p1.grad) < gtol) {
       ls_result = (dm_abs(p1.alpha) < m.eps) ? 2 : 0;
@@ -1607,7 +1606,6 @@ DEVN float linesearch(const Model& m, const E& e, int n_con) {
         p2 = p1; p2update = 1;
         p1 = ls_point_fn(m, e, n_con, p1.alpha - p1.grad / p1.hess, qg0, qg1, qg2);
         ls_it += 1;
-        if (ls_it < 20) { e.sv()[16 + 4 * ls_it] = p1.alpha; e.sv()[17 + 4 * ls_it] = p1.cost; e.sv()[18 + 4 * ls_it] = p1.grad; e.sv()[19 + 4 * ls_it] = p1.hess; }
         if (dm_abs(p1.grad) < gtol) { res_alpha = p1.alpha; done = true; break; }
       }
       if (!done) {
@@ -1620,7 +1618,6 @@ DEVN float linesearch(const Model& m, const E& e, int n_con) {
             float costs[3], grads[3], hess[3];
             ls_point_fn_3(m, e, n_con, al, qg0, qg1, qg2, costs, grads, hess);
             ls_it += 3;
-            if (ls_it < 20) for (int q = 0; q < 3; ++q) { int z = ls_it - 2 + q; e.sv()[16 + 4 * z] = al[q]; e.sv()[17 + 4 * z] = costs[q]; e.sv()[18 + 4 * z] = grads[q]; e.sv()[19 + 4 * z] = hess[q]; }
             float p1_next_alpha = al[0], p2_next_alpha = al[1];
             float best_alpha = 0.0f, best_cost = 0.0f; bool best_found = false;
 #pragma unroll
@@ -1646,7 +1643,6 @@ DEVN float linesearch(const Model& m, const E& e, int n_con) {
     }
   }
   e.si()[SI_LS_IT] = ls_it; e.si()[SI_LS_RESULT] = ls_result;
-  e.sv()[7] = res_alpha;
   return res_alpha;
 }
 
@@ -2819,6 +2815,11 @@ int go2sim_env_globals(go2sim_t* h, go2sim_env_globals_t* out, void* stream) {
   HIPCHK(hipMemcpyAsync(out, h->dglob, sizeof(Glob), hipMemcpyDeviceToHost, s));
   HIPCHK(hipStreamSynchronize(s));
   out->step_count = h->step_count; out->action_write_idx = h->action_write_idx;
+  return GO2SIM_E_OK;
+}
+int go2sim_env_globals_ptr(go2sim_t* h, void** ptr_out) {
+  if (!h || !ptr_out) return GO2SIM_E_BADARG;
+  *ptr_out = h->dglob;
   return GO2SIM_E_OK;
 }
 int go2sim_env_set_level(go2sim_t* h, float level, void* stream) {

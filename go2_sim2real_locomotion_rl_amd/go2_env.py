@@ -1,0 +1,191 @@
+"""Go2Env -- host-side mirror of the reference's walk environment class on top of the go2sim C ABI.
+
+Same constructor, methods, return values and attribute set as
+``examples/locomotion/final/go2_env_walk.py`` (class Go2Env :154; step :985-1109; get_observations :1145;
+get_privileged_observations :1151; reset :1242) so that ``rsl_rl.OnPolicyRunner`` and the reference's
+train / eval scripts can use it unchanged:
+
+    env = Go2Env(num_envs, env_cfg, obs_cfg, reward_cfg, command_cfg)
+    obs, extras = env.get_observations()
+    obs, rew, reset, extras = env.step(actions)         # all torch tensors on env.device
+
+Differences that are deliberate (DESIGN.md "boundary"):
+  * the whole step runs inside libgo2sim.so (HIP, gfx950); there is no per-call torch arithmetic and no
+    host synchronisation: the curriculum state machine and the "global" domain randomisation live on the device;
+  * ``extras["episode"]`` values are 0-dim device tensors instead of python floats (rsl_rl accepts both);
+  * random numbers come from the counter-based Philox stream of the C ABI (include/go2sim.h), not from
+    torch's global generator.
+"""
+import ctypes
+import math
+
+import torch
+
+from .capi import C, EnvGlobals, Go2Sim, Go2SimError, load_hip_lib
+from .configs import flatten_walk_cfg
+from .model_blob import pack_model
+
+_DEVICE = None
+_SEED = 1
+
+
+def init(backend=None, precision="32", logging_level=None, performance_mode=True, seed=None, device_index=0, **_):
+    """Counterpart of ``gs.init`` (genesis/__init__.py:60): selects the ROCm device and the RNG seed."""
+    global _DEVICE, _SEED
+    if str(precision) != "32":
+        raise Go2SimError("go2sim computes in fp32 only (the reference path runs gs.init(precision='32'))")
+    if not torch.cuda.is_available():
+        raise Go2SimError("no ROCm GPU visible: the go2sim product path has no CPU fallback")
+    torch.cuda.set_device(device_index)
+    _DEVICE = torch.device("cuda", device_index)
+    if seed is not None:
+        _SEED = int(seed)
+    return _DEVICE
+
+
+def _as_device_tensor(ptr, shape, dtype, device):
+    """Zero-copy torch view of library-owned device memory (no ownership transfer, include/go2sim.h)."""
+    itemsize = torch.empty((), dtype=dtype).element_size()
+    n = 1
+    for s in shape:
+        n *= s
+
+    class _Mem:
+        __cuda_array_interface__ = {
+            "shape": tuple(shape), "typestr": {torch.float32: "<f4", torch.int32: "<i4", torch.uint8: "|u1"}[dtype],
+            "data": (int(ptr), False), "version": 2, "strides": None,
+        }
+
+    assert n * itemsize > 0
+    return torch.as_tensor(_Mem(), device=device)
+
+
+class Go2Env:
+    def __init__(self, num_envs, env_cfg, obs_cfg, reward_cfg, command_cfg, show_viewer=False, *, seed=None, device=None,
+                 freeze_curriculum=False):
+        if show_viewer:
+            raise Go2SimError("the viewer is outside the accelerated path (SURVEY.md section 8f)")
+        self.device = device if device is not None else (_DEVICE if _DEVICE is not None else init())
+        self.num_envs = num_envs
+        self.num_obs = obs_cfg["num_obs"]
+        self.num_privileged_obs = obs_cfg.get("num_privileged_obs", None)
+        self.num_actions = env_cfg["num_actions"]
+        self.num_pos_actions = env_cfg.get("num_pos_actions", 12)
+        self.num_commands = command_cfg["num_commands"]
+        self.simulate_action_latency = env_cfg.get("simulate_action_latency", True)
+        self.dt = 0.02
+        self.max_episode_length = math.ceil(env_cfg["episode_length_s"] / self.dt)
+        self.env_cfg, self.obs_cfg, self.reward_cfg, self.command_cfg = env_cfg, obs_cfg, reward_cfg, command_cfg
+        self.obs_scales = obs_cfg["obs_scales"]
+        self.reward_scales = dict(reward_cfg["reward_scales"])
+
+        dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        self._sim = Go2Sim(load_hip_lib(), pack_model(), num_envs, dev_index, _SEED if seed is None else int(seed))
+        fcfg, icfg, self._reward_names = flatten_walk_cfg(num_envs, env_cfg, obs_cfg, reward_cfg, command_cfg,
+                                                          freeze_curriculum=freeze_curriculum)
+        if self.num_obs != 49 or self.num_privileged_obs not in (None, 104) or self.num_actions != 16:
+            raise Go2SimError("go2sim implements the walk observation layout (49 / 104) with 16 actions (go2_train_walk.py:300-320)")
+        self._sim.env_configure(fcfg, icfg)
+
+        B, dev = num_envs, self.device
+        self.obs_buf = torch.zeros(B, 49, device=dev)
+        self.privileged_obs_buf = torch.zeros(B, 104, device=dev)
+        self.rew_buf = torch.zeros(B, device=dev)
+        self.reset_buf = torch.zeros(B, dtype=torch.uint8, device=dev)
+        self._time_outs = torch.zeros(B, device=dev)
+        self._actions = torch.zeros(B, 16, device=dev)
+        self.extras = {"observations": {}}
+        # live device view of the curriculum / DR globals and the last reset's episode log
+        gptr = self._sim.env_globals_ptr()
+        self._glob_f32 = _as_device_tensor(gptr, (ctypes.sizeof(EnvGlobals) // 4,), torch.float32, dev)
+        self._ep_off = EnvGlobals.last_episode_rew.offset // 4
+        self._level_off = EnvGlobals.level.offset // 4
+        self._views = {}
+        self.reset()
+
+    # ---- reference API -------------------------------------------------------------------------
+    def step(self, actions):
+        """go2_env_walk.py:985-1109.  ``actions`` [num_envs, 16] float32 on ``self.device``."""
+        if actions.shape != (self.num_envs, self.num_actions):
+            raise Go2SimError(f"actions must have shape {(self.num_envs, self.num_actions)}, got {tuple(actions.shape)}")
+        a = actions
+        if a.dtype != torch.float32 or not a.is_contiguous() or a.device != self.device:
+            a = self._actions.copy_(actions)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        self._sim.env_step(a, self.obs_buf, self.privileged_obs_buf, self.rew_buf, self.reset_buf, self._time_outs, stream)
+        self.extras["time_outs"] = self._time_outs
+        self.extras["episode"] = {"rew_" + n: v for n, v in zip(self._reward_names, self._glob_f32[self._ep_off:self._ep_off + len(self._reward_names)].clone())}
+        self.extras["observations"]["critic"] = self.privileged_obs_buf if self.num_privileged_obs else self.obs_buf
+        return self.obs_buf, self.rew_buf, self.reset_buf, self.extras
+
+    def get_observations(self):
+        self.extras["observations"]["critic"] = self.privileged_obs_buf if self.num_privileged_obs else self.obs_buf
+        return self.obs_buf, self.extras
+
+    def get_privileged_observations(self):
+        return self.privileged_obs_buf if self.num_privileged_obs is not None else None
+
+    def reset(self):
+        """go2_env_walk.py:1242-1245 (reset_idx over all envs; obs_buf is not recomputed, as in the reference)."""
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        self._sim.env_reset(stream)
+        self.reset_buf.fill_(1)
+        return self.obs_buf, None
+
+    # ---- state the reference exposes as attributes ----------------------------------------------
+    def _env_view(self, name, k, dtype=torch.float32):
+        key = (name, k)
+        if key not in self._views:
+            self._views[key] = torch.zeros(k, self.num_envs, dtype=dtype, device=self.device)
+        buf = self._views[key]
+        self._sim.env_get(C["GO2SIM_EB_" + name], buf, torch.cuda.current_stream(self.device).cuda_stream)
+        return buf.t() if k > 1 else buf[0]
+
+    @property
+    def episode_length_buf(self):
+        return self._env_view("EPISODE_LENGTH", 1, torch.int32)
+
+    @episode_length_buf.setter
+    def episode_length_buf(self, value):
+        """rsl_rl ``init_at_random_ep_len`` assigns a fresh tensor here (on_policy_runner)."""
+        v = value.to(device=self.device, dtype=torch.int32).contiguous()
+        self._sim.env_set_episode_length(v, torch.cuda.current_stream(self.device).cuda_stream)
+
+    commands = property(lambda self: self._env_view("COMMANDS", 3))
+    base_lin_vel = property(lambda self: self._env_view("BASE_LIN_VEL", 3))
+    base_ang_vel = property(lambda self: self._env_view("BASE_ANG_VEL", 3))
+    projected_gravity = property(lambda self: self._env_view("PROJECTED_GRAVITY", 3))
+    dof_pos = property(lambda self: self._env_view("DOF_POS", 12))
+    dof_vel = property(lambda self: self._env_view("DOF_VEL", 12))
+    base_pos = property(lambda self: self._env_view("BASE_POS", 3))
+    base_quat = property(lambda self: self._env_view("BASE_QUAT", 4))
+    base_euler = property(lambda self: self._env_view("BASE_EULER", 3))
+
+    @property
+    def episode_sums(self):
+        sums = self._env_view("EPISODE_SUMS", 32)
+        return {n: sums[:, i] for i, n in enumerate(self._reward_names)}
+
+    def set_commands(self, commands):
+        """Eval scripts overwrite ``env.commands`` (go2_eval_walk.py); here through the setter of the C ABI."""
+        v = commands.to(device=self.device, dtype=torch.float32).contiguous()
+        self._sim.env_set_commands(v, torch.cuda.current_stream(self.device).cuda_stream)
+
+    @property
+    def curriculum_level(self):
+        return self._glob_f32[self._level_off]
+
+    def curriculum_state(self):
+        """extras["curriculum"] of the reference (go2_env_walk.py:674-690); this call synchronises the stream."""
+        return self._sim.env_globals(torch.cuda.current_stream(self.device).cuda_stream).as_dict()
+
+    def check_errno(self):
+        """rigid_solver.py:1208-1211: raises when the solver produced NaNs."""
+        v = self._sim.check_errno(torch.cuda.current_stream(self.device).cuda_stream)
+        if v & C["GO2SIM_ERR_INVALID_FORCE_NAN"]:
+            raise Go2SimError("Invalid constraint forces causing 'nan'. Some environments were not advanced.")
+        if v & C["GO2SIM_ERR_INVALID_ACC_NAN"]:
+            raise Go2SimError("Invalid accelerations causing 'nan'. Some environments were not advanced.")
+        if v & (C["GO2SIM_ERR_OVERFLOW_CANDIDATE_CONTACTS"] | C["GO2SIM_ERR_OVERFLOW_COLLISION_PAIRS"]):
+            raise Go2SimError("Exceeding max number of broad phase candidate contact pairs / contacts.")
+        return v

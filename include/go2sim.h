@@ -292,6 +292,10 @@ int go2sim_env_set_episode_length(go2sim_t* h, const int* ep_len_dev, void* stre
 int go2sim_env_set_commands(go2sim_t* h, const float* cmd_dev, void* stream);
 int go2sim_env_globals(go2sim_t* h, go2sim_env_globals_t* out_host, void* stream);
 int go2sim_env_set_level(go2sim_t* h, float level, void* stream);
+/* zero-copy address of the live go2sim_env_globals_t (device memory for the HIP library): lets the host shim expose
+ * extras["episode"] / extras["curriculum"] (go2_env_Omni_walk_16output.py:674-690, 1229-1234) as device tensors
+ * without a stream synchronisation. */
+int go2sim_env_globals_ptr(go2sim_t* h, void** ptr_out);
 
 /* hipEvent-timed duration (ms) of each kernel class accumulated since the last call with reset=1;
  * out[0..7] = dyn, collide, solve, integrate, env_pre, env_post, misc, total ; counts in cnt[0..7].

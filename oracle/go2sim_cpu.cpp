@@ -343,7 +343,6 @@ struct Env {
   real qacc[ND], Ma[ND], grad[ND], Mgrad[ND], search[ND], mv[ND], qfrc_constraint[ND], nt_vec[ND];
   real H[ND][ND];
   real cost, prev_cost, gauss, quad_gauss[3], gtol; int ls_it, ls_result, improved, solver_iters;
-  real dbg[96];
   V3 contact_force[NL];
   real vel_next[ND], qpos_next[NQ];
 };
@@ -1411,7 +1410,6 @@ real linesearch(const Model& m, Env& e) {
   } else {
     LsPoint p0 = ls_init_and_eval_p0(m, e);
     LsPoint p1 = ls_point_fn(m, e, p0.alpha - p0.grad / p0.hess);
-    e.dbg[8] = p0.cost; e.dbg[9] = p0.grad; e.dbg[10] = p0.hess; e.dbg[11] = p1.alpha; e.dbg[12] = p1.cost; e.dbg[13] = p1.grad; e.dbg[14] = p1.hess;
     if (p0.cost < p1.cost) p1 = p0;
     if (dm_abs(p1.grad) < gtol) {
       e.ls_result = (dm_abs(p1.alpha) < m.eps) ? 2 : 0;
@@ -1423,7 +1421,6 @@ real linesearch(const Model& m, Env& e) {
       while (p1.grad * (real)direction <= -gtol && e.ls_it < m.ls_iterations) {
         p2 = p1; p2update = 1;
         p1 = ls_point_fn(m, e, p1.alpha - p1.grad / p1.hess);
-        if (e.ls_it < 20) { e.dbg[16 + 4 * e.ls_it] = p1.alpha; e.dbg[17 + 4 * e.ls_it] = p1.cost; e.dbg[18 + 4 * e.ls_it] = p1.grad; e.dbg[19 + 4 * e.ls_it] = p1.hess; }
         if (dm_abs(p1.grad) < gtol) { res_alpha = p1.alpha; done = true; break; }
       }
       if (!done) {
@@ -1435,7 +1432,6 @@ real linesearch(const Model& m, Env& e) {
           while (e.ls_it < m.ls_iterations) {
             real costs[3], grads[3], hess[3];
             ls_point_fn_3(m, e, al, costs, grads, hess);
-            if (e.ls_it < 20) for (int q = 0; q < 3; ++q) { int z = e.ls_it - 2 + q; e.dbg[16 + 4 * z] = al[q]; e.dbg[17 + 4 * z] = costs[q]; e.dbg[18 + 4 * z] = grads[q]; e.dbg[19 + 4 * z] = hess[q]; }
             real p1_next_alpha = al[0], p2_next_alpha = al[1];
             real best_alpha = 0.0f, best_cost = 0.0f; bool best_found = false;
             for (int i = 0; i < 3; ++i)
@@ -1462,7 +1458,6 @@ real linesearch(const Model& m, Env& e) {
       }
     }
   }
-  e.dbg[7] = res_alpha; e.dbg[0] = e.cost; e.dbg[1] = e.prev_cost; e.dbg[2] = e.gauss; e.dbg[3] = e.quad_gauss[0]; e.dbg[4] = e.quad_gauss[1]; e.dbg[5] = e.quad_gauss[2]; e.dbg[6] = e.gtol;
   return res_alpha;
 }
 
@@ -2448,6 +2443,11 @@ int go2sim_cpu_env_globals(go2sim* h, go2sim_env_globals_t* out, void*) {
   *out = h->g;
   return GO2SIM_E_OK;
 }
+int go2sim_cpu_env_globals_ptr(go2sim* h, void** ptr_out) {
+  if (!h || !ptr_out) return GO2SIM_E_BADARG;
+  *ptr_out = &h->g;
+  return GO2SIM_E_OK;
+}
 int go2sim_cpu_env_set_level(go2sim* h, float level, void*) {
   if (!h || !h->cfg.set) return GO2SIM_E_BADARG;
   h->g.level = level;
@@ -2486,7 +2486,6 @@ int go2sim_cpu_debug_get(go2sim* h, const char* name, float* dst, int* k_out) {
     else if (!strcmp(name, "qacc")) { src = e.qacc; k = ND; }
     else if (!strcmp(name, "Ma")) { src = e.Ma; k = ND; }
     else if (!strcmp(name, "mv")) { src = e.mv; k = ND; }
-    else if (!strcmp(name, "sv")) { src = e.dbg; k = 96; }
     else if (!strcmp(name, "mass_L")) { src = &e.mass_L[0][0]; k = ND * ND; }
     else if (!strcmp(name, "cdof_ang")) { src = (const float*)e.cdof_ang; k = ND * 3; }
     else if (!strcmp(name, "cdof_vel")) { src = (const float*)e.cdof_vel; k = ND * 3; }

@@ -58,7 +58,7 @@ for s in range(NSUB):
         print(" contact geoms", cg[:nc], cg[150:150 + nc])
         print(" cpu pen", cpu.get_field_np(C["GO2SIM_F_CONTACT_PEN"])[:nc, e0], "gpu pen", gpu_field("F_CONTACT_PEN")[:nc, e0])
         import ctypes
-        for nm in ["cdof_ang", "cdof_vel", "mass_L", "jac", "diag", "aref", "efc_D", "Jaref", "jv", "H", "grad", "Mgrad", "search", "qacc", "Ma", "mv", "sv"]:
+        for nm in ["cdof_ang", "cdof_vel", "mass_L", "jac", "diag", "aref", "efc_D", "Jaref", "jv", "H", "grad", "Mgrad", "search", "qacc", "Ma", "mv"]:
             kk = ctypes.c_int(); ptr = ctypes.c_void_p(); ii = ctypes.c_int()
             assert gpu.L.lib.go2sim_debug_field(gpu.h, nm.encode(), ctypes.byref(ptr), ctypes.byref(kk), ctypes.byref(ii)) == 0
             k = kk.value
