@@ -1291,249 +1291,183 @@ __global__ __launch_bounds__(WG) void k_collide(Pool P, const Model* __restrict_
 // ---------------------------------------------------------------------------------------------
 // constraints + Newton solver  (R/constraint/solver.py)
 // ---------------------------------------------------------------------------------------------
-// add_collision_constraints, solver.py:498-595
-DEVN void add_collision_constraints(const Model& m, const E& e) {
-  auto jac = e.jac(); auto cdof_ang = e.cdof_ang(); auto cdof_vel = e.cdof_vel(); auto root_com = e.root_com(); auto vel = e.vel();
-  auto diag_ = e.diag(); auto aref_ = e.aref(); auto efc_D = e.efc_D();
-  int nc = e.n_contacts()[0];
-  int n_con_total = e.n_con()[0];
-  for (int i_col = 0; i_col < nc; ++i_col) {
-    int link_a = e.c_link()[i_col], link_b = e.c_link()[MAXC + i_col];
-    V3 cpos = e.c_pos()[i_col], cnormal = e.c_normal()[i_col];
-    float friction = e.c_friction()[i_col], pen = e.c_pen()[i_col];
-    float sol[7];
-    auto csol = e.c_sol()[i_col];
+// ---- exact line search helpers, solver.py:1888-2417 ----
+struct LsPoint { float alpha, cost, grad, hess; };
+DEVN int update_bracket(LsPoint& p, const float alphas[3], const float costs[3], const float grads[3], const float hess[3], float& p_next_alpha) {
+  int flag = 0;
 #pragma unroll
-    for (int k = 0; k < 7; ++k) sol[k] = csol[k];
-    V3 d1, d2;
-    orthogonals(cnormal, d1, d2);
-    float invweight = m.links[link_a].invweight[0];
-    if (link_b > -1) invweight = invweight + m.links[link_b].invweight[0];
-    for (int i = 0; i < 4; ++i) {
-      V3 d = (float)(2 * (i % 2) - 1) * ((i < 2) ? d1 : d2);
-      V3 n = d * friction - cnormal;
-      int n_con = n_con_total++;
-      auto row = jac[n_con];
-      for (int i_d = 0; i_d < ND; ++i_d) row[i_d] = 0.0f;
-      float jac_qvel = 0.0f;
-      for (int i_ab = 0; i_ab < 2; ++i_ab) {
-        float sign = -1.0f; int link = link_a;
-        if (i_ab == 1) { sign = 1.0f; link = link_b; }
-        while (link > -1) {
-          const Link& L = m.links[link];
-          V3 t_pos = cpos - (V3)root_com[link];
-          for (int i_d_ = 0; i_d_ < L.n_dofs; ++i_d_) {
-            int i_d = L.dof_end - 1 - i_d_;
-            V3 velv = (V3)cdof_vel[i_d] - cross(t_pos, cdof_ang[i_d]);
-            V3 diff = sign * velv;
-            float j = dot(diff, n);
-            jac_qvel = jac_qvel + j * vel[i_d];
-            row[i_d] = row[i_d] + j;
-          }
-          link = L.parent;
-        }
-      }
-      float imp, aref;
-      imp_aref(sol, -pen, jac_qvel, -pen, imp, aref);
-      float diag = invweight + friction * friction * invweight;
-      diag *= 2.0f * friction * friction * (1.0f - imp) / imp;
-      diag = fmx(diag, m.eps);
-      diag_[n_con] = diag; aref_[n_con] = aref; efc_D[n_con] = 1.0f / diag;
-    }
+  for (int i = 0; i < 3; ++i) {
+    if (p.grad < 0 && grads[i] < 0 && p.grad < grads[i]) { p.alpha = alphas[i]; p.cost = costs[i]; p.grad = grads[i]; p.hess = hess[i]; flag = 1; }
+    else if (p.grad > 0 && grads[i] > 0 && p.grad > grads[i]) { p.alpha = alphas[i]; p.cost = costs[i]; p.grad = grads[i]; p.hess = hess[i]; flag = 2; }
   }
-  e.n_con()[0] = n_con_total;
-}
-// add_joint_limit_constraints, solver.py:1088-1143
-DEVN void add_joint_limit_constraints(const Model& m, const E& e) {
-  auto qpos = e.qpos(); auto vel = e.vel(); auto jac = e.jac();
-  int n_con_total = e.n_con()[0];
-  for (int i_l = 0; i_l < NL; ++i_l)
-    for (int i_j = m.links[i_l].joint_start; i_j < m.links[i_l].joint_end; ++i_j) {
-      const Joint& J = m.joints[i_j];
-      if (J.type != JOINT_REVOLUTE) continue;
-      int i_q = J.q_start, i_d = J.dof_start;
-      float q = qpos[i_q];
-      float pos_delta_min = q - m.dofs[i_d].limit[0];
-      float pos_delta_max = m.dofs[i_d].limit[1] - q;
-      float pos_delta = fmn(pos_delta_min, pos_delta_max);
-      if (pos_delta < 0) {
-        float j = (float)((pos_delta_min < pos_delta_max) * 2 - 1);
-        float jac_qvel = j * vel[i_d];
-        float imp, aref;
-        imp_aref(J.sol_params, pos_delta, jac_qvel, pos_delta, imp, aref);
-        float diag = fmx(m.dofs[i_d].invweight * (1.0f - imp) / imp, m.eps);
-        int n_con = n_con_total++;
-        e.diag()[n_con] = diag; e.aref()[n_con] = aref; e.efc_D()[n_con] = 1.0f / diag;
-        auto row = jac[n_con];
-        for (int i_d2 = 0; i_d2 < ND; ++i_d2) row[i_d2] = 0.0f;
-        row[i_d] = j;
-      }
-    }
-  e.n_con()[0] = n_con_total;
+  p_next_alpha = p.alpha;
+  if (flag > 0) p_next_alpha = p.alpha - p.grad / p.hess;
+  return flag;
 }
 
-// func_hessian_direct_batch, solver.py:1285-1343
-DEVN void hessian_direct(const Model& m, const E& e, int n_con) {
-  auto H = e.H(); auto jac = e.jac(); auto efc_D = e.efc_D(); auto active = e.active(); auto mass_mat = e.mass_mat();
-  for (int i = 0; i < ND; ++i) for (int j = 0; j < i + 1; ++j) H[i][j] = 0.0f;
-  for (int i_d1 = 0; i_d1 < ND; ++i_d1) {
-    auto Hrow = H[i_d1];
-    for (int i_c = 0; i_c < n_con; ++i_c) {
-      auto row = jac[i_c];
-      float j1 = row[i_d1];
-      if (dm_abs(j1) > m.eps) {
-        float D = efc_D[i_c], act = (float)active[i_c];
-        for (int i_d2 = 0; i_d2 < i_d1 + 1; ++i_d2) Hrow[i_d2] = Hrow[i_d2] + row[i_d2] * j1 * D * act;
-      }
-    }
-  }
-  for (int i_d1 = 0; i_d1 < ND; ++i_d1)
-    for (int i_d2 = 0; i_d2 < i_d1 + 1; ++i_d2) H[i_d1][i_d2] = H[i_d1][i_d2] + mass_mat[i_d1][i_d2];
-}
-// func_cholesky_factor_direct_batch, solver.py:1467-1494
-DEVN void cholesky_factor_direct(const Model& m, const E& e) {
-  auto H = e.H();
-  for (int i_d = 0; i_d < ND; ++i_d) {
-    auto Hi = H[i_d];
-    float tmp = Hi[i_d];
-    for (int j_d = 0; j_d < i_d; ++j_d) { float h = Hi[j_d]; tmp = tmp - h * h; }
-    float dgn = dm_sqrt(fmx(tmp, m.eps));
-    Hi[i_d] = dgn;
-    tmp = 1.0f / dgn;
-    for (int j_d = i_d + 1; j_d < ND; ++j_d) {
-      auto Hj = H[j_d];
-      float dotv = 0.0f;
-      for (int k_d = 0; k_d < i_d; ++k_d) dotv = dotv + Hj[k_d] * Hi[k_d];
-      Hj[i_d] = (Hj[i_d] - dotv) * tmp;
-    }
-  }
-}
-// func_hessian_and_cholesky_factor_incremental_dense_batch, solver.py:1632-1675
-DEVN bool cholesky_incremental(const Model& m, const E& e, int n_con) {
-  auto H = e.H(); auto jac = e.jac(); auto nt_vec = e.nt_vec(); auto active = e.active(); auto prev_active = e.prev_active(); auto efc_D = e.efc_D();
-  bool is_degenerated = false;
-  for (int i_c = 0; i_c < n_con; ++i_c) {
-    bool is_active = active[i_c] != 0, is_active_prev = prev_active[i_c] != 0;
-    if (is_active ^ is_active_prev) {
-      float sign = is_active ? 1.0f : -1.0f;
-      float efc_D_sqrt = dm_sqrt(efc_D[i_c]);
-      auto row = jac[i_c];
-      for (int i_d = 0; i_d < ND; ++i_d) nt_vec[i_d] = row[i_d] * efc_D_sqrt;
-      for (int k = 0; k < ND; ++k) {
-        float vk = nt_vec[k];
-        if (dm_abs(vk) > m.eps) {
-          float Lkk = H[k][k];
-          float tmp = Lkk * Lkk + sign * (vk * vk);
-          if (tmp < m.eps) { is_degenerated = true; break; }
-          float r = dm_sqrt(tmp);
-          float c = r / Lkk;
-          float cinv = 1.0f / c;
-          float s = vk / Lkk;
-          H[k][k] = r;
-          for (int i = k + 1; i < ND; ++i) H[i][k] = (H[i][k] + s * nt_vec[i] * sign) * cinv;
-          for (int i = k + 1; i < ND; ++i) nt_vec[i] = nt_vec[i] * c - s * H[i][k];
-        }
-      }
-    }
-  }
-  return is_degenerated;
-}
-// func_cholesky_solve_batch, solver.py:1747-1765
-DEV void cholesky_solve(const E& e) {
-  auto H = e.H(); auto grad = e.grad(); auto Mgrad = e.Mgrad();
-  for (int i_d = 0; i_d < ND; ++i_d) {
-    auto Hi = H[i_d];
-    float cur = grad[i_d];
-    for (int j_d = 0; j_d < i_d; ++j_d) cur = cur - Hi[j_d] * Mgrad[j_d];
-    Mgrad[i_d] = cur / Hi[i_d];
-  }
-  for (int i_d_ = 0; i_d_ < ND; ++i_d_) {
-    int i_d = ND - 1 - i_d_;
-    float cur = Mgrad[i_d];
-    for (int j_d = i_d + 1; j_d < ND; ++j_d) cur = cur - H[j_d][i_d] * Mgrad[j_d];
-    Mgrad[i_d] = cur / H[i_d][i_d];
-  }
-}
-// func_update_constraint_batch, solver.py:2428-2503 (no equality / frictionloss rows for Go2)
-DEVN void update_constraint(const Model& m, const E& e, int n_con) {
-  auto sv = e.sv(); auto active = e.active(); auto prev_active = e.prev_active(); auto Jaref = e.Jaref(); auto efc_D = e.efc_D();
-  auto efc_force = e.efc_force(); auto jac = e.jac(); auto qfrc_constraint = e.qfrc_constraint();
-  sv[SV_PREV_COST] = sv[SV_COST];
-  float cost_i = 0.0f, gauss_i = 0.0f;
-  for (int i_c = 0; i_c < n_con; ++i_c) {
-    prev_active[i_c] = active[i_c];
-    float Ja = Jaref[i_c];
+// ---------------------------------------------------------------------------------------------
+// Team solver: T lanes cooperate on one environment, 64/T environments per wavefront, one wavefront per
+// workgroup.  The whole working set of the Newton solve (Jacobian rows, Hessian / Cholesky factor, mass
+// matrix, dof and row vectors) lives in LDS; HBM is touched once to stage the inputs and once to commit the
+// results.  Arithmetic is the serial reference order (solver.py), only *independent* outputs (rows, dofs,
+// Hessian entries) are spread over the lanes; every sum is still evaluated first-to-last by one lane, and
+// team-uniform scalars (costs, line-search points) are evaluated redundantly by all lanes of the team, so the
+// results are bit-identical to the one-lane-per-env formulation and to the CPU oracle.
+// Environments with more than RL rows fall back to the same code on a per-env global scratch block.
+// ---------------------------------------------------------------------------------------------
+constexpr int RL = 48;  // constraint rows held in LDS (12 contacts); typical walking uses 16
+
+template <int R>
+struct SolverData {
+  float J[R * ND];
+  float H[ND * ND];
+  float M[ND * ND];
+  float qacc[ND], Ma[ND], grad[ND], Mgrad[ND], search[ND], mv[ND], force[ND], acc_smooth[ND], qfrc[ND], ntv[ND], vel[ND];
+  float cdof_ang[ND * 3], cdof_vel[ND * 3], root_com[NL * 3];
+  float aref[R], efc_D[R], Jaref[R], jv[R], efc_force[R], qf0[R], qf1[R], qf2[R];
+  int active[R], prev_active[R];
+};
+
+// single-wavefront workgroups: the barrier is a compiler/LDS ordering fence only
+DEV void team_sync() { __syncthreads(); }
+DEV float gload(const E& e, int off, int k) { return e.f[(size_t)(off + k) * e.B]; }
+DEV void gstore(const E& e, int off, int k, float v) { e.f[(size_t)(off + k) * e.B] = v; }
+
+template <int T, class S>
+DEV void ts_update_constraint(const Model& m, S* s, int tl, int n_con, float& cost, float& prev_cost, float& gauss) {
+  prev_cost = cost;
+  for (int c = tl; c < n_con; c += T) {
+    s->prev_active[c] = s->active[c];
+    float Ja = s->Jaref[c];
     int act = Ja < 0.0f;
-    active[i_c] = act;
-    efc_force[i_c] = 0.0f + (-Ja * efc_D[i_c] * (float)act);
+    s->active[c] = act;
+    s->efc_force[c] = 0.0f + (-Ja * s->efc_D[c] * (float)act);
   }
-  for (int i_d = 0; i_d < ND; ++i_d) {
+  team_sync();
+  for (int d = tl; d < ND; d += T) {
     float q = 0.0f;
-    for (int i_c = 0; i_c < n_con; ++i_c) q = q + jac[i_c][i_d] * efc_force[i_c];
-    qfrc_constraint[i_d] = q;
+    for (int c = 0; c < n_con; ++c) q = q + s->J[c * ND + d] * s->efc_force[c];
+    s->qfrc[d] = q;
   }
-  auto Ma = e.Ma(); auto force = e.force(); auto qacc = e.qacc(); auto acc_smooth = e.acc_smooth();
-  for (int i_d = 0; i_d < ND; ++i_d) {
-    float v = 0.5f * (Ma[i_d] - force[i_d]) * (qacc[i_d] - acc_smooth[i_d]);
+  float cost_i = 0.0f, gauss_i = 0.0f;
+  for (int d = 0; d < ND; ++d) {
+    float v = 0.5f * (s->Ma[d] - s->force[d]) * (s->qacc[d] - s->acc_smooth[d]);
     gauss_i = gauss_i + v;
     cost_i = cost_i + v;
   }
-  for (int i_c = 0; i_c < n_con; ++i_c) { float Ja = Jaref[i_c]; cost_i = cost_i + 0.5f * (Ja * Ja * efc_D[i_c] * (float)active[i_c]); }
-  sv[SV_GAUSS] = gauss_i;
-  sv[SV_COST] = cost_i;
-}
-DEV void update_gradient(const E& e) {
-  auto grad = e.grad(); auto Ma = e.Ma(); auto force = e.force(); auto qfrc_constraint = e.qfrc_constraint();
-  for (int i_d = 0; i_d < ND; ++i_d) grad[i_d] = Ma[i_d] - force[i_d] - qfrc_constraint[i_d];
-  cholesky_solve(e);
+  for (int c = 0; c < n_con; ++c) { float Ja = s->Jaref[c]; cost_i = cost_i + 0.5f * (Ja * Ja * s->efc_D[c] * (float)s->active[c]); }
+  gauss = gauss_i; cost = cost_i;
+  team_sync();
 }
 
-// ---- exact line search, solver.py:1888-2417 -------------------------------------------------------
-struct LsPoint { float alpha, cost, grad, hess; };
-DEV LsPoint ls_init_and_eval_p0(const Model& m, const E& e, int n_con) {
-  auto mass_mat = e.mass_mat(); auto search = e.search(); auto mv_ = e.mv(); auto jac = e.jac(); auto jv_ = e.jv(); auto sv = e.sv();
-  for (int i_d1 = 0; i_d1 < ND; ++i_d1) {
-    auto Mr = mass_mat[i_d1];
-    float mv = 0.0f;
-    for (int i_d2 = 0; i_d2 < ND; ++i_d2) mv = mv + Mr[i_d2] * search[i_d2];
-    mv_[i_d1] = mv;
+template <int T, class S>
+DEV void ts_hessian_direct(const Model& m, S* s, int tl, int n_con) {
+  for (int idx = tl; idx < ND * (ND + 1) / 2; idx += T) {
+    int i = (int)((sqrtf(8.0f * (float)idx + 1.0f) - 1.0f) * 0.5f);
+    while (i * (i + 1) / 2 > idx) --i;
+    while ((i + 1) * (i + 2) / 2 <= idx) ++i;
+    int j = idx - i * (i + 1) / 2;
+    float h = 0.0f;
+    for (int c = 0; c < n_con; ++c) {
+      float j1 = s->J[c * ND + i];
+      if (dm_abs(j1) > m.eps) h = h + s->J[c * ND + j] * j1 * s->efc_D[c] * (float)s->active[c];
+    }
+    s->H[i * ND + j] = h + s->M[i * ND + j];
   }
-  for (int i_c = 0; i_c < n_con; ++i_c) {
-    auto row = jac[i_c];
-    float jv = 0.0f;
-    for (int i_d = 0; i_d < ND; ++i_d) jv = jv + row[i_d] * search[i_d];
-    jv_[i_c] = jv;
-  }
-  auto Ma = e.Ma(); auto force = e.force();
-  float qg1 = 0.0f, qg2 = 0.0f;
-  for (int i_d = 0; i_d < ND; ++i_d) {
-    float s = search[i_d];
-    qg1 = qg1 + (s * Ma[i_d] - s * force[i_d]);
-    qg2 = qg2 + 0.5f * s * mv_[i_d];
-  }
-  float gauss = sv[SV_GAUSS];
-  sv[SV_QG0] = gauss; sv[SV_QG1] = qg1; sv[SV_QG2] = qg2;
-  float t0 = gauss, t1 = qg1, t2 = qg2;
-  auto Jaref = e.Jaref(); auto efc_D = e.efc_D();
-  for (int i_c = 0; i_c < n_con; ++i_c) {
-    float Ja = Jaref[i_c], jv = jv_[i_c], D = efc_D[i_c];
-    float qf_0 = D * (0.5f * Ja * Ja), qf_1 = D * (jv * Ja), qf_2 = D * (0.5f * jv * jv);
-    float active = (float)(Ja < 0.0f);
-    t0 = t0 + qf_0 * active; t1 = t1 + qf_1 * active; t2 = t2 + qf_2 * active;
-  }
-  LsPoint p; p.alpha = 0.0f; p.cost = t0; p.grad = t1; p.hess = 2.0f * t2;
-  if (p.hess <= 0.0f) p.hess = m.eps;
-  return p;
+  team_sync();
 }
-DEV LsPoint ls_point_fn(const Model& m, const E& e, int n_con, float alpha, float qg0, float qg1, float qg2) {
-  auto Jaref = e.Jaref(); auto efc_D = e.efc_D(); auto jv_ = e.jv();
+
+template <int T, class S>
+DEV void ts_cholesky_factor(const Model& m, S* s, int tl) {
+  for (int i_d = 0; i_d < ND; ++i_d) {
+    float tmp = s->H[i_d * ND + i_d];
+    for (int j_d = 0; j_d < i_d; ++j_d) { float h = s->H[i_d * ND + j_d]; tmp = tmp - h * h; }
+    float dgn = dm_sqrt(fmx(tmp, m.eps));
+    float inv = 1.0f / dgn;
+    team_sync();
+    if (tl == 0) s->H[i_d * ND + i_d] = dgn;
+    for (int j_d = i_d + 1 + tl; j_d < ND; j_d += T) {
+      float dotv = 0.0f;
+      for (int k_d = 0; k_d < i_d; ++k_d) dotv = dotv + s->H[j_d * ND + k_d] * s->H[i_d * ND + k_d];
+      s->H[j_d * ND + i_d] = (s->H[j_d * ND + i_d] - dotv) * inv;
+    }
+    team_sync();
+  }
+}
+
+// returns true when the factor degenerated (caller rebuilds it from scratch)
+template <int T, class S>
+DEV bool ts_cholesky_incremental(const Model& m, S* s, int tl, int n_con) {
+  bool degenerated = false;
+  for (int c = 0; c < n_con && !degenerated; ++c) {
+    bool is_active = s->active[c] != 0, was_active = s->prev_active[c] != 0;
+    if (is_active ^ was_active) {
+      float sign = is_active ? 1.0f : -1.0f;
+      float efc_D_sqrt = dm_sqrt(s->efc_D[c]);
+      team_sync();
+      for (int d = tl; d < ND; d += T) s->ntv[d] = s->J[c * ND + d] * efc_D_sqrt;
+      team_sync();
+      for (int k = 0; k < ND; ++k) {
+        float vk = s->ntv[k];
+        if (dm_abs(vk) > m.eps) {
+          float Lkk = s->H[k * ND + k];
+          float tmp = Lkk * Lkk + sign * (vk * vk);
+          if (tmp < m.eps) { degenerated = true; break; }
+          float r = dm_sqrt(tmp);
+          float cc = r / Lkk;
+          float cinv = 1.0f / cc;
+          float sk = vk / Lkk;
+          team_sync();
+          if (tl == 0) s->H[k * ND + k] = r;
+          for (int i = k + 1 + tl; i < ND; i += T) {
+            float hik = (s->H[i * ND + k] + sk * s->ntv[i] * sign) * cinv;
+            s->H[i * ND + k] = hik;
+            s->ntv[i] = s->ntv[i] * cc - sk * hik;
+          }
+          team_sync();
+        }
+      }
+    }
+  }
+  return degenerated;
+}
+
+// grad, Mgrad = H^-1 grad (func_cholesky_solve_batch, solver.py:1747-1765): the two triangular solves are serial chains;
+// every lane runs them redundantly with the running vector in registers
+template <int T, class S>
+DEV void ts_update_gradient(S* s, int tl) {
+  for (int d = tl; d < ND; d += T) s->grad[d] = s->Ma[d] - s->force[d] - s->qfrc[d];
+  team_sync();
+  float y[ND];
+#pragma unroll
+  for (int i_d = 0; i_d < ND; ++i_d) {
+    float cur = s->grad[i_d];
+#pragma unroll
+    for (int j_d = 0; j_d < i_d; ++j_d) cur = cur - s->H[i_d * ND + j_d] * y[j_d];
+    y[i_d] = cur / s->H[i_d * ND + i_d];
+  }
+#pragma unroll
+  for (int i_d_ = 0; i_d_ < ND; ++i_d_) {
+    const int i_d = ND - 1 - i_d_;
+    float cur = y[i_d];
+#pragma unroll
+    for (int j_d = i_d + 1; j_d < ND; ++j_d) cur = cur - s->H[j_d * ND + i_d] * y[j_d];
+    y[i_d] = cur / s->H[i_d * ND + i_d];
+  }
+  if (tl == 0) {
+#pragma unroll
+    for (int d = 0; d < ND; ++d) s->Mgrad[d] = y[d];
+  }
+  team_sync();
+}
+
+template <class S>
+DEV LsPoint ts_ls_point(const Model& m, S* s, int n_con, float alpha, float qg0, float qg1, float qg2) {
   float t0 = qg0 + 0.0f, t1 = qg1 + 0.0f, t2 = qg2 + 0.0f;
-  for (int i_c = 0; i_c < n_con; ++i_c) {
-    float Ja = Jaref[i_c], jv = jv_[i_c], D = efc_D[i_c];
-    float x = Ja + alpha * jv;
+  for (int c = 0; c < n_con; ++c) {
+    float x = s->Jaref[c] + alpha * s->jv[c];
     float active = (float)(x < 0.0f);
-    float qf_0 = D * (0.5f * Ja * Ja), qf_1 = D * (jv * Ja), qf_2 = D * (0.5f * jv * jv);
-    t0 = t0 + qf_0 * active; t1 = t1 + qf_1 * active; t2 = t2 + qf_2 * active;
+    t0 = t0 + s->qf0[c] * active; t1 = t1 + s->qf1[c] * active; t2 = t2 + s->qf2[c] * active;
   }
   LsPoint p; p.alpha = alpha;
   p.cost = alpha * alpha * t2 + alpha * t1 + t0;
@@ -1542,13 +1476,13 @@ DEV LsPoint ls_point_fn(const Model& m, const E& e, int n_con, float alpha, floa
   if (p.hess <= 0.0f) p.hess = m.eps;
   return p;
 }
-DEV void ls_point_fn_3(const Model& m, const E& e, int n_con, const float a[3], float qg0, float qg1, float qg2, float costs[3], float grads[3], float hess[3]) {
-  auto Jaref = e.Jaref(); auto efc_D = e.efc_D(); auto jv_ = e.jv();
+template <class S>
+DEV void ts_ls_point3(const Model& m, S* s, int n_con, const float a[3], float qg0, float qg1, float qg2, float costs[3], float grads[3], float hess[3]) {
   float b0 = qg0 + 0.0f, b1 = qg1 + 0.0f, b2 = qg2 + 0.0f;
   float t00 = b0, t01 = b1, t02 = b2, t10 = b0, t11 = b1, t12 = b2, t20 = b0, t21 = b1, t22 = b2;
-  for (int i_c = 0; i_c < n_con; ++i_c) {
-    float Ja = Jaref[i_c], jv = jv_[i_c], D = efc_D[i_c];
-    float qf_0 = D * (0.5f * Ja * Ja), qf_1 = D * (jv * Ja), qf_2 = D * (0.5f * jv * jv);
+  for (int c = 0; c < n_con; ++c) {
+    float Ja = s->Jaref[c], jv = s->jv[c];
+    float qf_0 = s->qf0[c], qf_1 = s->qf1[c], qf_2 = s->qf2[c];
     float a0 = (float)((Ja + a[0] * jv) < 0.0f), a1 = (float)((Ja + a[1] * jv) < 0.0f), a2 = (float)((Ja + a[2] * jv) < 0.0f);
     t00 = t00 + qf_0 * a0; t01 = t01 + qf_1 * a0; t02 = t02 + qf_2 * a0;
     t10 = t10 + qf_0 * a1; t11 = t11 + qf_1 * a1; t12 = t12 + qf_2 * a1;
@@ -1563,184 +1497,248 @@ DEV void ls_point_fn_3(const Model& m, const E& e, int n_con, const float a[3], 
     if (hess[k] <= 0.0f) hess[k] = m.eps;
   }
 }
-DEV int update_bracket(LsPoint& p, const float alphas[3], const float costs[3], const float grads[3], const float hess[3], float& p_next_alpha) {
-  int flag = 0;
-#pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    if (p.grad < 0 && grads[i] < 0 && p.grad < grads[i]) { p.alpha = alphas[i]; p.cost = costs[i]; p.grad = grads[i]; p.hess = hess[i]; flag = 1; }
-    else if (p.grad > 0 && grads[i] > 0 && p.grad > grads[i]) { p.alpha = alphas[i]; p.cost = costs[i]; p.grad = grads[i]; p.hess = hess[i]; flag = 2; }
-  }
-  p_next_alpha = p.alpha;
-  if (flag > 0) p_next_alpha = p.alpha - p.grad / p.hess;
-  return flag;
-}
+
 // func_linesearch_batch, solver.py:2246-2417
-DEVN float linesearch(const Model& m, const E& e, int n_con) {
-  auto search = e.search();
+template <int T, class S>
+DEV float ts_linesearch(const Model& m, S* s, int tl, int n_con, float gauss) {
   float snorm = 0.0f;
-  for (int jd = 0; jd < ND; ++jd) { float s = search[jd]; snorm = snorm + s * s; }
+  for (int jd = 0; jd < ND; ++jd) { float sd = s->search[jd]; snorm = snorm + sd * sd; }
   snorm = dm_sqrt(snorm);
   float scale = m.meaninertia * (float)imx(1, ND);
   float gtol = m.tolerance * m.ls_tolerance * snorm * scale;
-  e.sv()[SV_GTOL] = gtol;
-  int ls_it = 0, ls_result = 0;
+  if (snorm < m.eps) return 0.0f;
+  // mv = M search, jv = J search, and the alpha-independent quadratic coefficients of every row
+  for (int d1 = tl; d1 < ND; d1 += T) {
+    float mv = 0.0f;
+    for (int d2 = 0; d2 < ND; ++d2) mv = mv + s->M[d1 * ND + d2] * s->search[d2];
+    s->mv[d1] = mv;
+  }
+  for (int c = tl; c < n_con; c += T) {
+    float jv = 0.0f;
+    for (int d = 0; d < ND; ++d) jv = jv + s->J[c * ND + d] * s->search[d];
+    s->jv[c] = jv;
+    float Ja = s->Jaref[c], D = s->efc_D[c];
+    s->qf0[c] = D * (0.5f * Ja * Ja); s->qf1[c] = D * (jv * Ja); s->qf2[c] = D * (0.5f * jv * jv);
+  }
+  team_sync();
+  float qg1 = 0.0f, qg2 = 0.0f;
+  for (int d = 0; d < ND; ++d) {
+    float sd = s->search[d];
+    qg1 = qg1 + (sd * s->Ma[d] - sd * s->force[d]);
+    qg2 = qg2 + 0.5f * sd * s->mv[d];
+  }
+  const float qg0 = gauss;
+  LsPoint p0;
+  {
+    float t0 = qg0, t1 = qg1, t2 = qg2;
+    for (int c = 0; c < n_con; ++c) {
+      float active = (float)(s->Jaref[c] < 0.0f);
+      t0 = t0 + s->qf0[c] * active; t1 = t1 + s->qf1[c] * active; t2 = t2 + s->qf2[c] * active;
+    }
+    p0.alpha = 0.0f; p0.cost = t0; p0.grad = t1; p0.hess = 2.0f * t2;
+    if (p0.hess <= 0.0f) p0.hess = m.eps;
+  }
+  int ls_it = 1;
   float res_alpha = 0.0f;
   bool done = false;
-  if (snorm < m.eps) {
-    ls_result = 1; res_alpha = 0.0f;
-  } else {
-    LsPoint p0 = ls_init_and_eval_p0(m, e, n_con);
-    ls_it = 1;
-    float qg0 = e.sv()[SV_QG0], qg1 = e.sv()[SV_QG1], qg2 = e.sv()[SV_QG2];
-    LsPoint p1 = ls_point_fn(m, e, n_con, p0.alpha - p0.grad / p0.hess, qg0, qg1, qg2);
+  LsPoint p1 = ts_ls_point(m, s, n_con, p0.alpha - p0.grad / p0.hess, qg0, qg1, qg2);
+  ls_it += 1;
+  if (p0.cost < p1.cost) p1 = p0;
+  if (dm_abs(p1.grad) < gtol) return p1.alpha;
+  int direction = (p1.grad < 0) * 2 - 1;
+  int p2update = 0;
+  LsPoint p2 = p1;
+  while (p1.grad * (float)direction <= -gtol && ls_it < m.ls_iterations) {
+    p2 = p1; p2update = 1;
+    p1 = ts_ls_point(m, s, n_con, p1.alpha - p1.grad / p1.hess, qg0, qg1, qg2);
     ls_it += 1;
-    if (p0.cost < p1.cost) p1 = p0;
-    if (dm_abs(p1.grad) < gtol) {
-      ls_result = (dm_abs(p1.alpha) < m.eps) ? 2 : 0;
-      res_alpha = p1.alpha;
-    } else {
-      int direction = (p1.grad < 0) * 2 - 1;
-      int p2update = 0;
-      LsPoint p2 = p1;
-      while (p1.grad * (float)direction <= -gtol && ls_it < m.ls_iterations) {
-        p2 = p1; p2update = 1;
-        p1 = ls_point_fn(m, e, n_con, p1.alpha - p1.grad / p1.hess, qg0, qg1, qg2);
-        ls_it += 1;
-        if (dm_abs(p1.grad) < gtol) { res_alpha = p1.alpha; done = true; break; }
-      }
-      if (!done) {
-        if (ls_it >= m.ls_iterations) { ls_result = 3; res_alpha = p1.alpha; done = true; }
-        if (!p2update && !done) { ls_result = 6; res_alpha = p1.alpha; done = true; }
-        if (!done) {
-          float al[3];
-          al[0] = p1.alpha - p1.grad / p1.hess; al[1] = p1.alpha; al[2] = (p1.alpha + p2.alpha) * 0.5f;
-          while (ls_it < m.ls_iterations) {
-            float costs[3], grads[3], hess[3];
-            ls_point_fn_3(m, e, n_con, al, qg0, qg1, qg2, costs, grads, hess);
-            ls_it += 3;
-            float p1_next_alpha = al[0], p2_next_alpha = al[1];
-            float best_alpha = 0.0f, best_cost = 0.0f; bool best_found = false;
+    if (dm_abs(p1.grad) < gtol) { res_alpha = p1.alpha; done = true; break; }
+  }
+  if (done) return res_alpha;
+  if (ls_it >= m.ls_iterations) return p1.alpha;
+  if (!p2update) return p1.alpha;
+  float al[3];
+  al[0] = p1.alpha - p1.grad / p1.hess; al[1] = p1.alpha; al[2] = (p1.alpha + p2.alpha) * 0.5f;
+  while (ls_it < m.ls_iterations) {
+    float costs[3], grads[3], hess[3];
+    ts_ls_point3(m, s, n_con, al, qg0, qg1, qg2, costs, grads, hess);
+    ls_it += 3;
+    float p1_next_alpha = al[0], p2_next_alpha = al[1];
+    float best_alpha = 0.0f, best_cost = 0.0f; bool best_found = false;
 #pragma unroll
-            for (int i = 0; i < 3; ++i)
-              if (dm_abs(grads[i]) < gtol && (!best_found || costs[i] < best_cost)) { best_alpha = al[i]; best_cost = costs[i]; best_found = true; }
-            if (best_found) {
-              res_alpha = best_alpha; done = true;
-            } else {
-              int b1 = update_bracket(p1, al, costs, grads, hess, p1_next_alpha);
-              int b2 = update_bracket(p2, al, costs, grads, hess, p2_next_alpha);
-              if (b1 == 0 && b2 == 0) { ls_result = (costs[2] < p0.cost) ? 0 : 7; res_alpha = al[2]; done = true; }
-            }
-            if (done) break;
-            al[0] = p1_next_alpha; al[1] = p2_next_alpha; al[2] = (p1.alpha + p2.alpha) * 0.5f;
-          }
-          if (!done) {
-            if (p1.cost <= p2.cost && p1.cost < p0.cost) { ls_result = 4; res_alpha = p1.alpha; }
-            else if (p2.cost <= p1.cost && p2.cost < p0.cost) { ls_result = 4; res_alpha = p2.alpha; }
-            else { ls_result = 5; res_alpha = 0.0f; }
-          }
+    for (int i = 0; i < 3; ++i)
+      if (dm_abs(grads[i]) < gtol && (!best_found || costs[i] < best_cost)) { best_alpha = al[i]; best_cost = costs[i]; best_found = true; }
+    if (best_found) return best_alpha;
+    int b1 = update_bracket(p1, al, costs, grads, hess, p1_next_alpha);
+    int b2 = update_bracket(p2, al, costs, grads, hess, p2_next_alpha);
+    if (b1 == 0 && b2 == 0) return al[2];
+    al[0] = p1_next_alpha; al[1] = p2_next_alpha; al[2] = (p1.alpha + p2.alpha) * 0.5f;
+  }
+  if (p1.cost <= p2.cost && p1.cost < p0.cost) return p1.alpha;
+  if (p2.cost <= p1.cost && p2.cost < p0.cost) return p2.alpha;
+  return 0.0f;
+}
+
+// rows + resolve for one environment (add_collision_constraints solver.py:498-595, add_joint_limit_constraints :1088-1143,
+// func_solve_init :2739-2859, func_solve_body :2941-2966, func_solve_iter :2862-2938)
+template <int T, class S>
+DEV int ts_solve(const Model& m, const E& e, S* s, int tl, int nc, int n_con) {
+  const int B = e.B; (void)B;
+  // ---- stage inputs ----
+  bool ws = (n_con > 0) && e.is_warmstart()[0];
+  for (int k = tl; k < ND * ND; k += T) s->M[k] = gload(e, FO(mass_mat), k);
+  for (int k = tl; k < ND * 3; k += T) { s->cdof_ang[k] = gload(e, FO(cdof_ang), k); s->cdof_vel[k] = gload(e, FO(cdof_vel), k); }
+  for (int k = tl; k < NL * 3; k += T) s->root_com[k] = gload(e, FO(root_com), k);
+  for (int d = tl; d < ND; d += T) {
+    s->vel[d] = gload(e, FO(vel), d);
+    s->force[d] = gload(e, FO(force), d);
+    float as = gload(e, FO(acc_smooth), d);
+    s->acc_smooth[d] = as;
+    s->qacc[d] = ws ? gload(e, FO(qacc_ws), d) : as;
+  }
+  team_sync();
+  // ---- contact rows: one lane per row ----
+  for (int r = tl; r < 4 * nc; r += T) {
+    int i_col = r >> 2, i = r & 3;
+    int link_a = e.c_link()[i_col], link_b = e.c_link()[MAXC + i_col];
+    V3 cpos = e.c_pos()[i_col], cnormal = e.c_normal()[i_col];
+    float friction = e.c_friction()[i_col], pen = e.c_pen()[i_col];
+    float sol[7];
+    auto csol = e.c_sol()[i_col];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) sol[k] = csol[k];
+    V3 d1, d2;
+    orthogonals(cnormal, d1, d2);
+    float invweight = m.links[link_a].invweight[0];
+    if (link_b > -1) invweight = invweight + m.links[link_b].invweight[0];
+    V3 d = (float)(2 * (i % 2) - 1) * ((i < 2) ? d1 : d2);
+    V3 n = d * friction - cnormal;
+    float* row = &s->J[r * ND];
+    for (int i_d = 0; i_d < ND; ++i_d) row[i_d] = 0.0f;
+    float jac_qvel = 0.0f;
+    for (int i_ab = 0; i_ab < 2; ++i_ab) {
+      float sign = -1.0f; int link = link_a;
+      if (i_ab == 1) { sign = 1.0f; link = link_b; }
+      while (link > -1) {
+        const Link& L = m.links[link];
+        V3 t_pos = cpos - v3(s->root_com[3 * link], s->root_com[3 * link + 1], s->root_com[3 * link + 2]);
+        for (int i_d_ = 0; i_d_ < L.n_dofs; ++i_d_) {
+          int i_d = L.dof_end - 1 - i_d_;
+          V3 ca = v3(s->cdof_ang[3 * i_d], s->cdof_ang[3 * i_d + 1], s->cdof_ang[3 * i_d + 2]);
+          V3 cv = v3(s->cdof_vel[3 * i_d], s->cdof_vel[3 * i_d + 1], s->cdof_vel[3 * i_d + 2]);
+          V3 velv = cv - cross(t_pos, ca);
+          V3 diff = sign * velv;
+          float j = dot(diff, n);
+          jac_qvel = jac_qvel + j * s->vel[i_d];
+          row[i_d] = row[i_d] + j;
         }
+        link = L.parent;
       }
     }
+    float imp, aref;
+    imp_aref(sol, -pen, jac_qvel, -pen, imp, aref);
+    float diag = invweight + friction * friction * invweight;
+    diag *= 2.0f * friction * friction * (1.0f - imp) / imp;
+    diag = fmx(diag, m.eps);
+    s->aref[r] = aref; s->efc_D[r] = 1.0f / diag;
   }
-  e.si()[SI_LS_IT] = ls_it; e.si()[SI_LS_RESULT] = ls_result;
-  return res_alpha;
-}
-
-// func_solve_init (non-mujoco branch), solver.py:2739-2859
-DEVN void solve_init(const Model& m, const E& e, int n_con) {
-  auto qacc = e.qacc(); auto qacc_ws = e.qacc_ws(); auto acc_smooth = e.acc_smooth(); auto mass_mat = e.mass_mat(); auto Ma = e.Ma();
-  bool ws = (n_con > 0) && e.is_warmstart()[0];
-  for (int i_d = 0; i_d < ND; ++i_d) qacc[i_d] = ws ? qacc_ws[i_d] : acc_smooth[i_d];
-  for (int i_d1 = 0; i_d1 < ND; ++i_d1) {
-    auto Mr = mass_mat[i_d1];
+  // ---- joint-limit rows: one lane per joint, ordered compaction ----
+  for (int i_j = tl; i_j < NJ; i_j += T) {
+    const Joint& Jt = m.joints[i_j];
+    if (Jt.type != JOINT_REVOLUTE) continue;
+    int i_d = Jt.dof_start;
+    float q = gload(e, FO(qpos), Jt.q_start);
+    float pos_delta_min = q - m.dofs[i_d].limit[0];
+    float pos_delta_max = m.dofs[i_d].limit[1] - q;
+    float pos_delta = fmn(pos_delta_min, pos_delta_max);
+    if (pos_delta < 0) {
+      int r = 4 * nc;
+      for (int k = 0; k < i_j; ++k) {
+        const Joint& Jk = m.joints[k];
+        if (Jk.type != JOINT_REVOLUTE) continue;
+        float qk = gload(e, FO(qpos), Jk.q_start);
+        if (fmn(qk - m.dofs[Jk.dof_start].limit[0], m.dofs[Jk.dof_start].limit[1] - qk) < 0) r++;
+      }
+      float j = (float)((pos_delta_min < pos_delta_max) * 2 - 1);
+      float jac_qvel = j * s->vel[i_d];
+      float imp, aref;
+      imp_aref(Jt.sol_params, pos_delta, jac_qvel, pos_delta, imp, aref);
+      float diag = fmx(m.dofs[i_d].invweight * (1.0f - imp) / imp, m.eps);
+      s->aref[r] = aref; s->efc_D[r] = 1.0f / diag;
+      float* row = &s->J[r * ND];
+      for (int i_d2 = 0; i_d2 < ND; ++i_d2) row[i_d2] = 0.0f;
+      row[i_d] = j;
+    }
+  }
+  team_sync();
+  // ---- func_solve_init ----
+  for (int d1 = tl; d1 < ND; d1 += T) {
     float Ma_ = 0.0f;
-    for (int i_d2 = 0; i_d2 < ND; ++i_d2) Ma_ = Ma_ + Mr[i_d2] * qacc[i_d2];
-    Ma[i_d1] = Ma_;
+    for (int d2 = 0; d2 < ND; ++d2) Ma_ = Ma_ + s->M[d1 * ND + d2] * s->qacc[d2];
+    s->Ma[d1] = Ma_;
   }
-  auto jac = e.jac(); auto aref = e.aref(); auto Jaref = e.Jaref();
-  for (int i_c = 0; i_c < n_con; ++i_c) {
-    auto row = jac[i_c];
-    float J = -aref[i_c];
-    for (int i_d = 0; i_d < ND; ++i_d) J = J + row[i_d] * qacc[i_d];
-    Jaref[i_c] = J;
+  for (int c = tl; c < n_con; c += T) {
+    float Jv = -s->aref[c];
+    for (int d = 0; d < ND; ++d) Jv = Jv + s->J[c * ND + d] * s->qacc[d];
+    s->Jaref[c] = Jv;
   }
-  update_constraint(m, e, n_con);
-  hessian_direct(m, e, n_con);
-  cholesky_factor_direct(m, e);
-  update_gradient(e);
-  auto search = e.search(); auto Mgrad = e.Mgrad();
-  for (int i_d = 0; i_d < ND; ++i_d) search[i_d] = -Mgrad[i_d];
-}
-// func_solve_iter, solver.py:2862-2938
-DEVN bool solve_iter(const Model& m, const E& e, int n_con) {
-  float alpha = linesearch(m, e, n_con);
-  bool improved;
-  if (dm_abs(alpha) < m.eps) {
-    improved = false;
-  } else {
-    auto qacc = e.qacc(); auto search = e.search(); auto Ma = e.Ma(); auto mv = e.mv(); auto Jaref = e.Jaref(); auto jv = e.jv();
-    for (int i_d = 0; i_d < ND; ++i_d) {
-      qacc[i_d] = qacc[i_d] + search[i_d] * alpha;
-      Ma[i_d] = Ma[i_d] + mv[i_d] * alpha;
-    }
-    for (int i_c = 0; i_c < n_con; ++i_c) Jaref[i_c] = Jaref[i_c] + jv[i_c] * alpha;
-    update_constraint(m, e, n_con);
-    if (cholesky_incremental(m, e, n_con)) { hessian_direct(m, e, n_con); cholesky_factor_direct(m, e); }
-    update_gradient(e);
-    float tol_scaled = (m.meaninertia * (float)imx(1, ND)) * m.tolerance;
-    float improvement = e.sv()[SV_PREV_COST] - e.sv()[SV_COST];
-    auto grad = e.grad();
-    float grad_norm = 0.0f;
-    for (int i_d = 0; i_d < ND; ++i_d) { float g = grad[i_d]; grad_norm = grad_norm + g * g; }
-    grad_norm = dm_sqrt(grad_norm);
-    improved = (grad_norm > tol_scaled) && (improvement > tol_scaled);
-    if (improved) {
-      auto Mgrad = e.Mgrad();
-      for (int i_d = 0; i_d < ND; ++i_d) search[i_d] = -Mgrad[i_d];
+  team_sync();
+  float cost = 0.0f, prev_cost = 0.0f, gauss = 0.0f;
+  ts_update_constraint<T>(m, s, tl, n_con, cost, prev_cost, gauss);
+  int iters = 0;
+  if (n_con > 0) {
+    ts_hessian_direct<T>(m, s, tl, n_con);
+    ts_cholesky_factor<T>(m, s, tl);
+    ts_update_gradient<T>(s, tl);
+    for (int d = tl; d < ND; d += T) s->search[d] = -s->Mgrad[d];
+    team_sync();
+    const float tol_scaled = (m.meaninertia * (float)imx(1, ND)) * m.tolerance;
+    for (int it = 0; it < m.iterations; ++it) {
+      float alpha = ts_linesearch<T>(m, s, tl, n_con, gauss);
+      iters++;
+      if (dm_abs(alpha) < m.eps) break;
+      team_sync();
+      for (int d = tl; d < ND; d += T) {
+        s->qacc[d] = s->qacc[d] + s->search[d] * alpha;
+        s->Ma[d] = s->Ma[d] + s->mv[d] * alpha;
+      }
+      for (int c = tl; c < n_con; c += T) s->Jaref[c] = s->Jaref[c] + s->jv[c] * alpha;
+      team_sync();
+      ts_update_constraint<T>(m, s, tl, n_con, cost, prev_cost, gauss);
+      if (ts_cholesky_incremental<T>(m, s, tl, n_con)) { team_sync(); ts_hessian_direct<T>(m, s, tl, n_con); ts_cholesky_factor<T>(m, s, tl); }
+      ts_update_gradient<T>(s, tl);
+      float improvement = prev_cost - cost;
+      float grad_norm = 0.0f;
+      for (int d = 0; d < ND; ++d) { float g = s->grad[d]; grad_norm = grad_norm + g * g; }
+      grad_norm = dm_sqrt(grad_norm);
+      bool improved = (grad_norm > tol_scaled) && (improvement > tol_scaled);
+      if (!improved) break;
+      for (int d = tl; d < ND; d += T) s->search[d] = -s->Mgrad[d];
+      team_sync();
     }
   }
-  e.si()[SI_IMPROVED] = improved;
-  return improved;
+  return iters;
 }
 
-// _func_constraint_force without the collider (rigid_solver.py:1230-1246): rows + ConstraintSolver.resolve (solver.py:177-209)
-__global__ __launch_bounds__(WG) void k_constraint_solve(Pool P, const Model* __restrict__ mp) {
-  int b = blockIdx.x * WG + threadIdx.x;
-  if (b >= P.B) return;
-  const Model& m = *mp;
-  E e(P, b);
-  e.n_con()[0] = 0;                                                  // add_equality_constraints, solver.py:791-809
-  add_collision_constraints(m, e);
-  add_joint_limit_constraints(m, e);
-  int n_con = e.n_con()[0];
-  solve_init(m, e, n_con);
-  int iters = 0;
-  if (n_con > 0) {                                                   // func_solve_body, solver.py:2941-2966
-    for (int it = 0; it < m.iterations; ++it) {
-      bool improved = solve_iter(m, e, n_con);
-      iters++;
-      if (!improved) break;
-    }
-  } else {
-    e.si()[SI_IMPROVED] = 0;
-  }
-  e.solver_iters()[0] = iters;
-  auto acc = e.acc(); auto qacc = e.qacc(); auto force = e.force(); auto qf_smooth = e.qf_smooth(); auto qfrc_constraint = e.qfrc_constraint();
-  auto qacc_ws = e.qacc_ws();
+
+// func_update_qacc (solver.py:3016-3037) + func_update_contact_force (:2974-3013) + public row outputs
+template <int T, class S>
+DEV void ts_commit(const Model& m, const E& e, S* s, int tl, int nc, int n_con, int iters) {
   int err = 0;
-  for (int i_d = 0; i_d < ND; ++i_d) {                               // func_update_qacc, solver.py:3016-3037
-    float q = qacc[i_d];
-    acc[i_d] = q;
-    force[i_d] = qf_smooth[i_d] + qfrc_constraint[i_d];
-    qacc_ws[i_d] = q;
+  for (int d = tl; d < ND; d += T) {
+    float q = s->qacc[d];
+    gstore(e, FO(acc), d, q);
+    gstore(e, FO(force), d, gload(e, FO(qf_smooth), d) + s->qfrc[d]);
+    gstore(e, FO(qacc_ws), d, q);
+    gstore(e, FO(qfrc_constraint), d, s->qfrc[d]);
     if (isnan_(q)) err |= GO2SIM_ERR_INVALID_FORCE_NAN;
   }
-  if (err) e.err()[0] |= err;
-  e.is_warmstart()[0] = 1;
-  auto contact_force = e.contact_force(); auto efc_force = e.efc_force();
-  for (int i_l = 0; i_l < NL; ++i_l) contact_force[i_l] = v3(0, 0, 0);  // func_update_contact_force, solver.py:2974-3013
-  int nc = e.n_contacts()[0];
-  for (int i_c = 0; i_c < nc; ++i_c) {
+  if (err) atomicOr(&e.err()[0], err);
+  for (int c = tl; c < n_con; c += T) gstore(e, FO(efc_force), c, s->efc_force[c]);
+  if (tl == 0) { e.is_warmstart()[0] = 1; e.n_con()[0] = n_con; e.solver_iters()[0] = iters; }
+  team_sync();
+  float* cf = s->J;  // the Jacobian is dead from here on: reuse its storage for the per-contact forces
+  for (int i_c = tl; i_c < nc; i_c += T) {
     V3 cnormal = e.c_normal()[i_c]; float friction = e.c_friction()[i_c];
     V3 f = v3(0, 0, 0), d1, d2;
     orthogonals(cnormal, d1, d2);
@@ -1748,12 +1746,51 @@ __global__ __launch_bounds__(WG) void k_constraint_solve(Pool P, const Model* __
     for (int i_dir = 0; i_dir < 4; ++i_dir) {
       V3 d = (float)(2 * (i_dir % 2) - 1) * ((i_dir < 2) ? d1 : d2);
       V3 n = d * friction - cnormal;
-      f = f + n * efc_force[i_c * 4 + i_dir];
+      f = f + n * s->efc_force[i_c * 4 + i_dir];
     }
     e.c_force()[i_c] = f;
-    int la = e.c_link()[i_c], lb = e.c_link()[MAXC + i_c];
-    contact_force[la] = (V3)contact_force[la] - f;
-    contact_force[lb] = (V3)contact_force[lb] + f;
+    cf[3 * i_c] = f.x; cf[3 * i_c + 1] = f.y; cf[3 * i_c + 2] = f.z;
+  }
+  team_sync();
+  for (int i_l = tl; i_l < NL; i_l += T) {
+    V3 acc = v3(0, 0, 0);
+    for (int i_c = 0; i_c < nc; ++i_c) {
+      int la = e.c_link()[i_c], lb = e.c_link()[MAXC + i_c];
+      V3 f = v3(cf[3 * i_c], cf[3 * i_c + 1], cf[3 * i_c + 2]);
+      if (la == i_l) acc = acc - f;
+      if (lb == i_l) acc = acc + f;
+    }
+    e.contact_force()[i_l] = acc;
+  }
+}
+
+template <int T>
+__global__ __launch_bounds__(64) void k_constraint_solve_team(Pool P, const Model* __restrict__ mp, SolverData<MAXR>* __restrict__ overflow) {
+  constexpr int EPW = 64 / T;
+  __shared__ SolverData<RL> lds[EPW];
+  const int tl = threadIdx.x % T, slot = threadIdx.x / T;
+  const int b = blockIdx.x * EPW + slot;
+  if (b >= P.B) return;
+  const Model& m = *mp;
+  E e(P, b);
+  const int nc = e.n_contacts()[0];
+  int n_lim = 0;
+  for (int i_j = 0; i_j < NJ; ++i_j) {
+    const Joint& Jt = m.joints[i_j];
+    if (Jt.type != JOINT_REVOLUTE) continue;
+    float q = gload(e, FO(qpos), Jt.q_start);
+    if (fmn(q - m.dofs[Jt.dof_start].limit[0], m.dofs[Jt.dof_start].limit[1] - q) < 0) n_lim++;
+  }
+  const int n_con = 4 * nc + n_lim;
+  int iters;
+  if (n_con <= RL) {
+    SolverData<RL>* s = &lds[slot];
+    iters = ts_solve<T>(m, e, s, tl, nc, n_con);
+    ts_commit<T>(m, e, s, tl, nc, n_con, iters);
+  } else {
+    SolverData<MAXR>* s = &overflow[b];
+    iters = ts_solve<T>(m, e, s, tl, nc, n_con);
+    ts_commit<T>(m, e, s, tl, nc, n_con, iters);
   }
 }
 
@@ -2492,6 +2529,8 @@ struct go2sim {
   Pool P = {nullptr, nullptr, 0};
   DCfg hcfg; DCfg* dcfg = nullptr; bool cfg_set = false;
   Glob* dglob = nullptr; Acc* dacc = nullptr; int* derr = nullptr;
+  SolverData<MAXR>* solver_ovf = nullptr;   // per-env global scratch for solves that do not fit in LDS (> RL rows)
+  int solver_team = 16;                     // lanes per environment in k_constraint_solve_team
   uint32_t step_count = 0; int action_write_idx = 0;
   // timing
   bool timing = false;
@@ -2513,7 +2552,7 @@ struct ScopedTimer {
   go2sim* h; hipStream_t s; int idx;
   ScopedTimer(go2sim* h_, hipStream_t s_, int cat) : h(h_), s(s_), idx(-1) {
     if (!h->timing) return;
-    if (h->ev_n == TIMING_RING) timing_flush(h);
+    if (h->ev_n == TIMING_RING) return;   // ring full inside a step: drop the sample (flushes happen at step boundaries only)
     idx = h->ev_n++;
     h->ev_cat[idx] = cat;
     (void)hipEventRecord(h->ev0[idx], s);
@@ -2525,7 +2564,14 @@ static int launch_substep(go2sim* h, hipStream_t s) {
   dim3 g = grid_for(h->B), b(WG);
   { ScopedTimer t(h, s, T_DYN); hipLaunchKernelGGL(k_dynamics, g, b, 0, s, h->P, h->dm); }
   { ScopedTimer t(h, s, T_COLLIDE); hipLaunchKernelGGL(k_collide, g, b, 0, s, h->P, h->dm); }
-  { ScopedTimer t(h, s, T_SOLVE); hipLaunchKernelGGL(k_constraint_solve, g, b, 0, s, h->P, h->dm); }
+  {
+    ScopedTimer t(h, s, T_SOLVE);
+    const int T = h->solver_team;
+    dim3 gs((h->B + 64 / T - 1) / (64 / T));
+    if (T == 16) hipLaunchKernelGGL(k_constraint_solve_team<16>, gs, b, 0, s, h->P, h->dm, h->solver_ovf);
+    else if (T == 32) hipLaunchKernelGGL(k_constraint_solve_team<32>, gs, b, 0, s, h->P, h->dm, h->solver_ovf);
+    else hipLaunchKernelGGL(k_constraint_solve_team<64>, gs, b, 0, s, h->P, h->dm, h->solver_ovf);
+  }
   { ScopedTimer t(h, s, T_INTEGRATE); hipLaunchKernelGGL(k_integrate_fk, g, b, 0, s, h->P, h->dm); }
   return GO2SIM_E_OK;
 }
@@ -2554,6 +2600,8 @@ int go2sim_create(const void* blob, size_t nbytes, int n_envs, int device, uint6
   HIPCHK(hipMalloc((void**)&h->dglob, sizeof(Glob)));
   HIPCHK(hipMalloc((void**)&h->dacc, sizeof(Acc)));
   HIPCHK(hipMalloc((void**)&h->derr, sizeof(int)));
+  HIPCHK(hipMalloc((void**)&h->solver_ovf, (size_t)n_envs * sizeof(SolverData<MAXR>)));
+  if (const char* t = getenv("GO2SIM_SOLVER_TEAM")) { int v = atoi(t); if (v == 16 || v == 32 || v == 64) h->solver_team = v; }
   Glob g0; memset(&g0, 0, sizeof(g0)); g0.friction = 1.0f;
   HIPCHK(hipMemcpy(h->dglob, &g0, sizeof(Glob), hipMemcpyHostToDevice));
   HIPCHK(hipMemset(h->dacc, 0, sizeof(Acc)));
@@ -2570,7 +2618,7 @@ int go2sim_destroy(go2sim_t* h) {
   (void)hipSetDevice(h->device);
   (void)hipDeviceSynchronize();
   if (h->ev_created) for (int i = 0; i < TIMING_RING; ++i) { (void)hipEventDestroy(h->ev0[i]); (void)hipEventDestroy(h->ev1[i]); }
-  (void)hipFree(h->P.f); (void)hipFree(h->P.i); (void)hipFree(h->dm); (void)hipFree(h->dcfg); (void)hipFree(h->dglob); (void)hipFree(h->dacc); (void)hipFree(h->derr);
+  (void)hipFree(h->P.f); (void)hipFree(h->P.i); (void)hipFree(h->dm); (void)hipFree(h->dcfg); (void)hipFree(h->dglob); (void)hipFree(h->dacc); (void)hipFree(h->derr); (void)hipFree(h->solver_ovf);
   delete h;
   return GO2SIM_E_OK;
 }
@@ -2742,6 +2790,7 @@ int go2sim_env_step(go2sim_t* h, const float* actions, float* obs, float* priv, 
   if (!h || !h->cfg_set || !actions) return GO2SIM_E_BADARG;
   hipStream_t s = (hipStream_t)stream;
   dim3 g = grid_for(h->B), b(WG);
+  if (h->timing && h->ev_n + 64 > TIMING_RING) timing_flush(h);   // all pending events belong to completed launches
   ScopedTimer total(h, s, T_TOTAL);
   { ScopedTimer t(h, s, T_ENV_PRE); hipLaunchKernelGGL(k_env_pre, g, b, 0, s, h->P, h->dm, h->dcfg, h->dglob, actions, h->seed, h->step_count, h->action_write_idx); }
   int substeps = h->hcfg.i[GO2SIM_IC_SUBSTEPS];

@@ -136,10 +136,10 @@ class Go2Env:
     def _env_view(self, name, k, dtype=torch.float32):
         key = (name, k)
         if key not in self._views:
-            self._views[key] = torch.zeros(k, self.num_envs, dtype=dtype, device=self.device)
-        buf = self._views[key]
+            self._views[key] = torch.zeros(self.num_envs, k, dtype=dtype, device=self.device)
+        buf = self._views[key]   # env_get delivers the reference's [n_envs, k] layout
         self._sim.env_get(C["GO2SIM_EB_" + name], buf, torch.cuda.current_stream(self.device).cuda_stream)
-        return buf.t() if k > 1 else buf[0]
+        return buf if k > 1 else buf[:, 0]
 
     @property
     def episode_length_buf(self):

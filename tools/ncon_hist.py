@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Distribution of contacts / constraint rows / Newton iterations over the bench workload (GPU)."""
+import os, sys
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from bench import make_actions
+from go2_sim2real_locomotion_rl_amd.capi import C, Go2Sim, load_hip_lib
+from go2_sim2real_locomotion_rl_amd.configs import flatten_walk_cfg, get_walk_cfgs
+from go2_sim2real_locomotion_rl_amd.model_blob import pack_model
+
+B = 4096
+dev = torch.device("cuda", 0)
+sim = Go2Sim(load_hip_lib(), pack_model(), B, 0, 1)
+f, i, _ = flatten_walk_cfg(B, *get_walk_cfgs(), freeze_curriculum=True)
+sim.env_configure(f, i); sim.env_reset()
+act = make_actions(300, B, dev)
+obs = torch.zeros(B, 49, device=dev); priv = torch.zeros(B, 104, device=dev); rew = torch.zeros(B, device=dev)
+rst = torch.zeros(B, dtype=torch.uint8, device=dev); to = torch.zeros(B, device=dev)
+buf = torch.zeros(B, dtype=torch.int32, device=dev)
+H = {"I_N_CONTACTS": [], "I_N_CONSTRAINTS": [], "I_SOLVER_ITERS": [], "I_N_BROAD": []}
+nreset = 0
+for s in range(300):
+    sim.env_step(act[s], obs, priv, rew, rst, to)
+    nreset += int(rst.sum())
+    if s % 5 == 0:
+        for k in H:
+            sim.get_field(C["GO2SIM_" + k], buf); H[k].append(buf.cpu().numpy().copy())
+print("resets", nreset)
+for k, v in H.items():
+    a = np.concatenate(v)
+    print(k, "mean %.2f" % a.mean(), "pcts 50/90/99/99.9/max", [int(np.percentile(a, p)) for p in (50, 90, 99, 99.9, 100)])
+    if k == "I_N_CONSTRAINTS":
+        for thr in (32, 48, 64, 96, 128):
+            print("   frac >", thr, float((a > thr).mean()))
+    pw = np.stack(v)  # per-wave max (64 consecutive envs)
+    print("   mean of per-64-env max: %.2f" % pw.reshape(len(v), -1, 64).max(-1).mean())

@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""GPU-vs-oracle probe at env-step granularity (development aid): first differing fields."""
+import os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+from util import CpuEnv, GpuEnv, make_actions
+from go2_sim2real_locomotion_rl_amd.capi import load_cpu_oracle_lib, load_hip_lib
+from go2_sim2real_locomotion_rl_amd.model_blob import pack_model
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+STEPS = int(sys.argv[2]) if len(sys.argv) > 2 else 60
+SEED = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+KIND = sys.argv[4] if len(sys.argv) > 4 else "0.5"
+FIELDS = ["F_MASS_MAT", "F_FORCE", "F_ACC_SMOOTH", "I_N_CONTACTS", "F_CONTACT_POS", "F_CONTACT_PEN", "I_N_CONSTRAINTS", "I_SOLVER_ITERS", "F_EFC_FORCE",
+          "F_QFRC_CONSTRAINT", "F_QACC_WS", "F_ACC", "F_CONTACT_FORCE", "F_QPOS", "F_VEL", "F_LINK_POS"]
+blob = pack_model()
+cpu, gpu = CpuEnv(load_cpu_oracle_lib(), blob, B, seed=SEED), GpuEnv(load_hip_lib(), blob, B, seed=SEED)
+cpu.reset(); gpu.reset()
+acts = make_actions(STEPS, B, seed=SEED, kind=KIND)
+for s, a in enumerate(acts):
+    cpu.step(a); gpu.step(a)
+    bad = []
+    for fn in FIELDS:
+        x, y = cpu.field(fn), gpu.field(fn)
+        if fn == "F_EFC_FORCE":
+            nc = cpu.field("I_N_CONSTRAINTS")[0]
+            m = np.arange(x.shape[0])[:, None] < nc[None, :]
+            x, y = np.where(m, x, 0), np.where(m, y, 0)
+        nd = (x.view(np.int32) != y.view(np.int32))
+        if nd.any():
+            bad.append((fn, nd, x, y))
+    if bad:
+        print("step", s, "differs:", [(fn, int(nd.sum())) for fn, nd, _, _ in bad])
+        fn, nd, x, y = bad[0]
+        for (j, e) in np.argwhere(nd)[:10]:
+            print("  ", fn, "elem", j, "env", e, "cpu", repr(x[j, e]), "gpu", repr(y[j, e]))
+        envs = sorted(set(int(e) for fn, nd, _, _ in bad for e in np.argwhere(nd)[:, 1]))
+        for e in envs[:4]:
+            print("   env", e, "n_con cpu/gpu", cpu.field("I_N_CONSTRAINTS")[0, e], gpu.field("I_N_CONSTRAINTS")[0, e], "iters", cpu.field("I_SOLVER_ITERS")[0, e], gpu.field("I_SOLVER_ITERS")[0, e],
+                  "n_contacts", cpu.field("I_N_CONTACTS")[0, e])
+        break
+else:
+    print("all", STEPS, "steps identical")
