@@ -236,6 +236,7 @@ struct Model {
       ccd_tolerance;
   Link links[NL]; Joint joints[NJ]; Dof dofs[ND]; Geom geoms[NG]; Entity entities[2];
   float qpos0[NQ]; float mass_parent_mask[ND][ND]; int pair_idx[NG][NG]; int theta_to_ring[180];
+  int pair_list[NPAIR];   // derived: valid pair p -> geom_a | geom_b << 8 (a < b)
 };
 
 bool parse_model(const void* blob, size_t nbytes, Model& m) {
@@ -299,7 +300,19 @@ bool parse_model(const void* blob, size_t nbytes, Model& m) {
   p += NG * NG;
   for (int i = 0; i < 180; ++i) m.theta_to_ring[i] = p[i];
   p += 180;
-  return (p - I) == ni;
+  if ((p - I) != ni) return false;
+  for (int i = 0; i < NPAIR; ++i) m.pair_list[i] = 0;
+  int n_found = 0;
+  for (int a = 0; a < NG; ++a) for (int b = a + 1; b < NG; ++b) {
+    int pi = m.pair_idx[a][b];
+    if (pi < 0) continue;
+    if (pi >= m.n_pairs) return false;
+    m.pair_list[pi] = a | (b << 8); n_found++;
+  }
+  if (n_found != m.n_pairs) return false;
+  int g_next = 0;   // geoms must be stored link-major (the SAP buffer is initialised in (link, geom) order)
+  for (int i = 0; i < NL; ++i) { if (m.links[i].geom_start != g_next) return false; g_next = m.links[i].geom_end; }
+  return g_next == NG;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -816,99 +829,6 @@ __global__ __launch_bounds__(WG) void k_fk(Pool P, const Model* __restrict__ mp,
 // ---------------------------------------------------------------------------------------------
 // collision detection  (R/collider/*.py)
 // ---------------------------------------------------------------------------------------------
-// kernel_update_geom_aabbs, forward_kinematics.py:1171-1193
-DEV void update_geom_aabbs(const Model& m, const E& e) {
-  const float inf = dm_bits2f(0x7f800000u);
-  auto g_pos = e.g_pos(); auto g_quat = e.g_quat(); auto aabb_min = e.aabb_min(); auto aabb_max = e.aabb_max();
-  for (int i_g = 0; i_g < NG; ++i_g) {
-    V3 lower = v3(inf, inf, inf), upper = v3(-inf, -inf, -inf);
-    V3 gp = g_pos[i_g]; Q4 gq = g_quat[i_g];
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      V3 corner = transform_by_trans_quat(m.geoms[i_g].aabb[c], gp, gq);
-      lower = vmin(lower, corner); upper = vmax(upper, corner);
-    }
-    aabb_min[i_g] = lower; aabb_max[i_g] = upper;
-  }
-}
-
-// func_is_geom_aabbs_overlap, collider/utils.py:102-107
-DEV bool aabbs_overlap(const E& e, int a, int b) {
-  V3 amax = e.aabb_max()[a], amin = e.aabb_min()[a], bmax = e.aabb_max()[b], bmin = e.aabb_min()[b];
-  bool any1 = (amax.x <= bmin.x) || (amax.y <= bmin.y) || (amax.z <= bmin.z);
-  bool any2 = (amin.x >= bmax.x) || (amin.y >= bmax.y) || (amin.z >= bmax.z);
-  return !(any1 || any2);
-}
-
-// func_collision_clear + func_broad_phase, collider/broadphase.py:73-138,141-396
-DEV void broad_phase(const Model& m, const E& e) {
-  auto n_contacts = e.n_contacts(); auto c_geom = e.c_geom(); auto c_link = e.c_link(); auto c_pen = e.c_pen(); auto c_pos = e.c_pos();
-  auto c_normal = e.c_normal(); auto c_force = e.c_force();
-  int nc = n_contacts[0];
-  for (int i_c = 0; i_c < nc; ++i_c) {
-    c_link[i_c] = -1; c_link[MAXC + i_c] = -1; c_geom[i_c] = -1; c_geom[MAXC + i_c] = -1;
-    c_pen[i_c] = 0.0f; c_pos[i_c] = v3(0, 0, 0); c_normal[i_c] = v3(0, 0, 0); c_force[i_c] = v3(0, 0, 0);
-  }
-  n_contacts[0] = 0;
-  auto sort_value = e.sort_value(); auto sort_ig = e.sort_ig(); auto aabb_min = e.aabb_min(); auto aabb_max = e.aabb_max();
-  const int n2 = 2 * NG;
-  if (e.first_time()[0]) {
-    int i_buffer = 0;
-    for (int i_l = 0; i_l < NL; ++i_l)
-      for (int i_g = m.links[i_l].geom_start; i_g < m.links[i_l].geom_end; ++i_g) {
-        V3 lo = aabb_min[i_g], hi = aabb_max[i_g];
-        sort_value[2 * i_buffer] = lo.x; sort_ig[2 * i_buffer] = i_g;
-        sort_value[2 * i_buffer + 1] = hi.x; sort_ig[2 * i_buffer + 1] = i_g | 0x100;
-        i_buffer++;
-      }
-    e.first_time()[0] = 0;
-  } else {
-    for (int i = 0; i < n2; ++i) {
-      int s = sort_ig[i];
-      V3 v = (s & 0x100) ? (V3)aabb_max[s & 0xff] : (V3)aabb_min[s & 0xff];
-      sort_value[i] = v.x;
-    }
-  }
-  for (int i = 1; i < n2; ++i) {
-    float key_value = sort_value[i]; int key_s = sort_ig[i];
-    int j = i - 1;
-    while (j >= 0 && key_value < sort_value[j]) {
-      sort_value[j + 1] = sort_value[j]; sort_ig[j + 1] = sort_ig[j];
-      j -= 1;
-    }
-    sort_value[j + 1] = key_value; sort_ig[j + 1] = key_s;
-  }
-  auto active_buf = e.active_buf(); auto broad = e.broad(); auto normal_cache = e.normal_cache();
-  int n_broad = 0, n_active = 0;
-  for (int i = 0; i < n2; ++i) {
-    int s = sort_ig[i];
-    if (!(s & 0x100)) {
-      for (int j = 0; j < n_active; ++j) {
-        int i_ga = active_buf[j], i_gb = s;
-        if (i_ga > i_gb) { int t = i_ga; i_ga = i_gb; i_gb = t; }
-        int pidx = m.pair_idx[i_ga][i_gb];
-        if (pidx == -1) continue;
-        if (!aabbs_overlap(e, i_ga, i_gb)) { normal_cache[pidx] = v3(0, 0, 0); continue; }
-        if (n_broad == m.max_broad_pairs) { e.err()[0] |= GO2SIM_ERR_OVERFLOW_CANDIDATE_CONTACTS; break; }
-        broad[2 * n_broad] = i_ga; broad[2 * n_broad + 1] = i_gb;
-        n_broad++;
-      }
-      active_buf[n_active] = s;
-      n_active++;
-    } else {
-      int rm = s & 0xff;
-      for (int j = 0; j < n_active; ++j)
-        if (active_buf[j] == rm) {
-          if (j < n_active - 1)
-            for (int k = j; k < n_active - 1; ++k) active_buf[k] = active_buf[k + 1];
-          n_active--;
-          break;
-        }
-    }
-  }
-  e.n_broad()[0] = n_broad;
-}
-
 // ---- support functions, collider/support_field.py ---------------------------------------------
 DEV int wrap180(float x) {
   if (!(x >= 0.0f)) return 0;
@@ -1149,23 +1069,6 @@ DEVN void mpr_contact(const Model& m, const Pair& pr, V3 normal_ws, bool& is_col
   }
 }
 
-// func_add_contact, collider/contact.py:165-199
-DEV void add_contact(const Model& m, const E& e, int i_ga, int i_gb, V3 normal, V3 contact_pos, float penetration) {
-  int i_c = e.n_contacts()[0];
-  if (i_c < m.max_contact_pairs) {
-    float friction_a = e.geom_friction()[i_ga] * e.friction_ratio()[i_ga];
-    float friction_b = e.geom_friction()[i_gb] * e.friction_ratio()[i_gb];
-    e.c_geom()[i_c] = i_ga; e.c_geom()[MAXC + i_c] = i_gb;
-    e.c_normal()[i_c] = normal; e.c_pos()[i_c] = contact_pos; e.c_pen()[i_c] = penetration;
-    e.c_friction()[i_c] = fmx(fmx(friction_a, friction_b), 1e-2f);
-    auto sol = e.c_sol()[i_c];
-    for (int k = 0; k < 7; ++k) sol[k] = 0.5f * (m.geoms[i_ga].sol_params[k] + m.geoms[i_gb].sol_params[k]);
-    e.c_link()[i_c] = m.geoms[i_ga].link; e.c_link()[MAXC + i_c] = m.geoms[i_gb].link;
-    e.n_contacts()[0] = i_c + 1;
-  } else {
-    e.err()[0] |= GO2SIM_ERR_OVERFLOW_COLLISION_PAIRS;
-  }
-}
 // func_compute_tolerance, contact.py:264-283
 DEV float compute_tolerance(const Model& m, int i_ga, int i_gb, float tolerance) {
   float size_b = norm(m.geoms[i_gb].aabb[7] - m.geoms[i_gb].aabb[0]);
@@ -1199,8 +1102,38 @@ DEV void rotate_frame(V3 pos, Q4 quat, V3 contact_pos, Q4 qrot, V3& new_pos, Q4&
   new_pos = pos - vec;
 }
 
-// func_convex_convex_contact (CCD_ALGORITHM_CODE.MPR branch), narrowphase.py:514-961
-DEV void convex_convex_contact(const Model& m, const E& e, int i_ga, int i_gb) {
+// single-wavefront workgroups: the barrier is a compiler/LDS ordering fence only
+DEV void team_sync() { __syncthreads(); }
+// ---------------------------------------------------------------------------------------------
+// Team collision detection: T lanes per environment.
+//   * AABBs: one lane per geom.
+//   * Sweep-and-prune: the warm-started insertion sort of the reference is a *stable* sort of the 56 x-endpoints, so its
+//     result equals a stable rank sort (rank = #smaller + #equal-before), evaluated one endpoint per lane.  The serial
+//     sweep emits the pair (a, s) when min(a) < min(s) < max(a) in sorted order, in the order (position of min(s), position of
+//     min(a)); the same list is produced by testing every valid geom pair in parallel and ordering the survivors by that key.
+//   * Narrow phase: one lane per broad-phase pair (MPR + multi-contact perturbations are independent per pair); the contacts of a
+//     pass of T pairs are compacted in pair order, which is the order in which the serial loop appends them.
+// ---------------------------------------------------------------------------------------------
+template <int T>
+struct CollideData {
+  float amin[NG * 3], amax[NG * 3];
+  float sval[2 * NG], sval_sorted[2 * NG];
+  int sig[2 * NG], sig_sorted[2 * NG];
+  int rank_min[NG], rank_max[NG];
+  int cand_key[MAXB], cand_pair[MAXB], pair_sorted[MAXB];
+  float stage[T][5][7];
+  int cnt[T];
+};
+struct ContactStage { float* st; int n; };   // per-lane staging of the (<= 5) contacts of one pair
+
+DEV void stage_contact(ContactStage& cs, V3 normal, V3 pos, float pen) {
+  float* p = cs.st + 7 * cs.n;
+  p[0] = normal.x; p[1] = normal.y; p[2] = normal.z; p[3] = pos.x; p[4] = pos.y; p[5] = pos.z; p[6] = pen;
+  cs.n++;
+}
+
+// func_convex_convex_contact (CCD_ALGORITHM_CODE.MPR branch), narrowphase.py:514-961; contacts go to the lane's staging buffer
+DEV void convex_convex_contact_staged(const Model& m, const E& e, int i_ga, int i_gb, ContactStage& cs) {
   const float EPS = m.eps;
   int type_a = m.geoms[i_ga].type, type_b = m.geoms[i_gb].type;
   bool multi_contact = (type_a != GEOM_SPHERE) && (type_b != GEOM_SPHERE);
@@ -1209,7 +1142,6 @@ DEV void convex_convex_contact(const Model& m, const E& e, int i_ga, int i_gb) {
   Pair pr; pr.i_ga = i_ga; pr.i_gb = i_gb; pr.pos_a = ga_pos_o; pr.quat_a = ga_quat_o; pr.pos_b = gb_pos_o; pr.quat_b = gb_quat_o;
   bool is_col_0 = false; V3 normal_0 = v3(0, 0, 0), contact_pos_0 = v3(0, 0, 0);
   bool is_col = false; float penetration = 0.0f; V3 normal = v3(0, 0, 0), contact_pos = v3(0, 0, 0);
-  int n_con = 0;
   V3 axis_0 = v3(0, 0, 0), axis_1 = v3(0, 0, 0); Q4 qrot = q4(0, 0, 0, 0);
   int i_pair = (i_ga > i_gb) ? m.pair_idx[i_gb][i_ga] : m.pair_idx[i_ga][i_gb];
   auto normal_cache = e.normal_cache();
@@ -1235,13 +1167,13 @@ DEV void convex_convex_contact(const Model& m, const E& e, int i_ga, int i_gb) {
         }
       }
       if (penetration > tolerance) prefer_gjk = !guess_available || (m.mc_tolerance * penetration >= m.mpr_to_gjk_ratio * tolerance);
-      if (prefer_gjk) e.gjk_fallback()[0] += 1;  // safe GJK+EPA fallback (narrowphase.py:734-845) not implemented yet: MPR result kept
+      if (prefer_gjk) atomicAdd(&e.gjk_fallback()[0], 1);  // safe GJK+EPA fallback (narrowphase.py:734-845) not implemented yet: MPR result kept
     }
     if (i_detection == 0) {
       is_col_0 = is_col; normal_0 = normal; contact_pos_0 = contact_pos;
       if (is_col_0) {
-        add_contact(m, e, i_ga, i_gb, normal, contact_pos, penetration);
-        if (multi_contact) { contact_orthogonals(m, e, i_ga, i_gb, normal, axis_0, axis_1); n_con = 1; }
+        stage_contact(cs, normal, contact_pos, penetration);
+        if (multi_contact) contact_orthogonals(m, e, i_ga, i_gb, normal, axis_0, axis_1);
         normal_cache[i_pair] = normal;
       } else {
         normal_cache[i_pair] = v3(0, 0, 0);
@@ -1256,36 +1188,150 @@ DEV void convex_convex_contact(const Model& m, const E& e, int i_ga, int i_gb) {
       normal = normal + cross(twist_rotvec, normal);
       penetration = dot(normal, contact_point_b - contact_point_a);
       bool repeated = false;
-      int nc = e.n_contacts()[0];
-      for (int i_c = 0; i_c < n_con; ++i_c)
+      for (int i_c = 0; i_c < cs.n; ++i_c)
         if (!repeated) {
-          int idx_prev = nc - 1 - i_c;
-          if (norm(contact_pos - (V3)e.c_pos()[idx_prev]) < tolerance) repeated = true;
+          const float* prev = cs.st + 7 * (cs.n - 1 - i_c);
+          if (norm(contact_pos - v3(prev[3], prev[4], prev[5])) < tolerance) repeated = true;
         }
       if (!repeated && penetration > -tolerance) {
         penetration = fmx(penetration, 0.0f);
-        add_contact(m, e, i_ga, i_gb, normal, contact_pos, penetration);
-        n_con++;
+        stage_contact(cs, normal, contact_pos, penetration);
       }
     }
   }
 }
 
-// Collider.detection, collider.py:436-528: AABBs -> SAP broad phase -> convex narrow phase
-__global__ __launch_bounds__(WG) void k_collide(Pool P, const Model* __restrict__ mp) {
-  int b = blockIdx.x * WG + threadIdx.x;
+template <int T>
+__global__ __launch_bounds__(64) void k_collide_team(Pool P, const Model* __restrict__ mp) {
+  constexpr int EPW = 64 / T;
+  __shared__ CollideData<T> lds[EPW];
+  const int tl = threadIdx.x % T, slot = threadIdx.x / T;
+  const int b = blockIdx.x * EPW + slot;
   if (b >= P.B) return;
   const Model& m = *mp;
   E e(P, b);
-  update_geom_aabbs(m, e);
-  broad_phase(m, e);
-  int n_broad = e.n_broad()[0];
-  auto broad = e.broad();
-  for (int i_pair = 0; i_pair < n_broad; ++i_pair) {                // func_narrow_phase_convex_vs_convex, narrowphase.py:964-1068
-    int i_ga = broad[2 * i_pair], i_gb = broad[2 * i_pair + 1];
-    if (m.geoms[i_ga].type > m.geoms[i_gb].type) { int t = i_ga; i_ga = i_gb; i_gb = t; }
-    convex_convex_contact(m, e, i_ga, i_gb);
+  CollideData<T>* s = &lds[slot];
+  const float inf = dm_bits2f(0x7f800000u);
+  // ---- func_collision_clear, broadphase.py:73-138 ----
+  const int nc_old = e.n_contacts()[0];
+  for (int i_c = tl; i_c < nc_old; i_c += T) {
+    e.c_link()[i_c] = -1; e.c_link()[MAXC + i_c] = -1; e.c_geom()[i_c] = -1; e.c_geom()[MAXC + i_c] = -1;
+    e.c_pen()[i_c] = 0.0f; e.c_pos()[i_c] = v3(0, 0, 0); e.c_normal()[i_c] = v3(0, 0, 0); e.c_force()[i_c] = v3(0, 0, 0);
   }
+  // ---- kernel_update_geom_aabbs, forward_kinematics.py:1171-1193 ----
+  for (int i_g = tl; i_g < NG; i_g += T) {
+    V3 lower = v3(inf, inf, inf), upper = v3(-inf, -inf, -inf);
+    V3 gp = e.g_pos()[i_g]; Q4 gq = e.g_quat()[i_g];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      V3 corner = transform_by_trans_quat(m.geoms[i_g].aabb[c], gp, gq);
+      lower = vmin(lower, corner); upper = vmax(upper, corner);
+    }
+    s->amin[3 * i_g] = lower.x; s->amin[3 * i_g + 1] = lower.y; s->amin[3 * i_g + 2] = lower.z;
+    s->amax[3 * i_g] = upper.x; s->amax[3 * i_g + 1] = upper.y; s->amax[3 * i_g + 2] = upper.z;
+  }
+  team_sync();
+  // ---- func_broad_phase, broadphase.py:141-396: endpoint refresh + stable sort ----
+  const int n2 = 2 * NG;
+  const bool first = e.first_time()[0] != 0;
+  for (int i = tl; i < n2; i += T) {
+    int sg;
+    if (first) {
+      // endpoints in (link, geom) order: geoms are stored link-major, so buffer slot i/2 holds geom i/2
+      sg = (i >> 1) | ((i & 1) ? 0x100 : 0);
+    } else {
+      sg = e.sort_ig()[i];
+    }
+    int g = sg & 0xff;
+    s->sig[i] = sg;
+    s->sval[i] = (sg & 0x100) ? s->amax[3 * g] : s->amin[3 * g];
+  }
+  team_sync();
+  for (int i = tl; i < n2; i += T) {
+    float v = s->sval[i];
+    int r = 0;
+    for (int j = 0; j < n2; ++j) { float w = s->sval[j]; r += (w < v) || (w == v && j < i); }
+    int sg = s->sig[i];
+    s->sval_sorted[r] = v; s->sig_sorted[r] = sg;
+    if (sg & 0x100) s->rank_max[sg & 0xff] = r; else s->rank_min[sg] = r;
+    e.sort_value()[r] = v; e.sort_ig()[r] = sg;
+  }
+  if (tl == 0 && first) e.first_time()[0] = 0;
+  team_sync();
+  // ---- candidate pairs: every valid geom pair is tested by one lane ----
+  int n_cand = 0;
+  const unsigned long long team_mask = (T == 64) ? ~0ull : ((1ull << T) - 1ull);
+  const int n_pair_iter = (m.n_pairs + T - 1) / T;
+  for (int it = 0; it < n_pair_iter; ++it) {
+    int pidx = it * T + tl;
+    bool is_cand = false; int key = 0, packed = 0;
+    if (pidx < m.n_pairs) {
+      packed = m.pair_list[pidx];
+      int a = packed & 0xff, bg = packed >> 8;
+      int ra = s->rank_min[a], rb = s->rank_min[bg];
+      int firstg = (ra < rb) ? a : bg, secondg = (ra < rb) ? bg : a;
+      int rs = (ra < rb) ? rb : ra, rf = (ra < rb) ? ra : rb;
+      if (rs < s->rank_max[firstg]) {
+        (void)secondg;
+        bool any1 = (s->amax[3 * a] <= s->amin[3 * bg]) || (s->amax[3 * a + 1] <= s->amin[3 * bg + 1]) || (s->amax[3 * a + 2] <= s->amin[3 * bg + 2]);
+        bool any2 = (s->amin[3 * a] >= s->amax[3 * bg]) || (s->amin[3 * a + 1] >= s->amax[3 * bg + 1]) || (s->amin[3 * a + 2] >= s->amax[3 * bg + 2]);
+        if (any1 || any2) e.normal_cache()[pidx] = v3(0, 0, 0);
+        else { is_cand = true; key = rs * 64 + rf; }
+      }
+    }
+    unsigned long long bal = __ballot(is_cand);
+    unsigned long long tm = (bal >> (slot * T)) & team_mask;
+    int pos = n_cand + __popcll(tm & ((1ull << tl) - 1ull));
+    if (is_cand && pos < MAXB) { s->cand_key[pos] = key; s->cand_pair[pos] = packed; }
+    n_cand += __popcll(tm);
+  }
+  if (n_cand > m.max_broad_pairs) { if (tl == 0) atomicOr(&e.err()[0], GO2SIM_ERR_OVERFLOW_CANDIDATE_CONTACTS); n_cand = m.max_broad_pairs; }
+  team_sync();
+  for (int c = tl; c < n_cand; c += T) {
+    int key = s->cand_key[c], r = 0;
+    for (int j = 0; j < n_cand; ++j) r += s->cand_key[j] < key;
+    s->pair_sorted[r] = s->cand_pair[c];
+  }
+  const int n_broad = n_cand;
+  team_sync();
+  for (int c = tl; c < n_broad; c += T) { int pk = s->pair_sorted[c]; e.broad()[2 * c] = pk & 0xff; e.broad()[2 * c + 1] = pk >> 8; }
+  // ---- func_narrow_phase_convex_vs_convex, narrowphase.py:964-1068: one lane per pair, ordered compaction ----
+  int nc_run = 0;
+  const int n_np_iter = (n_broad + T - 1) / T;
+  for (int it = 0; it < n_np_iter; ++it) {
+    int ip = it * T + tl;
+    ContactStage cs; cs.st = &s->stage[tl][0][0]; cs.n = 0;
+    int i_ga = 0, i_gb = 0;
+    if (ip < n_broad) {
+      int pk = s->pair_sorted[ip];
+      i_ga = pk & 0xff; i_gb = pk >> 8;
+      if (m.geoms[i_ga].type > m.geoms[i_gb].type) { int t = i_ga; i_ga = i_gb; i_gb = t; }
+      convex_convex_contact_staged(m, e, i_ga, i_gb, cs);
+    }
+    s->cnt[tl] = cs.n;
+    team_sync();
+    int off = 0, tot = 0;
+    for (int l = 0; l < T; ++l) { int c = s->cnt[l]; off += (l < tl) ? c : 0; tot += c; }
+    for (int k = 0; k < cs.n; ++k) {                                   // func_add_contact, contact.py:165-199
+      int i_c = nc_run + off + k;
+      if (i_c < m.max_contact_pairs) {
+        const float* p = cs.st + 7 * k;
+        float friction_a = e.geom_friction()[i_ga] * e.friction_ratio()[i_ga];
+        float friction_b = e.geom_friction()[i_gb] * e.friction_ratio()[i_gb];
+        e.c_geom()[i_c] = i_ga; e.c_geom()[MAXC + i_c] = i_gb;
+        e.c_normal()[i_c] = v3(p[0], p[1], p[2]); e.c_pos()[i_c] = v3(p[3], p[4], p[5]); e.c_pen()[i_c] = p[6];
+        e.c_friction()[i_c] = fmx(fmx(friction_a, friction_b), 1e-2f);
+        auto sol = e.c_sol()[i_c];
+        for (int q = 0; q < 7; ++q) sol[q] = 0.5f * (m.geoms[i_ga].sol_params[q] + m.geoms[i_gb].sol_params[q]);
+        e.c_link()[i_c] = m.geoms[i_ga].link; e.c_link()[MAXC + i_c] = m.geoms[i_gb].link;
+      } else {
+        atomicOr(&e.err()[0], GO2SIM_ERR_OVERFLOW_COLLISION_PAIRS);
+      }
+    }
+    nc_run += tot;
+    team_sync();
+  }
+  if (tl == 0) { e.n_broad()[0] = n_broad; e.n_contacts()[0] = imn(nc_run, m.max_contact_pairs); }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1328,8 +1374,6 @@ struct SolverData {
   int active[R], prev_active[R];
 };
 
-// single-wavefront workgroups: the barrier is a compiler/LDS ordering fence only
-DEV void team_sync() { __syncthreads(); }
 DEV float gload(const E& e, int off, int k) { return e.f[(size_t)(off + k) * e.B]; }
 DEV void gstore(const E& e, int off, int k, float v) { e.f[(size_t)(off + k) * e.B] = v; }
 
@@ -2530,6 +2574,7 @@ struct go2sim {
   DCfg hcfg; DCfg* dcfg = nullptr; bool cfg_set = false;
   Glob* dglob = nullptr; Acc* dacc = nullptr; int* derr = nullptr;
   SolverData<MAXR>* solver_ovf = nullptr;   // per-env global scratch for solves that do not fit in LDS (> RL rows)
+  int collide_team = 16;                    // lanes per environment in k_collide_team
   int solver_team = 16;                     // lanes per environment in k_constraint_solve_team
   uint32_t step_count = 0; int action_write_idx = 0;
   // timing
@@ -2563,7 +2608,14 @@ struct ScopedTimer {
 static int launch_substep(go2sim* h, hipStream_t s) {
   dim3 g = grid_for(h->B), b(WG);
   { ScopedTimer t(h, s, T_DYN); hipLaunchKernelGGL(k_dynamics, g, b, 0, s, h->P, h->dm); }
-  { ScopedTimer t(h, s, T_COLLIDE); hipLaunchKernelGGL(k_collide, g, b, 0, s, h->P, h->dm); }
+  {
+    ScopedTimer t(h, s, T_COLLIDE);
+    const int T = h->collide_team;
+    dim3 gc((h->B + 64 / T - 1) / (64 / T));
+    if (T == 16) hipLaunchKernelGGL(k_collide_team<16>, gc, b, 0, s, h->P, h->dm);
+    else if (T == 32) hipLaunchKernelGGL(k_collide_team<32>, gc, b, 0, s, h->P, h->dm);
+    else hipLaunchKernelGGL(k_collide_team<64>, gc, b, 0, s, h->P, h->dm);
+  }
   {
     ScopedTimer t(h, s, T_SOLVE);
     const int T = h->solver_team;
@@ -2601,6 +2653,7 @@ int go2sim_create(const void* blob, size_t nbytes, int n_envs, int device, uint6
   HIPCHK(hipMalloc((void**)&h->dacc, sizeof(Acc)));
   HIPCHK(hipMalloc((void**)&h->derr, sizeof(int)));
   HIPCHK(hipMalloc((void**)&h->solver_ovf, (size_t)n_envs * sizeof(SolverData<MAXR>)));
+  if (const char* t = getenv("GO2SIM_COLLIDE_TEAM")) { int v = atoi(t); if (v == 16 || v == 32 || v == 64) h->collide_team = v; }
   if (const char* t = getenv("GO2SIM_SOLVER_TEAM")) { int v = atoi(t); if (v == 16 || v == 32 || v == 64) h->solver_team = v; }
   Glob g0; memset(&g0, 0, sizeof(g0)); g0.friction = 1.0f;
   HIPCHK(hipMemcpy(h->dglob, &g0, sizeof(Glob), hipMemcpyHostToDevice));
