@@ -237,6 +237,9 @@ struct Model {
   Link links[NL]; Joint joints[NJ]; Dof dofs[ND]; Geom geoms[NG]; Entity entities[2];
   float qpos0[NQ]; float mass_parent_mask[ND][ND]; int pair_idx[NG][NG]; int theta_to_ring[180];
   int pair_list[NPAIR];   // derived: valid pair p -> geom_a | geom_b << 8 (a < b)
+  // derived tree tables: links grouped by depth, children of every link in DESCENDING index order (the order in which the
+  // reference's leaf->root loops add them to the parent), link of every dof
+  int n_levels, level_start[NL + 1], level_links[NL], child_start[NL + 1], child_list[NL], dof_link[ND];
 };
 
 bool parse_model(const void* blob, size_t nbytes, Model& m) {
@@ -310,6 +313,32 @@ bool parse_model(const void* blob, size_t nbytes, Model& m) {
     m.pair_list[pi] = a | (b << 8); n_found++;
   }
   if (n_found != m.n_pairs) return false;
+  {
+    int depth[NL];
+    int max_depth = 0;
+    for (int i = 0; i < NL; ++i) {
+      int par = m.links[i].parent;
+      if (par >= i) return false;   // parents precede children
+      depth[i] = (par < 0) ? 0 : depth[par] + 1;
+      if (depth[i] > max_depth) max_depth = depth[i];
+    }
+    m.n_levels = max_depth + 1;
+    int k = 0;
+    for (int lev = 0; lev <= max_depth; ++lev) {
+      m.level_start[lev] = k;
+      for (int i = 0; i < NL; ++i) if (depth[i] == lev) m.level_links[k++] = i;
+    }
+    for (int lev = max_depth + 1; lev <= NL; ++lev) m.level_start[lev] = k;
+    k = 0;
+    for (int par = 0; par < NL; ++par) {
+      m.child_start[par] = k;
+      for (int i = NL - 1; i > par; --i) if (m.links[i].parent == par) m.child_list[k++] = i;
+    }
+    m.child_start[NL] = k;
+    for (int d = 0; d < ND; ++d) m.dof_link[d] = -1;
+    for (int i = 0; i < NL; ++i) for (int d = m.links[i].dof_start; d < m.links[i].dof_end; ++d) m.dof_link[d] = i;
+    for (int d = 0; d < ND; ++d) if (m.dof_link[d] < 0) return false;
+  }
   int g_next = 0;   // geoms must be stored link-major (the SAP buffer is initialised in (link, geom) order)
   for (int i = 0; i < NL; ++i) { if (m.links[i].geom_start != g_next) return false; g_next = m.links[i].geom_end; }
   return g_next == NG;
@@ -437,6 +466,11 @@ struct E {
 #undef FA2
 #undef IA
 };
+// single-wavefront workgroups: the barrier is a compiler/LDS ordering fence only
+DEV void team_sync() { __syncthreads(); }
+DEV float gload(const E& e, int off, int k) { return e.f[(size_t)(off + k) * e.B]; }
+DEV void gstore(const E& e, int off, int k, float v) { e.f[(size_t)(off + k) * e.B] = v; }
+
 // scalar slots
 enum { SV_COST = 0, SV_PREV_COST, SV_GAUSS, SV_QG0, SV_QG1, SV_QG2, SV_GTOL };
 enum { SI_LS_IT = 0, SI_LS_RESULT, SI_IMPROVED };
@@ -827,6 +861,451 @@ __global__ __launch_bounds__(WG) void k_fk(Pool P, const Model* __restrict__ mp,
 }
 
 // ---------------------------------------------------------------------------------------------
+// Team kinematics / dynamics: T lanes per environment, link tree processed level by level
+// (Go2: base | 4 hips | 4 thighs | 4 calves), independent links / dofs / matrix entries spread over the lanes, every
+// chained sum evaluated in the serial order of the reference.
+// ---------------------------------------------------------------------------------------------
+DEV V3 ld3(const float* p, int i) { return v3(p[3 * i], p[3 * i + 1], p[3 * i + 2]); }
+DEV void st3(float* p, int i, V3 v) { p[3 * i] = v.x; p[3 * i + 1] = v.y; p[3 * i + 2] = v.z; }
+DEV Q4 ld4(const float* p, int i) { return q4(p[4 * i], p[4 * i + 1], p[4 * i + 2], p[4 * i + 3]); }
+DEV void st4(float* p, int i, Q4 q) { p[4 * i] = q.w; p[4 * i + 1] = q.x; p[4 * i + 2] = q.y; p[4 * i + 3] = q.z; }
+DEV M3 ld9(const float* p, int i) { M3 r;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) r.m[k / 3][k % 3] = p[9 * i + k];
+  return r; }
+DEV void st9(float* p, int i, const M3& r) {
+#pragma unroll
+  for (int k = 0; k < 9; ++k) p[9 * i + k] = r.m[k / 3][k % 3]; }
+// (row, col) of the idx-th entry of a lower triangle stored row by row
+DEV void tri_index(int idx, int& i, int& j) {
+  i = (int)((sqrtf(8.0f * (float)idx + 1.0f) - 1.0f) * 0.5f);
+  while (i * (i + 1) / 2 > idx) --i;
+  while ((i + 1) * (i + 2) / 2 <= idx) ++i;
+  j = idx - i * (i + 1) / 2;
+}
+
+struct KinData {
+  float qpos[NQ], vel[ND], qpos_next[NQ], vel_next[ND];
+  float l_pos[NL * 3], l_quat[NL * 4], i_pos[NL * 3], i_quat[NL * 4];
+  float xanchor[NJ * 3], xaxis[NJ * 3];
+  float cdof_ang[ND * 3], cdof_vel[ND * 3];
+  float cd_vel[NL * 3], cd_ang[NL * 3];
+  float mass[NL];
+  int valid;
+};
+
+// update_cartesian_space + forward_velocity of the state held in s->qpos / s->vel
+// (func_forward_kinematics_entity :463-618, func_COM_links_entity :224-459, func_update_geoms_entity :709-744,
+//  func_forward_velocity_entity :871-994 of forward_kinematics.py)
+template <int T>
+DEV void tk_kinematics(const Model& m, const E& e, KinData* s, int tl, bool force_update_fixed) {
+  for (int i_l = tl; i_l < NL; i_l += T) { st3(s->l_pos, i_l, e.l_pos()[i_l]); st4(s->l_quat, i_l, e.l_quat()[i_l]); }
+  team_sync();
+  for (int lev = 0; lev < m.n_levels; ++lev) {
+    for (int k = m.level_start[lev] + tl; k < m.level_start[lev + 1]; k += T) {
+      int i_l = m.level_links[k];
+      const Link& L = m.links[i_l];
+      V3 pos = L.pos; Q4 quat = L.quat;
+      if (L.parent != -1) {
+        Q4 pq = ld4(s->l_quat, L.parent);
+        pos = ld3(s->l_pos, L.parent) + transform_by_quat(L.pos, pq);
+        quat = transform_quat_by_quat(L.quat, pq);
+      }
+      for (int i_j = L.joint_start; i_j < L.joint_end; ++i_j) {
+        const Joint& J = m.joints[i_j];
+        int q_start = J.q_start, dof_start = J.dof_start;
+        if (J.type == JOINT_FREE) {
+          V3 pos_ = v3(s->qpos[q_start], s->qpos[q_start + 1], s->qpos[q_start + 2]);
+          st3(s->xanchor, i_j, pos_);
+          st3(s->xaxis, i_j, v3(0, 0, 1));
+          Q4 quat_ = q4(s->qpos[q_start + 3], s->qpos[q_start + 4], s->qpos[q_start + 5], s->qpos[q_start + 6]);
+          float n = dm_sqrt(norm_sqr(quat_));
+          quat_ = q4(quat_.w / n, quat_.x / n, quat_.y / n, quat_.z / n);
+          pos = pos_; quat = quat_;
+          gstore(e, FO(dof_pos), dof_start + 0, pos.x); gstore(e, FO(dof_pos), dof_start + 1, pos.y); gstore(e, FO(dof_pos), dof_start + 2, pos.z);
+        } else if (J.type == JOINT_REVOLUTE) {
+          V3 axis = m.dofs[dof_start].motion_ang;
+          V3 anchor = transform_by_quat(J.pos, quat) + pos;
+          st3(s->xanchor, i_j, anchor);
+          st3(s->xaxis, i_j, transform_by_quat(axis, quat));
+          float dp = s->qpos[q_start] - m.qpos0[q_start];
+          gstore(e, FO(dof_pos), dof_start, dp);
+          Q4 qloc = rotvec_to_quat(axis * dp, m.eps);
+          quat = transform_quat_by_quat(qloc, quat);
+          pos = anchor - transform_by_quat(J.pos, quat);
+        }
+      }
+      if (!(L.parent == -1 && L.is_fixed)) { st3(s->l_pos, i_l, pos); st4(s->l_quat, i_l, quat); e.l_pos()[i_l] = pos; e.l_quat()[i_l] = quat; }
+    }
+    team_sync();
+  }
+  // centre of mass of each kinematic tree
+  for (int i_l = tl; i_l < NL; i_l += T) {
+    const Link& L = m.links[i_l];
+    s->mass[i_l] = L.mass + gload(e, FO(mass_shift), i_l);
+    V3 ipbw; Q4 iq;
+    transform_pos_quat_by_trans_quat(L.inertial_pos + (V3)e.com_shift()[i_l], L.inertial_quat, ld3(s->l_pos, i_l), ld4(s->l_quat, i_l), ipbw, iq);
+    st3(s->i_pos, i_l, ipbw); st4(s->i_quat, i_l, iq);
+  }
+  team_sync();
+  V3 rc[2];
+#pragma unroll
+  for (int i_e = 0; i_e < 2; ++i_e) {
+    const Entity& en = m.entities[i_e];
+    V3 root_com_bw = v3(0, 0, 0); float mass_sum = 0.0f;
+    for (int i_l = en.link_start; i_l < en.link_end; ++i_l) {
+      float mass = s->mass[i_l];
+      mass_sum = mass_sum + mass;
+      root_com_bw = root_com_bw + mass * ld3(s->i_pos, i_l);
+    }
+    rc[i_e] = root_com_bw / mass_sum;
+  }
+  team_sync();
+  for (int i_l = tl; i_l < NL; i_l += T) {
+    const Link& L = m.links[i_l];
+    V3 r = (L.entity == 0) ? rc[0] : rc[1];
+    e.root_com()[i_l] = r;
+    V3 ip = ld3(s->i_pos, i_l) - r;
+    Q4 iq = ld4(s->i_quat, i_l);
+    e.i_pos()[i_l] = ip; e.i_quat()[i_l] = iq;
+    float i_mass = s->mass[i_l];
+    M3 oI; V3 op;
+    transform_inertia_by_trans_quat(L.inertial_i, i_mass, ip, iq, m.eps, oI, op);
+    e.cinr_inertial()[i_l] = oI; e.cinr_pos()[i_l] = op; e.cinr_mass()[i_l] = i_mass;
+  }
+  for (int i_j = tl; i_j < NJ; i_j += T) {
+    const Joint& J = m.joints[i_j];
+    const Link& L = m.links[J.link];
+    if (L.n_dofs == 0) continue;
+    V3 r = (L.entity == 0) ? rc[0] : rc[1];
+    V3 offset_pos = r - ld3(s->xanchor, i_j);
+    int ds = J.dof_start;
+    if (J.type == JOINT_REVOLUTE) {
+      V3 ax = ld3(s->xaxis, i_j);
+      V3 cv = cross(ax, offset_pos);
+      st3(s->cdof_ang, ds, ax); st3(s->cdof_vel, ds, cv);
+      e.cdof_ang()[ds] = ax; e.cdof_vel()[ds] = cv;
+    } else if (J.type == JOINT_FREE) {
+      for (int i = 0; i < 3; ++i) {
+        V3 cv = v3(0, 0, 0);
+        vset(cv, i, 1.0f);
+        st3(s->cdof_ang, i + ds, v3(0, 0, 0)); st3(s->cdof_vel, i + ds, cv);
+        e.cdof_ang()[i + ds] = v3(0, 0, 0); e.cdof_vel()[i + ds] = cv;
+      }
+      M3 xmat_T = transpose(quat_to_R(ld4(s->l_quat, J.link), m.eps));
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        V3 row = v3(xmat_T.m[i][0], xmat_T.m[i][1], xmat_T.m[i][2]);
+        V3 cv = cross(row, offset_pos);
+        st3(s->cdof_ang, i + ds + 3, row); st3(s->cdof_vel, i + ds + 3, cv);
+        e.cdof_ang()[i + ds + 3] = row; e.cdof_vel()[i + ds + 3] = cv;
+      }
+    }
+  }
+  for (int i_g = tl; i_g < NG; i_g += T) {
+    const Geom& G = m.geoms[i_g];
+    bool is_fixed = m.links[G.link].is_fixed;
+    if (force_update_fixed || !is_fixed) {
+      V3 p; Q4 q;
+      transform_pos_quat_by_trans_quat(G.pos, G.quat, ld3(s->l_pos, G.link), ld4(s->l_quat, G.link), p, q);
+      e.g_pos()[i_g] = p; e.g_quat()[i_g] = q;
+    }
+  }
+  team_sync();
+  // forward velocity
+  for (int lev = 0; lev < m.n_levels; ++lev) {
+    for (int k = m.level_start[lev] + tl; k < m.level_start[lev + 1]; k += T) {
+      int i_l = m.level_links[k];
+      const Link& L = m.links[i_l];
+      V3 cvel_vel = v3(0, 0, 0), cvel_ang = v3(0, 0, 0);
+      if (L.parent != -1) { cvel_vel = ld3(s->cd_vel, L.parent); cvel_ang = ld3(s->cd_ang, L.parent); }
+      for (int i_j = L.joint_start; i_j < L.joint_end; ++i_j) {
+        const Joint& J = m.joints[i_j];
+        int ds = J.dof_start;
+        if (J.type == JOINT_FREE) {
+          for (int i = 0; i < 3; ++i) {
+            float v = s->vel[ds + i];
+            cvel_vel = cvel_vel + ld3(s->cdof_vel, ds + i) * v;
+            cvel_ang = cvel_ang + ld3(s->cdof_ang, ds + i) * v;
+          }
+          for (int i = 0; i < 3; ++i) {
+            e.cdofd_ang()[ds + i] = v3(0, 0, 0); e.cdofd_vel()[ds + i] = v3(0, 0, 0);
+            V3 oa, ov;
+            motion_cross_motion(cvel_ang, cvel_vel, ld3(s->cdof_ang, ds + i + 3), ld3(s->cdof_vel, ds + i + 3), oa, ov);
+            e.cdofd_ang()[ds + i + 3] = oa; e.cdofd_vel()[ds + i + 3] = ov;
+          }
+          for (int i = 0; i < 3; ++i) {
+            float v = s->vel[ds + i + 3];
+            cvel_vel = cvel_vel + ld3(s->cdof_vel, ds + i + 3) * v;
+            cvel_ang = cvel_ang + ld3(s->cdof_ang, ds + i + 3) * v;
+          }
+        } else {
+          for (int i_d = ds; i_d < J.dof_end; ++i_d) {
+            V3 oa, ov;
+            motion_cross_motion(cvel_ang, cvel_vel, ld3(s->cdof_ang, i_d), ld3(s->cdof_vel, i_d), oa, ov);
+            e.cdofd_ang()[i_d] = oa; e.cdofd_vel()[i_d] = ov;
+          }
+          for (int i_d = ds; i_d < J.dof_end; ++i_d) {
+            float v = s->vel[i_d];
+            cvel_vel = cvel_vel + ld3(s->cdof_vel, i_d) * v;
+            cvel_ang = cvel_ang + ld3(s->cdof_ang, i_d) * v;
+          }
+        }
+      }
+      st3(s->cd_vel, i_l, cvel_vel); st3(s->cd_ang, i_l, cvel_ang);
+      e.cd_vel()[i_l] = cvel_vel; e.cd_ang()[i_l] = cvel_ang;
+    }
+    team_sync();
+  }
+}
+
+// kernel_step_2 (rigid_solver.py:3072-3180): func_integrate (forward_dynamics.py:1558-1699) + func_copy_next_to_curr
+// (abd/diff.py:25-54) + FK / forward velocity of the new state
+template <int T>
+__global__ __launch_bounds__(64) void k_integrate_fk_team(Pool P, const Model* __restrict__ mp) {
+  constexpr int EPW = 64 / T;
+  __shared__ KinData lds[EPW];
+  const int tl = threadIdx.x % T, slot = threadIdx.x / T;
+  const int b = blockIdx.x * EPW + slot;
+  if (b >= P.B) return;
+  const Model& m = *mp;
+  E e(P, b);
+  KinData* s = &lds[slot];
+  for (int d = tl; d < ND; d += T) { float v = gload(e, FO(vel), d); s->vel[d] = v; s->vel_next[d] = v + gload(e, FO(acc), d) * m.substep_dt; }
+  for (int q = tl; q < NQ; q += T) s->qpos[q] = gload(e, FO(qpos), q);
+  if (tl == 0) s->valid = 1;
+  team_sync();
+  for (int i_l = tl; i_l < NL; i_l += T) {
+    const Link& L = m.links[i_l];
+    if (L.n_dofs == 0) continue;
+    int ds = L.dof_start, qs = L.q_start;
+    int joint_type = m.joints[L.joint_start].type;
+    if (joint_type == JOINT_FREE) {
+      V3 pos = v3(s->qpos[qs], s->qpos[qs + 1], s->qpos[qs + 2]);
+      V3 v = v3(s->vel_next[ds], s->vel_next[ds + 1], s->vel_next[ds + 2]);
+      pos = pos + v * m.substep_dt;
+      s->qpos_next[qs] = pos.x; s->qpos_next[qs + 1] = pos.y; s->qpos_next[qs + 2] = pos.z;
+      Q4 rot0 = q4(s->qpos[qs + 3], s->qpos[qs + 4], s->qpos[qs + 5], s->qpos[qs + 6]);
+      V3 ang = v3(s->vel_next[ds + 3], s->vel_next[ds + 4], s->vel_next[ds + 5]) * m.substep_dt;
+      Q4 qrot = rotvec_to_quat(ang, m.eps);
+      Q4 rot = transform_quat_by_quat(qrot, rot0);
+      s->qpos_next[qs + 3] = rot.w; s->qpos_next[qs + 4] = rot.x; s->qpos_next[qs + 5] = rot.y; s->qpos_next[qs + 6] = rot.z;
+    } else {
+      for (int j_ = 0; j_ < L.q_end - qs; ++j_) s->qpos_next[qs + j_] = s->qpos[qs + j_] + s->vel_next[ds + j_] * m.substep_dt;
+    }
+  }
+  team_sync();
+  bool bad = false;
+  for (int d = tl; d < ND; d += T) bad |= isnan_(s->vel_next[d]);
+  for (int q = tl; q < NQ; q += T) bad |= isnan_(s->qpos_next[q]);
+  if (bad) s->valid = 0;
+  team_sync();
+  if (s->valid) {
+    for (int d = tl; d < ND; d += T) { float v = s->vel_next[d]; s->vel[d] = v; gstore(e, FO(vel), d, v); }
+    for (int q = tl; q < NQ; q += T) { float v = s->qpos_next[q]; s->qpos[q] = v; gstore(e, FO(qpos), q, v); }
+  } else if (tl == 0) {
+    atomicOr(&e.err()[0], GO2SIM_ERR_INVALID_ACC_NAN);
+  }
+  team_sync();
+  tk_kinematics<T>(m, e, s, tl, false);
+}
+
+// FK refresh of the current state; `cond` (device) gates the launch body: the reset path only needs it when an env was reset
+template <int T>
+__global__ __launch_bounds__(64) void k_fk_team(Pool P, const Model* __restrict__ mp, int force_update_fixed, const int* __restrict__ cond) {
+  constexpr int EPW = 64 / T;
+  __shared__ KinData lds[EPW];
+  if (cond && *cond <= 0) return;
+  const int tl = threadIdx.x % T, slot = threadIdx.x / T;
+  const int b = blockIdx.x * EPW + slot;
+  if (b >= P.B) return;
+  const Model& m = *mp;
+  E e(P, b);
+  KinData* s = &lds[slot];
+  for (int d = tl; d < ND; d += T) s->vel[d] = gload(e, FO(vel), d);
+  for (int q = tl; q < NQ; q += T) s->qpos[q] = gload(e, FO(qpos), q);
+  team_sync();
+  tk_kinematics<T>(m, e, s, tl, force_update_fixed != 0);
+}
+
+struct DynData {
+  float cinr_I[NL * 9], cinr_pos[NL * 3], cinr_mass[NL];
+  float crb_I[NL * 9], crb_pos[NL * 3], crb_mass[NL];
+  float cdof_ang[ND * 3], cdof_vel[ND * 3], cdofd_ang[ND * 3], cdofd_vel[ND * 3];
+  float cd_vel[NL * 3], cd_ang[NL * 3], cdd_vel[NL * 3], cdd_ang[NL * 3], cfrc_vel[NL * 3], cfrc_ang[NL * 3];
+  float f_ang[ND * 3], f_vel[ND * 3];
+  float vel[ND], qf_applied[ND], qf_passive[ND], force[ND], out[ND], Dinv[ND];
+  float M[ND * ND], L[ND * ND];
+};
+
+// kernel_step_1 without the (already fresh) FK, rigid_solver.py:3008-3069: func_compute_mass_matrix (forward_dynamics.py:291-541),
+// func_factor_mass :560-604, func_torque_and_passive_force :961-1174, func_update_acc/force/bias_force :1177-1478,
+// func_solve_mass_entity :818-900
+template <int T>
+__global__ __launch_bounds__(64) void k_dynamics_team(Pool P, const Model* __restrict__ mp) {
+  constexpr int EPW = 64 / T;
+  __shared__ DynData lds[EPW];
+  const int tl = threadIdx.x % T, slot = threadIdx.x / T;
+  const int b = blockIdx.x * EPW + slot;
+  if (b >= P.B) return;
+  const Model& m = *mp;
+  E e(P, b);
+  DynData* s = &lds[slot];
+  // ---- stage ----
+  for (int k = tl; k < NL * 9; k += T) { float v = gload(e, FO(cinr_inertial), k); s->cinr_I[k] = v; s->crb_I[k] = v; }
+  for (int k = tl; k < NL * 3; k += T) {
+    float v = gload(e, FO(cinr_pos), k); s->cinr_pos[k] = v; s->crb_pos[k] = v;
+    s->cd_vel[k] = gload(e, FO(cd_vel), k); s->cd_ang[k] = gload(e, FO(cd_ang), k);
+  }
+  for (int k = tl; k < NL; k += T) { float v = gload(e, FO(cinr_mass), k); s->cinr_mass[k] = v; s->crb_mass[k] = v; }
+  for (int k = tl; k < ND * 3; k += T) {
+    s->cdof_ang[k] = gload(e, FO(cdof_ang), k); s->cdof_vel[k] = gload(e, FO(cdof_vel), k);
+    s->cdofd_ang[k] = gload(e, FO(cdofd_ang), k); s->cdofd_vel[k] = gload(e, FO(cdofd_vel), k);
+  }
+  for (int d = tl; d < ND; d += T) s->vel[d] = gload(e, FO(vel), d);
+  team_sync();
+  // ---- composite rigid bodies, leaf -> root ----
+  for (int lev = m.n_levels - 2; lev >= 0; --lev) {
+    int n_par = m.level_start[lev + 1] - m.level_start[lev];
+    for (int w = tl; w < n_par * 13; w += T) {
+      int i_p = m.level_links[m.level_start[lev] + w / 13], comp = w % 13;
+      float* dst = (comp < 9) ? &s->crb_I[9 * i_p + comp] : ((comp < 12) ? &s->crb_pos[3 * i_p + comp - 9] : &s->crb_mass[i_p]);
+      float a = *dst;
+      for (int c = m.child_start[i_p]; c < m.child_start[i_p + 1]; ++c) {
+        int i_l = m.child_list[c];
+        float v = (comp < 9) ? s->crb_I[9 * i_l + comp] : ((comp < 12) ? s->crb_pos[3 * i_l + comp - 9] : s->crb_mass[i_l]);
+        a = a + v;
+      }
+      *dst = a;
+    }
+    team_sync();
+  }
+  for (int i_d = tl; i_d < ND; i_d += T) {
+    int i_l = m.dof_link[i_d];
+    V3 oa, ov;
+    inertial_mul(ld3(s->crb_pos, i_l), ld9(s->crb_I, i_l), s->crb_mass[i_l], ld3(s->cdof_vel, i_d), ld3(s->cdof_ang, i_d), oa, ov);
+    st3(s->f_ang, i_d, oa); st3(s->f_vel, i_d, ov);
+  }
+  team_sync();
+  for (int idx = tl; idx < ND * (ND + 1) / 2; idx += T) {
+    int i_d, j_d;
+    tri_index(idx, i_d, j_d);
+    float v = (dot(ld3(s->f_ang, i_d), ld3(s->cdof_ang, j_d)) + dot(ld3(s->f_vel, i_d), ld3(s->cdof_vel, j_d))) * m.mass_parent_mask[i_d][j_d];
+    if (i_d == j_d) {
+      v = v + m.dofs[i_d].armature;
+      v = v + m.dofs[i_d].damping * m.substep_dt;                      // implicit damping (approximate_implicitfast)
+      int cm = e.ctrl_mode()[i_d];
+      if (cm == CTRL_POSITION || cm == CTRL_VELOCITY) v = v + m.dofs[i_d].kv * m.substep_dt;
+    }
+    s->M[i_d * ND + j_d] = v; s->M[j_d * ND + i_d] = v;
+    s->L[i_d * ND + j_d] = v;
+    gstore(e, FO(mass_mat), i_d * ND + j_d, v);
+    if (i_d != j_d) gstore(e, FO(mass_mat), j_d * ND + i_d, v);
+  }
+  team_sync();
+  // ---- reverse-order LDL^T ----
+  for (int i_d_ = 0; i_d_ < ND; ++i_d_) {
+    const int i_d = ND - i_d_ - 1;
+    float D_inv = 1.0f / s->L[i_d * ND + i_d];
+    for (int idx = tl; idx < i_d * (i_d + 1) / 2; idx += T) {
+      int j_d, k_d;
+      tri_index(idx, j_d, k_d);
+      float a = s->L[i_d * ND + j_d] * D_inv;
+      s->L[j_d * ND + k_d] -= a * s->L[i_d * ND + k_d];
+    }
+    team_sync();
+    for (int j_d = tl; j_d < i_d; j_d += T) s->L[i_d * ND + j_d] = s->L[i_d * ND + j_d] * D_inv;
+    if (tl == 0) { s->Dinv[i_d] = D_inv; s->L[i_d * ND + i_d] = 1.0f; }
+    team_sync();
+  }
+  // ---- applied / passive joint forces ----
+  for (int i_d = tl; i_d < ND; i_d += T) {
+    const Dof& D = m.dofs[i_d];
+    const Link& L = m.links[m.dof_link[i_d]];
+    int joint_type = m.joints[L.joint_start].type;
+    float force = 0.0f;
+    int cm = e.ctrl_mode()[i_d];
+    if (cm == CTRL_FORCE) force = gload(e, FO(ctrl_force), i_d);
+    else if (cm == CTRL_VELOCITY) force = D.kv * (gload(e, FO(ctrl_vel), i_d) - s->vel[i_d]);
+    else if (cm == CTRL_POSITION && !(joint_type == JOINT_FREE && i_d >= L.dof_start + 3))
+      force = D.kp * (gload(e, FO(ctrl_pos), i_d) - gload(e, FO(dof_pos), i_d)) + D.kv * (gload(e, FO(ctrl_vel), i_d) - s->vel[i_d]);
+    s->qf_applied[i_d] = clampf(force, D.force_range[0], D.force_range[1]);
+    float qp = -D.damping * s->vel[i_d];
+    if (joint_type != JOINT_FREE && joint_type != JOINT_FIXED) qp = qp + (-gload(e, FO(dof_pos), i_d) * D.stiffness);
+    s->qf_passive[i_d] = qp;
+  }
+  // ---- bias forces: accelerations root -> leaf ----
+  for (int lev = 0; lev < m.n_levels; ++lev) {
+    for (int k = m.level_start[lev] + tl; k < m.level_start[lev + 1]; k += T) {
+      int i_l = m.level_links[k];
+      const Link& L = m.links[i_l];
+      V3 cv, ca;
+      if (L.parent == -1) { cv = -m.gravity * (1.0f - 0.0f); ca = v3(0, 0, 0); }
+      else { cv = ld3(s->cdd_vel, L.parent); ca = ld3(s->cdd_ang, L.parent); }
+      for (int i_d = L.dof_start; i_d < L.dof_end; ++i_d) {
+        float v = s->vel[i_d];
+        V3 local_cdd_vel = ld3(s->cdofd_vel, i_d) * v;
+        V3 local_cdd_ang = ld3(s->cdofd_ang, i_d) * v;
+        cv = cv + local_cdd_vel;
+        ca = ca + local_cdd_ang;
+      }
+      st3(s->cdd_vel, i_l, cv); st3(s->cdd_ang, i_l, ca);
+    }
+    team_sync();
+  }
+  for (int i_l = tl; i_l < NL; i_l += T) {
+    V3 f1_ang, f1_vel, f2_ang, f2_vel, f3_ang, f3_vel;
+    M3 I = ld9(s->cinr_I, i_l); V3 cp = ld3(s->cinr_pos, i_l); float cm = s->cinr_mass[i_l];
+    V3 cdv = ld3(s->cd_vel, i_l), cda = ld3(s->cd_ang, i_l);
+    inertial_mul(cp, I, cm, ld3(s->cdd_vel, i_l), ld3(s->cdd_ang, i_l), f1_ang, f1_vel);
+    inertial_mul(cp, I, cm, cdv, cda, f2_ang, f2_vel);
+    motion_cross_force(cda, cdv, f2_ang, f2_vel, f3_ang, f3_vel);
+    V3 ext_ang = v3(gload(e, FO(ext), 6 * i_l + 0), gload(e, FO(ext), 6 * i_l + 1), gload(e, FO(ext), 6 * i_l + 2));
+    V3 ext_vel = v3(gload(e, FO(ext), 6 * i_l + 3), gload(e, FO(ext), 6 * i_l + 4), gload(e, FO(ext), 6 * i_l + 5));
+    st3(s->cfrc_vel, i_l, f1_vel + f3_vel + ext_vel + v3(0, 0, 0));
+    st3(s->cfrc_ang, i_l, f1_ang + f3_ang + ext_ang + v3(0, 0, 0));
+  }
+  team_sync();
+  for (int lev = m.n_levels - 2; lev >= 0; --lev) {
+    int n_par = m.level_start[lev + 1] - m.level_start[lev];
+    for (int w = tl; w < n_par * 6; w += T) {
+      int i_p = m.level_links[m.level_start[lev] + w / 6], comp = w % 6;
+      float* dst = (comp < 3) ? &s->cfrc_vel[3 * i_p + comp] : &s->cfrc_ang[3 * i_p + comp - 3];
+      float a = *dst;
+      for (int c = m.child_start[i_p]; c < m.child_start[i_p + 1]; ++c) {
+        int i_l = m.child_list[c];
+        a = a + ((comp < 3) ? s->cfrc_vel[3 * i_l + comp] : s->cfrc_ang[3 * i_l + comp - 3]);
+      }
+      *dst = a;
+    }
+    team_sync();
+  }
+  for (int i_d = tl; i_d < ND; i_d += T) {
+    int i_l = m.dof_link[i_d];
+    float qf_bias = dot(ld3(s->cdof_ang, i_d), ld3(s->cfrc_ang, i_l)) + dot(ld3(s->cdof_vel, i_d), ld3(s->cfrc_vel, i_l));
+    float f = s->qf_passive[i_d] - qf_bias + s->qf_applied[i_d];
+    s->force[i_d] = f;
+    gstore(e, FO(force), i_d, f); gstore(e, FO(qf_smooth), i_d, f);
+  }
+  team_sync();
+  // ---- acc_smooth = L^-T D^-1 L^-1 force: serial chains, evaluated redundantly by every lane on the LDS copy ----
+  for (int i_d_ = 0; i_d_ < ND; ++i_d_) {
+    int i_d = ND - i_d_ - 1;
+    float cur = s->force[i_d];
+    for (int j_d = i_d + 1; j_d < ND; ++j_d) cur = cur - s->L[j_d * ND + i_d] * s->out[j_d];
+    s->out[i_d] = cur;
+  }
+  for (int i_d = 0; i_d < ND; ++i_d) s->out[i_d] = s->out[i_d] * s->Dinv[i_d];
+  for (int i_d = 0; i_d < ND; ++i_d) {
+    float cur = s->out[i_d];
+    for (int j_d = 0; j_d < i_d; ++j_d) cur = cur - s->L[i_d * ND + j_d] * s->out[j_d];
+    s->out[i_d] = cur;
+  }
+  team_sync();
+  for (int i_d = tl; i_d < ND; i_d += T) { float a = s->out[i_d]; gstore(e, FO(acc_smooth), i_d, a); gstore(e, FO(acc), i_d, a); }
+}
+
+// ---------------------------------------------------------------------------------------------
 // collision detection  (R/collider/*.py)
 // ---------------------------------------------------------------------------------------------
 // ---- support functions, collider/support_field.py ---------------------------------------------
@@ -1102,8 +1581,6 @@ DEV void rotate_frame(V3 pos, Q4 quat, V3 contact_pos, Q4 qrot, V3& new_pos, Q4&
   new_pos = pos - vec;
 }
 
-// single-wavefront workgroups: the barrier is a compiler/LDS ordering fence only
-DEV void team_sync() { __syncthreads(); }
 // ---------------------------------------------------------------------------------------------
 // Team collision detection: T lanes per environment.
 //   * AABBs: one lane per geom.
@@ -1374,8 +1851,6 @@ struct SolverData {
   int active[R], prev_active[R];
 };
 
-DEV float gload(const E& e, int off, int k) { return e.f[(size_t)(off + k) * e.B]; }
-DEV void gstore(const E& e, int off, int k, float v) { e.f[(size_t)(off + k) * e.B] = v; }
 
 template <int T, class S>
 DEV void ts_update_constraint(const Model& m, S* s, int tl, int n_con, float& cost, float& prev_cost, float& gauss) {
@@ -2377,7 +2852,7 @@ DEV void env_reset_one(const Model& m, const DCfg& c, const Glob& g, const E& e,
   cmd[0] = cx; cmd[1] = cy; cmd[2] = cz;
 }
 
-// per-env tail of a reset call: reset flagged envs, broadcast the "global" DR scalars, refresh FK for the
+// per-env tail of a reset call: reset flagged envs, broadcast the "global" DR scalars; the caller then refreshes FK for the
 // full batch (the reference's set_dofs_position/set_pos/set_quat/zero_all_dofs_velocity each run a
 // full-batch FK: rigid_solver.py:1928-1943,2412-2427)
 DEV void reset_tail(const Model& m, const DCfg& c, const Glob& g, const E& e, int b, uint64_t seed) {
@@ -2388,8 +2863,7 @@ DEV void reset_tail(const Model& m, const DCfg& c, const Glob& g, const E& e, in
   if (c.i[GO2SIM_IC_HAS_MASS_DR]) e.mass_shift()[bl] = g.mass_shift;
   if (c.i[GO2SIM_IC_HAS_COM_DR]) e.com_shift()[bl] = v3(g.com_shift[0], g.com_shift[1], g.com_shift[2]);
   if (c.i[GO2SIM_IC_HAS_LEGM_DR]) for (int k = 0; k < 4; ++k) e.mass_shift()[c.i[GO2SIM_IC_HIP_LINK0 + k]] = g.leg_mass_shift[k];
-  update_cartesian_space(m, e, true);
-  forward_velocity(m, e);
+  // the full-batch FK refresh follows as k_fk_team gated on g.n_reset_now (launch_fk_team)
 }
 
 __global__ __launch_bounds__(WG) void k_env_reset_tail(Pool P, const Model* __restrict__ mp, const DCfg* __restrict__ cp, const Glob* __restrict__ gp, uint64_t seed) {
@@ -2574,6 +3048,7 @@ struct go2sim {
   DCfg hcfg; DCfg* dcfg = nullptr; bool cfg_set = false;
   Glob* dglob = nullptr; Acc* dacc = nullptr; int* derr = nullptr;
   SolverData<MAXR>* solver_ovf = nullptr;   // per-env global scratch for solves that do not fit in LDS (> RL rows)
+  int dyn_team = 16;                        // lanes per environment in k_dynamics_team / k_integrate_fk_team / k_fk_team
   int collide_team = 16;                    // lanes per environment in k_collide_team
   int solver_team = 16;                     // lanes per environment in k_constraint_solve_team
   uint32_t step_count = 0; int action_write_idx = 0;
@@ -2605,9 +3080,24 @@ struct ScopedTimer {
   ~ScopedTimer() { if (idx >= 0) (void)hipEventRecord(h->ev1[idx], s); }
 };
 
+static void launch_fk_team(go2sim* h, hipStream_t s, int force_update_fixed, const int* cond) {
+  const int T = h->dyn_team;
+  dim3 gd((h->B + 64 / T - 1) / (64 / T)), b(64);
+  if (T == 16) hipLaunchKernelGGL(k_fk_team<16>, gd, b, 0, s, h->P, h->dm, force_update_fixed, cond);
+  else if (T == 32) hipLaunchKernelGGL(k_fk_team<32>, gd, b, 0, s, h->P, h->dm, force_update_fixed, cond);
+  else hipLaunchKernelGGL(k_fk_team<64>, gd, b, 0, s, h->P, h->dm, force_update_fixed, cond);
+}
+
 static int launch_substep(go2sim* h, hipStream_t s) {
   dim3 g = grid_for(h->B), b(WG);
-  { ScopedTimer t(h, s, T_DYN); hipLaunchKernelGGL(k_dynamics, g, b, 0, s, h->P, h->dm); }
+  {
+    ScopedTimer t(h, s, T_DYN);
+    const int T = h->dyn_team;
+    dim3 gd((h->B + 64 / T - 1) / (64 / T));
+    if (T == 16) hipLaunchKernelGGL(k_dynamics_team<16>, gd, b, 0, s, h->P, h->dm);
+    else if (T == 32) hipLaunchKernelGGL(k_dynamics_team<32>, gd, b, 0, s, h->P, h->dm);
+    else hipLaunchKernelGGL(k_dynamics_team<64>, gd, b, 0, s, h->P, h->dm);
+  }
   {
     ScopedTimer t(h, s, T_COLLIDE);
     const int T = h->collide_team;
@@ -2624,7 +3114,14 @@ static int launch_substep(go2sim* h, hipStream_t s) {
     else if (T == 32) hipLaunchKernelGGL(k_constraint_solve_team<32>, gs, b, 0, s, h->P, h->dm, h->solver_ovf);
     else hipLaunchKernelGGL(k_constraint_solve_team<64>, gs, b, 0, s, h->P, h->dm, h->solver_ovf);
   }
-  { ScopedTimer t(h, s, T_INTEGRATE); hipLaunchKernelGGL(k_integrate_fk, g, b, 0, s, h->P, h->dm); }
+  {
+    ScopedTimer t(h, s, T_INTEGRATE);
+    const int T = h->dyn_team;
+    dim3 gd((h->B + 64 / T - 1) / (64 / T));
+    if (T == 16) hipLaunchKernelGGL(k_integrate_fk_team<16>, gd, b, 0, s, h->P, h->dm);
+    else if (T == 32) hipLaunchKernelGGL(k_integrate_fk_team<32>, gd, b, 0, s, h->P, h->dm);
+    else hipLaunchKernelGGL(k_integrate_fk_team<64>, gd, b, 0, s, h->P, h->dm);
+  }
   return GO2SIM_E_OK;
 }
 
@@ -2653,6 +3150,7 @@ int go2sim_create(const void* blob, size_t nbytes, int n_envs, int device, uint6
   HIPCHK(hipMalloc((void**)&h->dacc, sizeof(Acc)));
   HIPCHK(hipMalloc((void**)&h->derr, sizeof(int)));
   HIPCHK(hipMalloc((void**)&h->solver_ovf, (size_t)n_envs * sizeof(SolverData<MAXR>)));
+  if (const char* t = getenv("GO2SIM_DYN_TEAM")) { int v = atoi(t); if (v == 16 || v == 32 || v == 64) h->dyn_team = v; }
   if (const char* t = getenv("GO2SIM_COLLIDE_TEAM")) { int v = atoi(t); if (v == 16 || v == 32 || v == 64) h->collide_team = v; }
   if (const char* t = getenv("GO2SIM_SOLVER_TEAM")) { int v = atoi(t); if (v == 16 || v == 32 || v == 64) h->solver_team = v; }
   Glob g0; memset(&g0, 0, sizeof(g0)); g0.friction = 1.0f;
@@ -2704,7 +3202,7 @@ int go2sim_forward_kinematics(go2sim_t* h, void* stream) {
   if (!h) return GO2SIM_E_BADARG;
   hipStream_t s = (hipStream_t)stream;
   ScopedTimer t(h, s, T_MISC);
-  hipLaunchKernelGGL(k_fk, grid_for(h->B), dim3(WG), 0, s, h->P, h->dm, 1);
+  launch_fk_team(h, s, 1, nullptr);
   HIPCHK(hipGetLastError());
   return GO2SIM_E_OK;
 }
@@ -2854,6 +3352,7 @@ int go2sim_env_step(go2sim_t* h, const float* actions, float* obs, float* priv, 
     hipLaunchKernelGGL(k_env_post_a, g, b, 0, s, h->P, h->dm, h->dcfg, h->dglob, h->dacc, h->seed, h->step_count);
     hipLaunchKernelGGL(k_env_globals, dim3(1), dim3(1), 0, s, h->dcfg, h->dglob, h->dacc, h->seed, 1);
     hipLaunchKernelGGL(k_env_post_b, g, b, 0, s, h->P, h->dm, h->dcfg, h->dglob, h->seed, h->step_count, obs, priv, rew, reset, timeout);
+    launch_fk_team(h, s, 1, &h->dglob->n_reset_now);
   }
   HIPCHK(hipGetLastError());
   h->action_write_idx = (h->action_write_idx + 1) % 2;
@@ -2869,6 +3368,7 @@ int go2sim_env_reset(go2sim_t* h, void* stream) {
   hipLaunchKernelGGL(k_env_mark_all, g, b, 0, s, h->P, h->dcfg, h->dacc);
   hipLaunchKernelGGL(k_env_globals, dim3(1), dim3(1), 0, s, h->dcfg, h->dglob, h->dacc, h->seed, 0);
   hipLaunchKernelGGL(k_env_reset_tail, g, b, 0, s, h->P, h->dm, h->dcfg, h->dglob, h->seed);
+  launch_fk_team(h, s, 1, &h->dglob->n_reset_now);
   HIPCHK(hipGetLastError());
   return GO2SIM_E_OK;
 }
