@@ -471,6 +471,17 @@ DEV void team_sync() { __syncthreads(); }
 DEV float gload(const E& e, int off, int k) { return e.f[(size_t)(off + k) * e.B]; }
 DEV void gstore(const E& e, int off, int k, float v) { e.f[(size_t)(off + k) * e.B] = v; }
 
+
+// ---- optional per-phase cycle accounting (build with -DGO2SIM_PHASE_PROFILE; development aid, see tools/phase_profile.py) ----
+#ifdef GO2SIM_PHASE_PROFILE
+__device__ unsigned long long g_phase_cycles[64];
+#define PH_BEGIN unsigned long long ph_t = __builtin_readcyclecounter();
+#define PH(i) { unsigned long long ph_n = __builtin_readcyclecounter(); if (threadIdx.x == 0) atomicAdd(&g_phase_cycles[i], ph_n - ph_t); ph_t = __builtin_readcyclecounter(); }
+#else
+#define PH_BEGIN
+#define PH(i)
+#endif
+
 // scalar slots
 enum { SV_COST = 0, SV_PREV_COST, SV_GAUSS, SV_QG0, SV_QG1, SV_QG2, SV_GTOL };
 enum { SI_LS_IT = 0, SI_LS_RESULT, SI_IMPROVED };
@@ -1838,19 +1849,21 @@ DEVN int update_bracket(LsPoint& p, const float alphas[3], const float costs[3],
 // results are bit-identical to the one-lane-per-env formulation and to the CPU oracle.
 // Environments with more than RL rows fall back to the same code on a per-env global scratch block.
 // ---------------------------------------------------------------------------------------------
-constexpr int RL = 48;  // constraint rows held in LDS (12 contacts); typical walking uses 16
+constexpr int RL = 32;  // constraint rows held in LDS (8 contacts); typical walking uses 16; more rows take the global-scratch path
+constexpr int DS = 20;  // padded stride of dof-indexed rows in the solver working set (16-byte aligned rows => wide LDS accesses)
 
 template <int R>
-struct SolverData {
-  float J[R * ND];
-  float H[ND * ND];
-  float M[ND * ND];
-  float qacc[ND], Ma[ND], grad[ND], Mgrad[ND], search[ND], mv[ND], force[ND], acc_smooth[ND], qfrc[ND], ntv[ND], vel[ND];
+struct alignas(16) SolverData {
+  float J[R * DS];
+  float H[ND * DS];   // lower triangle: Hessian, then its Cholesky factor; the strict upper triangle mirrors it so that columns read as rows
+  float M[ND * DS];
+  float qacc[DS], Ma[DS], grad[DS], Mgrad[DS], search[DS], mv[DS], force[DS], acc_smooth[DS], qfrc[DS], ntv[DS], vel[DS];
   float cdof_ang[ND * 3], cdof_vel[ND * 3], root_com[NL * 3];
-  float aref[R], efc_D[R], Jaref[R], jv[R], efc_force[R], qf0[R], qf1[R], qf2[R];
+  float aref[R], efc_D[R], Jaref[R], jv[R], efc_force[R], qf0[R], qf1[R], qf2[R], DA[R];
   int active[R], prev_active[R];
 };
-
+// link topology needed by the Jacobian chain walk, staged once per workgroup (avoids dependent global loads)
+struct LinkTable { int parent[NL], n_dofs[NL], dof_end[NL]; float invweight[NL]; };
 
 template <int T, class S>
 DEV void ts_update_constraint(const Model& m, S* s, int tl, int n_con, float& cost, float& prev_cost, float& gauss) {
@@ -1860,61 +1873,76 @@ DEV void ts_update_constraint(const Model& m, S* s, int tl, int n_con, float& co
     float Ja = s->Jaref[c];
     int act = Ja < 0.0f;
     s->active[c] = act;
-    s->efc_force[c] = 0.0f + (-Ja * s->efc_D[c] * (float)act);
+    float D = s->efc_D[c];
+    s->DA[c] = D * (float)act;
+    s->efc_force[c] = 0.0f + (-Ja * D * (float)act);
   }
   team_sync();
   for (int d = tl; d < ND; d += T) {
     float q = 0.0f;
-    for (int c = 0; c < n_con; ++c) q = q + s->J[c * ND + d] * s->efc_force[c];
+#pragma unroll 8
+    for (int c = 0; c < n_con; ++c) q = q + s->J[c * DS + d] * s->efc_force[c];
     s->qfrc[d] = q;
   }
   float cost_i = 0.0f, gauss_i = 0.0f;
+#pragma unroll
   for (int d = 0; d < ND; ++d) {
     float v = 0.5f * (s->Ma[d] - s->force[d]) * (s->qacc[d] - s->acc_smooth[d]);
     gauss_i = gauss_i + v;
     cost_i = cost_i + v;
   }
-  for (int c = 0; c < n_con; ++c) { float Ja = s->Jaref[c]; cost_i = cost_i + 0.5f * (Ja * Ja * s->efc_D[c] * (float)s->active[c]); }
+#pragma unroll 8
+  for (int c = 0; c < n_con; ++c) { float Ja = s->Jaref[c]; cost_i = cost_i + 0.5f * (Ja * Ja * s->DA[c]); }
   gauss = gauss_i; cost = cost_i;
   team_sync();
 }
 
+// func_hessian_direct_batch, solver.py:1285-1343: one lane per lower-triangle entry, rows summed first to last
 template <int T, class S>
 DEV void ts_hessian_direct(const Model& m, S* s, int tl, int n_con) {
   for (int idx = tl; idx < ND * (ND + 1) / 2; idx += T) {
-    int i = (int)((sqrtf(8.0f * (float)idx + 1.0f) - 1.0f) * 0.5f);
-    while (i * (i + 1) / 2 > idx) --i;
-    while ((i + 1) * (i + 2) / 2 <= idx) ++i;
-    int j = idx - i * (i + 1) / 2;
+    int i, j;
+    tri_index(idx, i, j);
     float h = 0.0f;
+#pragma unroll 8
     for (int c = 0; c < n_con; ++c) {
-      float j1 = s->J[c * ND + i];
-      if (dm_abs(j1) > m.eps) h = h + s->J[c * ND + j] * j1 * s->efc_D[c] * (float)s->active[c];
+      float j1 = s->J[c * DS + i];
+      float t = s->J[c * DS + j] * j1 * s->DA[c];     // (row[j] * j1 * D) * active, active in {0,1}
+      h = (dm_abs(j1) > m.eps) ? (h + t) : h;
     }
-    s->H[i * ND + j] = h + s->M[i * ND + j];
+    h = h + s->M[i * DS + j];
+    s->H[i * DS + j] = h;
   }
   team_sync();
 }
 
+// func_cholesky_factor_direct_batch, solver.py:1467-1494 (column by column; statically unrolled so that the pivot-row prefix is
+// fetched with wide LDS reads that are all in flight at once)
 template <int T, class S>
 DEV void ts_cholesky_factor(const Model& m, S* s, int tl) {
+#pragma unroll
   for (int i_d = 0; i_d < ND; ++i_d) {
-    float tmp = s->H[i_d * ND + i_d];
-    for (int j_d = 0; j_d < i_d; ++j_d) { float h = s->H[i_d * ND + j_d]; tmp = tmp - h * h; }
+    float pr[ND];
+#pragma unroll
+    for (int k = 0; k < i_d; ++k) pr[k] = s->H[i_d * DS + k];
+    float tmp = s->H[i_d * DS + i_d];
+#pragma unroll
+    for (int k = 0; k < i_d; ++k) tmp = tmp - pr[k] * pr[k];
     float dgn = dm_sqrt(fmx(tmp, m.eps));
     float inv = 1.0f / dgn;
-    team_sync();
-    if (tl == 0) s->H[i_d * ND + i_d] = dgn;
+    if (tl == 0) s->H[i_d * DS + i_d] = dgn;
     for (int j_d = i_d + 1 + tl; j_d < ND; j_d += T) {
       float dotv = 0.0f;
-      for (int k_d = 0; k_d < i_d; ++k_d) dotv = dotv + s->H[j_d * ND + k_d] * s->H[i_d * ND + k_d];
-      s->H[j_d * ND + i_d] = (s->H[j_d * ND + i_d] - dotv) * inv;
+#pragma unroll
+      for (int k = 0; k < i_d; ++k) dotv = dotv + s->H[j_d * DS + k] * pr[k];
+      float v = (s->H[j_d * DS + i_d] - dotv) * inv;
+      s->H[j_d * DS + i_d] = v; s->H[i_d * DS + j_d] = v;
     }
     team_sync();
   }
 }
 
-// returns true when the factor degenerated (caller rebuilds it from scratch)
+// func_hessian_and_cholesky_factor_incremental_dense_batch, solver.py:1632-1675; returns true when the factor degenerated
 template <int T, class S>
 DEV bool ts_cholesky_incremental(const Model& m, S* s, int tl, int n_con) {
   bool degenerated = false;
@@ -1924,12 +1952,12 @@ DEV bool ts_cholesky_incremental(const Model& m, S* s, int tl, int n_con) {
       float sign = is_active ? 1.0f : -1.0f;
       float efc_D_sqrt = dm_sqrt(s->efc_D[c]);
       team_sync();
-      for (int d = tl; d < ND; d += T) s->ntv[d] = s->J[c * ND + d] * efc_D_sqrt;
+      for (int d = tl; d < ND; d += T) s->ntv[d] = s->J[c * DS + d] * efc_D_sqrt;
       team_sync();
       for (int k = 0; k < ND; ++k) {
         float vk = s->ntv[k];
         if (dm_abs(vk) > m.eps) {
-          float Lkk = s->H[k * ND + k];
+          float Lkk = s->H[k * DS + k];
           float tmp = Lkk * Lkk + sign * (vk * vk);
           if (tmp < m.eps) { degenerated = true; break; }
           float r = dm_sqrt(tmp);
@@ -1937,11 +1965,12 @@ DEV bool ts_cholesky_incremental(const Model& m, S* s, int tl, int n_con) {
           float cinv = 1.0f / cc;
           float sk = vk / Lkk;
           team_sync();
-          if (tl == 0) s->H[k * ND + k] = r;
+          if (tl == 0) s->H[k * DS + k] = r;
           for (int i = k + 1 + tl; i < ND; i += T) {
-            float hik = (s->H[i * ND + k] + sk * s->ntv[i] * sign) * cinv;
-            s->H[i * ND + k] = hik;
-            s->ntv[i] = s->ntv[i] * cc - sk * hik;
+            float nv = s->ntv[i];
+            float hik = (s->H[i * DS + k] + sk * nv * sign) * cinv;
+            s->H[i * DS + k] = hik; s->H[k * DS + i] = hik;
+            s->ntv[i] = nv * cc - sk * hik;
           }
           team_sync();
         }
@@ -1951,8 +1980,8 @@ DEV bool ts_cholesky_incremental(const Model& m, S* s, int tl, int n_con) {
   return degenerated;
 }
 
-// grad, Mgrad = H^-1 grad (func_cholesky_solve_batch, solver.py:1747-1765): the two triangular solves are serial chains;
-// every lane runs them redundantly with the running vector in registers
+// grad = Ma - force - qfrc;  Mgrad = H^-1 grad (func_cholesky_solve_batch, solver.py:1747-1765): two serial triangular solves, run
+// redundantly by every lane with the running vector in registers; rows (and, through the mirror, columns) arrive as wide reads
 template <int T, class S>
 DEV void ts_update_gradient(S* s, int tl) {
   for (int d = tl; d < ND; d += T) s->grad[d] = s->Ma[d] - s->force[d] - s->qfrc[d];
@@ -1962,16 +1991,16 @@ DEV void ts_update_gradient(S* s, int tl) {
   for (int i_d = 0; i_d < ND; ++i_d) {
     float cur = s->grad[i_d];
 #pragma unroll
-    for (int j_d = 0; j_d < i_d; ++j_d) cur = cur - s->H[i_d * ND + j_d] * y[j_d];
-    y[i_d] = cur / s->H[i_d * ND + i_d];
+    for (int j_d = 0; j_d < i_d; ++j_d) cur = cur - s->H[i_d * DS + j_d] * y[j_d];
+    y[i_d] = cur / s->H[i_d * DS + i_d];
   }
 #pragma unroll
   for (int i_d_ = 0; i_d_ < ND; ++i_d_) {
     const int i_d = ND - 1 - i_d_;
     float cur = y[i_d];
 #pragma unroll
-    for (int j_d = i_d + 1; j_d < ND; ++j_d) cur = cur - s->H[j_d * ND + i_d] * y[j_d];
-    y[i_d] = cur / s->H[i_d * ND + i_d];
+    for (int j_d = i_d + 1; j_d < ND; ++j_d) cur = cur - s->H[i_d * DS + j_d] * y[j_d];   // H[i][j] mirrors L[j][i]
+    y[i_d] = cur / s->H[i_d * DS + i_d];
   }
   if (tl == 0) {
 #pragma unroll
@@ -1983,6 +2012,7 @@ DEV void ts_update_gradient(S* s, int tl) {
 template <class S>
 DEV LsPoint ts_ls_point(const Model& m, S* s, int n_con, float alpha, float qg0, float qg1, float qg2) {
   float t0 = qg0 + 0.0f, t1 = qg1 + 0.0f, t2 = qg2 + 0.0f;
+#pragma unroll 4
   for (int c = 0; c < n_con; ++c) {
     float x = s->Jaref[c] + alpha * s->jv[c];
     float active = (float)(x < 0.0f);
@@ -1999,6 +2029,7 @@ template <class S>
 DEV void ts_ls_point3(const Model& m, S* s, int n_con, const float a[3], float qg0, float qg1, float qg2, float costs[3], float grads[3], float hess[3]) {
   float b0 = qg0 + 0.0f, b1 = qg1 + 0.0f, b2 = qg2 + 0.0f;
   float t00 = b0, t01 = b1, t02 = b2, t10 = b0, t11 = b1, t12 = b2, t20 = b0, t21 = b1, t22 = b2;
+#pragma unroll 4
   for (int c = 0; c < n_con; ++c) {
     float Ja = s->Jaref[c], jv = s->jv[c];
     float qf_0 = s->qf0[c], qf_1 = s->qf1[c], qf_2 = s->qf2[c];
@@ -2020,8 +2051,12 @@ DEV void ts_ls_point3(const Model& m, S* s, int n_con, const float a[3], float q
 // func_linesearch_batch, solver.py:2246-2417
 template <int T, class S>
 DEV float ts_linesearch(const Model& m, S* s, int tl, int n_con, float gauss) {
+  float sr[ND];
+#pragma unroll
+  for (int d = 0; d < ND; ++d) sr[d] = s->search[d];
   float snorm = 0.0f;
-  for (int jd = 0; jd < ND; ++jd) { float sd = s->search[jd]; snorm = snorm + sd * sd; }
+#pragma unroll
+  for (int jd = 0; jd < ND; ++jd) snorm = snorm + sr[jd] * sr[jd];
   snorm = dm_sqrt(snorm);
   float scale = m.meaninertia * (float)imx(1, ND);
   float gtol = m.tolerance * m.ls_tolerance * snorm * scale;
@@ -2029,20 +2064,23 @@ DEV float ts_linesearch(const Model& m, S* s, int tl, int n_con, float gauss) {
   // mv = M search, jv = J search, and the alpha-independent quadratic coefficients of every row
   for (int d1 = tl; d1 < ND; d1 += T) {
     float mv = 0.0f;
-    for (int d2 = 0; d2 < ND; ++d2) mv = mv + s->M[d1 * ND + d2] * s->search[d2];
+#pragma unroll
+    for (int d2 = 0; d2 < ND; ++d2) mv = mv + s->M[d1 * DS + d2] * sr[d2];
     s->mv[d1] = mv;
   }
   for (int c = tl; c < n_con; c += T) {
     float jv = 0.0f;
-    for (int d = 0; d < ND; ++d) jv = jv + s->J[c * ND + d] * s->search[d];
+#pragma unroll
+    for (int d = 0; d < ND; ++d) jv = jv + s->J[c * DS + d] * sr[d];
     s->jv[c] = jv;
     float Ja = s->Jaref[c], D = s->efc_D[c];
     s->qf0[c] = D * (0.5f * Ja * Ja); s->qf1[c] = D * (jv * Ja); s->qf2[c] = D * (0.5f * jv * jv);
   }
   team_sync();
   float qg1 = 0.0f, qg2 = 0.0f;
+#pragma unroll
   for (int d = 0; d < ND; ++d) {
-    float sd = s->search[d];
+    float sd = sr[d];
     qg1 = qg1 + (sd * s->Ma[d] - sd * s->force[d]);
     qg2 = qg2 + 0.5f * sd * s->mv[d];
   }
@@ -2050,6 +2088,7 @@ DEV float ts_linesearch(const Model& m, S* s, int tl, int n_con, float gauss) {
   LsPoint p0;
   {
     float t0 = qg0, t1 = qg1, t2 = qg2;
+#pragma unroll 4
     for (int c = 0; c < n_con; ++c) {
       float active = (float)(s->Jaref[c] < 0.0f);
       t0 = t0 + s->qf0[c] * active; t1 = t1 + s->qf1[c] * active; t2 = t2 + s->qf2[c] * active;
@@ -2101,21 +2140,29 @@ DEV float ts_linesearch(const Model& m, S* s, int tl, int n_con, float gauss) {
 // rows + resolve for one environment (add_collision_constraints solver.py:498-595, add_joint_limit_constraints :1088-1143,
 // func_solve_init :2739-2859, func_solve_body :2941-2966, func_solve_iter :2862-2938)
 template <int T, class S>
-DEV int ts_solve(const Model& m, const E& e, S* s, int tl, int nc, int n_con) {
-  const int B = e.B; (void)B;
+DEV int ts_solve(const Model& m, const E& e, const LinkTable* lt, S* s, int tl, int nc, int n_con) {
+  PH_BEGIN
   // ---- stage inputs ----
   bool ws = (n_con > 0) && e.is_warmstart()[0];
-  for (int k = tl; k < ND * ND; k += T) s->M[k] = gload(e, FO(mass_mat), k);
-  for (int k = tl; k < ND * 3; k += T) { s->cdof_ang[k] = gload(e, FO(cdof_ang), k); s->cdof_vel[k] = gload(e, FO(cdof_vel), k); }
-  for (int k = tl; k < NL * 3; k += T) s->root_com[k] = gload(e, FO(root_com), k);
-  for (int d = tl; d < ND; d += T) {
-    s->vel[d] = gload(e, FO(vel), d);
-    s->force[d] = gload(e, FO(force), d);
-    float as = gload(e, FO(acc_smooth), d);
-    s->acc_smooth[d] = as;
-    s->qacc[d] = ws ? gload(e, FO(qacc_ws), d) : as;
+#pragma unroll
+  for (int k0 = 0; k0 < ND * ND; k0 += T) { int k = k0 + tl; if (k < ND * ND) s->M[(k / ND) * DS + (k % ND)] = gload(e, FO(mass_mat), k); }
+#pragma unroll
+  for (int k0 = 0; k0 < ND * 3; k0 += T) { int k = k0 + tl; if (k < ND * 3) { s->cdof_ang[k] = gload(e, FO(cdof_ang), k); s->cdof_vel[k] = gload(e, FO(cdof_vel), k); } }
+#pragma unroll
+  for (int k0 = 0; k0 < NL * 3; k0 += T) { int k = k0 + tl; if (k < NL * 3) s->root_com[k] = gload(e, FO(root_com), k); }
+#pragma unroll
+  for (int d0 = 0; d0 < ND; d0 += T) {
+    int d = d0 + tl;
+    if (d < ND) {
+      s->vel[d] = gload(e, FO(vel), d);
+      s->force[d] = gload(e, FO(force), d);
+      float as = gload(e, FO(acc_smooth), d);
+      s->acc_smooth[d] = as;
+      s->qacc[d] = ws ? gload(e, FO(qacc_ws), d) : as;
+    }
   }
   team_sync();
+  PH(0)
   // ---- contact rows: one lane per row ----
   for (int r = tl; r < 4 * nc; r += T) {
     int i_col = r >> 2, i = r & 3;
@@ -2128,21 +2175,22 @@ DEV int ts_solve(const Model& m, const E& e, S* s, int tl, int nc, int n_con) {
     for (int k = 0; k < 7; ++k) sol[k] = csol[k];
     V3 d1, d2;
     orthogonals(cnormal, d1, d2);
-    float invweight = m.links[link_a].invweight[0];
-    if (link_b > -1) invweight = invweight + m.links[link_b].invweight[0];
+    float invweight = lt->invweight[link_a];
+    if (link_b > -1) invweight = invweight + lt->invweight[link_b];
     V3 d = (float)(2 * (i % 2) - 1) * ((i < 2) ? d1 : d2);
     V3 n = d * friction - cnormal;
-    float* row = &s->J[r * ND];
-    for (int i_d = 0; i_d < ND; ++i_d) row[i_d] = 0.0f;
+    float* row = &s->J[r * DS];
+#pragma unroll
+    for (int i_d = 0; i_d < DS; ++i_d) row[i_d] = 0.0f;
     float jac_qvel = 0.0f;
     for (int i_ab = 0; i_ab < 2; ++i_ab) {
       float sign = -1.0f; int link = link_a;
       if (i_ab == 1) { sign = 1.0f; link = link_b; }
       while (link > -1) {
-        const Link& L = m.links[link];
         V3 t_pos = cpos - v3(s->root_com[3 * link], s->root_com[3 * link + 1], s->root_com[3 * link + 2]);
-        for (int i_d_ = 0; i_d_ < L.n_dofs; ++i_d_) {
-          int i_d = L.dof_end - 1 - i_d_;
+        const int nd = lt->n_dofs[link], de = lt->dof_end[link];
+        for (int i_d_ = 0; i_d_ < nd; ++i_d_) {
+          int i_d = de - 1 - i_d_;
           V3 ca = v3(s->cdof_ang[3 * i_d], s->cdof_ang[3 * i_d + 1], s->cdof_ang[3 * i_d + 2]);
           V3 cv = v3(s->cdof_vel[3 * i_d], s->cdof_vel[3 * i_d + 1], s->cdof_vel[3 * i_d + 2]);
           V3 velv = cv - cross(t_pos, ca);
@@ -2151,7 +2199,7 @@ DEV int ts_solve(const Model& m, const E& e, S* s, int tl, int nc, int n_con) {
           jac_qvel = jac_qvel + j * s->vel[i_d];
           row[i_d] = row[i_d] + j;
         }
-        link = L.parent;
+        link = lt->parent[link];
       }
     }
     float imp, aref;
@@ -2184,36 +2232,63 @@ DEV int ts_solve(const Model& m, const E& e, S* s, int tl, int nc, int n_con) {
       imp_aref(Jt.sol_params, pos_delta, jac_qvel, pos_delta, imp, aref);
       float diag = fmx(m.dofs[i_d].invweight * (1.0f - imp) / imp, m.eps);
       s->aref[r] = aref; s->efc_D[r] = 1.0f / diag;
-      float* row = &s->J[r * ND];
-      for (int i_d2 = 0; i_d2 < ND; ++i_d2) row[i_d2] = 0.0f;
+      float* row = &s->J[r * DS];
+#pragma unroll
+      for (int i_d2 = 0; i_d2 < DS; ++i_d2) row[i_d2] = 0.0f;
       row[i_d] = j;
     }
   }
   team_sync();
+  PH(1)
   // ---- func_solve_init ----
-  for (int d1 = tl; d1 < ND; d1 += T) {
-    float Ma_ = 0.0f;
-    for (int d2 = 0; d2 < ND; ++d2) Ma_ = Ma_ + s->M[d1 * ND + d2] * s->qacc[d2];
-    s->Ma[d1] = Ma_;
-  }
-  for (int c = tl; c < n_con; c += T) {
-    float Jv = -s->aref[c];
-    for (int d = 0; d < ND; ++d) Jv = Jv + s->J[c * ND + d] * s->qacc[d];
-    s->Jaref[c] = Jv;
+  {
+    float qa[ND];
+#pragma unroll
+    for (int d = 0; d < ND; ++d) qa[d] = s->qacc[d];
+    for (int d1 = tl; d1 < ND; d1 += T) {
+      float Ma_ = 0.0f;
+#pragma unroll
+      for (int d2 = 0; d2 < ND; ++d2) Ma_ = Ma_ + s->M[d1 * DS + d2] * qa[d2];
+      s->Ma[d1] = Ma_;
+    }
+    for (int c = tl; c < n_con; c += T) {
+      float Jv = -s->aref[c];
+#pragma unroll
+      for (int d = 0; d < ND; ++d) Jv = Jv + s->J[c * DS + d] * qa[d];
+      s->Jaref[c] = Jv;
+    }
   }
   team_sync();
   float cost = 0.0f, prev_cost = 0.0f, gauss = 0.0f;
   ts_update_constraint<T>(m, s, tl, n_con, cost, prev_cost, gauss);
+  PH(2)
   int iters = 0;
   if (n_con > 0) {
-    ts_hessian_direct<T>(m, s, tl, n_con);
-    ts_cholesky_factor<T>(m, s, tl);
-    ts_update_gradient<T>(s, tl);
-    for (int d = tl; d < ND; d += T) s->search[d] = -s->Mgrad[d];
-    team_sync();
     const float tol_scaled = (m.meaninertia * (float)imx(1, ND)) * m.tolerance;
-    for (int it = 0; it < m.iterations; ++it) {
+    bool need_full = true;
+    for (int it = 0;; ++it) {
+      if (need_full) {                       // single call site of the direct Hessian + factorisation (init and degenerate rebuild)
+        ts_hessian_direct<T>(m, s, tl, n_con);
+        PH(3)
+        ts_cholesky_factor<T>(m, s, tl);
+        PH(4)
+      }
+      ts_update_gradient<T>(s, tl);
+      PH(5)
+      if (it > 0) {
+        float improvement = prev_cost - cost;
+        float grad_norm = 0.0f;
+#pragma unroll
+        for (int d = 0; d < ND; ++d) { float g = s->grad[d]; grad_norm = grad_norm + g * g; }
+        grad_norm = dm_sqrt(grad_norm);
+        bool improved = (grad_norm > tol_scaled) && (improvement > tol_scaled);
+        if (!improved) break;
+      }
+      if (it == m.iterations) break;
+      for (int d = tl; d < ND; d += T) s->search[d] = -s->Mgrad[d];
+      team_sync();
       float alpha = ts_linesearch<T>(m, s, tl, n_con, gauss);
+      PH(6)
       iters++;
       if (dm_abs(alpha) < m.eps) break;
       team_sync();
@@ -2224,21 +2299,14 @@ DEV int ts_solve(const Model& m, const E& e, S* s, int tl, int nc, int n_con) {
       for (int c = tl; c < n_con; c += T) s->Jaref[c] = s->Jaref[c] + s->jv[c] * alpha;
       team_sync();
       ts_update_constraint<T>(m, s, tl, n_con, cost, prev_cost, gauss);
-      if (ts_cholesky_incremental<T>(m, s, tl, n_con)) { team_sync(); ts_hessian_direct<T>(m, s, tl, n_con); ts_cholesky_factor<T>(m, s, tl); }
-      ts_update_gradient<T>(s, tl);
-      float improvement = prev_cost - cost;
-      float grad_norm = 0.0f;
-      for (int d = 0; d < ND; ++d) { float g = s->grad[d]; grad_norm = grad_norm + g * g; }
-      grad_norm = dm_sqrt(grad_norm);
-      bool improved = (grad_norm > tol_scaled) && (improvement > tol_scaled);
-      if (!improved) break;
-      for (int d = tl; d < ND; d += T) s->search[d] = -s->Mgrad[d];
+      PH(7)
+      need_full = ts_cholesky_incremental<T>(m, s, tl, n_con);
       team_sync();
+      PH(8)
     }
   }
   return iters;
 }
-
 
 // func_update_qacc (solver.py:3016-3037) + func_update_contact_force (:2974-3013) + public row outputs
 template <int T, class S>
@@ -2268,14 +2336,17 @@ DEV void ts_commit(const Model& m, const E& e, S* s, int tl, int nc, int n_con, 
       f = f + n * s->efc_force[i_c * 4 + i_dir];
     }
     e.c_force()[i_c] = f;
-    cf[3 * i_c] = f.x; cf[3 * i_c + 1] = f.y; cf[3 * i_c + 2] = f.z;
+    cf[4 * i_c] = f.x; cf[4 * i_c + 1] = f.y; cf[4 * i_c + 2] = f.z;
+    ((int*)cf)[4 * i_c + 3] = e.c_link()[i_c] | (e.c_link()[MAXC + i_c] << 8);
   }
   team_sync();
   for (int i_l = tl; i_l < NL; i_l += T) {
     V3 acc = v3(0, 0, 0);
+#pragma unroll 4
     for (int i_c = 0; i_c < nc; ++i_c) {
-      int la = e.c_link()[i_c], lb = e.c_link()[MAXC + i_c];
-      V3 f = v3(cf[3 * i_c], cf[3 * i_c + 1], cf[3 * i_c + 2]);
+      int lk = ((const int*)cf)[4 * i_c + 3];
+      int la = lk & 0xff, lb = lk >> 8;
+      V3 f = v3(cf[4 * i_c], cf[4 * i_c + 1], cf[4 * i_c + 2]);
       if (la == i_l) acc = acc - f;
       if (lb == i_l) acc = acc + f;
     }
@@ -2283,14 +2354,26 @@ DEV void ts_commit(const Model& m, const E& e, S* s, int tl, int nc, int n_con, 
   }
 }
 
+// cold path: more rows than fit in LDS; same code on a per-env global scratch block
 template <int T>
-__global__ __launch_bounds__(64) void k_constraint_solve_team(Pool P, const Model* __restrict__ mp, SolverData<MAXR>* __restrict__ overflow) {
+DEVN void ts_solve_overflow(const Model& m, const E& e, const LinkTable* lt, SolverData<MAXR>* s, int tl, int nc, int n_con) {
+  int iters = ts_solve<T>(m, e, lt, s, tl, nc, n_con);
+  ts_commit<T>(m, e, s, tl, nc, n_con, iters);
+}
+
+template <int T>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_constraint_solve_team(Pool P, const Model* __restrict__ mp, SolverData<MAXR>* __restrict__ overflow) {
   constexpr int EPW = 64 / T;
   __shared__ SolverData<RL> lds[EPW];
+  __shared__ LinkTable lt;
+  const Model& m = *mp;
+  for (int i = threadIdx.x; i < NL; i += 64) {
+    lt.parent[i] = m.links[i].parent; lt.n_dofs[i] = m.links[i].n_dofs; lt.dof_end[i] = m.links[i].dof_end; lt.invweight[i] = m.links[i].invweight[0];
+  }
+  __syncthreads();
   const int tl = threadIdx.x % T, slot = threadIdx.x / T;
   const int b = blockIdx.x * EPW + slot;
   if (b >= P.B) return;
-  const Model& m = *mp;
   E e(P, b);
   const int nc = e.n_contacts()[0];
   int n_lim = 0;
@@ -2301,15 +2384,14 @@ __global__ __launch_bounds__(64) void k_constraint_solve_team(Pool P, const Mode
     if (fmn(q - m.dofs[Jt.dof_start].limit[0], m.dofs[Jt.dof_start].limit[1] - q) < 0) n_lim++;
   }
   const int n_con = 4 * nc + n_lim;
-  int iters;
   if (n_con <= RL) {
     SolverData<RL>* s = &lds[slot];
-    iters = ts_solve<T>(m, e, s, tl, nc, n_con);
+    int iters = ts_solve<T>(m, e, &lt, s, tl, nc, n_con);
+    PH_BEGIN
     ts_commit<T>(m, e, s, tl, nc, n_con, iters);
+    PH(11)
   } else {
-    SolverData<MAXR>* s = &overflow[b];
-    iters = ts_solve<T>(m, e, s, tl, nc, n_con);
-    ts_commit<T>(m, e, s, tl, nc, n_con, iters);
+    ts_solve_overflow<T>(m, e, &lt, &overflow[b], tl, nc, n_con);
   }
 }
 
@@ -3050,7 +3132,7 @@ struct go2sim {
   SolverData<MAXR>* solver_ovf = nullptr;   // per-env global scratch for solves that do not fit in LDS (> RL rows)
   int dyn_team = 16;                        // lanes per environment in k_dynamics_team / k_integrate_fk_team / k_fk_team
   int collide_team = 16;                    // lanes per environment in k_collide_team
-  int solver_team = 16;                     // lanes per environment in k_constraint_solve_team
+  int solver_team = 32;                     // lanes per environment in k_constraint_solve_team
   uint32_t step_count = 0; int action_write_idx = 0;
   // timing
   bool timing = false;
@@ -3455,6 +3537,15 @@ int go2sim_read_timing(go2sim_t* h, float* ms_out8, int* cnt_out8, int reset) {
 }
 
 /* development/test aid (not declared in include/go2sim.h): device address of ANY pool field by name */
+#ifdef GO2SIM_PHASE_PROFILE
+int go2sim_debug_phases(go2sim_t* h, unsigned long long* out64, int reset) {
+  if (!h || !out64) return GO2SIM_E_BADARG;
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_phase_cycles), sizeof(unsigned long long) * 64));
+  if (reset) { unsigned long long z[64] = {0}; HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_phase_cycles), z, sizeof(z))); }
+  return GO2SIM_E_OK;
+}
+#endif
 int go2sim_debug_field(go2sim_t* h, const char* name, void** ptr, int* k, int* is_int) {
   if (!h || !name || !ptr) return GO2SIM_E_BADARG;
 #define X(n, c) if (!strcmp(name, #n)) { *ptr = h->P.f + (size_t)FO(n) * h->B; if (k) *k = (c); if (is_int) *is_int = 0; return GO2SIM_E_OK; }
