@@ -344,6 +344,89 @@ bool parse_model(const void* blob, size_t nbytes, Model& m) {
   return g_next == NG;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// ModelS: the small tables of the model (tree topology, link / joint / dof constants, geom frames, derived level and
+// child lists, lower-triangle index LUT).  Team kernels copy it to LDS once per workgroup so that the lane-varying table
+// walks (parent chains, per-level link lists) are LDS reads instead of dependent global loads.  Member names match Model.
+// ---------------------------------------------------------------------------------------------
+struct LinkS {
+  int parent, entity, is_fixed, joint_start, joint_end, dof_start, dof_end, q_start, q_end, n_dofs;
+  V3 pos; Q4 quat; V3 inertial_pos; Q4 inertial_quat; M3 inertial_i; float mass; float invweight[2];
+};
+struct GeomS { int type, link; V3 pos; Q4 quat; };
+constexpr int NTRI = ND * (ND + 1) / 2;
+struct ModelS {
+  int n_levels, iterations, ls_iterations, pad0;
+  float substep_dt; V3 gravity; float eps, tolerance, ls_tolerance, meaninertia;
+  LinkS links[NL]; Joint joints[NJ]; Dof dofs[ND]; GeomS geoms[NG]; Entity entities[2];
+  float qpos0[NQ]; unsigned mass_mask_bits[ND];
+  int level_start[NL + 1], level_links[NL], child_start[NL + 1], child_list[NL], dof_link[ND];
+  unsigned char tri_i[NTRI + 1], tri_j[NTRI + 1];
+};
+static_assert(sizeof(ModelS) % 4 == 0, "ModelS is copied word by word");
+
+bool build_model_s(const Model& m, ModelS& o) {
+  memset(&o, 0, sizeof(o));
+  o.n_levels = m.n_levels; o.iterations = m.iterations; o.ls_iterations = m.ls_iterations;
+  o.substep_dt = m.substep_dt; o.gravity = m.gravity; o.eps = m.eps; o.tolerance = m.tolerance; o.ls_tolerance = m.ls_tolerance; o.meaninertia = m.meaninertia;
+  for (int i = 0; i < NL; ++i) {
+    const Link& a = m.links[i]; LinkS& b = o.links[i];
+    b.parent = a.parent; b.entity = a.entity; b.is_fixed = a.is_fixed; b.joint_start = a.joint_start; b.joint_end = a.joint_end; b.dof_start = a.dof_start;
+    b.dof_end = a.dof_end; b.q_start = a.q_start; b.q_end = a.q_end; b.n_dofs = a.n_dofs; b.pos = a.pos; b.quat = a.quat; b.inertial_pos = a.inertial_pos;
+    b.inertial_quat = a.inertial_quat; b.inertial_i = a.inertial_i; b.mass = a.mass; b.invweight[0] = a.invweight[0]; b.invweight[1] = a.invweight[1];
+  }
+  for (int i = 0; i < NJ; ++i) o.joints[i] = m.joints[i];
+  for (int i = 0; i < ND; ++i) o.dofs[i] = m.dofs[i];
+  for (int i = 0; i < NG; ++i) { o.geoms[i].type = m.geoms[i].type; o.geoms[i].link = m.geoms[i].link; o.geoms[i].pos = m.geoms[i].pos; o.geoms[i].quat = m.geoms[i].quat; }
+  for (int i = 0; i < 2; ++i) o.entities[i] = m.entities[i];
+  for (int i = 0; i < NQ; ++i) o.qpos0[i] = m.qpos0[i];
+  for (int i = 0; i < ND; ++i) {
+    unsigned bits = 0;
+    for (int j = 0; j < ND; ++j) {
+      float v = m.mass_parent_mask[i][j];
+      if (v == 1.0f) bits |= 1u << j; else if (v != 0.0f) return false;   // the mask must be a 0/1 matrix
+    }
+    o.mass_mask_bits[i] = bits;
+  }
+  for (int i = 0; i <= NL; ++i) { o.level_start[i] = m.level_start[i]; o.child_start[i] = m.child_start[i]; }
+  for (int i = 0; i < NL; ++i) { o.level_links[i] = m.level_links[i]; o.child_list[i] = m.child_list[i]; }
+  for (int i = 0; i < ND; ++i) o.dof_link[i] = m.dof_link[i];
+  int k = 0;
+  for (int i = 0; i < ND; ++i) for (int j = 0; j <= i; ++j) { o.tri_i[k] = (unsigned char)i; o.tri_j[k] = (unsigned char)j; k++; }
+  return true;
+}
+DEV float mass_mask(const ModelS& m, int i, int j) { return (float)((m.mass_mask_bits[i] >> j) & 1u); }
+DEV void tri_index(const ModelS& m, int idx, int& i, int& j) { i = m.tri_i[idx]; j = m.tri_j[idx]; }
+
+// View used by the team kernels: scalars come from the global copy through uniform (scalar) loads and live in SGPRs, tables point into LDS
+struct ModelView {
+  int n_levels, iterations, ls_iterations; float substep_dt; V3 gravity; float eps, tolerance, ls_tolerance, meaninertia;
+  const LinkS* links; const Joint* joints; const Dof* dofs; const GeomS* geoms; const Entity* entities; const float* qpos0;
+  const unsigned* mass_mask_bits; const int *level_start, *level_links, *child_start, *child_list, *dof_link; const unsigned char *tri_i, *tri_j;
+  DEV ModelView(const ModelS* t, const ModelS* __restrict__ g)
+      : n_levels(g->n_levels), iterations(g->iterations), ls_iterations(g->ls_iterations), substep_dt(g->substep_dt), gravity(g->gravity), eps(g->eps),
+        tolerance(g->tolerance), ls_tolerance(g->ls_tolerance), meaninertia(g->meaninertia), links(t->links), joints(t->joints), dofs(t->dofs),
+        geoms(t->geoms), entities(t->entities), qpos0(t->qpos0), mass_mask_bits(t->mass_mask_bits), level_start(t->level_start),
+        level_links(t->level_links), child_start(t->child_start), child_list(t->child_list), dof_link(t->dof_link), tri_i(t->tri_i), tri_j(t->tri_j) {}
+  // solver flavour: only the link table and the triangle LUT are staged in LDS; joint / dof constants are read with uniform indices and stay
+  // behind scalar loads of the global model
+  DEV ModelView(const LinkS* lds_links, const unsigned char* lds_tri_i, const unsigned char* lds_tri_j, const Model* __restrict__ g)
+      : n_levels(g->n_levels), iterations(g->iterations), ls_iterations(g->ls_iterations), substep_dt(g->substep_dt), gravity(g->gravity), eps(g->eps),
+        tolerance(g->tolerance), ls_tolerance(g->ls_tolerance), meaninertia(g->meaninertia), links(lds_links), joints(g->joints), dofs(g->dofs),
+        geoms(nullptr), entities(g->entities), qpos0(g->qpos0), mass_mask_bits(nullptr), level_start(nullptr), level_links(nullptr), child_start(nullptr),
+        child_list(nullptr), dof_link(nullptr), tri_i(lds_tri_i), tri_j(lds_tri_j) {}
+};
+DEV float mass_mask(const ModelView& m, int i, int j) { return (float)((m.mass_mask_bits[i] >> j) & 1u); }
+DEV void tri_index(const ModelView& m, int idx, int& i, int& j) { i = m.tri_i[idx]; j = m.tri_j[idx]; }
+// workgroup-cooperative copy of the compact model into LDS (64 threads)
+DEV void load_model_s(ModelS* dst, const ModelS* __restrict__ src) {
+  const int* sp = (const int*)src; int* dp = (int*)dst;
+#pragma unroll 4
+  for (int i = threadIdx.x; i < (int)(sizeof(ModelS) / 4); i += 64) dp[i] = sp[i];
+  __syncthreads();
+}
+
 // ---------------------------------------------------------------------------------------------
 // SoA state pool.  X(name, floats_per_env).  Order of the first group matches enum go2sim_field so
 // that go2sim_get_field / go2sim_set_field are plain device copies.
@@ -908,14 +991,14 @@ struct KinData {
 // update_cartesian_space + forward_velocity of the state held in s->qpos / s->vel
 // (func_forward_kinematics_entity :463-618, func_COM_links_entity :224-459, func_update_geoms_entity :709-744,
 //  func_forward_velocity_entity :871-994 of forward_kinematics.py)
-template <int T>
-DEV void tk_kinematics(const Model& m, const E& e, KinData* s, int tl, bool force_update_fixed) {
+template <int T, class MT>
+DEV void tk_kinematics(const MT& m, const E& e, KinData* s, int tl, bool force_update_fixed) {
   for (int i_l = tl; i_l < NL; i_l += T) { st3(s->l_pos, i_l, e.l_pos()[i_l]); st4(s->l_quat, i_l, e.l_quat()[i_l]); }
   team_sync();
   for (int lev = 0; lev < m.n_levels; ++lev) {
     for (int k = m.level_start[lev] + tl; k < m.level_start[lev + 1]; k += T) {
       int i_l = m.level_links[k];
-      const Link& L = m.links[i_l];
+      const auto& L = m.links[i_l];
       V3 pos = L.pos; Q4 quat = L.quat;
       if (L.parent != -1) {
         Q4 pq = ld4(s->l_quat, L.parent);
@@ -952,7 +1035,7 @@ DEV void tk_kinematics(const Model& m, const E& e, KinData* s, int tl, bool forc
   }
   // centre of mass of each kinematic tree
   for (int i_l = tl; i_l < NL; i_l += T) {
-    const Link& L = m.links[i_l];
+    const auto& L = m.links[i_l];
     s->mass[i_l] = L.mass + gload(e, FO(mass_shift), i_l);
     V3 ipbw; Q4 iq;
     transform_pos_quat_by_trans_quat(L.inertial_pos + (V3)e.com_shift()[i_l], L.inertial_quat, ld3(s->l_pos, i_l), ld4(s->l_quat, i_l), ipbw, iq);
@@ -973,7 +1056,7 @@ DEV void tk_kinematics(const Model& m, const E& e, KinData* s, int tl, bool forc
   }
   team_sync();
   for (int i_l = tl; i_l < NL; i_l += T) {
-    const Link& L = m.links[i_l];
+    const auto& L = m.links[i_l];
     V3 r = (L.entity == 0) ? rc[0] : rc[1];
     e.root_com()[i_l] = r;
     V3 ip = ld3(s->i_pos, i_l) - r;
@@ -986,7 +1069,7 @@ DEV void tk_kinematics(const Model& m, const E& e, KinData* s, int tl, bool forc
   }
   for (int i_j = tl; i_j < NJ; i_j += T) {
     const Joint& J = m.joints[i_j];
-    const Link& L = m.links[J.link];
+    const auto& L = m.links[J.link];
     if (L.n_dofs == 0) continue;
     V3 r = (L.entity == 0) ? rc[0] : rc[1];
     V3 offset_pos = r - ld3(s->xanchor, i_j);
@@ -1014,7 +1097,7 @@ DEV void tk_kinematics(const Model& m, const E& e, KinData* s, int tl, bool forc
     }
   }
   for (int i_g = tl; i_g < NG; i_g += T) {
-    const Geom& G = m.geoms[i_g];
+    const auto& G = m.geoms[i_g];
     bool is_fixed = m.links[G.link].is_fixed;
     if (force_update_fixed || !is_fixed) {
       V3 p; Q4 q;
@@ -1027,7 +1110,7 @@ DEV void tk_kinematics(const Model& m, const E& e, KinData* s, int tl, bool forc
   for (int lev = 0; lev < m.n_levels; ++lev) {
     for (int k = m.level_start[lev] + tl; k < m.level_start[lev + 1]; k += T) {
       int i_l = m.level_links[k];
-      const Link& L = m.links[i_l];
+      const auto& L = m.links[i_l];
       V3 cvel_vel = v3(0, 0, 0), cvel_ang = v3(0, 0, 0);
       if (L.parent != -1) { cvel_vel = ld3(s->cd_vel, L.parent); cvel_ang = ld3(s->cd_ang, L.parent); }
       for (int i_j = L.joint_start; i_j < L.joint_end; ++i_j) {
@@ -1073,21 +1156,24 @@ DEV void tk_kinematics(const Model& m, const E& e, KinData* s, int tl, bool forc
 // kernel_step_2 (rigid_solver.py:3072-3180): func_integrate (forward_dynamics.py:1558-1699) + func_copy_next_to_curr
 // (abd/diff.py:25-54) + FK / forward velocity of the new state
 template <int T>
-__global__ __launch_bounds__(64) void k_integrate_fk_team(Pool P, const Model* __restrict__ mp) {
+__global__ __launch_bounds__(64) void k_integrate_fk_team(Pool P, const ModelS* __restrict__ mp) {
   constexpr int EPW = 64 / T;
   __shared__ KinData lds[EPW];
+  __shared__ ModelS ms;
+  load_model_s(&ms, mp);
   const int tl = threadIdx.x % T, slot = threadIdx.x / T;
   const int b = blockIdx.x * EPW + slot;
   if (b >= P.B) return;
-  const Model& m = *mp;
+  const ModelView m(&ms, mp);
   E e(P, b);
   KinData* s = &lds[slot];
+  PH_BEGIN
   for (int d = tl; d < ND; d += T) { float v = gload(e, FO(vel), d); s->vel[d] = v; s->vel_next[d] = v + gload(e, FO(acc), d) * m.substep_dt; }
   for (int q = tl; q < NQ; q += T) s->qpos[q] = gload(e, FO(qpos), q);
   if (tl == 0) s->valid = 1;
   team_sync();
   for (int i_l = tl; i_l < NL; i_l += T) {
-    const Link& L = m.links[i_l];
+    const auto& L = m.links[i_l];
     if (L.n_dofs == 0) continue;
     int ds = L.dof_start, qs = L.q_start;
     int joint_type = m.joints[L.joint_start].type;
@@ -1118,19 +1204,23 @@ __global__ __launch_bounds__(64) void k_integrate_fk_team(Pool P, const Model* _
     atomicOr(&e.err()[0], GO2SIM_ERR_INVALID_ACC_NAN);
   }
   team_sync();
+  PH(40)
   tk_kinematics<T>(m, e, s, tl, false);
+  PH(41)
 }
 
 // FK refresh of the current state; `cond` (device) gates the launch body: the reset path only needs it when an env was reset
 template <int T>
-__global__ __launch_bounds__(64) void k_fk_team(Pool P, const Model* __restrict__ mp, int force_update_fixed, const int* __restrict__ cond) {
+__global__ __launch_bounds__(64) void k_fk_team(Pool P, const ModelS* __restrict__ mp, int force_update_fixed, const int* __restrict__ cond) {
   constexpr int EPW = 64 / T;
   __shared__ KinData lds[EPW];
+  __shared__ ModelS ms;
   if (cond && *cond <= 0) return;
+  load_model_s(&ms, mp);
   const int tl = threadIdx.x % T, slot = threadIdx.x / T;
   const int b = blockIdx.x * EPW + slot;
   if (b >= P.B) return;
-  const Model& m = *mp;
+  const ModelView m(&ms, mp);
   E e(P, b);
   KinData* s = &lds[slot];
   for (int d = tl; d < ND; d += T) s->vel[d] = gload(e, FO(vel), d);
@@ -1153,15 +1243,18 @@ struct DynData {
 // func_factor_mass :560-604, func_torque_and_passive_force :961-1174, func_update_acc/force/bias_force :1177-1478,
 // func_solve_mass_entity :818-900
 template <int T>
-__global__ __launch_bounds__(64) void k_dynamics_team(Pool P, const Model* __restrict__ mp) {
+__global__ __launch_bounds__(64) void k_dynamics_team(Pool P, const ModelS* __restrict__ mp) {
   constexpr int EPW = 64 / T;
   __shared__ DynData lds[EPW];
+  __shared__ ModelS ms;
+  load_model_s(&ms, mp);
   const int tl = threadIdx.x % T, slot = threadIdx.x / T;
   const int b = blockIdx.x * EPW + slot;
   if (b >= P.B) return;
-  const Model& m = *mp;
+  const ModelView m(&ms, mp);
   E e(P, b);
   DynData* s = &lds[slot];
+  PH_BEGIN
   // ---- stage ----
   for (int k = tl; k < NL * 9; k += T) { float v = gload(e, FO(cinr_inertial), k); s->cinr_I[k] = v; s->crb_I[k] = v; }
   for (int k = tl; k < NL * 3; k += T) {
@@ -1175,6 +1268,7 @@ __global__ __launch_bounds__(64) void k_dynamics_team(Pool P, const Model* __res
   }
   for (int d = tl; d < ND; d += T) s->vel[d] = gload(e, FO(vel), d);
   team_sync();
+  PH(20)
   // ---- composite rigid bodies, leaf -> root ----
   for (int lev = m.n_levels - 2; lev >= 0; --lev) {
     int n_par = m.level_start[lev + 1] - m.level_start[lev];
@@ -1191,6 +1285,7 @@ __global__ __launch_bounds__(64) void k_dynamics_team(Pool P, const Model* __res
     }
     team_sync();
   }
+  PH(21)
   for (int i_d = tl; i_d < ND; i_d += T) {
     int i_l = m.dof_link[i_d];
     V3 oa, ov;
@@ -1200,8 +1295,8 @@ __global__ __launch_bounds__(64) void k_dynamics_team(Pool P, const Model* __res
   team_sync();
   for (int idx = tl; idx < ND * (ND + 1) / 2; idx += T) {
     int i_d, j_d;
-    tri_index(idx, i_d, j_d);
-    float v = (dot(ld3(s->f_ang, i_d), ld3(s->cdof_ang, j_d)) + dot(ld3(s->f_vel, i_d), ld3(s->cdof_vel, j_d))) * m.mass_parent_mask[i_d][j_d];
+    tri_index(m, idx, i_d, j_d);
+    float v = (dot(ld3(s->f_ang, i_d), ld3(s->cdof_ang, j_d)) + dot(ld3(s->f_vel, i_d), ld3(s->cdof_vel, j_d))) * mass_mask(m, i_d, j_d);
     if (i_d == j_d) {
       v = v + m.dofs[i_d].armature;
       v = v + m.dofs[i_d].damping * m.substep_dt;                      // implicit damping (approximate_implicitfast)
@@ -1214,13 +1309,14 @@ __global__ __launch_bounds__(64) void k_dynamics_team(Pool P, const Model* __res
     if (i_d != j_d) gstore(e, FO(mass_mat), j_d * ND + i_d, v);
   }
   team_sync();
+  PH(22)
   // ---- reverse-order LDL^T ----
   for (int i_d_ = 0; i_d_ < ND; ++i_d_) {
     const int i_d = ND - i_d_ - 1;
     float D_inv = 1.0f / s->L[i_d * ND + i_d];
     for (int idx = tl; idx < i_d * (i_d + 1) / 2; idx += T) {
       int j_d, k_d;
-      tri_index(idx, j_d, k_d);
+      tri_index(m, idx, j_d, k_d);
       float a = s->L[i_d * ND + j_d] * D_inv;
       s->L[j_d * ND + k_d] -= a * s->L[i_d * ND + k_d];
     }
@@ -1229,10 +1325,11 @@ __global__ __launch_bounds__(64) void k_dynamics_team(Pool P, const Model* __res
     if (tl == 0) { s->Dinv[i_d] = D_inv; s->L[i_d * ND + i_d] = 1.0f; }
     team_sync();
   }
+  PH(23)
   // ---- applied / passive joint forces ----
   for (int i_d = tl; i_d < ND; i_d += T) {
     const Dof& D = m.dofs[i_d];
-    const Link& L = m.links[m.dof_link[i_d]];
+    const auto& L = m.links[m.dof_link[i_d]];
     int joint_type = m.joints[L.joint_start].type;
     float force = 0.0f;
     int cm = e.ctrl_mode()[i_d];
@@ -1249,7 +1346,7 @@ __global__ __launch_bounds__(64) void k_dynamics_team(Pool P, const Model* __res
   for (int lev = 0; lev < m.n_levels; ++lev) {
     for (int k = m.level_start[lev] + tl; k < m.level_start[lev + 1]; k += T) {
       int i_l = m.level_links[k];
-      const Link& L = m.links[i_l];
+      const auto& L = m.links[i_l];
       V3 cv, ca;
       if (L.parent == -1) { cv = -m.gravity * (1.0f - 0.0f); ca = v3(0, 0, 0); }
       else { cv = ld3(s->cdd_vel, L.parent); ca = ld3(s->cdd_ang, L.parent); }
@@ -1299,6 +1396,7 @@ __global__ __launch_bounds__(64) void k_dynamics_team(Pool P, const Model* __res
     gstore(e, FO(force), i_d, f); gstore(e, FO(qf_smooth), i_d, f);
   }
   team_sync();
+  PH(24)
   // ---- acc_smooth = L^-T D^-1 L^-1 force: serial chains, evaluated redundantly by every lane on the LDS copy ----
   for (int i_d_ = 0; i_d_ < ND; ++i_d_) {
     int i_d = ND - i_d_ - 1;
@@ -1314,6 +1412,7 @@ __global__ __launch_bounds__(64) void k_dynamics_team(Pool P, const Model* __res
   }
   team_sync();
   for (int i_d = tl; i_d < ND; i_d += T) { float a = s->out[i_d]; gstore(e, FO(acc_smooth), i_d, a); gstore(e, FO(acc), i_d, a); }
+  PH(25)
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1700,6 +1799,7 @@ __global__ __launch_bounds__(64) void k_collide_team(Pool P, const Model* __rest
   E e(P, b);
   CollideData<T>* s = &lds[slot];
   const float inf = dm_bits2f(0x7f800000u);
+  PH_BEGIN
   // ---- func_collision_clear, broadphase.py:73-138 ----
   const int nc_old = e.n_contacts()[0];
   for (int i_c = tl; i_c < nc_old; i_c += T) {
@@ -1719,6 +1819,7 @@ __global__ __launch_bounds__(64) void k_collide_team(Pool P, const Model* __rest
     s->amax[3 * i_g] = upper.x; s->amax[3 * i_g + 1] = upper.y; s->amax[3 * i_g + 2] = upper.z;
   }
   team_sync();
+  PH(30)
   // ---- func_broad_phase, broadphase.py:141-396: endpoint refresh + stable sort ----
   const int n2 = 2 * NG;
   const bool first = e.first_time()[0] != 0;
@@ -1746,6 +1847,7 @@ __global__ __launch_bounds__(64) void k_collide_team(Pool P, const Model* __rest
   }
   if (tl == 0 && first) e.first_time()[0] = 0;
   team_sync();
+  PH(31)
   // ---- candidate pairs: every valid geom pair is tested by one lane ----
   int n_cand = 0;
   const unsigned long long team_mask = (T == 64) ? ~0ull : ((1ull << T) - 1ull);
@@ -1783,6 +1885,7 @@ __global__ __launch_bounds__(64) void k_collide_team(Pool P, const Model* __rest
   const int n_broad = n_cand;
   team_sync();
   for (int c = tl; c < n_broad; c += T) { int pk = s->pair_sorted[c]; e.broad()[2 * c] = pk & 0xff; e.broad()[2 * c + 1] = pk >> 8; }
+  PH(32)
   // ---- func_narrow_phase_convex_vs_convex, narrowphase.py:964-1068: one lane per pair, ordered compaction ----
   int nc_run = 0;
   const int n_np_iter = (n_broad + T - 1) / T;
@@ -1820,6 +1923,7 @@ __global__ __launch_bounds__(64) void k_collide_team(Pool P, const Model* __rest
     team_sync();
   }
   if (tl == 0) { e.n_broad()[0] = n_broad; e.n_contacts()[0] = imn(nc_run, m.max_contact_pairs); }
+  PH(33)
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1862,11 +1966,9 @@ struct alignas(16) SolverData {
   float aref[R], efc_D[R], Jaref[R], jv[R], efc_force[R], qf0[R], qf1[R], qf2[R], DA[R];
   int active[R], prev_active[R];
 };
-// link topology needed by the Jacobian chain walk, staged once per workgroup (avoids dependent global loads)
-struct LinkTable { int parent[NL], n_dofs[NL], dof_end[NL]; float invweight[NL]; };
 
-template <int T, class S>
-DEV void ts_update_constraint(const Model& m, S* s, int tl, int n_con, float& cost, float& prev_cost, float& gauss) {
+template <int T, class S, class MT>
+DEV void ts_update_constraint(const MT& m, S* s, int tl, int n_con, float& cost, float& prev_cost, float& gauss) {
   prev_cost = cost;
   for (int c = tl; c < n_con; c += T) {
     s->prev_active[c] = s->active[c];
@@ -1898,11 +2000,11 @@ DEV void ts_update_constraint(const Model& m, S* s, int tl, int n_con, float& co
 }
 
 // func_hessian_direct_batch, solver.py:1285-1343: one lane per lower-triangle entry, rows summed first to last
-template <int T, class S>
-DEV void ts_hessian_direct(const Model& m, S* s, int tl, int n_con) {
+template <int T, class S, class MT>
+DEV void ts_hessian_direct(const MT& m, S* s, int tl, int n_con) {
   for (int idx = tl; idx < ND * (ND + 1) / 2; idx += T) {
     int i, j;
-    tri_index(idx, i, j);
+    tri_index(m, idx, i, j);
     float h = 0.0f;
 #pragma unroll 8
     for (int c = 0; c < n_con; ++c) {
@@ -1918,8 +2020,8 @@ DEV void ts_hessian_direct(const Model& m, S* s, int tl, int n_con) {
 
 // func_cholesky_factor_direct_batch, solver.py:1467-1494 (column by column; statically unrolled so that the pivot-row prefix is
 // fetched with wide LDS reads that are all in flight at once)
-template <int T, class S>
-DEV void ts_cholesky_factor(const Model& m, S* s, int tl) {
+template <int T, class S, class MT>
+DEV void ts_cholesky_factor(const MT& m, S* s, int tl) {
 #pragma unroll
   for (int i_d = 0; i_d < ND; ++i_d) {
     float pr[ND];
@@ -1943,8 +2045,8 @@ DEV void ts_cholesky_factor(const Model& m, S* s, int tl) {
 }
 
 // func_hessian_and_cholesky_factor_incremental_dense_batch, solver.py:1632-1675; returns true when the factor degenerated
-template <int T, class S>
-DEV bool ts_cholesky_incremental(const Model& m, S* s, int tl, int n_con) {
+template <int T, class S, class MT>
+DEV bool ts_cholesky_incremental(const MT& m, S* s, int tl, int n_con) {
   bool degenerated = false;
   for (int c = 0; c < n_con && !degenerated; ++c) {
     bool is_active = s->active[c] != 0, was_active = s->prev_active[c] != 0;
@@ -2009,8 +2111,8 @@ DEV void ts_update_gradient(S* s, int tl) {
   team_sync();
 }
 
-template <class S>
-DEV LsPoint ts_ls_point(const Model& m, S* s, int n_con, float alpha, float qg0, float qg1, float qg2) {
+template <class S, class MT>
+DEV LsPoint ts_ls_point(const MT& m, S* s, int n_con, float alpha, float qg0, float qg1, float qg2) {
   float t0 = qg0 + 0.0f, t1 = qg1 + 0.0f, t2 = qg2 + 0.0f;
 #pragma unroll 4
   for (int c = 0; c < n_con; ++c) {
@@ -2025,8 +2127,8 @@ DEV LsPoint ts_ls_point(const Model& m, S* s, int n_con, float alpha, float qg0,
   if (p.hess <= 0.0f) p.hess = m.eps;
   return p;
 }
-template <class S>
-DEV void ts_ls_point3(const Model& m, S* s, int n_con, const float a[3], float qg0, float qg1, float qg2, float costs[3], float grads[3], float hess[3]) {
+template <class S, class MT>
+DEV void ts_ls_point3(const MT& m, S* s, int n_con, const float a[3], float qg0, float qg1, float qg2, float costs[3], float grads[3], float hess[3]) {
   float b0 = qg0 + 0.0f, b1 = qg1 + 0.0f, b2 = qg2 + 0.0f;
   float t00 = b0, t01 = b1, t02 = b2, t10 = b0, t11 = b1, t12 = b2, t20 = b0, t21 = b1, t22 = b2;
 #pragma unroll 4
@@ -2049,8 +2151,8 @@ DEV void ts_ls_point3(const Model& m, S* s, int n_con, const float a[3], float q
 }
 
 // func_linesearch_batch, solver.py:2246-2417
-template <int T, class S>
-DEV float ts_linesearch(const Model& m, S* s, int tl, int n_con, float gauss) {
+template <int T, class S, class MT>
+DEV float ts_linesearch(const MT& m, S* s, int tl, int n_con, float gauss) {
   float sr[ND];
 #pragma unroll
   for (int d = 0; d < ND; ++d) sr[d] = s->search[d];
@@ -2139,8 +2241,8 @@ DEV float ts_linesearch(const Model& m, S* s, int tl, int n_con, float gauss) {
 
 // rows + resolve for one environment (add_collision_constraints solver.py:498-595, add_joint_limit_constraints :1088-1143,
 // func_solve_init :2739-2859, func_solve_body :2941-2966, func_solve_iter :2862-2938)
-template <int T, class S>
-DEV int ts_solve(const Model& m, const E& e, const LinkTable* lt, S* s, int tl, int nc, int n_con) {
+template <int T, class S, class MT>
+DEV int ts_solve(const MT& m, const E& e, S* s, int tl, int nc, int n_con) {
   PH_BEGIN
   // ---- stage inputs ----
   bool ws = (n_con > 0) && e.is_warmstart()[0];
@@ -2175,8 +2277,8 @@ DEV int ts_solve(const Model& m, const E& e, const LinkTable* lt, S* s, int tl, 
     for (int k = 0; k < 7; ++k) sol[k] = csol[k];
     V3 d1, d2;
     orthogonals(cnormal, d1, d2);
-    float invweight = lt->invweight[link_a];
-    if (link_b > -1) invweight = invweight + lt->invweight[link_b];
+    float invweight = m.links[link_a].invweight[0];
+    if (link_b > -1) invweight = invweight + m.links[link_b].invweight[0];
     V3 d = (float)(2 * (i % 2) - 1) * ((i < 2) ? d1 : d2);
     V3 n = d * friction - cnormal;
     float* row = &s->J[r * DS];
@@ -2188,7 +2290,7 @@ DEV int ts_solve(const Model& m, const E& e, const LinkTable* lt, S* s, int tl, 
       if (i_ab == 1) { sign = 1.0f; link = link_b; }
       while (link > -1) {
         V3 t_pos = cpos - v3(s->root_com[3 * link], s->root_com[3 * link + 1], s->root_com[3 * link + 2]);
-        const int nd = lt->n_dofs[link], de = lt->dof_end[link];
+        const int nd = m.links[link].n_dofs, de = m.links[link].dof_end;
         for (int i_d_ = 0; i_d_ < nd; ++i_d_) {
           int i_d = de - 1 - i_d_;
           V3 ca = v3(s->cdof_ang[3 * i_d], s->cdof_ang[3 * i_d + 1], s->cdof_ang[3 * i_d + 2]);
@@ -2199,7 +2301,7 @@ DEV int ts_solve(const Model& m, const E& e, const LinkTable* lt, S* s, int tl, 
           jac_qvel = jac_qvel + j * s->vel[i_d];
           row[i_d] = row[i_d] + j;
         }
-        link = lt->parent[link];
+        link = m.links[link].parent;
       }
     }
     float imp, aref;
@@ -2309,8 +2411,8 @@ DEV int ts_solve(const Model& m, const E& e, const LinkTable* lt, S* s, int tl, 
 }
 
 // func_update_qacc (solver.py:3016-3037) + func_update_contact_force (:2974-3013) + public row outputs
-template <int T, class S>
-DEV void ts_commit(const Model& m, const E& e, S* s, int tl, int nc, int n_con, int iters) {
+template <int T, class S, class MT>
+DEV void ts_commit(const MT& m, const E& e, S* s, int tl, int nc, int n_con, int iters) {
   int err = 0;
   for (int d = tl; d < ND; d += T) {
     float q = s->qacc[d];
@@ -2355,22 +2457,25 @@ DEV void ts_commit(const Model& m, const E& e, S* s, int tl, int nc, int n_con, 
 }
 
 // cold path: more rows than fit in LDS; same code on a per-env global scratch block
-template <int T>
-DEVN void ts_solve_overflow(const Model& m, const E& e, const LinkTable* lt, SolverData<MAXR>* s, int tl, int nc, int n_con) {
-  int iters = ts_solve<T>(m, e, lt, s, tl, nc, n_con);
+template <int T, class MT>
+DEVN void ts_solve_overflow(const MT& m, const E& e, SolverData<MAXR>* s, int tl, int nc, int n_con) {
+  int iters = ts_solve<T>(m, e, s, tl, nc, n_con);
   ts_commit<T>(m, e, s, tl, nc, n_con, iters);
 }
 
 template <int T>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_constraint_solve_team(Pool P, const Model* __restrict__ mp, SolverData<MAXR>* __restrict__ overflow) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_constraint_solve_team(Pool P, const Model* __restrict__ gm, const ModelS* __restrict__ mp, SolverData<MAXR>* __restrict__ overflow) {
   constexpr int EPW = 64 / T;
   __shared__ SolverData<RL> lds[EPW];
-  __shared__ LinkTable lt;
-  const Model& m = *mp;
-  for (int i = threadIdx.x; i < NL; i += 64) {
-    lt.parent[i] = m.links[i].parent; lt.n_dofs[i] = m.links[i].n_dofs; lt.dof_end[i] = m.links[i].dof_end; lt.invweight[i] = m.links[i].invweight[0];
+  __shared__ LinkS lnk[NL];
+  __shared__ unsigned char tri_i[NTRI + 1], tri_j[NTRI + 1];
+  {
+    const int* sp = (const int*)mp->links; int* dp = (int*)lnk;
+    for (int i = threadIdx.x; i < (int)(sizeof(LinkS) * NL / 4); i += 64) dp[i] = sp[i];
+    for (int i = threadIdx.x; i < NTRI; i += 64) { tri_i[i] = mp->tri_i[i]; tri_j[i] = mp->tri_j[i]; }
+    __syncthreads();
   }
-  __syncthreads();
+  const ModelView m(lnk, tri_i, tri_j, gm);
   const int tl = threadIdx.x % T, slot = threadIdx.x / T;
   const int b = blockIdx.x * EPW + slot;
   if (b >= P.B) return;
@@ -2386,12 +2491,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   const int n_con = 4 * nc + n_lim;
   if (n_con <= RL) {
     SolverData<RL>* s = &lds[slot];
-    int iters = ts_solve<T>(m, e, &lt, s, tl, nc, n_con);
+    int iters = ts_solve<T>(m, e, s, tl, nc, n_con);
     PH_BEGIN
     ts_commit<T>(m, e, s, tl, nc, n_con, iters);
     PH(11)
   } else {
-    ts_solve_overflow<T>(m, e, &lt, &overflow[b], tl, nc, n_con);
+    ts_solve_overflow<T>(m, e, &overflow[b], tl, nc, n_con);
   }
 }
 
@@ -3126,6 +3231,7 @@ struct go2sim {
   uint64_t seed = 0;
   Model hm;                 // host copy of the model
   Model* dm = nullptr;      // device copy
+  ModelS* dms = nullptr;    // device copy of the compact tables (staged into LDS by the team kernels)
   Pool P = {nullptr, nullptr, 0};
   DCfg hcfg; DCfg* dcfg = nullptr; bool cfg_set = false;
   Glob* dglob = nullptr; Acc* dacc = nullptr; int* derr = nullptr;
@@ -3165,9 +3271,9 @@ struct ScopedTimer {
 static void launch_fk_team(go2sim* h, hipStream_t s, int force_update_fixed, const int* cond) {
   const int T = h->dyn_team;
   dim3 gd((h->B + 64 / T - 1) / (64 / T)), b(64);
-  if (T == 16) hipLaunchKernelGGL(k_fk_team<16>, gd, b, 0, s, h->P, h->dm, force_update_fixed, cond);
-  else if (T == 32) hipLaunchKernelGGL(k_fk_team<32>, gd, b, 0, s, h->P, h->dm, force_update_fixed, cond);
-  else hipLaunchKernelGGL(k_fk_team<64>, gd, b, 0, s, h->P, h->dm, force_update_fixed, cond);
+  if (T == 16) hipLaunchKernelGGL(k_fk_team<16>, gd, b, 0, s, h->P, h->dms, force_update_fixed, cond);
+  else if (T == 32) hipLaunchKernelGGL(k_fk_team<32>, gd, b, 0, s, h->P, h->dms, force_update_fixed, cond);
+  else hipLaunchKernelGGL(k_fk_team<64>, gd, b, 0, s, h->P, h->dms, force_update_fixed, cond);
 }
 
 static int launch_substep(go2sim* h, hipStream_t s) {
@@ -3176,9 +3282,9 @@ static int launch_substep(go2sim* h, hipStream_t s) {
     ScopedTimer t(h, s, T_DYN);
     const int T = h->dyn_team;
     dim3 gd((h->B + 64 / T - 1) / (64 / T));
-    if (T == 16) hipLaunchKernelGGL(k_dynamics_team<16>, gd, b, 0, s, h->P, h->dm);
-    else if (T == 32) hipLaunchKernelGGL(k_dynamics_team<32>, gd, b, 0, s, h->P, h->dm);
-    else hipLaunchKernelGGL(k_dynamics_team<64>, gd, b, 0, s, h->P, h->dm);
+    if (T == 16) hipLaunchKernelGGL(k_dynamics_team<16>, gd, b, 0, s, h->P, h->dms);
+    else if (T == 32) hipLaunchKernelGGL(k_dynamics_team<32>, gd, b, 0, s, h->P, h->dms);
+    else hipLaunchKernelGGL(k_dynamics_team<64>, gd, b, 0, s, h->P, h->dms);
   }
   {
     ScopedTimer t(h, s, T_COLLIDE);
@@ -3192,17 +3298,17 @@ static int launch_substep(go2sim* h, hipStream_t s) {
     ScopedTimer t(h, s, T_SOLVE);
     const int T = h->solver_team;
     dim3 gs((h->B + 64 / T - 1) / (64 / T));
-    if (T == 16) hipLaunchKernelGGL(k_constraint_solve_team<16>, gs, b, 0, s, h->P, h->dm, h->solver_ovf);
-    else if (T == 32) hipLaunchKernelGGL(k_constraint_solve_team<32>, gs, b, 0, s, h->P, h->dm, h->solver_ovf);
-    else hipLaunchKernelGGL(k_constraint_solve_team<64>, gs, b, 0, s, h->P, h->dm, h->solver_ovf);
+    if (T == 16) hipLaunchKernelGGL(k_constraint_solve_team<16>, gs, b, 0, s, h->P, h->dm, h->dms, h->solver_ovf);
+    else if (T == 32) hipLaunchKernelGGL(k_constraint_solve_team<32>, gs, b, 0, s, h->P, h->dm, h->dms, h->solver_ovf);
+    else hipLaunchKernelGGL(k_constraint_solve_team<64>, gs, b, 0, s, h->P, h->dm, h->dms, h->solver_ovf);
   }
   {
     ScopedTimer t(h, s, T_INTEGRATE);
     const int T = h->dyn_team;
     dim3 gd((h->B + 64 / T - 1) / (64 / T));
-    if (T == 16) hipLaunchKernelGGL(k_integrate_fk_team<16>, gd, b, 0, s, h->P, h->dm);
-    else if (T == 32) hipLaunchKernelGGL(k_integrate_fk_team<32>, gd, b, 0, s, h->P, h->dm);
-    else hipLaunchKernelGGL(k_integrate_fk_team<64>, gd, b, 0, s, h->P, h->dm);
+    if (T == 16) hipLaunchKernelGGL(k_integrate_fk_team<16>, gd, b, 0, s, h->P, h->dms);
+    else if (T == 32) hipLaunchKernelGGL(k_integrate_fk_team<32>, gd, b, 0, s, h->P, h->dms);
+    else hipLaunchKernelGGL(k_integrate_fk_team<64>, gd, b, 0, s, h->P, h->dms);
   }
   return GO2SIM_E_OK;
 }
@@ -3227,6 +3333,12 @@ int go2sim_create(const void* blob, size_t nbytes, int n_envs, int device, uint6
   HIPCHK(hipMemset(h->P.i, 0, ni * sizeof(int)));
   HIPCHK(hipMalloc((void**)&h->dm, sizeof(Model)));
   HIPCHK(hipMemcpy(h->dm, &h->hm, sizeof(Model), hipMemcpyHostToDevice));
+  {
+    ModelS hs;
+    if (!build_model_s(h->hm, hs)) return GO2SIM_E_BADMODEL;
+    HIPCHK(hipMalloc((void**)&h->dms, sizeof(ModelS)));
+    HIPCHK(hipMemcpy(h->dms, &hs, sizeof(ModelS), hipMemcpyHostToDevice));
+  }
   HIPCHK(hipMalloc((void**)&h->dcfg, sizeof(DCfg)));
   HIPCHK(hipMalloc((void**)&h->dglob, sizeof(Glob)));
   HIPCHK(hipMalloc((void**)&h->dacc, sizeof(Acc)));
@@ -3251,7 +3363,7 @@ int go2sim_destroy(go2sim_t* h) {
   (void)hipSetDevice(h->device);
   (void)hipDeviceSynchronize();
   if (h->ev_created) for (int i = 0; i < TIMING_RING; ++i) { (void)hipEventDestroy(h->ev0[i]); (void)hipEventDestroy(h->ev1[i]); }
-  (void)hipFree(h->P.f); (void)hipFree(h->P.i); (void)hipFree(h->dm); (void)hipFree(h->dcfg); (void)hipFree(h->dglob); (void)hipFree(h->dacc); (void)hipFree(h->derr); (void)hipFree(h->solver_ovf);
+  (void)hipFree(h->P.f); (void)hipFree(h->P.i); (void)hipFree(h->dm); (void)hipFree(h->dcfg); (void)hipFree(h->dglob); (void)hipFree(h->dacc); (void)hipFree(h->derr); (void)hipFree(h->solver_ovf); (void)hipFree(h->dms);
   delete h;
   return GO2SIM_E_OK;
 }
