@@ -3061,81 +3061,86 @@ __global__ __launch_bounds__(WG) void k_env_reset_tail(Pool P, const Model* __re
 }
 
 // Go2Env.step post-physics part B: reset_idx tail + observations (go2_env_walk.py:1080-1141)
-__global__ __launch_bounds__(WG) void k_env_post_b(Pool P, const Model* __restrict__ mp, const DCfg* __restrict__ cp, const Glob* __restrict__ gp,
-                                                   uint64_t seed, uint32_t step_count, float* __restrict__ obs_out, float* __restrict__ priv_out,
-                                                   float* __restrict__ rew_out, uint8_t* __restrict__ reset_out, float* __restrict__ timeout_out) {
-  int b = blockIdx.x * WG + threadIdx.x;
+// Go2Env.step tail (go2_env_walk.py:1078-1109): reset_idx of the flagged envs, observation + privileged observation assembly, output
+// copies.  Team kernel: T lanes per env.  The reset (rare, serial) runs on lane 0; the 49 observations are produced four per lane (one
+// Philox block of noise each), the privileged tail one entry per lane, and the [n_envs, k] outputs are written with coalesced rows.
+template <int T>
+__global__ __launch_bounds__(64) void k_env_post_b_team(Pool P, const Model* __restrict__ mp, const DCfg* __restrict__ cp, const Glob* __restrict__ gp,
+                                                        uint64_t seed, uint32_t step_count, float* __restrict__ obs_out, float* __restrict__ priv_out,
+                                                        float* __restrict__ rew_out, uint8_t* __restrict__ reset_out, float* __restrict__ timeout_out) {
+  constexpr int EPW = 64 / T;
+  const int tl = threadIdx.x % T, slot = threadIdx.x / T;
+  const int b = blockIdx.x * EPW + slot;
   if (b >= P.B) return;
   const Model& m = *mp; const DCfg& c = *cp; const Glob& g = *gp;
   E e(P, b);
-  int was_reset = e.reset_buf()[0];
-  reset_tail(m, c, g, e, b, seed);
+  const int was_reset = e.reset_buf()[0];
+  if (g.n_reset_now > 0) {                                             // reset_tail, spread over the team
+    if (tl == 0 && was_reset) env_reset_one(m, c, g, e, b, seed);
+    if (c.i[GO2SIM_IC_HAS_FRICTION_DR]) for (int i = tl; i < NG; i += T) e.geom_friction()[i] = g.friction;
+    if (tl == 0) {
+      int bl = c.i[GO2SIM_IC_BASE_LINK];
+      if (c.i[GO2SIM_IC_HAS_MASS_DR]) e.mass_shift()[bl] = g.mass_shift;
+      if (c.i[GO2SIM_IC_HAS_COM_DR]) e.com_shift()[bl] = v3(g.com_shift[0], g.com_shift[1], g.com_shift[2]);
+      if (c.i[GO2SIM_IC_HAS_LEGM_DR]) for (int k = 0; k < 4; ++k) e.mass_shift()[c.i[GO2SIM_IC_HIP_LINK0 + k]] = g.leg_mass_shift[k];
+    }
+    team_sync();
+  }
   const int na = c.i[GO2SIM_IC_NUM_ACTIONS], nobs = c.i[GO2SIM_IC_NUM_OBS], npriv = c.i[GO2SIM_IC_NUM_PRIV_OBS];
-  auto o = e.obs(); auto p = e.priv();
-  auto bav = e.base_ang_vel(); auto pg = e.projected_gravity(); auto goff = e.gravity_offset(); auto cmd = e.commands(); auto dof_pos = e.e_dof_pos();
-  auto dof_vel = e.e_dof_vel(); auto applied = e.applied_actions();
-  const float cs[3] = {c.f[GO2SIM_FC_OBS_SCALE_LIN_VEL], c.f[GO2SIM_FC_OBS_SCALE_LIN_VEL], c.f[GO2SIM_FC_OBS_SCALE_ANG_VEL]};
-  for (int k = 0; k < 3; ++k) o[k] = bav[k] * c.f[GO2SIM_FC_OBS_SCALE_ANG_VEL];
-  for (int k = 0; k < 3; ++k) o[3 + k] = pg[k] + goff[k];
-  for (int k = 0; k < 3; ++k) o[6 + k] = cmd[k] * cs[k];
-  for (int i = 0; i < NM; ++i) o[9 + i] = (dof_pos[i] - c.f[GO2SIM_FC_DEFAULT_DOF_POS0 + i]) * c.f[GO2SIM_FC_OBS_SCALE_DOF_POS];
-  for (int i = 0; i < NM; ++i) o[21 + i] = dof_vel[i] * c.f[GO2SIM_FC_OBS_SCALE_DOF_VEL];
-  for (int i = 0; i < na; ++i) o[33 + i] = applied[i];
-  if (c.i[GO2SIM_IC_HAS_OBS_NOISE] && c.f[GO2SIM_FC_OBS_NOISE_LEVEL_MAX] > 0.0f) {
-    float lvl = g.obs_noise_level_cur;
-    for (int blk = 0; blk * 4 < nobs; ++blk) {
+  const bool noisy = c.i[GO2SIM_IC_HAS_OBS_NOISE] && c.f[GO2SIM_FC_OBS_NOISE_LEVEL_MAX] > 0.0f;
+  const float lvl = g.obs_noise_level_cur;
+  for (int blk = tl; blk * 4 < nobs; blk += T) {
+    float n[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (noisy) {
       dm_u4 r = rng4(seed, RNG_OBS_NOISE, b, step_count, blk);
-      float n[4];
       dm_normal2(r.v[0], r.v[1], &n[0], &n[1]); dm_normal2(r.v[2], r.v[3], &n[2], &n[3]);
+    }
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        int i = 4 * blk + k;
-        if (i < nobs) {
-          float nv = 0.0f;
-          if (i < 3) nv = c.f[GO2SIM_FC_OBS_NOISE_ANG_VEL] * c.f[GO2SIM_FC_OBS_SCALE_ANG_VEL] * lvl;
-          else if (i < 6) nv = c.f[GO2SIM_FC_OBS_NOISE_GRAVITY] * lvl;
-          else if (i < 9) nv = 0.0f;
-          else if (i < 21) nv = c.f[GO2SIM_FC_OBS_NOISE_DOF_POS] * c.f[GO2SIM_FC_OBS_SCALE_DOF_POS] * lvl;
-          else if (i < 33) nv = c.f[GO2SIM_FC_OBS_NOISE_DOF_VEL] * c.f[GO2SIM_FC_OBS_SCALE_DOF_VEL] * lvl;
-          o[i] = o[i] + n[k] * nv;
-        }
+    for (int k = 0; k < 4; ++k) {
+      int i = 4 * blk + k;
+      if (i < nobs) {
+        float v, nv = 0.0f;
+        if (i < 3) { v = gload(e, FO(base_ang_vel), i) * c.f[GO2SIM_FC_OBS_SCALE_ANG_VEL]; nv = c.f[GO2SIM_FC_OBS_NOISE_ANG_VEL] * c.f[GO2SIM_FC_OBS_SCALE_ANG_VEL] * lvl; }
+        else if (i < 6) { v = gload(e, FO(projected_gravity), i - 3) + gload(e, FO(gravity_offset), i - 3); nv = c.f[GO2SIM_FC_OBS_NOISE_GRAVITY] * lvl; }
+        else if (i < 9) { v = gload(e, FO(commands), i - 6) * ((i - 6 < 2) ? c.f[GO2SIM_FC_OBS_SCALE_LIN_VEL] : c.f[GO2SIM_FC_OBS_SCALE_ANG_VEL]); nv = 0.0f; }
+        else if (i < 21) { v = (gload(e, FO(e_dof_pos), i - 9) - c.f[GO2SIM_FC_DEFAULT_DOF_POS0 + i - 9]) * c.f[GO2SIM_FC_OBS_SCALE_DOF_POS]; nv = c.f[GO2SIM_FC_OBS_NOISE_DOF_POS] * c.f[GO2SIM_FC_OBS_SCALE_DOF_POS] * lvl; }
+        else if (i < 33) { v = gload(e, FO(e_dof_vel), i - 21) * c.f[GO2SIM_FC_OBS_SCALE_DOF_VEL]; nv = c.f[GO2SIM_FC_OBS_NOISE_DOF_VEL] * c.f[GO2SIM_FC_OBS_SCALE_DOF_VEL] * lvl; }
+        else { v = (i - 33 < na) ? gload(e, FO(applied_actions), i - 33) : gload(e, FO(obs), i); }
+        if (noisy) v = v + n[k] * nv;
+        gstore(e, FO(obs), i, v); gstore(e, FO(priv), i, v);
+        if (obs_out) obs_out[(size_t)b * nobs + i] = v;
+        if (priv_out) priv_out[(size_t)b * npriv + i] = v;
       }
     }
   }
-  for (int i = 0; i < nobs; ++i) p[i] = o[i];
-  int idx = nobs;
-  auto blv = e.base_lin_vel(); auto kpf = e.kp_factors(); auto kdf = e.kd_factors(); auto mst = e.motor_strength(); auto cpf = e.current_push_force();
-  for (int k = 0; k < 3; ++k) p[idx + k] = blv[k] * c.f[GO2SIM_FC_OBS_SCALE_LIN_VEL];
-  idx += 3;
-  p[idx] = g.friction; idx += 1;
-  for (int i = 0; i < NM; ++i) p[idx + i] = kpf[i];
-  idx += 12;
-  for (int i = 0; i < NM; ++i) p[idx + i] = kdf[i];
-  idx += 12;
-  for (int i = 0; i < NM; ++i) p[idx + i] = mst[i];
-  idx += 12;
-  p[idx] = g.mass_shift; idx += 1;
-  for (int k = 0; k < 3; ++k) p[idx + k] = g.com_shift[k];
-  idx += 3;
-  for (int k = 0; k < 4; ++k) p[idx + k] = g.leg_mass_shift[k];
-  idx += 4;
-  for (int k = 0; k < 3; ++k) p[idx + k] = goff[k];
-  idx += 3;
-  for (int k = 0; k < 3; ++k) p[idx + k] = cpf[k];
-  idx += 3;
-  if (c.i[GO2SIM_IC_MAX_DELAY] > 0) p[idx] = (float)e.delay_steps()[0] / (float)c.i[GO2SIM_IC_MAX_DELAY];
-  idx += 1;
-  for (int i = idx; i < npriv; ++i) p[i] = 0.0f;
-  { auto la = e.last_actions(); auto a = e.actions(); for (int i = 0; i < na; ++i) la[i] = a[i]; }
-  { auto ldv = e.last_dof_vel(); for (int i = 0; i < NM; ++i) ldv[i] = dof_vel[i]; }
-  if (obs_out) for (int i = 0; i < nobs; ++i) obs_out[(size_t)b * nobs + i] = o[i];
-  if (priv_out) for (int i = 0; i < npriv; ++i) priv_out[(size_t)b * npriv + i] = p[i];
-  if (rew_out) rew_out[b] = e.rew()[0];
-  if (reset_out) reset_out[b] = (uint8_t)was_reset;
-  if (timeout_out) timeout_out[b] = e.time_out()[0];
+  // privileged tail (go2_env_walk.py:1115-1143)
+  for (int i = nobs + tl; i < npriv; i += T) {
+    int j = i - nobs;
+    float v; bool write = true;
+    if (j < 3) v = gload(e, FO(base_lin_vel), j) * c.f[GO2SIM_FC_OBS_SCALE_LIN_VEL];
+    else if (j < 4) v = g.friction;
+    else if (j < 16) v = gload(e, FO(kp_factors), j - 4);
+    else if (j < 28) v = gload(e, FO(kd_factors), j - 16);
+    else if (j < 40) v = gload(e, FO(motor_strength), j - 28);
+    else if (j < 41) v = g.mass_shift;
+    else if (j < 44) v = g.com_shift[j - 41];
+    else if (j < 48) v = g.leg_mass_shift[j - 44];
+    else if (j < 51) v = gload(e, FO(gravity_offset), j - 48);
+    else if (j < 54) v = gload(e, FO(current_push_force), j - 51);
+    else if (j < 55) { write = c.i[GO2SIM_IC_MAX_DELAY] > 0; v = write ? (float)e.delay_steps()[0] / (float)c.i[GO2SIM_IC_MAX_DELAY] : gload(e, FO(priv), i); }
+    else v = 0.0f;
+    if (write) gstore(e, FO(priv), i, v);
+    if (priv_out) priv_out[(size_t)b * npriv + i] = v;
+  }
+  for (int i = tl; i < na; i += T) gstore(e, FO(last_actions), i, gload(e, FO(actions), i));
+  for (int i = tl; i < NM; i += T) gstore(e, FO(last_dof_vel), i, gload(e, FO(e_dof_vel), i));
+  if (tl == 0) {
+    if (rew_out) rew_out[b] = e.rew()[0];
+    if (reset_out) reset_out[b] = (uint8_t)was_reset;
+    if (timeout_out) timeout_out[b] = e.time_out()[0];
+  }
 }
 
-// small device helpers for the host API
 __global__ __launch_bounds__(WG) void k_init_state(Pool P, const Model* __restrict__ mp, int keep_dr) {
   int b = blockIdx.x * WG + threadIdx.x;
   if (b >= P.B) return;
@@ -3545,7 +3550,7 @@ int go2sim_env_step(go2sim_t* h, const float* actions, float* obs, float* priv, 
     HIPCHK(hipMemsetAsync(h->dacc, 0, sizeof(Acc), s));
     hipLaunchKernelGGL(k_env_post_a, g, b, 0, s, h->P, h->dm, h->dcfg, h->dglob, h->dacc, h->seed, h->step_count);
     hipLaunchKernelGGL(k_env_globals, dim3(1), dim3(1), 0, s, h->dcfg, h->dglob, h->dacc, h->seed, 1);
-    hipLaunchKernelGGL(k_env_post_b, g, b, 0, s, h->P, h->dm, h->dcfg, h->dglob, h->seed, h->step_count, obs, priv, rew, reset, timeout);
+    hipLaunchKernelGGL(k_env_post_b_team<16>, dim3((h->B + 3) / 4), dim3(64), 0, s, h->P, h->dm, h->dcfg, h->dglob, h->seed, h->step_count, obs, priv, rew, reset, timeout);
     launch_fk_team(h, s, 1, &h->dglob->n_reset_now);
   }
   HIPCHK(hipGetLastError());
