@@ -555,6 +555,27 @@ DEV float gload(const E& e, int off, int k) { return e.f[(size_t)(off + k) * e.B
 DEV void gstore(const E& e, int off, int k, float v) { e.f[(size_t)(off + k) * e.B] = v; }
 
 
+// Workgroup-cooperative staging between the SoA pool and per-env LDS blocks: adjacent lanes address adjacent environments of the same
+// pool row, so one wave instruction touches 64/EPW rows with EPW contiguous floats each instead of 64 separate sectors.
+template <int EPW, class F>
+DEV void wg_load(const Pool& P, int b0, int off, int count, F put) {
+  const int ev = threadIdx.x % EPW, k0 = threadIdx.x / EPW;
+  const int b = b0 + ev;
+  if (b < P.B) {
+#pragma unroll 4
+    for (int k = k0; k < count; k += 64 / EPW) put(ev, k, P.f[(size_t)(off + k) * P.B + b]);
+  }
+}
+template <int EPW, class F>
+DEV void wg_store(const Pool& P, int b0, int off, int count, F get) {
+  const int ev = threadIdx.x % EPW, k0 = threadIdx.x / EPW;
+  const int b = b0 + ev;
+  if (b < P.B) {
+#pragma unroll 4
+    for (int k = k0; k < count; k += 64 / EPW) P.f[(size_t)(off + k) * P.B + b] = get(ev, k);
+  }
+}
+
 // ---- optional per-phase cycle accounting (build with -DGO2SIM_PHASE_PROFILE; development aid, see tools/phase_profile.py) ----
 #ifdef GO2SIM_PHASE_PROFILE
 __device__ unsigned long long g_phase_cycles[64];
@@ -1248,25 +1269,26 @@ __global__ __launch_bounds__(64) void k_dynamics_team(Pool P, const ModelS* __re
   __shared__ DynData lds[EPW];
   __shared__ ModelS ms;
   load_model_s(&ms, mp);
+  {  // ---- stage (cooperative, before any lane retires) ----
+    const int b0 = blockIdx.x * EPW;
+    wg_load<EPW>(P, b0, FO(cinr_inertial), NL * 9, [&](int ev, int k, float v) { lds[ev].cinr_I[k] = v; lds[ev].crb_I[k] = v; });
+    wg_load<EPW>(P, b0, FO(cinr_pos), NL * 3, [&](int ev, int k, float v) { lds[ev].cinr_pos[k] = v; lds[ev].crb_pos[k] = v; });
+    wg_load<EPW>(P, b0, FO(cd_vel), NL * 3, [&](int ev, int k, float v) { lds[ev].cd_vel[k] = v; });
+    wg_load<EPW>(P, b0, FO(cd_ang), NL * 3, [&](int ev, int k, float v) { lds[ev].cd_ang[k] = v; });
+    wg_load<EPW>(P, b0, FO(cinr_mass), NL, [&](int ev, int k, float v) { lds[ev].cinr_mass[k] = v; lds[ev].crb_mass[k] = v; });
+    wg_load<EPW>(P, b0, FO(cdof_ang), ND * 3, [&](int ev, int k, float v) { lds[ev].cdof_ang[k] = v; });
+    wg_load<EPW>(P, b0, FO(cdof_vel), ND * 3, [&](int ev, int k, float v) { lds[ev].cdof_vel[k] = v; });
+    wg_load<EPW>(P, b0, FO(cdofd_ang), ND * 3, [&](int ev, int k, float v) { lds[ev].cdofd_ang[k] = v; });
+    wg_load<EPW>(P, b0, FO(cdofd_vel), ND * 3, [&](int ev, int k, float v) { lds[ev].cdofd_vel[k] = v; });
+    wg_load<EPW>(P, b0, FO(vel), ND, [&](int ev, int k, float v) { lds[ev].vel[k] = v; });
+  }
   const int tl = threadIdx.x % T, slot = threadIdx.x / T;
   const int b = blockIdx.x * EPW + slot;
-  if (b >= P.B) return;
+  const bool env_valid = b < P.B;
   const ModelView m(&ms, mp);
-  E e(P, b);
+  E e(P, env_valid ? b : P.B - 1);
   DynData* s = &lds[slot];
   PH_BEGIN
-  // ---- stage ----
-  for (int k = tl; k < NL * 9; k += T) { float v = gload(e, FO(cinr_inertial), k); s->cinr_I[k] = v; s->crb_I[k] = v; }
-  for (int k = tl; k < NL * 3; k += T) {
-    float v = gload(e, FO(cinr_pos), k); s->cinr_pos[k] = v; s->crb_pos[k] = v;
-    s->cd_vel[k] = gload(e, FO(cd_vel), k); s->cd_ang[k] = gload(e, FO(cd_ang), k);
-  }
-  for (int k = tl; k < NL; k += T) { float v = gload(e, FO(cinr_mass), k); s->cinr_mass[k] = v; s->crb_mass[k] = v; }
-  for (int k = tl; k < ND * 3; k += T) {
-    s->cdof_ang[k] = gload(e, FO(cdof_ang), k); s->cdof_vel[k] = gload(e, FO(cdof_vel), k);
-    s->cdofd_ang[k] = gload(e, FO(cdofd_ang), k); s->cdofd_vel[k] = gload(e, FO(cdofd_vel), k);
-  }
-  for (int d = tl; d < ND; d += T) s->vel[d] = gload(e, FO(vel), d);
   team_sync();
   PH(20)
   // ---- composite rigid bodies, leaf -> root ----
@@ -1305,8 +1327,6 @@ __global__ __launch_bounds__(64) void k_dynamics_team(Pool P, const ModelS* __re
     }
     s->M[i_d * ND + j_d] = v; s->M[j_d * ND + i_d] = v;
     s->L[i_d * ND + j_d] = v;
-    gstore(e, FO(mass_mat), i_d * ND + j_d, v);
-    if (i_d != j_d) gstore(e, FO(mass_mat), j_d * ND + i_d, v);
   }
   team_sync();
   PH(22)
@@ -1393,7 +1413,7 @@ __global__ __launch_bounds__(64) void k_dynamics_team(Pool P, const ModelS* __re
     float qf_bias = dot(ld3(s->cdof_ang, i_d), ld3(s->cfrc_ang, i_l)) + dot(ld3(s->cdof_vel, i_d), ld3(s->cfrc_vel, i_l));
     float f = s->qf_passive[i_d] - qf_bias + s->qf_applied[i_d];
     s->force[i_d] = f;
-    gstore(e, FO(force), i_d, f); gstore(e, FO(qf_smooth), i_d, f);
+    if (env_valid) { gstore(e, FO(force), i_d, f); gstore(e, FO(qf_smooth), i_d, f); }
   }
   team_sync();
   PH(24)
@@ -1411,7 +1431,8 @@ __global__ __launch_bounds__(64) void k_dynamics_team(Pool P, const ModelS* __re
     s->out[i_d] = cur;
   }
   team_sync();
-  for (int i_d = tl; i_d < ND; i_d += T) { float a = s->out[i_d]; gstore(e, FO(acc_smooth), i_d, a); gstore(e, FO(acc), i_d, a); }
+  if (env_valid) for (int i_d = tl; i_d < ND; i_d += T) { float a = s->out[i_d]; gstore(e, FO(acc_smooth), i_d, a); gstore(e, FO(acc), i_d, a); }
+  wg_store<EPW>(P, blockIdx.x * EPW, FO(mass_mat), ND * ND, [&](int ev, int k) { return lds[ev].M[k]; });
   PH(25)
 }
 
@@ -1839,7 +1860,8 @@ __global__ __launch_bounds__(64) void k_collide_team(Pool P, const Model* __rest
   for (int i = tl; i < n2; i += T) {
     float v = s->sval[i];
     int r = 0;
-    for (int j = 0; j < n2; ++j) { float w = s->sval[j]; r += (w < v) || (w == v && j < i); }
+#pragma unroll
+    for (int j = 0; j < 2 * NG; ++j) { float w = s->sval[j]; r += (w < v) || (w == v && j < i); }
     int sg = s->sig[i];
     s->sval_sorted[r] = v; s->sig_sorted[r] = sg;
     if (sg & 0x100) s->rank_max[sg & 0xff] = r; else s->rank_min[sg] = r;
@@ -2971,6 +2993,9 @@ __global__ void k_env_globals(const DCfg* __restrict__ cp, Glob* gp, Acc* acc, u
     g.last_reset_count = n;
     for (int k = 0; k < NREW; ++k) g.last_episode_rew[k] = (float)(acc->ep[k] / (double)n);
     g.reset_calls += 1;
+    // consumed: clear the accumulators for the next reset call (they are only ever non-zero when n > 0)
+    acc->timeouts = 0.0; acc->tracking = 0.0; acc->n_reset_now = 0;
+    for (int k = 0; k < NREW; ++k) acc->ep[k] = 0.0;
   }
 }
 
@@ -3547,7 +3572,6 @@ int go2sim_env_step(go2sim_t* h, const float* actions, float* obs, float* priv, 
   for (int i = 0; i < substeps; ++i) launch_substep(h, s);
   {
     ScopedTimer t(h, s, T_ENV_POST);
-    HIPCHK(hipMemsetAsync(h->dacc, 0, sizeof(Acc), s));
     hipLaunchKernelGGL(k_env_post_a, g, b, 0, s, h->P, h->dm, h->dcfg, h->dglob, h->dacc, h->seed, h->step_count);
     hipLaunchKernelGGL(k_env_globals, dim3(1), dim3(1), 0, s, h->dcfg, h->dglob, h->dacc, h->seed, 1);
     hipLaunchKernelGGL(k_env_post_b_team<16>, dim3((h->B + 3) / 4), dim3(64), 0, s, h->P, h->dm, h->dcfg, h->dglob, h->seed, h->step_count, obs, priv, rew, reset, timeout);
