@@ -26,6 +26,7 @@
 
 #include "../../include/go2sim.h"
 #include "../../include/go2sim_detmath.h"
+#include "../../include/go2sim_gjk.h"
 
 #define DEV __device__ __forceinline__
 #define DEVN __device__ __noinline__
@@ -1451,7 +1452,7 @@ DEV int clampidx(float x) {
 }
 // _func_support_mesh for a cylinder (support_field.py:138-180); the 180x180 direction-grid table is
 // reproduced analytically: vertex set = 32-gon ring x {+h/2,-h/2} (tools/compile_go2_model.py)
-DEV V3 support_cylinder_local(const Model& m, const Geom& G, V3 d_mesh) {
+DEV V3 support_cylinder_local(const Model& m, const Geom& G, V3 d_mesh, int* vid_out = nullptr) {
   const float PI = 3.14159265358979323846f;
   float theta = dm_atan2(d_mesh.y, d_mesh.x);
   float phi = dm_acos(d_mesh.z);
@@ -1460,6 +1461,7 @@ DEV V3 support_cylinder_local(const Model& m, const Geom& G, V3 d_mesh) {
   float jj = phi / PI * support_res;
   float dot_max = -1e20f;
   V3 v = v3(0, 0, 0);
+  int vid = 0;
   float half = 0.5f * G.data[1];
   for (int i4 = 0; i4 < 4; ++i4) {
     int i, j;
@@ -1469,8 +1471,9 @@ DEV V3 support_cylinder_local(const Model& m, const Geom& G, V3 d_mesh) {
     int k = m.theta_to_ring[i];
     V3 pos = v3(G.rim[k][0], G.rim[k][1], (j <= 90) ? half : -half);
     float d = dot(pos, d_mesh);
-    if (d > dot_max) { v = pos; dot_max = d; }
+    if (d > dot_max) { v = pos; dot_max = d; vid = k + ((j <= 90) ? 0 : 32); }
   }
+  if (vid_out) *vid_out = vid;
   return v;
 }
 // support_driver, collider/mpr.py:146-176
@@ -1495,6 +1498,60 @@ DEVN void compute_support(const Model& m, V3 direction, const Pair& pr, V3& v, V
   v1 = support_driver(m, direction, pr.i_ga, pr.pos_a, pr.quat_a);
   v2 = support_driver(m, -direction, pr.i_gb, pr.pos_b, pr.quat_b);
   v = v1 - v2;
+}
+
+
+// ---- safe GJK + EPA fallback (include/go2sim_gjk.h): geometric queries of collider/gjk_support.py:62-186, support_field.py:183-306,
+//      gjk.py:1652-1700,1854-1907.  Vertex ids only need to be unique per (geom, vertex): 64 ids are reserved per geom. ----
+DEV V3 gjk_support_driver(const Model& m, V3 direction, int i_g, V3 pos, Q4 quat, int& vid) {
+  const Geom& G = m.geoms[i_g];
+  if (G.type == GEOM_SPHERE) {
+    vid = -1;
+    return pos + direction * G.data[0];
+  } else if (G.type == GEOM_BOX) {
+    V3 d_box = inv_transform_by_quat(direction, quat);
+    V3 v_ = v3((d_box.x < 0.0f ? -1.0f : 1.0f) * G.data[0] * 0.5f, (d_box.y < 0.0f ? -1.0f : 1.0f) * G.data[1] * 0.5f,
+               (d_box.z < 0.0f ? -1.0f : 1.0f) * G.data[2] * 0.5f);
+    vid = (v_.x > 0.0f) * 1 + (v_.y > 0.0f) * 2 + (v_.z > 0.0f) * 4 + 64 * i_g;
+    return transform_by_trans_quat(v_, pos, quat);
+  } else {
+    V3 d_mesh = transform_by_quat(direction, inv_quat(quat));
+    int k = 0;
+    V3 v_ = support_cylinder_local(m, G, d_mesh, &k);
+    vid = k + 64 * i_g;
+    return transform_by_trans_quat(v_, pos, quat);
+  }
+}
+struct GjkSup {
+  const Model& m; int i_ga, i_gb; V3 pos_a; Q4 quat_a; V3 pos_b; Q4 quat_b; float eps; bool discrete; int nverts_a, nverts_b;
+  DEV static G3 to_g(V3 v) { return g3(v.x, v.y, v.z); }
+  DEV void support(G3 d, G3& o1, G3& o2, int& id1, int& id2) const {
+    V3 dv = v3(d.x, d.y, d.z);
+    o1 = to_g(gjk_support_driver(m, dv, i_ga, pos_a, quat_a, id1));
+    o2 = to_g(gjk_support_driver(m, -dv, i_gb, pos_b, quat_b, id2));
+  }
+  DEV int count_one(V3 d, int i_g, Q4 quat) const {
+    if (m.geoms[i_g].type == GEOM_BOX) {
+      V3 d_box = inv_transform_by_quat(d, quat);
+      int zeros = (d_box.x == 0.0f) + (d_box.y == 0.0f) + (d_box.z == 0.0f);
+      return 1 << zeros;
+    }
+    return 1;
+  }
+  DEV int count(G3 d) const { V3 dv = v3(d.x, d.y, d.z); return count_one(dv, i_ga, quat_a) * count_one(-dv, i_gb, quat_b); }
+  DEV void discrete_vertex(int which, int i_v, G3& obj, int& id) const {
+    int i_g = which == 0 ? i_ga : i_gb;
+    const Geom& G = m.geoms[i_g];
+    V3 v_ = v3(((i_v & 1) ? 1.0f : -1.0f) * G.data[0] * 0.5f, ((i_v & 2) ? 1.0f : -1.0f) * G.data[1] * 0.5f, ((i_v & 4) ? 1.0f : -1.0f) * G.data[2] * 0.5f);
+    obj = to_g(transform_by_trans_quat(v_, which == 0 ? pos_a : pos_b, which == 0 ? quat_a : quat_b));
+    id = 64 * i_g + i_v;
+  }
+};
+// cold path of the narrow phase (a few percent of the substeps): kept out of line
+DEVN GjkResult gjk_contact_pair(const Model& m, GjkScratch* scratch, const Pair& pr) {
+  bool disc = m.geoms[pr.i_ga].type == GEOM_BOX && m.geoms[pr.i_gb].type == GEOM_BOX;
+  GjkSup sup{m, pr.i_ga, pr.i_gb, pr.pos_a, pr.quat_a, pr.pos_b, pr.quat_b, m.eps, disc, 8, 8};
+  return gjk_contact(sup, *scratch);
 }
 
 // ---- MPR, collider/mpr.py: the 4-vertex portal simplex lives in registers -----------------------
@@ -1741,7 +1798,7 @@ DEV void stage_contact(ContactStage& cs, V3 normal, V3 pos, float pen) {
 }
 
 // func_convex_convex_contact (CCD_ALGORITHM_CODE.MPR branch), narrowphase.py:514-961; contacts go to the lane's staging buffer
-DEV void convex_convex_contact_staged(const Model& m, const E& e, int i_ga, int i_gb, ContactStage& cs) {
+DEV void convex_convex_contact_staged(const Model& m, const E& e, int i_ga, int i_gb, ContactStage& cs, GjkScratch* gjk_scratch) {
   const float EPS = m.eps;
   int type_a = m.geoms[i_ga].type, type_b = m.geoms[i_gb].type;
   bool multi_contact = (type_a != GEOM_SPHERE) && (type_b != GEOM_SPHERE);
@@ -1775,7 +1832,13 @@ DEV void convex_convex_contact_staged(const Model& m, const E& e, int i_ga, int 
         }
       }
       if (penetration > tolerance) prefer_gjk = !guess_available || (m.mc_tolerance * penetration >= m.mpr_to_gjk_ratio * tolerance);
-      if (prefer_gjk) atomicAdd(&e.gjk_fallback()[0], 1);  // safe GJK+EPA fallback (narrowphase.py:734-845) not implemented yet: MPR result kept
+      if (prefer_gjk) {                                          // narrowphase.py:734-845: safe GJK + EPA replaces the MPR answer
+        atomicAdd(&e.gjk_fallback()[0], 1);
+        GjkResult gr = gjk_contact_pair(m, gjk_scratch, pr);
+        is_col = gr.is_col != 0;
+        penetration = gr.penetration;
+        if (is_col) { contact_pos = v3(gr.pos.x, gr.pos.y, gr.pos.z); normal = v3(gr.normal.x, gr.normal.y, gr.normal.z); }
+      }
     }
     if (i_detection == 0) {
       is_col_0 = is_col; normal_0 = normal; contact_pos_0 = contact_pos;
@@ -1810,7 +1873,7 @@ DEV void convex_convex_contact_staged(const Model& m, const E& e, int i_ga, int 
 }
 
 template <int T>
-__global__ __launch_bounds__(64) void k_collide_team(Pool P, const Model* __restrict__ mp) {
+__global__ __launch_bounds__(64) void k_collide_team(Pool P, const Model* __restrict__ mp, GjkScratch* __restrict__ gjk_scratch) {
   constexpr int EPW = 64 / T;
   __shared__ CollideData<T> lds[EPW];
   const int tl = threadIdx.x % T, slot = threadIdx.x / T;
@@ -1919,7 +1982,7 @@ __global__ __launch_bounds__(64) void k_collide_team(Pool P, const Model* __rest
       int pk = s->pair_sorted[ip];
       i_ga = pk & 0xff; i_gb = pk >> 8;
       if (m.geoms[i_ga].type > m.geoms[i_gb].type) { int t = i_ga; i_ga = i_gb; i_gb = t; }
-      convex_convex_contact_staged(m, e, i_ga, i_gb, cs);
+      convex_convex_contact_staged(m, e, i_ga, i_gb, cs, &gjk_scratch[(size_t)b * T + tl]);
     }
     s->cnt[tl] = cs.n;
     team_sync();
@@ -3265,6 +3328,7 @@ struct go2sim {
   Pool P = {nullptr, nullptr, 0};
   DCfg hcfg; DCfg* dcfg = nullptr; bool cfg_set = false;
   Glob* dglob = nullptr; Acc* dacc = nullptr; int* derr = nullptr;
+  GjkScratch* gjk_scratch = nullptr;        // working memory of the GJK/EPA fallback: one block per (env, narrow-phase lane)
   SolverData<MAXR>* solver_ovf = nullptr;   // per-env global scratch for solves that do not fit in LDS (> RL rows)
   int dyn_team = 16;                        // lanes per environment in k_dynamics_team / k_integrate_fk_team / k_fk_team
   int collide_team = 16;                    // lanes per environment in k_collide_team
@@ -3320,9 +3384,9 @@ static int launch_substep(go2sim* h, hipStream_t s) {
     ScopedTimer t(h, s, T_COLLIDE);
     const int T = h->collide_team;
     dim3 gc((h->B + 64 / T - 1) / (64 / T));
-    if (T == 16) hipLaunchKernelGGL(k_collide_team<16>, gc, b, 0, s, h->P, h->dm);
-    else if (T == 32) hipLaunchKernelGGL(k_collide_team<32>, gc, b, 0, s, h->P, h->dm);
-    else hipLaunchKernelGGL(k_collide_team<64>, gc, b, 0, s, h->P, h->dm);
+    if (T == 16) hipLaunchKernelGGL(k_collide_team<16>, gc, b, 0, s, h->P, h->dm, h->gjk_scratch);
+    else if (T == 32) hipLaunchKernelGGL(k_collide_team<32>, gc, b, 0, s, h->P, h->dm, h->gjk_scratch);
+    else hipLaunchKernelGGL(k_collide_team<64>, gc, b, 0, s, h->P, h->dm, h->gjk_scratch);
   }
   {
     ScopedTimer t(h, s, T_SOLVE);
@@ -3376,6 +3440,7 @@ int go2sim_create(const void* blob, size_t nbytes, int n_envs, int device, uint6
   HIPCHK(hipMalloc((void**)&h->solver_ovf, (size_t)n_envs * sizeof(SolverData<MAXR>)));
   if (const char* t = getenv("GO2SIM_DYN_TEAM")) { int v = atoi(t); if (v == 16 || v == 32 || v == 64) h->dyn_team = v; }
   if (const char* t = getenv("GO2SIM_COLLIDE_TEAM")) { int v = atoi(t); if (v == 16 || v == 32 || v == 64) h->collide_team = v; }
+  HIPCHK(hipMalloc((void**)&h->gjk_scratch, (size_t)n_envs * h->collide_team * sizeof(GjkScratch)));   // ~31 KB per narrow-phase lane
   if (const char* t = getenv("GO2SIM_SOLVER_TEAM")) { int v = atoi(t); if (v == 16 || v == 32 || v == 64) h->solver_team = v; }
   Glob g0; memset(&g0, 0, sizeof(g0)); g0.friction = 1.0f;
   HIPCHK(hipMemcpy(h->dglob, &g0, sizeof(Glob), hipMemcpyHostToDevice));
@@ -3393,7 +3458,7 @@ int go2sim_destroy(go2sim_t* h) {
   (void)hipSetDevice(h->device);
   (void)hipDeviceSynchronize();
   if (h->ev_created) for (int i = 0; i < TIMING_RING; ++i) { (void)hipEventDestroy(h->ev0[i]); (void)hipEventDestroy(h->ev1[i]); }
-  (void)hipFree(h->P.f); (void)hipFree(h->P.i); (void)hipFree(h->dm); (void)hipFree(h->dcfg); (void)hipFree(h->dglob); (void)hipFree(h->dacc); (void)hipFree(h->derr); (void)hipFree(h->solver_ovf); (void)hipFree(h->dms);
+  (void)hipFree(h->P.f); (void)hipFree(h->P.i); (void)hipFree(h->dm); (void)hipFree(h->dcfg); (void)hipFree(h->dglob); (void)hipFree(h->dacc); (void)hipFree(h->derr); (void)hipFree(h->solver_ovf); (void)hipFree(h->gjk_scratch); (void)hipFree(h->dms);
   delete h;
   return GO2SIM_E_OK;
 }

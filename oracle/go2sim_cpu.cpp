@@ -25,6 +25,7 @@
 
 #include "../include/go2sim.h"
 #include "../include/go2sim_detmath.h"
+#include "../include/go2sim_gjk.h"
 
 namespace {
 
@@ -335,7 +336,7 @@ struct Env {
   int n_broad; int broad[MAXB][2];
   int n_contacts; Contact contacts[MAXC];
   V3 mpr_v[4], mpr_v1[4], mpr_v2[4];
-  int gjk_fallback_count;  // number of pairs for which the reference would have switched to GJK
+  int gjk_fallback_count;  // number of pairs that switched from MPR to the safe GJK + EPA
   // constraints
   int n_con;
   real jac[MAXR][ND], diag[MAXR], aref[MAXR], efc_D[MAXR], Jaref[MAXR], jv[MAXR], efc_force[MAXR];
@@ -779,7 +780,7 @@ inline int clampidx(real x) {  // int(clamp(x, 0, 179)), NaN-safe
   if (!(x >= 0.0f)) return 0;
   return (x >= 179.0f) ? 179 : (int)x;
 }
-V3 support_cylinder_local(const Model& m, const Geom& G, V3 d_mesh) {
+V3 support_cylinder_local(const Model& m, const Geom& G, V3 d_mesh, int* vid_out = nullptr) {
   const real PI = 3.14159265358979323846f;
   real theta = dm_atan2(d_mesh.y, d_mesh.x);
   real phi = dm_acos(d_mesh.z);
@@ -788,6 +789,7 @@ V3 support_cylinder_local(const Model& m, const Geom& G, V3 d_mesh) {
   real jj = phi / PI * support_res;
   real dot_max = -1e20f;
   V3 v = v3(0, 0, 0);
+  int vid = 0;
   real half = 0.5f * G.data[1];
   for (int i4 = 0; i4 < 4; ++i4) {
     int i, j;
@@ -802,8 +804,9 @@ V3 support_cylinder_local(const Model& m, const Geom& G, V3 d_mesh) {
     int k = m.theta_to_ring[i];
     V3 pos = v3(G.rim[k][0], G.rim[k][1], (j <= 90) ? half : -half);
     real d = dot(pos, d_mesh);
-    if (d > dot_max) { v = pos; dot_max = d; }
+    if (d > dot_max) { v = pos; dot_max = d; vid = k + ((j <= 90) ? 0 : 32); }
   }
+  if (vid_out) *vid_out = vid;
   return v;
 }
 // support_driver, collider/mpr.py:146-176 (sphere / box / table-driven mesh)
@@ -822,6 +825,59 @@ V3 support_driver(const Model& m, V3 direction, int i_g, V3 pos, Q4 quat) {
     return transform_by_trans_quat(v_, pos, quat);
   }
 }
+// ---- safe GJK + EPA fallback (include/go2sim_gjk.h): geometric queries of collider/gjk_support.py:62-186, support_field.py:183-306,
+//      gjk.py:1652-1700,1854-1907 ----
+// vertex ids only need to be unique per (geom, vertex): 64 ids are reserved per geom
+inline V3 gjk_support_driver(const Model& m, V3 direction, int i_g, V3 pos, Q4 quat, int& vid) {
+  const Geom& G = m.geoms[i_g];
+  if (G.type == GEOM_SPHERE) {                                   // _func_support_sphere (shrink = False): vid = -1
+    vid = -1;
+    return pos + direction * G.data[0];
+  } else if (G.type == GEOM_BOX) {                               // _func_support_box
+    V3 d_box = inv_transform_by_quat(direction, quat);
+    V3 v_ = v3((d_box.x < 0.0f ? -1.0f : 1.0f) * G.data[0] * 0.5f, (d_box.y < 0.0f ? -1.0f : 1.0f) * G.data[1] * 0.5f,
+               (d_box.z < 0.0f ? -1.0f : 1.0f) * G.data[2] * 0.5f);
+    vid = (v_.x > 0.0f) * 1 + (v_.y > 0.0f) * 2 + (v_.z > 0.0f) * 4 + 64 * i_g;
+    return transform_by_trans_quat(v_, pos, quat);
+  } else {                                                       // _func_support_world
+    V3 d_mesh = transform_by_quat(direction, inv_quat(quat));
+    int k = 0;
+    V3 v_ = support_cylinder_local(m, G, d_mesh, &k);
+    vid = k + 64 * i_g;
+    return transform_by_trans_quat(v_, pos, quat);
+  }
+}
+struct GjkSup {
+  const Model& m; int i_ga, i_gb; V3 pos_a; Q4 quat_a; V3 pos_b; Q4 quat_b; float eps; bool discrete; int nverts_a, nverts_b;
+  static G3 to_g(V3 v) { return g3(v.x, v.y, v.z); }
+  void support(G3 d, G3& o1, G3& o2, int& id1, int& id2) const {   // func_support, gjk_support.py:113-186
+    V3 dv = v3(d.x, d.y, d.z);
+    o1 = to_g(gjk_support_driver(m, dv, i_ga, pos_a, quat_a, id1));
+    o2 = to_g(gjk_support_driver(m, -dv, i_gb, pos_b, quat_b, id2));
+  }
+  int count_one(V3 d, int i_g, Q4 quat) const {                   // count_support_driver, gjk.py:1854-1877
+    if (m.geoms[i_g].type == GEOM_BOX) {                          // _func_count_supports_box
+      V3 d_box = inv_transform_by_quat(d, quat);
+      int zeros = (d_box.x == 0.0f) + (d_box.y == 0.0f) + (d_box.z == 0.0f);
+      return 1 << zeros;
+    }
+    return 1;   // spheres; the tessellated cylinders are GEOM_TYPE.CYLINDER, not MESH
+  }
+  int count(G3 d) const { V3 dv = v3(d.x, d.y, d.z); return count_one(dv, i_ga, quat_a) * count_one(-dv, i_gb, quat_b); }
+  void discrete_vertex(int which, int i_v, G3& obj, int& id) const {   // func_get_discrete_geom_vertex (BOX), gjk.py:1666-1700
+    int i_g = which == 0 ? i_ga : i_gb;
+    const Geom& G = m.geoms[i_g];
+    V3 v_ = v3(((i_v & 1) ? 1.0f : -1.0f) * G.data[0] * 0.5f, ((i_v & 2) ? 1.0f : -1.0f) * G.data[1] * 0.5f, ((i_v & 4) ? 1.0f : -1.0f) * G.data[2] * 0.5f);
+    obj = to_g(transform_by_trans_quat(v_, which == 0 ? pos_a : pos_b, which == 0 ? quat_a : quat_b));
+    id = 64 * i_g + i_v;
+  }
+};
+inline GjkResult gjk_contact_pair(const Model& m, GjkScratch& scratch, int i_ga, int i_gb, V3 pos_a, Q4 quat_a, V3 pos_b, Q4 quat_b) {
+  bool disc = m.geoms[i_ga].type == GEOM_BOX && m.geoms[i_gb].type == GEOM_BOX;   // func_is_discrete_geoms, collider/utils.py:105-126
+  GjkSup sup{m, i_ga, i_gb, pos_a, quat_a, pos_b, quat_b, m.eps, disc, 8, 8};
+  return gjk_contact(sup, scratch);
+}
+
 // compute_support, collider/mpr.py:179-202
 inline void compute_support(const Model& m, V3 direction, int i_ga, int i_gb, V3 pos_a, Q4 quat_a, V3 pos_b, Q4 quat_b, V3& v, V3& v1, V3& v2) {
   v1 = support_driver(m, direction, i_ga, pos_a, quat_a);
@@ -1092,10 +1148,13 @@ void convex_convex_contact(const Model& m, Env& e, int i_ga, int i_gb) {
       }
       if (penetration > tolerance)
         prefer_gjk = !guess_available || (m.mc_tolerance * penetration >= m.mpr_to_gjk_ratio * tolerance);
-      if (prefer_gjk) {
-        // The reference switches to its safe GJK+EPA here (narrowphase.py:734-845, gjk.py:1200, epa.py:970).
-        // Not restated yet: the MPR result is kept and the event is counted (see DESIGN.md "known gaps").
+      if (prefer_gjk) {                                            // narrowphase.py:734-845: safe GJK + EPA replaces the MPR answer
         e.gjk_fallback_count++;
+        static thread_local GjkScratch gjk_scratch;   // working memory of one GJK/EPA query
+        GjkResult gr = gjk_contact_pair(m, gjk_scratch, i_ga, i_gb, ga_pos, ga_quat, gb_pos, gb_quat);
+        is_col = gr.is_col != 0;
+        penetration = gr.penetration;
+        if (is_col) { contact_pos = v3(gr.pos.x, gr.pos.y, gr.pos.z); normal = v3(gr.normal.x, gr.normal.y, gr.normal.z); }
       }
     }
     if (i_detection == 0) {
@@ -2458,6 +2517,22 @@ int go2sim_cpu_enable_timing(go2sim*, int) { return GO2SIM_E_BADARG; }
 int go2sim_cpu_read_timing(go2sim*, float*, int*, int) { return GO2SIM_E_BADARG; }
 
 // extra oracle-only diagnostics
+// one narrow-phase query on explicit poses: which = 0 -> MPR (cold start), 1 -> safe GJK + EPA.  out = {is_col, penetration, normal[3], pos[3]}
+int go2sim_cpu_debug_narrowphase(go2sim* h, int which, int i_ga, int i_gb, const float* pa, const float* qa, const float* pb, const float* qb, float* out8) {
+  if (!h || !out8 || i_ga < 0 || i_gb < 0 || i_ga >= NG || i_gb >= NG) return GO2SIM_E_BADARG;
+  V3 pos_a = v3(pa[0], pa[1], pa[2]), pos_b = v3(pb[0], pb[1], pb[2]);
+  Q4 quat_a = q4(qa[0], qa[1], qa[2], qa[3]), quat_b = q4(qb[0], qb[1], qb[2], qb[3]);
+  bool is_col = false; V3 normal = v3(0, 0, 0), pos = v3(0, 0, 0); real pen = 0.0f;
+  if (which == 0) {
+    mpr_contact(h->m, h->envs[0], i_ga, i_gb, v3(0, 0, 0), pos_a, quat_a, pos_b, quat_b, is_col, normal, pen, pos);
+  } else {
+    static thread_local GjkScratch scratch;
+    GjkResult r = gjk_contact_pair(h->m, scratch, i_ga, i_gb, pos_a, quat_a, pos_b, quat_b);
+    is_col = r.is_col != 0; pen = r.penetration; normal = v3(r.normal.x, r.normal.y, r.normal.z); pos = v3(r.pos.x, r.pos.y, r.pos.z);
+  }
+  out8[0] = is_col ? 1.0f : 0.0f; out8[1] = pen; out8[2] = normal.x; out8[3] = normal.y; out8[4] = normal.z; out8[5] = pos.x; out8[6] = pos.y; out8[7] = pos.z;
+  return GO2SIM_E_OK;
+}
 int go2sim_cpu_gjk_fallback_count(go2sim* h, long long* out) {
   if (!h || !out) return GO2SIM_E_BADARG;
   long long s = 0;
