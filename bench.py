@@ -56,6 +56,16 @@ def make_actions(n_steps, n_envs, device, dt=0.02):
     return act.contiguous()
 
 
+def pmc_traffic_bytes(kernel, n_envs):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (profiles/r01_pmc_traffic.json; PMC counters cannot be
+    collected from inside the timed process).  FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, both in KB; only valid for 4096 envs."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if n_envs != ENVS_PER_GPU or not os.path.exists(path):
+        return None
+    rec = json.load(open(path)).get(kernel)
+    return None if rec is None else int((2 * rec["fetch_size_kb"] + rec["write_size_kb"]) * 1000)
+
+
 def cpu_baseline(n_envs, steps, warmup):
     from go2_sim2real_locomotion_rl_amd.capi import load_cpu_oracle_lib
 
@@ -174,7 +184,7 @@ def main():
         achieved = ALGO_BYTES_WALK * units / (per_launch[dom] * 1e-3) / 1e9 if per_launch[dom] > 0 else 0.0
         roofline = {
             "bound": "hbm", "kernel": KERNEL_CLASSES[dom], "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic_bytes(KERNEL_CLASSES[dom], B),
             "avg_launch_ms": round(per_launch[dom], 4), "avg_launch_ms_incl_warmup": round(per_launch_all[dom], 4),
             "launches_timed": cnt[dom], "algo_bytes_per_env_step": ALGO_BYTES_WALK, "units_per_launch_env_steps": units,
             "ms_per_step_by_kernel": {KERNEL_CLASSES[k]: round(per_step[k], 4) for k in range(8)},
@@ -184,7 +194,7 @@ def main():
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        n_cpu_envs, n_cpu_steps = 4096, 12
+        n_cpu_envs, n_cpu_steps = 4096, 200   # ~13 s on the 256 host threads of the GPU box
         v, dt = cpu_baseline(n_cpu_envs, n_cpu_steps, 3)
         cpu = {"value": round(v, 1), "unit": "env-steps/s", "cores": os.cpu_count(), "kind": "port",
                "sample": f"CPU oracle (OpenMP over envs, all host cores), same walk cfg/action set, {n_cpu_envs} envs x {n_cpu_steps} steps after 3 warm-up steps ({dt:.1f} s)"}
