@@ -233,3 +233,117 @@ def flatten_walk_cfg(num_envs, env_cfg, obs_cfg, reward_cfg, command_cfg, *, mod
     i[I("PER_ENV_GLOBAL_DR")] = int(per_env_global_dr)
     i[I("FREEZE_CURRICULUM")] = int(freeze_curriculum)
     return f, i, names
+
+
+# ---------------------------------------------------------------------------------------------
+# base env (crouch / jump): examples/locomotion/final/go2_env_base.py + go2_train_crouch.py / go2_train_jump.py
+# ---------------------------------------------------------------------------------------------
+BASE_REWARD_IDS = {
+    "tracking_lin_vel": "GO2SIM_R_TRACKING_LIN_VEL", "tracking_ang_vel": "GO2SIM_R_TRACKING_ANG_VEL", "lin_vel_z": "GO2SIM_R_LIN_VEL_Z",
+    "action_rate": "GO2SIM_R_ACTION_RATE", "similar_to_default": "GO2SIM_R_SIMILAR_TO_DEFAULT", "base_height": "GO2SIM_R_BASE_HEIGHT",
+    "jump_impulse": "GO2SIM_R_JUMP_IMPULSE", "jump_apex": "GO2SIM_R_JUMP_APEX", "xy_stability": "GO2SIM_R_XY_STABILITY",
+    "orientation": "GO2SIM_R_ORIENTATION", "no_shake": "GO2SIM_R_NO_SHAKE", "crouch": "GO2SIM_R_CROUCH", "crouch_2": "GO2SIM_R_CROUCH_2",
+    "ground_penalty": "GO2SIM_R_GROUND_PENALTY", "crouch_target": "GO2SIM_R_CROUCH_TARGET", "no_fall": "GO2SIM_R_NO_FALL",
+    "y_stability": "GO2SIM_R_Y_STABILITY", "torque_load": "GO2SIM_R_TORQUE_LOAD_BASE", "crouch_progress": "GO2SIM_R_CROUCH_PROGRESS",
+    "crouch_speed": "GO2SIM_R_CROUCH_SPEED",
+}
+
+_BASE_JOINTS = {
+    "default_joint_angles": {
+        "FL_hip_joint": 0.0, "FR_hip_joint": 0.0, "RL_hip_joint": 0.0, "RR_hip_joint": 0.0,
+        "FL_thigh_joint": 0.8, "FR_thigh_joint": 0.8, "RL_thigh_joint": 1.0, "RR_thigh_joint": 1.0,
+        "FL_calf_joint": -1.5, "FR_calf_joint": -1.5, "RL_calf_joint": -1.5, "RR_calf_joint": -1.5,
+    },
+    "joint_names": ["FR_hip_joint", "FR_thigh_joint", "FR_calf_joint", "FL_hip_joint", "FL_thigh_joint", "FL_calf_joint",
+                    "RR_hip_joint", "RR_thigh_joint", "RR_calf_joint", "RL_hip_joint", "RL_thigh_joint", "RL_calf_joint"],
+}
+_BASE_OBS = {"num_obs": 45, "obs_scales": {"lin_vel": 2.0, "ang_vel": 0.25, "dof_pos": 1.0, "dof_vel": 0.05}}
+_ZERO_CMD = {"num_commands": 3, "lin_vel_x_range": [0, 0], "lin_vel_y_range": [0, 0], "ang_vel_range": [0, 0]}
+
+
+def get_crouch_cfgs():
+    """go2_train_crouch.py:10-91 (values transcribed)."""
+    env_cfg = dict(_BASE_JOINTS, num_actions=12, kp=60.0, kd=2.0, termination_if_roll_greater_than=10, termination_if_pitch_greater_than=10,
+                   termination_if_z_vel_greater_than=0.7, termination_if_y_vel_greater_than=0.05, base_init_pos=[0.0, 0.0, 0.35],
+                   base_init_quat=[0.0, 0.0, 0.0, 1.0], episode_length_s=10.0, resampling_time_s=2.0, action_scale=0.65,
+                   simulate_action_latency=True, clip_actions=100.0, crouch_speed=5.0)
+    reward_cfg = {"reward_scales": {"crouch_target": 50.0, "ground_penalty": 10.0, "orientation": 30.0, "no_shake": 0.0, "xy_stability": 0.0,
+                                    "action_rate": -0.05, "similar_to_default": 1.0, "no_fall": 0.0, "torque_load": 0.0, "crouch_progress": 50.0}}
+    return env_cfg, copy.deepcopy(_BASE_OBS), reward_cfg, copy.deepcopy(_ZERO_CMD)
+
+
+def get_jump_cfgs():
+    """go2_train_jump.py:10-101 (values transcribed; the DR / push keys of that file are not read by go2_env_base.py)."""
+    env_cfg = dict(_BASE_JOINTS, num_actions=12, kp=60.0, kd=2.0, termination_if_roll_greater_than=25, termination_if_pitch_greater_than=25,
+                   termination_if_z_vel_greater_than=100.0, termination_if_y_vel_greater_than=100.0, base_init_pos=[0.0, 0.0, 0.42],
+                   base_init_quat=[0.0, 0.0, 0.0, 1.0], episode_length_s=3.0, resampling_time_s=2.0, action_scale=0.65,
+                   simulate_action_latency=True, clip_actions=100.0, crouch_speed=5.0, friction_range=(0.4, 0.9), kp_scale_range=(0.4, 1.5),
+                   kd_scale_range=(0.25, 2.0), push_enable=True, push_interval_s=1.0, push_prob=1.0, push_force_range=(0.0, 0.0),
+                   push_z_scale=0.0, push_duration_s=0.15, push_direction_mode="random")
+    reward_cfg = {"jump_apex_height": 0.55, "jump_apex_sigma": 0.06,
+                  "reward_scales": {"jump_impulse": 6.0, "jump_apex": 20.0, "xy_stability": 12.0, "orientation": 3.0, "no_shake": 1.0, "crouch": 6.0}}
+    return env_cfg, copy.deepcopy(_BASE_OBS), reward_cfg, copy.deepcopy(_ZERO_CMD)
+
+
+def flatten_base_cfg(num_envs, env_cfg, obs_cfg, reward_cfg, command_cfg, *, model=None):
+    """Go2Env.__init__ of go2_env_base.py:12-121 as data (ENV_KIND = 1): engine PD (`control_dofs_position`), one-step action
+    latency, no domain randomisation / noise / pushes / curriculum, reset before the reward, 45 observations."""
+    model = load_model_json() if model is None else model
+    links, joints = _name_maps(model)
+    f = np.zeros(C["GO2SIM_FC_COUNT"], dtype=np.float32)
+    i = np.zeros(C["GO2SIM_IC_COUNT"], dtype=np.int32)
+    dt = 0.02
+    F = lambda name: C["GO2SIM_FC_" + name]
+    I = lambda name: C["GO2SIM_IC_" + name]
+    if env_cfg["num_actions"] != 12 or obs_cfg["num_obs"] != 45:
+        raise ValueError("the base env has 12 actions and 45 observations (go2_env_base.py:176-187)")
+    f[F("DT")] = dt
+    f[F("ACTION_SCALE")], f[F("CLIP_ACTIONS")] = env_cfg["action_scale"], env_cfg["clip_actions"]
+    f[F("KP")], f[F("KD")] = env_cfg["kp"], env_cfg["kd"]
+    f[F("TORQUE_LIMIT0"):F("TORQUE_LIMIT0") + 12] = 0.0
+    f[F("DEFAULT_DOF_POS0"):F("DEFAULT_DOF_POS0") + 12] = [env_cfg["default_joint_angles"][n] for n in env_cfg["joint_names"]]
+    f[F("TERM_PITCH_DEG")], f[F("TERM_ROLL_DEG")] = env_cfg["termination_if_pitch_greater_than"], env_cfg["termination_if_roll_greater_than"]
+    f[F("TERM_ZVEL")], f[F("TERM_YVEL")] = env_cfg["termination_if_z_vel_greater_than"], env_cfg["termination_if_y_vel_greater_than"]
+    f[F("BASE_INIT_POS0"):F("BASE_INIT_POS0") + 3] = env_cfg["base_init_pos"]
+    f[F("BASE_INIT_QUAT0"):F("BASE_INIT_QUAT0") + 4] = env_cfg["base_init_quat"]
+    sc = obs_cfg["obs_scales"]
+    f[F("OBS_SCALE_LIN_VEL")], f[F("OBS_SCALE_ANG_VEL")] = sc["lin_vel"], sc["ang_vel"]
+    f[F("OBS_SCALE_DOF_POS")], f[F("OBS_SCALE_DOF_VEL")] = sc["dof_pos"], sc["dof_vel"]
+    f[F("TRACKING_SIGMA")] = reward_cfg.get("tracking_sigma", 0.25)
+    f[F("BASE_HEIGHT_TARGET")] = reward_cfg.get("base_height_target", 0.3)
+    f[F("JUMP_APEX_HEIGHT")] = reward_cfg.get("jump_apex_height", 0.0)
+    f[F("JUMP_APEX_SIGMA")] = reward_cfg.get("jump_apex_sigma", 0.05)
+    f[F("EPISODE_LENGTH_S")] = env_cfg["episode_length_s"]
+    names = list(reward_cfg["reward_scales"].keys())
+    assert len(names) <= 32
+    for k, name in enumerate(names):
+        if name not in BASE_REWARD_IDS:
+            raise AttributeError(f"'Go2Env' object has no attribute '_reward_{name}'")
+        f[F("REWARD_SCALE0") + k] = reward_cfg["reward_scales"][name] * dt
+        i[I("REWARD_ID0") + k] = C[BASE_REWARD_IDS[name]]
+    i[I("N_REWARDS")] = len(names)
+    f[F("CMD_X_LO")], f[F("CMD_X_HI")] = command_cfg["lin_vel_x_range"]
+    f[F("CMD_Y_LO")], f[F("CMD_Y_HI")] = command_cfg["lin_vel_y_range"]
+    f[F("CMD_YAW_LO")], f[F("CMD_YAW_HI")] = command_cfg["ang_vel_range"]
+    i[I("COMPOUND_COMMANDS")] = 1
+    i[I("ENV_KIND")] = 1
+    i[I("NUM_ACTIONS")], i[I("NUM_POS_ACTIONS")] = 12, 12
+    i[I("NUM_OBS")], i[I("NUM_PRIV_OBS")] = 45, 45
+    i[I("MANUAL_PD")] = 0
+    i[I("SUBSTEPS")] = 2
+    i[I("MAX_EPISODE_LENGTH")] = math.ceil(env_cfg["episode_length_s"] / dt)
+    i[I("RESAMPLE_STEPS")] = int(env_cfg["resampling_time_s"] / dt)
+    latency = 1 if env_cfg.get("simulate_action_latency", True) else 0
+    i[I("MIN_DELAY")] = i[I("MAX_DELAY")] = i[I("DELAY_EASY_MAX")] = latency     # exec_actions = last_actions (go2_env_base.py:124)
+    for k, jn in enumerate(env_cfg["joint_names"]):
+        i[I("MOTOR_DOF0") + k] = joints[jn]["dof_start"]
+    for k, ln in enumerate(["FR_calf", "FL_calf", "RR_calf", "RL_calf"]):
+        i[I("FOOT_LINK0") + k] = links[ln]
+    for k, ln in enumerate(["FR_hip", "FL_hip", "RR_hip", "RL_hip"]):
+        i[I("HIP_LINK0") + k] = links[ln]
+    robot_links = [idx for idx, l in enumerate(model["links"]) if l["entity"] == 1]
+    i[I("BASE_LINK")], i[I("PUSH_LINK")] = robot_links[0], robot_links[1]
+    i[I("CURR_UPDATE_EVERY")] = 1 << 30
+    i[I("GLOBAL_DR_INTERVAL")] = 1 << 30
+    i[I("FREEZE_CURRICULUM")] = 1
+    return f, i, names

@@ -453,7 +453,7 @@ DEV void load_model_s(ModelS* dst, const ModelS* __restrict__ src) {
   X(e_dof_pos, NM) X(e_dof_vel, NM) X(last_dof_vel, NM) X(torque, NM) X(base_pos, 3) X(base_quat, 4) X(base_lin_vel, 3) \
   X(base_ang_vel, 3) X(projected_gravity, 3) X(base_euler, 3) X(commands, 3) X(time_out, 1) X(kp_factors, NM)          \
   X(kd_factors, NM) X(motor_strength, NM) X(gravity_offset, 3) X(current_push_force, 3) X(push_stored_force, 3)       \
-  X(feet_air_time, 4) X(episode_sums, NREW) X(rew_terms, NREW) X(rew, 1) X(obs, NOBS_MAX) X(priv, NPRIV_MAX)
+  X(feet_air_time, 4) X(base_vel_world, 3) X(episode_sums, NREW) X(rew_terms, NREW) X(rew, 1) X(obs, NOBS_MAX) X(priv, NPRIV_MAX)
 
 #define GO2SIM_INT_FIELDS(X)                                                                                         \
   X(n_contacts, 1) X(c_geom, 2 * MAXC) X(n_con, 1) X(err, 1) X(is_warmstart, 1) X(first_time, 1) X(sort_ig, 2 * NG)      \
@@ -538,7 +538,7 @@ struct E {
   FA(search) FA(mv) FA(qfrc_constraint) FA(nt_vec) FA2(H, ND) FA(sv) FA3(contact_force) FA(vel_next) FA(qpos_next)
   FA(actions) FA(last_actions) FA(applied_actions) FA2(action_history, NA) FA(target_dof_pos) FA(e_dof_pos) FA(e_dof_vel) FA(last_dof_vel)
   FA(torque) FA(base_pos) FA(base_quat) FA(base_lin_vel) FA(base_ang_vel) FA(projected_gravity) FA(base_euler) FA(commands) FA(time_out)
-  FA(kp_factors) FA(kd_factors) FA(motor_strength) FA(gravity_offset) FA(current_push_force) FA(push_stored_force) FA(feet_air_time)
+  FA(kp_factors) FA(kd_factors) FA(motor_strength) FA(gravity_offset) FA(current_push_force) FA(push_stored_force) FA(feet_air_time) FA(base_vel_world)
   FA(episode_sums) FA(rew_terms) FA(rew) FA(obs) FA(priv)
   IA(n_contacts) IA(c_geom) IA(n_con) IA(err) IA(is_warmstart) IA(first_time) IA(sort_ig) IA(n_broad) IA(solver_iters) IA(ctrl_mode)
   IA(active_buf) IA(broad) IA(c_link) IA(active) IA(prev_active) IA(si) IA(gjk_fallback) IA(delay_steps) IA(episode_length) IA(reset_buf)
@@ -2792,6 +2792,15 @@ __global__ __launch_bounds__(WG) void k_env_pre(Pool P, const Model* __restrict_
   }
   auto target_dof_pos = e.target_dof_pos(); auto kp_factors = e.kp_factors(); auto kd_factors = e.kd_factors(); auto motor_strength = e.motor_strength();
   auto dof_pos = e.e_dof_pos(); auto dof_vel = e.e_dof_vel(); auto torque_ = e.torque(); auto ctrl_mode = e.ctrl_mode(); auto ctrl_force = e.ctrl_force();
+  if (!c.i[GO2SIM_IC_MANUAL_PD]) {                                   // go2_env_base.py:127: control_dofs_position (engine PD)
+    auto ctrl_pos = e.ctrl_pos(); auto ctrl_vel = e.ctrl_vel();
+    for (int i = 0; i < NM; ++i) {
+      target_dof_pos[i] = target[i];
+      int d = c.i[GO2SIM_IC_MOTOR_DOF0 + i];
+      ctrl_mode[d] = CTRL_POSITION; ctrl_pos[d] = target[i]; ctrl_vel[d] = 0.0f; ctrl_force[d] = 0.0f;
+      torque_[i] = 0.0f;
+    }
+  } else
 #pragma unroll
   for (int i = 0; i < NM; ++i) {
     target_dof_pos[i] = target[i];
@@ -2839,7 +2848,7 @@ __global__ __launch_bounds__(WG) void k_env_pre(Pool P, const Model* __restrict_
   }
 }
 
-struct RewCtx { float link_vel_xy[8], foot_z[4]; };
+struct RewCtx { float link_vel_xy[8], foot_z[4]; float vel_world[3]; int was_reset; };
 // reward terms, go2_env_walk.py:1251-1366
 DEV float reward_term(const Model& m, const DCfg& c, const E& e, int id, const RewCtx& rc) {
   const float dt = c.f[GO2SIM_FC_DT];
@@ -2899,6 +2908,37 @@ DEV float reward_term(const Model& m, const DCfg& c, const E& e, int id, const R
       }
       return s;
     }
+    // ---- go2_env_base.py:246-390 (crouch / jump) ----
+    case GO2SIM_R_JUMP_IMPULSE: { float gate = (e.base_pos()[2] < 0.50f) ? 1.0f : 0.0f; return gate * fmx(blv[2], 0.0f); }
+    case GO2SIM_R_JUMP_APEX: { float q = (e.base_pos()[2] - c.f[GO2SIM_FC_JUMP_APEX_HEIGHT]) / c.f[GO2SIM_FC_JUMP_APEX_SIGMA]; return dm_exp(-(q * q)); }
+    case GO2SIM_R_XY_STABILITY: { float vx = rc.vel_world[0], vy = rc.vel_world[1]; return -(vx * vx + vy * vy); }
+    case GO2SIM_R_ORIENTATION: return -e.projected_gravity()[2];
+    case GO2SIM_R_NO_SHAKE: { float a = bav[0], b2 = bav[1], c3 = bav[2]; return -((a * a + b2 * b2) + c3 * c3) / 1.0f; }
+    case GO2SIM_R_CROUCH: return (e.base_pos()[2] < 0.25f) ? 1.0f : 0.0f;
+    case GO2SIM_R_CROUCH_2: { float z = e.base_pos()[2]; return (z <= 0.30f && z >= 0.20f) ? 1.0f : 0.0f; }
+    case GO2SIM_R_GROUND_PENALTY: { float v = (0.15f - e.base_pos()[2]) / 0.1f; v = fmn(fmx(v, 0.0f), 1.0f); return -(v * v); }
+    case GO2SIM_R_CROUCH_TARGET: { float q = (e.base_pos()[2] - 0.15f) / 0.03f; return dm_exp(-(q * q)); }
+    case GO2SIM_R_NO_FALL: { float dn = fmx(-blv[2] - 0.5f, 0.0f); return -(dn * dn); }
+    case GO2SIM_R_Y_STABILITY: { float vy = rc.vel_world[1]; return -(vy * vy); }
+    case GO2SIM_R_TORQUE_LOAD_BASE: {                                  // get_dofs_control_force of the current state, accessor.py:848-875
+      float s = 0.0f; auto ctrl_mode = e.ctrl_mode(); auto cf = e.ctrl_force(); auto cp = e.ctrl_pos(); auto cv = e.ctrl_vel(); auto vel = e.vel(); auto sdp = e.dof_pos();
+      for (int i = 0; i < NM; ++i) {
+        int d = c.i[GO2SIM_IC_MOTOR_DOF0 + i];
+        const Dof& D = m.dofs[d];
+        // a freshly reset env has (qpos0 + default) - qpos0 and zero velocity once its FK refresh has run (it follows this kernel)
+        float pos_d = rc.was_reset ? ((m.qpos0[d + 1] + dof_pos[i]) - m.qpos0[d + 1]) : sdp[d];
+        float vel_d = rc.was_reset ? 0.0f : vel[d];
+        float force = 0.0f;
+        int cm = ctrl_mode[d];
+        if (cm == CTRL_FORCE) force = cf[d];
+        else if (cm == CTRL_VELOCITY) force = D.kv * (cv[d] - vel_d);
+        else if (cm == CTRL_POSITION) force = D.kp * (cp[d] - pos_d) + D.kv * (cv[d] - vel_d);
+        s = s + dm_abs(clampf(force, D.force_range[0], D.force_range[1]));
+      }
+      return -0.001f * s;
+    }
+    case GO2SIM_R_CROUCH_PROGRESS: return fmx(0.35f - e.base_pos()[2], 0.0f);
+    case GO2SIM_R_CROUCH_SPEED: return -(blv[2] * blv[2]);
   }
   return 0.0f;
 }
@@ -2927,6 +2967,7 @@ __global__ __launch_bounds__(WG) void k_env_post_a(Pool P, const Model* __restri
   V3 rcom = e.root_com()[bl];
   V3 cda = e.cd_ang()[bl];
   V3 velw = (V3)e.cd_vel()[bl] + cross(cda, bp - rcom);
+  { auto bvw = e.base_vel_world(); bvw[0] = velw.x; bvw[1] = velw.y; bvw[2] = velw.z; }
   V3 blv = tc_transform_by_quat(velw, inv_bq), bav = tc_transform_by_quat(cda, inv_bq);
   V3 pg = tc_transform_by_quat(v3(0.0f, 0.0f, -1.0f), inv_bq);
   auto o_blv = e.base_lin_vel(); auto o_bav = e.base_ang_vel(); auto o_pg = e.projected_gravity();
@@ -2935,7 +2976,7 @@ __global__ __launch_bounds__(WG) void k_env_post_a(Pool P, const Model* __restri
   o_pg[0] = pg.x; o_pg[1] = pg.y; o_pg[2] = pg.z;
   auto dof_pos = e.e_dof_pos(); auto dof_vel = e.e_dof_vel(); auto sdof_pos = e.dof_pos(); auto vel = e.vel();
   for (int i = 0; i < NM; ++i) { int d = c.i[GO2SIM_IC_MOTOR_DOF0 + i]; dof_pos[i] = sdof_pos[d]; dof_vel[i] = vel[d]; }
-  RewCtx rc;
+  RewCtx rc; rc.was_reset = 0; rc.vel_world[0] = velw.x; rc.vel_world[1] = velw.y; rc.vel_world[2] = velw.z;
   auto fc = e.foot_contact(); auto lfc = e.last_foot_contact();
   for (int i = 0; i < 4; ++i) {
     int l = c.i[GO2SIM_IC_FOOT_LINK0 + i];
@@ -2966,20 +3007,24 @@ __global__ __launch_bounds__(WG) void k_env_post_a(Pool P, const Model* __restri
   auto rew_terms = e.rew_terms(); auto episode_sums = e.episode_sums();
   int nrew = c.i[GO2SIM_IC_N_REWARDS];
   float tracking_int = 0.0f;
+  const bool base_env = c.i[GO2SIM_IC_ENV_KIND] == 1;               // base env: rewards follow the reset (k_env_post_b_team)
   for (int k = 0; k < nrew; ++k) {
     int id = c.i[GO2SIM_IC_REWARD_ID0 + k];
-    float r = reward_term(m, c, e, id, rc) * c.f[GO2SIM_FC_REWARD_SCALE0 + k];
-    rew_terms[k] = r;
-    rew = rew + r;
-    float es = episode_sums[k] + r;
-    episode_sums[k] = es;
+    float es = episode_sums[k];
+    if (!base_env) {
+      float r = reward_term(m, c, e, id, rc) * c.f[GO2SIM_FC_REWARD_SCALE0 + k];
+      rew_terms[k] = r;
+      rew = rew + r;
+      es = es + r;
+      episode_sums[k] = es;
+    }
     if (id == GO2SIM_R_TRACKING_LIN_VEL || id == GO2SIM_R_TRACKING_ANG_VEL) tracking_int = tracking_int + es;
   }
-  e.rew()[0] = rew;
+  if (!base_env) e.rew()[0] = rew;
   if (rst) {
     float ep_steps = fmx((float)ep_len, 1.0f);
     float ep_seconds = ep_steps * c.f[GO2SIM_FC_DT];
-    for (int k = 0; k < nrew; ++k) atomicAdd(&acc->ep[k], (double)(episode_sums[k] / ep_seconds));
+    for (int k = 0; k < nrew; ++k) atomicAdd(&acc->ep[k], base_env ? (double)episode_sums[k] : (double)(episode_sums[k] / ep_seconds));
     atomicAdd(&acc->tracking, (double)(tracking_int / ep_seconds));
     atomicAdd(&acc->timeouts, (double)time_out);
     atomicAdd(&acc->n_reset_now, 1);
@@ -3054,7 +3099,8 @@ __global__ void k_env_globals(const DCfg* __restrict__ cp, Glob* gp, Acc* acc, u
     if (c.i[GO2SIM_IC_HAS_LEGM_DR])
       for (int k = 0; k < 4; ++k) g.leg_mass_shift[k] = rand_float(lerp_lo(c, GO2SIM_FC_LEGM_EASY_LO, ts), lerp_hi(c, GO2SIM_FC_LEGM_EASY_LO, ts), r2.v[k]);
     g.last_reset_count = n;
-    for (int k = 0; k < NREW; ++k) g.last_episode_rew[k] = (float)(acc->ep[k] / (double)n);
+    for (int k = 0; k < NREW; ++k)
+      g.last_episode_rew[k] = (c.i[GO2SIM_IC_ENV_KIND] == 1) ? (float)((double)(float)(acc->ep[k] / (double)n) / (double)c.f[GO2SIM_FC_EPISODE_LENGTH_S]) : (float)(acc->ep[k] / (double)n);
     g.reset_calls += 1;
     // consumed: clear the accumulators for the next reset call (they are only ever non-zero when n > 0)
     acc->timeouts = 0.0; acc->tracking = 0.0; acc->n_reset_now = 0;
@@ -3175,6 +3221,43 @@ __global__ __launch_bounds__(64) void k_env_post_b_team(Pool P, const Model* __r
     team_sync();
   }
   const int na = c.i[GO2SIM_IC_NUM_ACTIONS], nobs = c.i[GO2SIM_IC_NUM_OBS], npriv = c.i[GO2SIM_IC_NUM_PRIV_OBS];
+  if (c.i[GO2SIM_IC_ENV_KIND] == 1) {                                  // go2_env_base.py:165-196: rewards after the reset, 45 observations
+    if (tl == 0) {
+      RewCtx rc; rc.was_reset = was_reset;
+      auto bvw = e.base_vel_world();
+      for (int k = 0; k < 3; ++k) rc.vel_world[k] = was_reset ? 0.0f : bvw[k];    // get_vel() after zero_all_dofs_velocity
+      float rew = 0.0f;
+      auto rew_terms = e.rew_terms(); auto episode_sums = e.episode_sums();
+      for (int k = 0; k < c.i[GO2SIM_IC_N_REWARDS]; ++k) {
+        float r = reward_term(m, c, e, c.i[GO2SIM_IC_REWARD_ID0 + k], rc) * c.f[GO2SIM_FC_REWARD_SCALE0 + k];
+        rew_terms[k] = r;
+        rew = rew + r;
+        episode_sums[k] = episode_sums[k] + r;
+      }
+      e.rew()[0] = rew;
+    }
+    team_sync();
+    for (int i = tl; i < nobs; i += T) {
+      float v;
+      if (i < 3) v = gload(e, FO(base_ang_vel), i) * c.f[GO2SIM_FC_OBS_SCALE_ANG_VEL];
+      else if (i < 6) v = gload(e, FO(projected_gravity), i - 3);
+      else if (i < 9) v = gload(e, FO(commands), i - 6) * ((i - 6 < 2) ? c.f[GO2SIM_FC_OBS_SCALE_LIN_VEL] : c.f[GO2SIM_FC_OBS_SCALE_ANG_VEL]);
+      else if (i < 21) v = (gload(e, FO(e_dof_pos), i - 9) - c.f[GO2SIM_FC_DEFAULT_DOF_POS0 + i - 9]) * c.f[GO2SIM_FC_OBS_SCALE_DOF_POS];
+      else if (i < 33) v = gload(e, FO(e_dof_vel), i - 21) * c.f[GO2SIM_FC_OBS_SCALE_DOF_VEL];
+      else v = (i - 33 < na) ? gload(e, FO(actions), i - 33) : gload(e, FO(obs), i);
+      gstore(e, FO(obs), i, v); gstore(e, FO(priv), i, v);
+      if (obs_out) obs_out[(size_t)b * nobs + i] = v;
+      if (priv_out && i < npriv) priv_out[(size_t)b * npriv + i] = v;
+    }
+    for (int i = tl; i < na; i += T) gstore(e, FO(last_actions), i, gload(e, FO(actions), i));
+    for (int i = tl; i < NM; i += T) gstore(e, FO(last_dof_vel), i, gload(e, FO(e_dof_vel), i));
+    if (tl == 0) {
+      if (rew_out) rew_out[b] = e.rew()[0];
+      if (reset_out) reset_out[b] = (uint8_t)was_reset;
+      if (timeout_out) timeout_out[b] = e.time_out()[0];
+    }
+    return;
+  }
   const bool noisy = c.i[GO2SIM_IC_HAS_OBS_NOISE] && c.f[GO2SIM_FC_OBS_NOISE_LEVEL_MAX] > 0.0f;
   const float lvl = g.obs_noise_level_cur;
   for (int blk = tl; blk * 4 < nobs; blk += T) {
@@ -3581,6 +3664,7 @@ int go2sim_set_dof_gains(go2sim_t* h, int d, float kp, float kv, float flo, floa
   if (!h || d < 0 || d >= ND) return GO2SIM_E_BADARG;
   h->hm.dofs[d].kp = kp; h->hm.dofs[d].kv = kv; h->hm.dofs[d].force_range[0] = flo; h->hm.dofs[d].force_range[1] = fhi;
   HIPCHK(hipMemcpy(&h->dm->dofs[d], &h->hm.dofs[d], sizeof(Dof), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(&h->dms->dofs[d], &h->hm.dofs[d], sizeof(Dof), hipMemcpyHostToDevice));
   return GO2SIM_E_OK;
 }
 int go2sim_check_errno(go2sim_t* h, int* out, void* stream) {
@@ -3621,6 +3705,7 @@ int go2sim_env_configure(go2sim_t* h, const float* f, int nf, const int* i, int 
     if (c.i[GO2SIM_IC_MANUAL_PD]) { h->hm.dofs[d].kp = 0.0f; h->hm.dofs[d].kv = 0.0f; } else { h->hm.dofs[d].kp = c.f[GO2SIM_FC_KP]; h->hm.dofs[d].kv = c.f[GO2SIM_FC_KD]; }
   }
   HIPCHK(hipMemcpy(h->dm, &h->hm, sizeof(Model), hipMemcpyHostToDevice));
+  { ModelS hs; if (!build_model_s(h->hm, hs)) return GO2SIM_E_BADMODEL; HIPCHK(hipMemcpy(h->dms, &hs, sizeof(ModelS), hipMemcpyHostToDevice)); }
   HIPCHK(hipDeviceSynchronize());
   h->step_count = 0; h->action_write_idx = 0; h->cfg_set = true;
   return GO2SIM_E_OK;

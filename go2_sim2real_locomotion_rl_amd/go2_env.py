@@ -22,7 +22,7 @@ import math
 import torch
 
 from .capi import C, EnvGlobals, Go2Sim, Go2SimError, load_hip_lib
-from .configs import flatten_walk_cfg
+from .configs import flatten_base_cfg, flatten_walk_cfg
 from .model_blob import pack_model
 
 _DEVICE = None
@@ -81,19 +81,26 @@ class Go2Env:
 
         dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
         self._sim = Go2Sim(load_hip_lib(), pack_model(), num_envs, dev_index, _SEED if seed is None else int(seed))
-        fcfg, icfg, self._reward_names = flatten_walk_cfg(num_envs, env_cfg, obs_cfg, reward_cfg, command_cfg,
-                                                          freeze_curriculum=freeze_curriculum)
-        if self.num_obs != 49 or self.num_privileged_obs not in (None, 104) or self.num_actions != 16:
-            raise Go2SimError("go2sim implements the walk observation layout (49 / 104) with 16 actions (go2_train_walk.py:300-320)")
+        # the two env families of the reference: walk (go2_env_walk.py: 16 actions, 49 / 104 obs) and base (go2_env_base.py: 12 / 45)
+        self.is_base_env = self.num_obs == 45 and self.num_actions == 12
+        if self.is_base_env:
+            fcfg, icfg, self._reward_names = flatten_base_cfg(num_envs, env_cfg, obs_cfg, reward_cfg, command_cfg)
+            self.num_privileged_obs = None
+        else:
+            fcfg, icfg, self._reward_names = flatten_walk_cfg(num_envs, env_cfg, obs_cfg, reward_cfg, command_cfg,
+                                                              freeze_curriculum=freeze_curriculum)
+            if self.num_obs != 49 or self.num_privileged_obs not in (None, 104) or self.num_actions != 16:
+                raise Go2SimError("go2sim implements the walk layout (16 actions, 49 / 104 obs; go2_train_walk.py:300-320) and the base layout "
+                                  "(12 actions, 45 obs; go2_train_crouch.py / go2_train_jump.py)")
         self._sim.env_configure(fcfg, icfg)
 
         B, dev = num_envs, self.device
-        self.obs_buf = torch.zeros(B, 49, device=dev)
-        self.privileged_obs_buf = torch.zeros(B, 104, device=dev)
+        self.obs_buf = torch.zeros(B, self.num_obs, device=dev)
+        self.privileged_obs_buf = torch.zeros(B, 45 if self.is_base_env else 104, device=dev)
         self.rew_buf = torch.zeros(B, device=dev)
         self.reset_buf = torch.zeros(B, dtype=torch.uint8, device=dev)
         self._time_outs = torch.zeros(B, device=dev)
-        self._actions = torch.zeros(B, 16, device=dev)
+        self._actions = torch.zeros(B, self.num_actions, device=dev)
         self.extras = {"observations": {}}
         # live device view of the curriculum / DR globals and the last reset's episode log
         gptr = self._sim.env_globals_ptr()

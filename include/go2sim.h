@@ -162,10 +162,12 @@ enum go2sim_fcfg {
   GO2SIM_FC_CURR_READY_TIMEOUT_RATE, GO2SIM_FC_CURR_READY_TRACKING, GO2SIM_FC_CURR_READY_FALL_RATE,
   GO2SIM_FC_CURR_HARD_FALL_RATE, GO2SIM_FC_CURR_STEP_UP, GO2SIM_FC_CURR_STEP_DOWN,
   GO2SIM_FC_CURR_MIX_PROB_CURRENT, GO2SIM_FC_CURR_MIX_LEVEL_LOW, GO2SIM_FC_CURR_MIX_LEVEL_HIGH,
+  /* base env (go2_env_base.py): episode-log normalisation and jump rewards */
+  GO2SIM_FC_EPISODE_LENGTH_S, GO2SIM_FC_JUMP_APEX_HEIGHT, GO2SIM_FC_JUMP_APEX_SIGMA,
   GO2SIM_FC_COUNT
 };
 enum go2sim_icfg {
-  GO2SIM_IC_ENV_KIND = 0, /* 0 = walk (go2_env_walk.py) */
+  GO2SIM_IC_ENV_KIND = 0, /* 0 = walk (go2_env_walk.py), 1 = base (go2_env_base.py: crouch / jump; engine PD, reset before reward, 45 obs) */
   GO2SIM_IC_NUM_ACTIONS, GO2SIM_IC_NUM_POS_ACTIONS, GO2SIM_IC_NUM_OBS, GO2SIM_IC_NUM_PRIV_OBS,
   GO2SIM_IC_PLS_ENABLE, GO2SIM_IC_MANUAL_PD, GO2SIM_IC_SUBSTEPS,
   GO2SIM_IC_MAX_EPISODE_LENGTH, GO2SIM_IC_RESAMPLE_STEPS,
@@ -192,7 +194,12 @@ enum go2sim_reward {
   GO2SIM_R_ACTION_RATE, GO2SIM_R_SIMILAR_TO_DEFAULT, GO2SIM_R_ORIENTATION_PENALTY, GO2SIM_R_DOF_ACC,
   GO2SIM_R_DOF_VEL, GO2SIM_R_ANG_VEL_XY, GO2SIM_R_FEET_AIR_TIME, GO2SIM_R_FOOT_SLIP, GO2SIM_R_FOOT_CLEARANCE,
   GO2SIM_R_JOINT_TRACKING, GO2SIM_R_ENERGY, GO2SIM_R_TORQUE_LOAD, GO2SIM_R_STAND_STILL, GO2SIM_R_STAND_STILL_VEL,
-  GO2SIM_R_FEET_STANCE, GO2SIM_R_COUNT
+  GO2SIM_R_FEET_STANCE,
+  /* reward terms of go2_env_base.py:246-390 (crouch / jump tasks) */
+  GO2SIM_R_JUMP_IMPULSE, GO2SIM_R_JUMP_APEX, GO2SIM_R_XY_STABILITY, GO2SIM_R_ORIENTATION, GO2SIM_R_NO_SHAKE, GO2SIM_R_CROUCH,
+  GO2SIM_R_CROUCH_2, GO2SIM_R_GROUND_PENALTY, GO2SIM_R_CROUCH_TARGET, GO2SIM_R_NO_FALL, GO2SIM_R_Y_STABILITY, GO2SIM_R_TORQUE_LOAD_BASE,
+  GO2SIM_R_CROUCH_PROGRESS, GO2SIM_R_CROUCH_SPEED,
+  GO2SIM_R_COUNT
 };
 
 /* env-level buffers readable with go2sim_env_get (row-major [n_envs][k], device pointers) */

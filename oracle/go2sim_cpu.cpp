@@ -1661,6 +1661,7 @@ struct EnvBuf {
   real target_dof_pos[NM], dof_pos[NM], dof_vel[NM], last_dof_vel[NM], torque[NM];
   real base_pos[3], base_quat[4], base_lin_vel[3], base_ang_vel[3], projected_gravity[3], base_euler[3];
   real commands[3]; int episode_length, reset_buf; real time_out;
+  real base_vel_world[3];   // robot.get_vel() (world frame), used by the base-env rewards
   real kp_factors[NM], kd_factors[NM], motor_strength[NM], gravity_offset[3], current_push_force[3];
   real push_stored_force[3]; int push_remaining;
   int foot_contact[4], last_foot_contact[4]; real feet_air_time[4];
@@ -1834,6 +1835,13 @@ void env_pre(go2sim* h, int b, const real* actions) {
   } else {
     for (int i = 0; i < NM; ++i) { eff_kp[i] = c.f[GO2SIM_FC_KP] * x.kp_factors[i]; eff_kd[i] = c.f[GO2SIM_FC_KD] * x.kd_factors[i]; }
   }
+  if (!c.i[GO2SIM_IC_MANUAL_PD]) {                                                      // go2_env_base.py:127: control_dofs_position (engine PD)
+    for (int i = 0; i < NM; ++i) {
+      int d = c.i[GO2SIM_IC_MOTOR_DOF0 + i];
+      e.ctrl_mode[d] = CTRL_POSITION; e.ctrl_pos[d] = target[i]; e.ctrl_vel[d] = 0.0f; e.ctrl_force[d] = 0.0f;
+      x.torque[i] = 0.0f;
+    }
+  } else
   for (int i = 0; i < NM; ++i) {                                                       // :1012-1019
     real pos_error = target[i] - x.dof_pos[i];
     real torque = eff_kp[i] * pos_error - eff_kd[i] * x.dof_vel[i];
@@ -1865,6 +1873,8 @@ void env_pre(go2sim* h, int b, const real* actions) {
   }
 }
 
+inline real fmaxr(real a, real b) { return (a < b) ? b : a; }   // torch.clamp(min=) on non-NaN input
+inline real fminr(real a, real b) { return (b < a) ? b : a; }
 inline real reward_term(const go2sim* h, int b, int id, const real* link_vel_xy /*[4][2]*/, const real* foot_z) {
   const Cfg& c = h->cfg; const Env& e = h->envs[b]; EnvBuf& x = const_cast<EnvBuf&>(h->eb[b]);
   const real dt = c.f[GO2SIM_FC_DT];
@@ -1929,6 +1939,33 @@ inline real reward_term(const go2sim* h, int b, int id, const real* link_vel_xy 
       }
       return s;
     }
+    // ---- go2_env_base.py:246-390 (crouch / jump) ----
+    case GO2SIM_R_JUMP_IMPULSE: { real gate = (x.base_pos[2] < 0.50f) ? 1.0f : 0.0f; return gate * fmaxr(x.base_lin_vel[2], 0.0f); }
+    case GO2SIM_R_JUMP_APEX: { real q = (x.base_pos[2] - c.f[GO2SIM_FC_JUMP_APEX_HEIGHT]) / c.f[GO2SIM_FC_JUMP_APEX_SIGMA]; return dm_exp(-(q * q)); }
+    case GO2SIM_R_XY_STABILITY: return -(x.base_vel_world[0] * x.base_vel_world[0] + x.base_vel_world[1] * x.base_vel_world[1]);
+    case GO2SIM_R_ORIENTATION: return -x.projected_gravity[2];
+    case GO2SIM_R_NO_SHAKE: return -((x.base_ang_vel[0] * x.base_ang_vel[0] + x.base_ang_vel[1] * x.base_ang_vel[1]) + x.base_ang_vel[2] * x.base_ang_vel[2]) / 1.0f;
+    case GO2SIM_R_CROUCH: return (x.base_pos[2] < 0.25f) ? 1.0f : 0.0f;
+    case GO2SIM_R_CROUCH_2: return (x.base_pos[2] <= 0.30f && x.base_pos[2] >= 0.20f) ? 1.0f : 0.0f;
+    case GO2SIM_R_GROUND_PENALTY: { real v = (0.15f - x.base_pos[2]) / 0.1f; v = fminr(fmaxr(v, 0.0f), 1.0f); return -(v * v); }
+    case GO2SIM_R_CROUCH_TARGET: { real q = (x.base_pos[2] - 0.15f) / 0.03f; return dm_exp(-(q * q)); }
+    case GO2SIM_R_NO_FALL: { real dn = fmaxr(-x.base_lin_vel[2] - 0.5f, 0.0f); return -(dn * dn); }
+    case GO2SIM_R_Y_STABILITY: return -(x.base_vel_world[1] * x.base_vel_world[1]);
+    case GO2SIM_R_TORQUE_LOAD_BASE: {                                                    // get_dofs_control_force of the current state, accessor.py:848-875
+      real s = 0.0f;
+      for (int i = 0; i < NM; ++i) {
+        int d = c.i[GO2SIM_IC_MOTOR_DOF0 + i];
+        const Dof& D = h->m.dofs[d];
+        real force = 0.0f;
+        if (e.ctrl_mode[d] == CTRL_FORCE) force = e.ctrl_force[d];
+        else if (e.ctrl_mode[d] == CTRL_VELOCITY) force = D.kv * (e.ctrl_vel[d] - e.vel[d]);
+        else if (e.ctrl_mode[d] == CTRL_POSITION) force = D.kp * (e.ctrl_pos[d] - e.dof_pos[d]) + D.kv * (e.ctrl_vel[d] - e.vel[d]);
+        s = s + dm_abs(clampf(force, D.force_range[0], D.force_range[1]));
+      }
+      return -0.001f * s;
+    }
+    case GO2SIM_R_CROUCH_PROGRESS: return fmaxr(0.35f - x.base_pos[2], 0.0f);
+    case GO2SIM_R_CROUCH_SPEED: return -(x.base_lin_vel[2] * x.base_lin_vel[2]);
   }
   return 0.0f;
 }
@@ -1947,6 +1984,7 @@ void env_post_a(go2sim* h, int b) {
   x.base_euler[0] = eul.x; x.base_euler[1] = eul.y; x.base_euler[2] = eul.z;
   Q4 inv_bq = inv_quat(bq);
   V3 vel = e.cd_vel[bl] + cross(e.cd_ang[bl], e.l_pos[bl] - e.root_com[bl]);             // get_vel: kernel_get_links_vel ref=link_origin
+  x.base_vel_world[0] = vel.x; x.base_vel_world[1] = vel.y; x.base_vel_world[2] = vel.z;
   V3 blv = tc_transform_by_quat(vel, inv_bq), bav = tc_transform_by_quat(e.cd_ang[bl], inv_bq);
   V3 pg = tc_transform_by_quat(v3(0.0f, 0.0f, -1.0f), inv_bq);
   x.base_lin_vel[0] = blv.x; x.base_lin_vel[1] = blv.y; x.base_lin_vel[2] = blv.z;
@@ -1976,6 +2014,7 @@ void env_post_a(go2sim* h, int b) {
   rst |= dm_abs(x.base_lin_vel[1]) > c.f[GO2SIM_FC_TERM_YVEL];
   x.reset_buf = rst;
   x.time_out = (x.episode_length > maxlen) ? 1.0f : 0.0f;
+  if (c.i[GO2SIM_IC_ENV_KIND] == 1) return;                                              // base env: rewards follow the reset (go2_env_base.py:165-172)
   x.rew = 0.0f;                                                                          // :1072-1077
   for (int k = 0; k < c.i[GO2SIM_IC_N_REWARDS]; ++k) {
     real r = reward_term(h, b, c.i[GO2SIM_IC_REWARD_ID0 + k], link_vel_xy, foot_z) * c.f[GO2SIM_FC_REWARD_SCALE0 + k];
@@ -1994,7 +2033,8 @@ void env_reset_stats(go2sim* h, int b) {
   for (int k = 0; k < c.i[GO2SIM_IC_N_REWARDS]; ++k) {
     int id = c.i[GO2SIM_IC_REWARD_ID0 + k];
     if (id == GO2SIM_R_TRACKING_LIN_VEL || id == GO2SIM_R_TRACKING_ANG_VEL) tracking_int = tracking_int + x.episode_sums[k];
-    h->acc_ep[k] += (double)(x.episode_sums[k] / ep_seconds);
+    if (c.i[GO2SIM_IC_ENV_KIND] == 1) h->acc_ep[k] += (double)x.episode_sums[k];          // go2_env_base.py:232-236: mean(sum) / episode_length_s
+    else h->acc_ep[k] += (double)(x.episode_sums[k] / ep_seconds);
   }
   h->acc_tracking += (double)(tracking_int / ep_seconds);
   h->acc_timeouts += (double)x.time_out;
@@ -2044,7 +2084,8 @@ void env_globals_update(go2sim* h, bool count_push) {
     if (c.i[GO2SIM_IC_HAS_LEGM_DR])                                                        // _randomize_leg_mass :834-848
       for (int k = 0; k < 4; ++k) g.leg_mass_shift[k] = rand_float(lerp_lo(c, GO2SIM_FC_LEGM_EASY_LO, ts), lerp_hi(c, GO2SIM_FC_LEGM_EASY_LO, ts), r2.v[k]);
     g.last_reset_count = n;
-    for (int k = 0; k < NREW; ++k) g.last_episode_rew[k] = (float)(h->acc_ep[k] / (double)n);
+    for (int k = 0; k < NREW; ++k)
+      g.last_episode_rew[k] = (c.i[GO2SIM_IC_ENV_KIND] == 1) ? (float)((double)(float)(h->acc_ep[k] / (double)n) / (double)c.f[GO2SIM_FC_EPISODE_LENGTH_S]) : (float)(h->acc_ep[k] / (double)n);
     g.reset_calls += 1;
   }
 }
@@ -2131,6 +2172,28 @@ void env_post_b(go2sim* h, int b, real* obs, real* priv) {
   const int na = c.i[GO2SIM_IC_NUM_ACTIONS], nobs = c.i[GO2SIM_IC_NUM_OBS], npriv = c.i[GO2SIM_IC_NUM_PRIV_OBS];
   real* o = x.obs;
   const real cs[3] = {c.f[GO2SIM_FC_OBS_SCALE_LIN_VEL], c.f[GO2SIM_FC_OBS_SCALE_LIN_VEL], c.f[GO2SIM_FC_OBS_SCALE_ANG_VEL]};
+  if (c.i[GO2SIM_IC_ENV_KIND] == 1) {                                                       // go2_env_base.py:165-196
+    if (x.reset_buf) { x.base_vel_world[0] = x.base_vel_world[1] = x.base_vel_world[2] = 0.0f; }   // get_vel() after zero_all_dofs_velocity
+    x.rew = 0.0f;
+    for (int k = 0; k < c.i[GO2SIM_IC_N_REWARDS]; ++k) {
+      real r = reward_term(h, b, c.i[GO2SIM_IC_REWARD_ID0 + k], nullptr, nullptr) * c.f[GO2SIM_FC_REWARD_SCALE0 + k];
+      x.rew_terms[k] = r;
+      x.rew = x.rew + r;
+      x.episode_sums[k] = x.episode_sums[k] + r;
+    }
+    for (int k = 0; k < 3; ++k) o[k] = x.base_ang_vel[k] * c.f[GO2SIM_FC_OBS_SCALE_ANG_VEL];
+    for (int k = 0; k < 3; ++k) o[3 + k] = x.projected_gravity[k];
+    for (int k = 0; k < 3; ++k) o[6 + k] = x.commands[k] * cs[k];
+    for (int i = 0; i < NM; ++i) o[9 + i] = (x.dof_pos[i] - c.f[GO2SIM_FC_DEFAULT_DOF_POS0 + i]) * c.f[GO2SIM_FC_OBS_SCALE_DOF_POS];
+    for (int i = 0; i < NM; ++i) o[21 + i] = x.dof_vel[i] * c.f[GO2SIM_FC_OBS_SCALE_DOF_VEL];
+    for (int i = 0; i < na; ++i) o[33 + i] = x.actions[i];
+    for (int i = 0; i < nobs; ++i) x.priv[i] = o[i];
+    for (int i = 0; i < na; ++i) x.last_actions[i] = x.actions[i];
+    for (int i = 0; i < NM; ++i) x.last_dof_vel[i] = x.dof_vel[i];
+    if (obs) for (int i = 0; i < nobs; ++i) obs[i] = o[i];
+    if (priv) for (int i = 0; i < npriv; ++i) priv[i] = x.priv[i];
+    return;
+  }
   for (int k = 0; k < 3; ++k) o[k] = x.base_ang_vel[k] * c.f[GO2SIM_FC_OBS_SCALE_ANG_VEL];
   for (int k = 0; k < 3; ++k) o[3 + k] = x.projected_gravity[k] + x.gravity_offset[k];
   for (int k = 0; k < 3; ++k) o[6 + k] = x.commands[k] * cs[k];
