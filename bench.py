@@ -104,6 +104,10 @@ def main():
             raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run --nproc-per-node N")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU (the product has no CPU fallback)")
+    # rehearsal knobs for a one-GPU box (never set by the driver): all ranks on device 0 and a gloo process group
+    rehearsal = os.environ.get("GO2SIM_BENCH_REHEARSAL", "0") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
@@ -111,8 +115,12 @@ def main():
         import torch.distributed as dist_mod
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist_mod.init_process_group(backend="nccl", device_id=device)
+        if rehearsal:
+            dist_mod.init_process_group(backend="gloo")
+        else:
+            dist_mod.init_process_group(backend="nccl", device_id=device)
         dist = dist_mod
+    coll_device = torch.device("cpu") if rehearsal else device
 
     B = args.envs_per_gpu
     sim = Go2Sim(load_hip_lib(), pack_model(), B, local_rank, 1 + rank)
@@ -124,7 +132,7 @@ def main():
     obs = torch.zeros(B, 49, device=device); priv = torch.zeros(B, 104, device=device)
     rew = torch.zeros(B, device=device); rst = torch.zeros(B, dtype=torch.uint8, device=device); to = torch.zeros(B, device=device)
     stats = torch.zeros(3, device=device)
-    gathered = torch.zeros(3 * world, device=device) if world > 1 else None
+    gathered = torch.zeros(3 * world, device=coll_device) if world > 1 else None
     stream = torch.cuda.current_stream().cuda_stream
 
     def step(s):
@@ -132,7 +140,7 @@ def main():
         if world > 1 and (s + 1) % ROLLOUT_LEN == 0:
             # rollout advantage-normalisation statistics: [sum, sum of squares, count] per rank, all-gathered over xGMI
             stats[0] = rew.sum(); stats[1] = (rew * rew).sum(); stats[2] = float(B)
-            dist.all_gather_into_tensor(gathered, stats)
+            dist.all_gather_into_tensor(gathered, stats.to(coll_device))
 
     for s in range(W):
         step(s)
@@ -149,7 +157,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        tt = torch.tensor([elapsed], device=coll_device, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     errno = sim.check_errno()
