@@ -432,22 +432,13 @@ DEV void load_model_s(ModelS* dst, const ModelS* __restrict__ src) {
 // SoA state pool.  X(name, floats_per_env).  Order of the first group matches enum go2sim_field so
 // that go2sim_get_field / go2sim_set_field are plain device copies.
 // ---------------------------------------------------------------------------------------------
+// Two pools.  SoA rows [feature][n_envs] hold what the lane-per-env Go2Env kernels touch (coalesced across envs); the AoS records
+// [n_envs][record] hold the physics-internal arrays that only the team kernels (and the field API) touch: the lanes of a team then
+// read / write consecutive words of one record (coalesced across the team) instead of one 64-byte sector per word.
 #define GO2SIM_FLOAT_FIELDS(X)                                                                                       \
-  X(qpos, NQ) X(vel, ND) X(acc, ND) X(qacc_ws, ND) X(ctrl_force, ND) X(ext, NL * 6) X(mass_shift, NL) X(com_shift, NL * 3) \
+  X(qpos, NQ) X(vel, ND) X(ctrl_force, ND) X(ext, NL * 6) X(mass_shift, NL) X(com_shift, NL * 3)                        \
   X(friction_ratio, NG) X(l_pos, NL * 3) X(l_quat, NL * 4) X(cd_vel, NL * 3) X(cd_ang, NL * 3) X(root_com, NL * 3)     \
-  X(contact_force, NL * 3) X(mass_mat, ND * ND) X(qf_smooth, ND) X(acc_smooth, ND) X(c_pos, MAXC * 3) X(c_normal, MAXC * 3) \
-  X(c_pen, MAXC) X(normal_cache, NPAIR * 3) X(sort_value, 2 * NG) X(geom_friction, NG) X(efc_force, MAXR)               \
-  X(qfrc_constraint, ND)                                                                                             \
-  X(ctrl_pos, ND) X(ctrl_vel, ND) X(i_pos, NL * 3) X(i_quat, NL * 4) X(cinr_inertial, NL * 9) X(cinr_pos, NL * 3)       \
-  X(cinr_mass, NL) X(xanchor, NJ * 3) X(xaxis, NJ * 3) X(dof_pos, ND) X(cdof_ang, ND * 3) X(cdof_vel, ND * 3)            \
-  X(cdofd_ang, ND * 3) X(cdofd_vel, ND * 3) X(g_pos, NG * 3) X(g_quat, NG * 4) X(aabb_min, NG * 3) X(aabb_max, NG * 3)  \
-  X(crb_inertial, NL * 9) X(crb_pos, NL * 3) X(crb_mass, NL) X(f_ang, ND * 3) X(f_vel, ND * 3) X(mass_L, ND * ND)      \
-  X(mass_Dinv, ND) X(qf_applied, ND) X(qf_passive, ND) X(force, ND) X(cdd_vel, NL * 3) X(cdd_ang, NL * 3)              \
-  X(cfrc_vel, NL * 3) X(cfrc_ang, NL * 3) X(c_friction, MAXC) X(c_sol, MAXC * 7) X(c_force, MAXC * 3)                  \
-  X(mpr_v, 12) X(mpr_v1, 12) X(mpr_v2, 12) X(jac, MAXR * ND) X(diag, MAXR) X(aref, MAXR) X(efc_D, MAXR) X(Jaref, MAXR) \
-  X(jv, MAXR) X(qacc, ND) X(Ma, ND) X(grad, ND) X(Mgrad, ND) X(search, ND) X(mv, ND) X(nt_vec, ND) X(H, ND * ND)        \
-  X(sv, 8) /* cost, prev_cost, gauss, quad_gauss[3], gtol */                                                      \
-  X(vel_next, ND) X(qpos_next, NQ)                                                                                   \
+  X(contact_force, NL * 3) X(normal_cache, NPAIR * 3) X(geom_friction, NG) X(ctrl_pos, ND) X(ctrl_vel, ND) X(dof_pos, ND) \
   /* ---- Go2Env buffers ---- */                                                                                     \
   X(actions, NA) X(last_actions, NA) X(applied_actions, NA) X(action_history, 2 * NA) X(target_dof_pos, NM)            \
   X(e_dof_pos, NM) X(e_dof_vel, NM) X(last_dof_vel, NM) X(torque, NM) X(base_pos, 3) X(base_quat, 4) X(base_lin_vel, 3) \
@@ -456,11 +447,18 @@ DEV void load_model_s(ModelS* dst, const ModelS* __restrict__ src) {
   X(feet_air_time, 4) X(base_vel_world, 3) X(episode_sums, NREW) X(rew_terms, NREW) X(rew, 1) X(obs, NOBS_MAX) X(priv, NPRIV_MAX)
 
 #define GO2SIM_INT_FIELDS(X)                                                                                         \
-  X(n_contacts, 1) X(c_geom, 2 * MAXC) X(n_con, 1) X(err, 1) X(is_warmstart, 1) X(first_time, 1) X(sort_ig, 2 * NG)      \
-  X(n_broad, 1) X(solver_iters, 1) X(ctrl_mode, ND)                                                                  \
-  X(active_buf, NG) X(broad, MAXB * 2) X(c_link, 2 * MAXC) X(active, MAXR) X(prev_active, MAXR) X(si, 4) /* ls_it, ls_result, improved, - */ \
+  X(n_contacts, 1) X(n_con, 1) X(err, 1) X(is_warmstart, 1) X(first_time, 1) X(n_broad, 1) X(solver_iters, 1) X(ctrl_mode, ND) \
   X(gjk_fallback, 1) X(delay_steps, 1) X(episode_length, 1) X(reset_buf, 1) X(push_remaining, 1) X(foot_contact, 4)    \
   X(last_foot_contact, 4)
+
+#define GO2SIM_AOS_FLOAT_FIELDS(X)                                                                                   \
+  X(acc, ND) X(qacc_ws, ND) X(force, ND) X(qf_smooth, ND) X(acc_smooth, ND) X(qfrc_constraint, ND) X(mass_mat, ND * ND)  \
+  X(cdof_ang, ND * 3) X(cdof_vel, ND * 3) X(cdofd_ang, ND * 3) X(cdofd_vel, ND * 3) X(cinr_inertial, NL * 9)            \
+  X(cinr_pos, NL * 3) X(cinr_mass, NL) X(i_pos, NL * 3) X(i_quat, NL * 4) X(g_pos, NG * 3) X(g_quat, NG * 4)              \
+  X(sort_value, 2 * NG) X(c_pos, MAXC * 3) X(c_normal, MAXC * 3) X(c_pen, MAXC) X(c_friction, MAXC) X(c_sol, MAXC * 7)    \
+  X(c_force, MAXC * 3) X(efc_force, MAXR)
+
+#define GO2SIM_AOS_INT_FIELDS(X) X(sort_ig, 2 * NG) X(broad, MAXB * 2) X(c_geom, 2 * MAXC) X(c_link, 2 * MAXC)
 
 enum FOff : int {
 #define X(n, c) FO_##n##_, FO_##n##_end = FO_##n##_ + (c) - 1,
@@ -474,8 +472,24 @@ enum IOff : int {
 #undef X
   IO_TOTAL
 };
+enum AOff : int {
+#define X(n, c) AO_##n##_, AO_##n##_end = AO_##n##_ + (c) - 1,
+  GO2SIM_AOS_FLOAT_FIELDS(X)
+#undef X
+  AO_TOTAL
+};
+enum AIOff : int {
+#define X(n, c) AIO_##n##_, AIO_##n##_end = AIO_##n##_ + (c) - 1,
+  GO2SIM_AOS_INT_FIELDS(X)
+#undef X
+  AIO_TOTAL
+};
 #define FO(n) FO_##n##_
 #define IO(n) IO_##n##_
+#define AO(n) AO_##n##_
+#define AIO(n) AIO_##n##_
+constexpr int ASTRIDE = (AO_TOTAL + 15) / 16 * 16;     // floats per AoS record (64-byte aligned records)
+constexpr int AISTRIDE = (AIO_TOTAL + 15) / 16 * 16;   // ints per AoS record
 
 // per-lane view of the pool
 template <typename T>
@@ -516,44 +530,53 @@ struct Arr2 {
   DEV Arr<float> operator[](int i) const { return Arr<float>{p + (size_t)(W * i) * B, B}; }
 };
 
-struct Pool { float* f; int* i; int B; };
+struct Pool { float* f; int* i; int B; float* fa; int* ia; };
 
 // Env view: field accessors of lane b
 struct E {
-  float* f; int* i; int B; int b;
-  DEV E(const Pool& P, int b_) : f(P.f + b_), i(P.i + b_), B(P.B), b(b_) {}
+  float* f; int* i; int B; int b; float* fa; int* ia;
+  DEV E(const Pool& P, int b_) : f(P.f + b_), i(P.i + b_), B(P.B), b(b_), fa(P.fa + (size_t)b_ * ASTRIDE), ia(P.ia + (size_t)b_ * AISTRIDE) {}
 #define FA(name) DEV Arr<float> name() const { return Arr<float>{f + (size_t)FO(name) * B, B}; }
 #define FA3(name) DEV Arr3 name() const { return Arr3{f + (size_t)FO(name) * B, B}; }
 #define FA4(name) DEV Arr4 name() const { return Arr4{f + (size_t)FO(name) * B, B}; }
-#define FA9(name) DEV Arr9 name() const { return Arr9{f + (size_t)FO(name) * B, B}; }
 #define FA2(name, W) DEV Arr2<W> name() const { return Arr2<W>{f + (size_t)FO(name) * B, B}; }
 #define IA(name) DEV Arr<int> name() const { return Arr<int>{i + (size_t)IO(name) * B, B}; }
-  FA(qpos) FA(vel) FA(acc) FA(qacc_ws) FA(ctrl_force) FA(ctrl_pos) FA(ctrl_vel) FA(ext) FA(mass_shift) FA3(com_shift) FA(friction_ratio)
-  FA(geom_friction) FA(sort_value) FA3(normal_cache) FA3(l_pos) FA4(l_quat) FA3(i_pos) FA4(i_quat) FA3(root_com) FA9(cinr_inertial)
-  FA3(cinr_pos) FA(cinr_mass) FA3(xanchor) FA3(xaxis) FA(dof_pos) FA3(cdof_ang) FA3(cdof_vel) FA3(cdofd_ang) FA3(cdofd_vel) FA3(cd_vel)
-  FA3(cd_ang) FA3(g_pos) FA4(g_quat) FA3(aabb_min) FA3(aabb_max) FA9(crb_inertial) FA3(crb_pos) FA(crb_mass) FA3(f_ang) FA3(f_vel)
-  FA2(mass_mat, ND) FA2(mass_L, ND) FA(mass_Dinv) FA(qf_applied) FA(qf_passive) FA(force) FA(qf_smooth) FA(acc_smooth) FA3(cdd_vel)
-  FA3(cdd_ang) FA3(cfrc_vel) FA3(cfrc_ang) FA3(c_pos) FA3(c_normal) FA(c_pen) FA(c_friction) FA2(c_sol, 7) FA3(c_force) FA3(mpr_v)
-  FA3(mpr_v1) FA3(mpr_v2) FA2(jac, ND) FA(diag) FA(aref) FA(efc_D) FA(Jaref) FA(jv) FA(efc_force) FA(qacc) FA(Ma) FA(grad) FA(Mgrad)
-  FA(search) FA(mv) FA(qfrc_constraint) FA(nt_vec) FA2(H, ND) FA(sv) FA3(contact_force) FA(vel_next) FA(qpos_next)
+#define AA(name) DEV Arr<float> name() const { return Arr<float>{fa + AO(name), 1}; }
+#define AA3(name) DEV Arr3 name() const { return Arr3{fa + AO(name), 1}; }
+#define AA4(name) DEV Arr4 name() const { return Arr4{fa + AO(name), 1}; }
+#define AA9(name) DEV Arr9 name() const { return Arr9{fa + AO(name), 1}; }
+#define AA2(name, W) DEV Arr2<W> name() const { return Arr2<W>{fa + AO(name), 1}; }
+#define AIA(name) DEV Arr<int> name() const { return Arr<int>{ia + AIO(name), 1}; }
+  FA(qpos) FA(vel) FA(ctrl_force) FA(ctrl_pos) FA(ctrl_vel) FA(ext) FA(mass_shift) FA3(com_shift) FA(friction_ratio)
+  FA(geom_friction) FA3(normal_cache) FA3(l_pos) FA4(l_quat) FA3(root_com) FA(dof_pos) FA3(cd_vel) FA3(cd_ang) FA3(contact_force)
   FA(actions) FA(last_actions) FA(applied_actions) FA2(action_history, NA) FA(target_dof_pos) FA(e_dof_pos) FA(e_dof_vel) FA(last_dof_vel)
   FA(torque) FA(base_pos) FA(base_quat) FA(base_lin_vel) FA(base_ang_vel) FA(projected_gravity) FA(base_euler) FA(commands) FA(time_out)
   FA(kp_factors) FA(kd_factors) FA(motor_strength) FA(gravity_offset) FA(current_push_force) FA(push_stored_force) FA(feet_air_time) FA(base_vel_world)
   FA(episode_sums) FA(rew_terms) FA(rew) FA(obs) FA(priv)
-  IA(n_contacts) IA(c_geom) IA(n_con) IA(err) IA(is_warmstart) IA(first_time) IA(sort_ig) IA(n_broad) IA(solver_iters) IA(ctrl_mode)
-  IA(active_buf) IA(broad) IA(c_link) IA(active) IA(prev_active) IA(si) IA(gjk_fallback) IA(delay_steps) IA(episode_length) IA(reset_buf)
-  IA(push_remaining) IA(foot_contact) IA(last_foot_contact)
+  IA(n_contacts) IA(n_con) IA(err) IA(is_warmstart) IA(first_time) IA(n_broad) IA(solver_iters) IA(ctrl_mode)
+  IA(gjk_fallback) IA(delay_steps) IA(episode_length) IA(reset_buf) IA(push_remaining) IA(foot_contact) IA(last_foot_contact)
+  AA(acc) AA(qacc_ws) AA(force) AA(qf_smooth) AA(acc_smooth) AA(qfrc_constraint) AA2(mass_mat, ND) AA3(cdof_ang) AA3(cdof_vel) AA3(cdofd_ang)
+  AA3(cdofd_vel) AA9(cinr_inertial) AA3(cinr_pos) AA(cinr_mass) AA3(i_pos) AA4(i_quat) AA3(g_pos) AA4(g_quat) AA(sort_value) AA3(c_pos) AA3(c_normal)
+  AA(c_pen) AA(c_friction) AA2(c_sol, 7) AA3(c_force) AA(efc_force)
+  AIA(sort_ig) AIA(broad) AIA(c_geom) AIA(c_link)
 #undef FA
 #undef FA3
 #undef FA4
-#undef FA9
 #undef FA2
 #undef IA
+#undef AA
+#undef AA3
+#undef AA4
+#undef AA9
+#undef AA2
+#undef AIA
 };
 // single-wavefront workgroups: the barrier is a compiler/LDS ordering fence only
 DEV void team_sync() { __syncthreads(); }
 DEV float gload(const E& e, int off, int k) { return e.f[(size_t)(off + k) * e.B]; }
 DEV void gstore(const E& e, int off, int k, float v) { e.f[(size_t)(off + k) * e.B] = v; }
+DEV float aload(const E& e, int off, int k) { return e.fa[off + k]; }              // AoS record word
+DEV void astore(const E& e, int off, int k, float v) { e.fa[off + k] = v; }
 
 
 // Workgroup-cooperative staging between the SoA pool and per-env LDS blocks: adjacent lanes address adjacent environments of the same
@@ -590,391 +613,6 @@ __device__ unsigned long long g_phase_cycles[64];
 // scalar slots
 enum { SV_COST = 0, SV_PREV_COST, SV_GAUSS, SV_QG0, SV_QG1, SV_QG2, SV_GTOL };
 enum { SI_LS_IT = 0, SI_LS_RESULT, SI_IMPROVED };
-
-// ---------------------------------------------------------------------------------------------
-// kinematics  (R/abd/forward_kinematics.py)
-// ---------------------------------------------------------------------------------------------
-// func_forward_kinematics_entity, forward_kinematics.py:463-618
-DEV void forward_kinematics_entity(const Model& m, const E& e, int i_e) {
-  const Entity& en = m.entities[i_e];
-  auto l_pos = e.l_pos(); auto l_quat = e.l_quat(); auto qpos = e.qpos(); auto xanchor = e.xanchor(); auto xaxis = e.xaxis(); auto dof_pos = e.dof_pos();
-  for (int i_l = en.link_start; i_l < en.link_end; ++i_l) {
-    const Link& L = m.links[i_l];
-    V3 pos = L.pos; Q4 quat = L.quat;
-    if (L.parent != -1) {
-      Q4 pq = l_quat[L.parent];
-      pos = (V3)l_pos[L.parent] + transform_by_quat(L.pos, pq);
-      quat = transform_quat_by_quat(L.quat, pq);
-    }
-    for (int i_j = L.joint_start; i_j < L.joint_end; ++i_j) {
-      const Joint& J = m.joints[i_j];
-      int q_start = J.q_start, dof_start = J.dof_start;
-      if (J.type == JOINT_FREE) {
-        V3 pos_ = v3(qpos[q_start], qpos[q_start + 1], qpos[q_start + 2]);
-        xanchor[i_j] = pos_;
-        xaxis[i_j] = v3(0, 0, 1);
-        Q4 quat_ = q4(qpos[q_start + 3], qpos[q_start + 4], qpos[q_start + 5], qpos[q_start + 6]);
-        float n = dm_sqrt(norm_sqr(quat_));
-        quat_ = q4(quat_.w / n, quat_.x / n, quat_.y / n, quat_.z / n);
-        pos = pos_; quat = quat_;
-        dof_pos[dof_start + 0] = pos.x; dof_pos[dof_start + 1] = pos.y; dof_pos[dof_start + 2] = pos.z;
-      } else if (J.type == JOINT_REVOLUTE) {
-        V3 axis = m.dofs[dof_start].motion_ang;
-        V3 anchor = transform_by_quat(J.pos, quat) + pos;
-        xanchor[i_j] = anchor;
-        xaxis[i_j] = transform_by_quat(axis, quat);
-        float dp = qpos[q_start] - m.qpos0[q_start];
-        dof_pos[dof_start] = dp;
-        Q4 qloc = rotvec_to_quat(axis * dp, m.eps);
-        quat = transform_quat_by_quat(qloc, quat);
-        pos = anchor - transform_by_quat(J.pos, quat);
-      }
-    }
-    if (!(L.parent == -1 && L.is_fixed)) { l_pos[i_l] = pos; l_quat[i_l] = quat; }
-  }
-}
-
-// func_COM_links_entity, forward_kinematics.py:224-459
-DEV void com_links_entity(const Model& m, const E& e, int i_e) {
-  const Entity& en = m.entities[i_e];
-  auto l_pos = e.l_pos(); auto l_quat = e.l_quat(); auto i_pos = e.i_pos(); auto i_quat = e.i_quat(); auto root_com = e.root_com();
-  auto mass_shift = e.mass_shift(); auto com_shift = e.com_shift();
-  // one kinematic tree per entity: root = first link of the entity
-  V3 root_com_bw = v3(0, 0, 0); float mass_sum = 0.0f;
-  for (int i_l = en.link_start; i_l < en.link_end; ++i_l) {
-    const Link& L = m.links[i_l];
-    float mass = L.mass + mass_shift[i_l];
-    V3 ipbw; Q4 iq;
-    transform_pos_quat_by_trans_quat(L.inertial_pos + (V3)com_shift[i_l], L.inertial_quat, l_pos[i_l], l_quat[i_l], ipbw, iq);
-    i_pos[i_l] = ipbw;  // holds i_pos_bw until the root COM is known
-    i_quat[i_l] = iq;
-    mass_sum = mass_sum + mass;
-    root_com_bw = root_com_bw + mass * ipbw;
-  }
-  V3 rc = root_com_bw / mass_sum;
-  for (int i_l = en.link_start; i_l < en.link_end; ++i_l) root_com[i_l] = rc;
-  auto cinr_inertial = e.cinr_inertial(); auto cinr_pos = e.cinr_pos(); auto cinr_mass = e.cinr_mass();
-  for (int i_l = en.link_start; i_l < en.link_end; ++i_l) {
-    const Link& L = m.links[i_l];
-    V3 ip = (V3)i_pos[i_l] - rc;
-    i_pos[i_l] = ip;
-    float i_mass = L.mass + mass_shift[i_l];
-    M3 oI; V3 op;
-    transform_inertia_by_trans_quat(L.inertial_i, i_mass, ip, i_quat[i_l], m.eps, oI, op);
-    cinr_inertial[i_l] = oI; cinr_pos[i_l] = op; cinr_mass[i_l] = i_mass;
-  }
-  auto xanchor = e.xanchor(); auto xaxis = e.xaxis(); auto cdof_ang = e.cdof_ang(); auto cdof_vel = e.cdof_vel();
-  for (int i_l = en.link_start; i_l < en.link_end; ++i_l) {
-    const Link& L = m.links[i_l];
-    if (L.n_dofs == 0) continue;
-    for (int i_j = L.joint_start; i_j < L.joint_end; ++i_j) {
-      const Joint& J = m.joints[i_j];
-      V3 offset_pos = rc - (V3)xanchor[i_j];
-      int ds = J.dof_start;
-      if (J.type == JOINT_REVOLUTE) {
-        V3 ax = xaxis[i_j];
-        cdof_ang[ds] = ax;
-        cdof_vel[ds] = cross(ax, offset_pos);
-      } else if (J.type == JOINT_FREE) {
-        for (int i = 0; i < 3; ++i) {
-          cdof_ang[i + ds] = v3(0, 0, 0);
-          V3 cv = v3(0, 0, 0);
-          vset(cv, i, 1.0f);
-          cdof_vel[i + ds] = cv;
-        }
-        M3 xmat_T = transpose(quat_to_R(l_quat[i_l], m.eps));
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-          V3 row = v3(xmat_T.m[i][0], xmat_T.m[i][1], xmat_T.m[i][2]);
-          cdof_ang[i + ds + 3] = row;
-          cdof_vel[i + ds + 3] = cross(row, offset_pos);
-        }
-      }
-    }
-  }
-}
-
-// func_update_geoms_entity, forward_kinematics.py:709-744
-DEV void update_geoms_entity(const Model& m, const E& e, int i_e, bool force_update_fixed) {
-  const Entity& en = m.entities[i_e];
-  auto l_pos = e.l_pos(); auto l_quat = e.l_quat(); auto g_pos = e.g_pos(); auto g_quat = e.g_quat();
-  for (int i_g = en.geom_start; i_g < en.geom_end; ++i_g) {
-    const Geom& G = m.geoms[i_g];
-    bool is_fixed = m.links[G.link].is_fixed;
-    if (force_update_fixed || !is_fixed) {
-      V3 p; Q4 q;
-      transform_pos_quat_by_trans_quat(G.pos, G.quat, l_pos[G.link], l_quat[G.link], p, q);
-      g_pos[i_g] = p; g_quat[i_g] = q;
-    }
-  }
-}
-
-// func_forward_velocity_entity, forward_kinematics.py:871-994
-DEV void forward_velocity_entity(const Model& m, const E& e, int i_e) {
-  const Entity& en = m.entities[i_e];
-  auto cd_vel = e.cd_vel(); auto cd_ang = e.cd_ang(); auto cdof_ang = e.cdof_ang(); auto cdof_vel = e.cdof_vel(); auto cdofd_ang = e.cdofd_ang();
-  auto cdofd_vel = e.cdofd_vel(); auto vel = e.vel();
-  for (int i_l = en.link_start; i_l < en.link_end; ++i_l) {
-    const Link& L = m.links[i_l];
-    V3 cvel_vel = v3(0, 0, 0), cvel_ang = v3(0, 0, 0);
-    if (L.parent != -1) { cvel_vel = cd_vel[L.parent]; cvel_ang = cd_ang[L.parent]; }
-    for (int i_j = L.joint_start; i_j < L.joint_end; ++i_j) {
-      const Joint& J = m.joints[i_j];
-      int ds = J.dof_start;
-      if (J.type == JOINT_FREE) {
-        for (int i = 0; i < 3; ++i) {
-          float v = vel[ds + i];
-          cvel_vel = cvel_vel + (V3)cdof_vel[ds + i] * v;
-          cvel_ang = cvel_ang + (V3)cdof_ang[ds + i] * v;
-        }
-        for (int i = 0; i < 3; ++i) {
-          cdofd_ang[ds + i] = v3(0, 0, 0); cdofd_vel[ds + i] = v3(0, 0, 0);
-          V3 oa, ov;
-          motion_cross_motion(cvel_ang, cvel_vel, cdof_ang[ds + i + 3], cdof_vel[ds + i + 3], oa, ov);
-          cdofd_ang[ds + i + 3] = oa; cdofd_vel[ds + i + 3] = ov;
-        }
-        for (int i = 0; i < 3; ++i) {
-          float v = vel[ds + i + 3];
-          cvel_vel = cvel_vel + (V3)cdof_vel[ds + i + 3] * v;
-          cvel_ang = cvel_ang + (V3)cdof_ang[ds + i + 3] * v;
-        }
-      } else {
-        for (int i_d = ds; i_d < J.dof_end; ++i_d) {
-          V3 oa, ov;
-          motion_cross_motion(cvel_ang, cvel_vel, cdof_ang[i_d], cdof_vel[i_d], oa, ov);
-          cdofd_ang[i_d] = oa; cdofd_vel[i_d] = ov;
-        }
-        for (int i_d = ds; i_d < J.dof_end; ++i_d) {
-          float v = vel[i_d];
-          cvel_vel = cvel_vel + (V3)cdof_vel[i_d] * v;
-          cvel_ang = cvel_ang + (V3)cdof_ang[i_d] * v;
-        }
-      }
-    }
-    cd_vel[i_l] = cvel_vel; cd_ang[i_l] = cvel_ang;
-  }
-}
-
-DEV void update_cartesian_space(const Model& m, const E& e, bool force_update_fixed) {
-  for (int i_e = 0; i_e < 2; ++i_e) {
-    forward_kinematics_entity(m, e, i_e);
-    com_links_entity(m, e, i_e);
-    update_geoms_entity(m, e, i_e, force_update_fixed);
-  }
-}
-DEV void forward_velocity(const Model& m, const E& e) {
-  for (int i_e = 0; i_e < 2; ++i_e) forward_velocity_entity(m, e, i_e);
-}
-
-// ---------------------------------------------------------------------------------------------
-// forward dynamics  (R/abd/forward_dynamics.py)
-// ---------------------------------------------------------------------------------------------
-// func_compute_mass_matrix, forward_dynamics.py:291-541
-DEV void compute_mass_matrix(const Model& m, const E& e, bool implicit_damping) {
-  auto crb_inertial = e.crb_inertial(); auto crb_pos = e.crb_pos(); auto crb_mass = e.crb_mass();
-  auto cinr_inertial = e.cinr_inertial(); auto cinr_pos = e.cinr_pos(); auto cinr_mass = e.cinr_mass();
-  for (int i_l = 0; i_l < NL; ++i_l) { crb_inertial[i_l] = cinr_inertial[i_l]; crb_pos[i_l] = cinr_pos[i_l]; crb_mass[i_l] = cinr_mass[i_l]; }
-  for (int i_e = 0; i_e < 2; ++i_e) {
-    const Entity& en = m.entities[i_e];
-    int n = en.link_end - en.link_start;
-    for (int i = 0; i < n; ++i) {
-      int i_l = en.link_end - 1 - i, i_p = m.links[i_l].parent;
-      if (i_p != -1) {
-        M3 a = crb_inertial[i_p], b2 = crb_inertial[i_l];
-        crb_inertial[i_p] = a + b2;
-        crb_mass[i_p] = crb_mass[i_p] + crb_mass[i_l];
-        crb_pos[i_p] = (V3)crb_pos[i_p] + (V3)crb_pos[i_l];
-      }
-    }
-  }
-  auto cdof_ang = e.cdof_ang(); auto cdof_vel = e.cdof_vel(); auto f_ang = e.f_ang(); auto f_vel = e.f_vel(); auto mass_mat = e.mass_mat();
-  for (int i_l = 0; i_l < NL; ++i_l) {
-    const Link& L = m.links[i_l];
-    if (L.dof_start == L.dof_end) continue;
-    M3 I = crb_inertial[i_l]; V3 cp = crb_pos[i_l]; float cm = crb_mass[i_l];
-    for (int i_d = L.dof_start; i_d < L.dof_end; ++i_d) {
-      V3 oa, ov;
-      inertial_mul(cp, I, cm, cdof_vel[i_d], cdof_ang[i_d], oa, ov);
-      f_ang[i_d] = oa; f_vel[i_d] = ov;
-    }
-  }
-  for (int i_e = 0; i_e < 2; ++i_e) {
-    const Entity& en = m.entities[i_e];
-    for (int i_d = en.dof_start; i_d < en.dof_end; ++i_d) {
-      V3 fa = f_ang[i_d], fv = f_vel[i_d];
-      auto row = mass_mat[i_d];
-      for (int j_d = en.dof_start; j_d < en.dof_end; ++j_d)
-        row[j_d] = (dot(fa, cdof_ang[j_d]) + dot(fv, cdof_vel[j_d])) * m.mass_parent_mask[i_d][j_d];
-    }
-    for (int i_d = en.dof_start; i_d < en.dof_end; ++i_d)
-      for (int j_d = i_d + 1; j_d < en.dof_end; ++j_d) mass_mat[i_d][j_d] = mass_mat[j_d][i_d];
-  }
-  auto ctrl_mode = e.ctrl_mode();
-  for (int i_d = 0; i_d < ND; ++i_d) {
-    float v = mass_mat[i_d][i_d] + m.dofs[i_d].armature;
-    if (implicit_damping) {
-      v = v + m.dofs[i_d].damping * m.substep_dt;
-      int cm = ctrl_mode[i_d];
-      if (cm == CTRL_POSITION || cm == CTRL_VELOCITY) v = v + m.dofs[i_d].kv * m.substep_dt;
-    }
-    mass_mat[i_d][i_d] = v;
-  }
-}
-
-// func_factor_mass (serial branch), forward_dynamics.py:560-604
-DEV void factor_mass(const Model& m, const E& e) {
-  auto mass_mat = e.mass_mat(); auto mass_L = e.mass_L(); auto mass_Dinv = e.mass_Dinv();
-  for (int i_e = 0; i_e < 2; ++i_e) {
-    const Entity& en = m.entities[i_e];
-    int ds = en.dof_start, de = en.dof_end, n = de - ds;
-    for (int i_d = ds; i_d < de; ++i_d)
-      for (int j_d = ds; j_d < i_d + 1; ++j_d) mass_L[i_d][j_d] = mass_mat[i_d][j_d];
-    for (int i_d_ = 0; i_d_ < n; ++i_d_) {
-      int i_d = de - i_d_ - 1;
-      float D_inv = 1.0f / mass_L[i_d][i_d];
-      mass_Dinv[i_d] = D_inv;
-      for (int j_d_ = 0; j_d_ < i_d - ds; ++j_d_) {
-        int j_d = i_d - j_d_ - 1;
-        float a = mass_L[i_d][j_d] * D_inv;
-        for (int k_d = ds; k_d < j_d + 1; ++k_d) mass_L[j_d][k_d] -= a * mass_L[i_d][k_d];
-        mass_L[i_d][j_d] = a;
-      }
-      mass_L[i_d][i_d] = 1.0f;
-    }
-  }
-}
-
-// func_solve_mass_entity, forward_dynamics.py:818-900
-DEV void solve_mass(const Model& m, const E& e, Arr<float> vec, Arr<float> out) {
-  auto mass_L = e.mass_L(); auto mass_Dinv = e.mass_Dinv();
-  for (int i_e = 0; i_e < 2; ++i_e) {
-    const Entity& en = m.entities[i_e];
-    int ds = en.dof_start, de = en.dof_end, n = de - ds;
-    for (int i_d_ = 0; i_d_ < n; ++i_d_) {
-      int i_d = de - i_d_ - 1;
-      float cur = vec[i_d];
-      for (int j_d = i_d + 1; j_d < de; ++j_d) cur = cur - mass_L[j_d][i_d] * out[j_d];
-      out[i_d] = cur;
-    }
-    for (int i_d = ds; i_d < de; ++i_d) out[i_d] = out[i_d] * mass_Dinv[i_d];
-    for (int i_d = ds; i_d < de; ++i_d) {
-      float cur = out[i_d];
-      for (int j_d = ds; j_d < i_d; ++j_d) cur = cur - mass_L[i_d][j_d] * out[j_d];
-      out[i_d] = cur;
-    }
-  }
-}
-
-// func_torque_and_passive_force, forward_dynamics.py:961-1174
-DEV void torque_and_passive_force(const Model& m, const E& e) {
-  auto ctrl_mode = e.ctrl_mode(); auto ctrl_force = e.ctrl_force(); auto ctrl_pos = e.ctrl_pos(); auto ctrl_vel = e.ctrl_vel(); auto vel = e.vel();
-  auto dof_pos = e.dof_pos(); auto qf_applied = e.qf_applied(); auto qf_passive = e.qf_passive();
-  for (int i_l = 0; i_l < NL; ++i_l) {
-    const Link& L = m.links[i_l];
-    if (L.n_dofs == 0) continue;
-    int joint_type = m.joints[L.joint_start].type;
-    for (int i_d = L.dof_start; i_d < L.dof_end; ++i_d) {
-      const Dof& D = m.dofs[i_d];
-      float force = 0.0f;
-      int cm = ctrl_mode[i_d];
-      if (cm == CTRL_FORCE) force = ctrl_force[i_d];
-      else if (cm == CTRL_VELOCITY) force = D.kv * (ctrl_vel[i_d] - vel[i_d]);
-      else if (cm == CTRL_POSITION && !(joint_type == JOINT_FREE && i_d >= L.dof_start + 3))
-        force = D.kp * (ctrl_pos[i_d] - dof_pos[i_d]) + D.kv * (ctrl_vel[i_d] - vel[i_d]);
-      qf_applied[i_d] = clampf(force, D.force_range[0], D.force_range[1]);
-    }
-  }
-  for (int i_d = 0; i_d < ND; ++i_d) qf_passive[i_d] = -m.dofs[i_d].damping * vel[i_d];
-  for (int i_l = 0; i_l < NL; ++i_l) {
-    const Link& L = m.links[i_l];
-    if (L.n_dofs == 0) continue;
-    int joint_type = m.joints[L.joint_start].type;
-    if (joint_type != JOINT_FREE && joint_type != JOINT_FIXED)
-      for (int j_d = L.dof_start; j_d < L.dof_end; ++j_d) qf_passive[j_d] = qf_passive[j_d] + (-dof_pos[j_d] * m.dofs[j_d].stiffness);
-  }
-}
-
-// func_update_acc(update_cacc=False) + func_update_force + func_bias_force, forward_dynamics.py:1177-1478
-DEV void bias_forces(const Model& m, const E& e) {
-  auto cdd_vel = e.cdd_vel(); auto cdd_ang = e.cdd_ang(); auto cdofd_vel = e.cdofd_vel(); auto cdofd_ang = e.cdofd_ang(); auto vel = e.vel();
-  for (int i_e = 0; i_e < 2; ++i_e) {
-    const Entity& en = m.entities[i_e];
-    for (int i_l = en.link_start; i_l < en.link_end; ++i_l) {
-      const Link& L = m.links[i_l];
-      V3 cv, ca;
-      if (L.parent == -1) { cv = -m.gravity * (1.0f - 0.0f); ca = v3(0, 0, 0); }
-      else { cv = cdd_vel[L.parent]; ca = cdd_ang[L.parent]; }
-      for (int i_d = L.dof_start; i_d < L.dof_end; ++i_d) {
-        float v = vel[i_d];
-        V3 local_cdd_vel = (V3)cdofd_vel[i_d] * v;
-        V3 local_cdd_ang = (V3)cdofd_ang[i_d] * v;
-        cv = cv + local_cdd_vel;
-        ca = ca + local_cdd_ang;
-      }
-      cdd_vel[i_l] = cv; cdd_ang[i_l] = ca;
-    }
-  }
-  auto cinr_inertial = e.cinr_inertial(); auto cinr_pos = e.cinr_pos(); auto cinr_mass = e.cinr_mass(); auto cd_vel = e.cd_vel(); auto cd_ang = e.cd_ang();
-  auto cfrc_vel = e.cfrc_vel(); auto cfrc_ang = e.cfrc_ang(); auto ext = e.ext();
-  for (int i_l = 0; i_l < NL; ++i_l) {
-    V3 f1_ang, f1_vel, f2_ang, f2_vel, f3_ang, f3_vel;
-    M3 I = cinr_inertial[i_l]; V3 cp = cinr_pos[i_l]; float cm = cinr_mass[i_l];
-    V3 cdv = cd_vel[i_l], cda = cd_ang[i_l];
-    inertial_mul(cp, I, cm, cdd_vel[i_l], cdd_ang[i_l], f1_ang, f1_vel);
-    inertial_mul(cp, I, cm, cdv, cda, f2_ang, f2_vel);
-    motion_cross_force(cda, cdv, f2_ang, f2_vel, f3_ang, f3_vel);
-    V3 ext_ang = v3(ext[6 * i_l + 0], ext[6 * i_l + 1], ext[6 * i_l + 2]), ext_vel = v3(ext[6 * i_l + 3], ext[6 * i_l + 4], ext[6 * i_l + 5]);
-    cfrc_vel[i_l] = f1_vel + f3_vel + ext_vel + v3(0, 0, 0);
-    cfrc_ang[i_l] = f1_ang + f3_ang + ext_ang + v3(0, 0, 0);
-  }
-  for (int i_e = 0; i_e < 2; ++i_e) {
-    const Entity& en = m.entities[i_e];
-    int n = en.link_end - en.link_start;
-    for (int i = 0; i < n; ++i) {
-      int i_l = en.link_end - 1 - i, i_p = m.links[i_l].parent;
-      if (i_p != -1) {
-        cfrc_vel[i_p] = (V3)cfrc_vel[i_p] + (V3)cfrc_vel[i_l];
-        cfrc_ang[i_p] = (V3)cfrc_ang[i_p] + (V3)cfrc_ang[i_l];
-      }
-    }
-  }
-  auto cdof_ang = e.cdof_ang(); auto cdof_vel = e.cdof_vel(); auto qf_passive = e.qf_passive(); auto qf_applied = e.qf_applied();
-  auto force = e.force(); auto qf_smooth = e.qf_smooth();
-  for (int i_l = 0; i_l < NL; ++i_l) {
-    const Link& L = m.links[i_l];
-    if (L.dof_start == L.dof_end) continue;
-    V3 fa = cfrc_ang[i_l], fv = cfrc_vel[i_l];
-    for (int i_d = L.dof_start; i_d < L.dof_end; ++i_d) {
-      float qf_bias = dot(cdof_ang[i_d], fa) + dot(cdof_vel[i_d], fv);
-      float f = qf_passive[i_d] - qf_bias + qf_applied[i_d];
-      force[i_d] = f; qf_smooth[i_d] = f;
-    }
-  }
-}
-
-// kernel_step_1 without the (already fresh) FK, rigid_solver.py:3008-3069
-__global__ __launch_bounds__(WG) void k_dynamics(Pool P, const Model* __restrict__ mp) {
-  int b = blockIdx.x * WG + threadIdx.x;
-  if (b >= P.B) return;
-  const Model& m = *mp;
-  E e(P, b);
-  compute_mass_matrix(m, e, true);
-  factor_mass(m, e);
-  torque_and_passive_force(m, e);
-  bias_forces(m, e);
-  solve_mass(m, e, e.force(), e.acc_smooth());
-  auto acc = e.acc(); auto acc_smooth = e.acc_smooth();
-  for (int i_d = 0; i_d < ND; ++i_d) acc[i_d] = acc_smooth[i_d];
-}
-
-__global__ __launch_bounds__(WG) void k_fk(Pool P, const Model* __restrict__ mp, int force_update_fixed) {
-  int b = blockIdx.x * WG + threadIdx.x;
-  if (b >= P.B) return;
-  const Model& m = *mp;
-  E e(P, b);
-  update_cartesian_space(m, e, force_update_fixed != 0);
-  forward_velocity(m, e);
-}
 
 // ---------------------------------------------------------------------------------------------
 // Team kinematics / dynamics: T lanes per environment, link tree processed level by level
@@ -1190,7 +828,7 @@ __global__ __launch_bounds__(64) void k_integrate_fk_team(Pool P, const ModelS* 
   E e(P, b);
   KinData* s = &lds[slot];
   PH_BEGIN
-  for (int d = tl; d < ND; d += T) { float v = gload(e, FO(vel), d); s->vel[d] = v; s->vel_next[d] = v + gload(e, FO(acc), d) * m.substep_dt; }
+  for (int d = tl; d < ND; d += T) { float v = gload(e, FO(vel), d); s->vel[d] = v; s->vel_next[d] = v + aload(e, AO(acc), d) * m.substep_dt; }
   for (int q = tl; q < NQ; q += T) s->qpos[q] = gload(e, FO(qpos), q);
   if (tl == 0) s->valid = 1;
   team_sync();
@@ -1270,17 +908,10 @@ __global__ __launch_bounds__(64) void k_dynamics_team(Pool P, const ModelS* __re
   __shared__ DynData lds[EPW];
   __shared__ ModelS ms;
   load_model_s(&ms, mp);
-  {  // ---- stage (cooperative, before any lane retires) ----
+  {  // ---- stage the SoA inputs cooperatively (adjacent lanes = adjacent envs), before any lane retires ----
     const int b0 = blockIdx.x * EPW;
-    wg_load<EPW>(P, b0, FO(cinr_inertial), NL * 9, [&](int ev, int k, float v) { lds[ev].cinr_I[k] = v; lds[ev].crb_I[k] = v; });
-    wg_load<EPW>(P, b0, FO(cinr_pos), NL * 3, [&](int ev, int k, float v) { lds[ev].cinr_pos[k] = v; lds[ev].crb_pos[k] = v; });
     wg_load<EPW>(P, b0, FO(cd_vel), NL * 3, [&](int ev, int k, float v) { lds[ev].cd_vel[k] = v; });
     wg_load<EPW>(P, b0, FO(cd_ang), NL * 3, [&](int ev, int k, float v) { lds[ev].cd_ang[k] = v; });
-    wg_load<EPW>(P, b0, FO(cinr_mass), NL, [&](int ev, int k, float v) { lds[ev].cinr_mass[k] = v; lds[ev].crb_mass[k] = v; });
-    wg_load<EPW>(P, b0, FO(cdof_ang), ND * 3, [&](int ev, int k, float v) { lds[ev].cdof_ang[k] = v; });
-    wg_load<EPW>(P, b0, FO(cdof_vel), ND * 3, [&](int ev, int k, float v) { lds[ev].cdof_vel[k] = v; });
-    wg_load<EPW>(P, b0, FO(cdofd_ang), ND * 3, [&](int ev, int k, float v) { lds[ev].cdofd_ang[k] = v; });
-    wg_load<EPW>(P, b0, FO(cdofd_vel), ND * 3, [&](int ev, int k, float v) { lds[ev].cdofd_vel[k] = v; });
     wg_load<EPW>(P, b0, FO(vel), ND, [&](int ev, int k, float v) { lds[ev].vel[k] = v; });
   }
   const int tl = threadIdx.x % T, slot = threadIdx.x / T;
@@ -1290,6 +921,14 @@ __global__ __launch_bounds__(64) void k_dynamics_team(Pool P, const ModelS* __re
   E e(P, env_valid ? b : P.B - 1);
   DynData* s = &lds[slot];
   PH_BEGIN
+  // AoS record: the team reads consecutive words
+  for (int k = tl; k < NL * 9; k += T) { float v = aload(e, AO(cinr_inertial), k); s->cinr_I[k] = v; s->crb_I[k] = v; }
+  for (int k = tl; k < NL * 3; k += T) { float v = aload(e, AO(cinr_pos), k); s->cinr_pos[k] = v; s->crb_pos[k] = v; }
+  for (int k = tl; k < NL; k += T) { float v = aload(e, AO(cinr_mass), k); s->cinr_mass[k] = v; s->crb_mass[k] = v; }
+  for (int k = tl; k < ND * 3; k += T) {
+    s->cdof_ang[k] = aload(e, AO(cdof_ang), k); s->cdof_vel[k] = aload(e, AO(cdof_vel), k);
+    s->cdofd_ang[k] = aload(e, AO(cdofd_ang), k); s->cdofd_vel[k] = aload(e, AO(cdofd_vel), k);
+  }
   team_sync();
   PH(20)
   // ---- composite rigid bodies, leaf -> root ----
@@ -1414,7 +1053,7 @@ __global__ __launch_bounds__(64) void k_dynamics_team(Pool P, const ModelS* __re
     float qf_bias = dot(ld3(s->cdof_ang, i_d), ld3(s->cfrc_ang, i_l)) + dot(ld3(s->cdof_vel, i_d), ld3(s->cfrc_vel, i_l));
     float f = s->qf_passive[i_d] - qf_bias + s->qf_applied[i_d];
     s->force[i_d] = f;
-    if (env_valid) { gstore(e, FO(force), i_d, f); gstore(e, FO(qf_smooth), i_d, f); }
+    if (env_valid) { astore(e, AO(force), i_d, f); astore(e, AO(qf_smooth), i_d, f); }
   }
   team_sync();
   PH(24)
@@ -1432,8 +1071,8 @@ __global__ __launch_bounds__(64) void k_dynamics_team(Pool P, const ModelS* __re
     s->out[i_d] = cur;
   }
   team_sync();
-  if (env_valid) for (int i_d = tl; i_d < ND; i_d += T) { float a = s->out[i_d]; gstore(e, FO(acc_smooth), i_d, a); gstore(e, FO(acc), i_d, a); }
-  wg_store<EPW>(P, blockIdx.x * EPW, FO(mass_mat), ND * ND, [&](int ev, int k) { return lds[ev].M[k]; });
+  if (env_valid) for (int i_d = tl; i_d < ND; i_d += T) { float a = s->out[i_d]; astore(e, AO(acc_smooth), i_d, a); astore(e, AO(acc), i_d, a); }
+  if (env_valid) for (int k = tl; k < ND * ND; k += T) astore(e, AO(mass_mat), k, s->M[k]);
   PH(25)
 }
 
@@ -2332,9 +1971,9 @@ DEV int ts_solve(const MT& m, const E& e, S* s, int tl, int nc, int n_con) {
   // ---- stage inputs ----
   bool ws = (n_con > 0) && e.is_warmstart()[0];
 #pragma unroll
-  for (int k0 = 0; k0 < ND * ND; k0 += T) { int k = k0 + tl; if (k < ND * ND) s->M[(k / ND) * DS + (k % ND)] = gload(e, FO(mass_mat), k); }
+  for (int k0 = 0; k0 < ND * ND; k0 += T) { int k = k0 + tl; if (k < ND * ND) s->M[(k / ND) * DS + (k % ND)] = aload(e, AO(mass_mat), k); }
 #pragma unroll
-  for (int k0 = 0; k0 < ND * 3; k0 += T) { int k = k0 + tl; if (k < ND * 3) { s->cdof_ang[k] = gload(e, FO(cdof_ang), k); s->cdof_vel[k] = gload(e, FO(cdof_vel), k); } }
+  for (int k0 = 0; k0 < ND * 3; k0 += T) { int k = k0 + tl; if (k < ND * 3) { s->cdof_ang[k] = aload(e, AO(cdof_ang), k); s->cdof_vel[k] = aload(e, AO(cdof_vel), k); } }
 #pragma unroll
   for (int k0 = 0; k0 < NL * 3; k0 += T) { int k = k0 + tl; if (k < NL * 3) s->root_com[k] = gload(e, FO(root_com), k); }
 #pragma unroll
@@ -2342,10 +1981,10 @@ DEV int ts_solve(const MT& m, const E& e, S* s, int tl, int nc, int n_con) {
     int d = d0 + tl;
     if (d < ND) {
       s->vel[d] = gload(e, FO(vel), d);
-      s->force[d] = gload(e, FO(force), d);
-      float as = gload(e, FO(acc_smooth), d);
+      s->force[d] = aload(e, AO(force), d);
+      float as = aload(e, AO(acc_smooth), d);
       s->acc_smooth[d] = as;
-      s->qacc[d] = ws ? gload(e, FO(qacc_ws), d) : as;
+      s->qacc[d] = ws ? aload(e, AO(qacc_ws), d) : as;
     }
   }
   team_sync();
@@ -2501,14 +2140,14 @@ DEV void ts_commit(const MT& m, const E& e, S* s, int tl, int nc, int n_con, int
   int err = 0;
   for (int d = tl; d < ND; d += T) {
     float q = s->qacc[d];
-    gstore(e, FO(acc), d, q);
-    gstore(e, FO(force), d, gload(e, FO(qf_smooth), d) + s->qfrc[d]);
-    gstore(e, FO(qacc_ws), d, q);
-    gstore(e, FO(qfrc_constraint), d, s->qfrc[d]);
+    astore(e, AO(acc), d, q);
+    astore(e, AO(force), d, aload(e, AO(qf_smooth), d) + s->qfrc[d]);
+    astore(e, AO(qacc_ws), d, q);
+    astore(e, AO(qfrc_constraint), d, s->qfrc[d]);
     if (isnan_(q)) err |= GO2SIM_ERR_INVALID_FORCE_NAN;
   }
   if (err) atomicOr(&e.err()[0], err);
-  for (int c = tl; c < n_con; c += T) gstore(e, FO(efc_force), c, s->efc_force[c]);
+  for (int c = tl; c < n_con; c += T) astore(e, AO(efc_force), c, s->efc_force[c]);
   if (tl == 0) { e.is_warmstart()[0] = 1; e.n_con()[0] = n_con; e.solver_iters()[0] = iters; }
   team_sync();
   float* cf = s->J;  // the Jacobian is dead from here on: reuse its storage for the per-contact forces
@@ -2583,47 +2222,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   } else {
     ts_solve_overflow<T>(m, e, &overflow[b], tl, nc, n_con);
   }
-}
-
-// kernel_step_2 (rigid_solver.py:3072-3180): func_integrate (forward_dynamics.py:1558-1699) + func_copy_next_to_curr
-// (abd/diff.py:25-54) + FK / forward velocity of the new state
-__global__ __launch_bounds__(WG) void k_integrate_fk(Pool P, const Model* __restrict__ mp) {
-  int b = blockIdx.x * WG + threadIdx.x;
-  if (b >= P.B) return;
-  const Model& m = *mp;
-  E e(P, b);
-  auto vel = e.vel(); auto acc = e.acc(); auto qpos = e.qpos(); auto vel_next = e.vel_next(); auto qpos_next = e.qpos_next();
-  for (int i_d = 0; i_d < ND; ++i_d) vel_next[i_d] = vel[i_d] + acc[i_d] * m.substep_dt;
-  for (int i_l = 0; i_l < NL; ++i_l) {
-    const Link& L = m.links[i_l];
-    if (L.n_dofs == 0) continue;
-    int ds = L.dof_start, qs = L.q_start;
-    int joint_type = m.joints[L.joint_start].type;
-    if (joint_type == JOINT_FREE) {
-      V3 pos = v3(qpos[qs], qpos[qs + 1], qpos[qs + 2]);
-      V3 v = v3(vel_next[ds], vel_next[ds + 1], vel_next[ds + 2]);
-      pos = pos + v * m.substep_dt;
-      qpos_next[qs] = pos.x; qpos_next[qs + 1] = pos.y; qpos_next[qs + 2] = pos.z;
-      Q4 rot0 = q4(qpos[qs + 3], qpos[qs + 4], qpos[qs + 5], qpos[qs + 6]);
-      V3 ang = v3(vel_next[ds + 3], vel_next[ds + 4], vel_next[ds + 5]) * m.substep_dt;
-      Q4 qrot = rotvec_to_quat(ang, m.eps);
-      Q4 rot = transform_quat_by_quat(qrot, rot0);
-      qpos_next[qs + 3] = rot.w; qpos_next[qs + 4] = rot.x; qpos_next[qs + 5] = rot.y; qpos_next[qs + 6] = rot.z;
-    } else {
-      for (int j_ = 0; j_ < L.q_end - qs; ++j_) qpos_next[qs + j_] = qpos[qs + j_] + vel_next[ds + j_] * m.substep_dt;
-    }
-  }
-  bool is_valid = true;
-  for (int i_d = 0; i_d < ND; ++i_d) is_valid &= !isnan_(vel_next[i_d]);
-  for (int i_q = 0; i_q < NQ; ++i_q) is_valid &= !isnan_(qpos_next[i_q]);
-  if (is_valid) {
-    for (int i_d = 0; i_d < ND; ++i_d) vel[i_d] = vel_next[i_d];
-    for (int i_q = 0; i_q < NQ; ++i_q) qpos[i_q] = qpos_next[i_q];
-  } else {
-    e.err()[0] |= GO2SIM_ERR_INVALID_ACC_NAN;
-  }
-  update_cartesian_space(m, e, false);
-  forward_velocity(m, e);
 }
 
 __global__ __launch_bounds__(WG) void k_clear_ext(Pool P) {             // kernel_clear_external_force, abd/misc.py:874
@@ -3327,8 +2925,7 @@ __global__ __launch_bounds__(WG) void k_init_state(Pool P, const Model* __restri
   auto l_pos = e.l_pos(); auto l_quat = e.l_quat();
   for (int i = 0; i < NL; ++i) { l_pos[i] = m.links[i].pos; l_quat[i] = m.links[i].quat; }
   e.first_time()[0] = 1;
-  update_cartesian_space(m, e, true);
-  forward_velocity(m, e);
+  // FK / velocities of the initial state: launch_fk_team right after this kernel
 }
 __global__ __launch_bounds__(WG) void k_scene_reset_clear(Pool P) {   // RigidSolver.set_state + collider.clear + constraint_solver.clear
   int b = blockIdx.x * WG + threadIdx.x;
@@ -3379,6 +2976,19 @@ __global__ void k_errno_reduce(Pool P, int* out) {
   if (v) atomicOr(out, v);
 }
 // [n_envs][k] row-major copy of an env buffer
+// field API <-> AoS records (32-bit words): rows[j][b] = rec[b][off + j]
+__global__ void k_aos_to_rows(const int* __restrict__ rec, int stride, int off, int k, int B, int* __restrict__ rows) {
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= k * B) return;
+  int j = t / B, b = t % B;
+  rows[t] = rec[(size_t)b * stride + off + j];
+}
+__global__ void k_rows_to_aos(const int* __restrict__ rows, int* __restrict__ rec, int stride, int off, int k, int B) {
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= k * B) return;
+  int j = t / B, b = t % B;
+  rec[(size_t)b * stride + off + j] = rows[t];
+}
 __global__ void k_gather(const void* __restrict__ src, void* __restrict__ dst, int k, int B) {
   int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= k * B) return;
@@ -3408,7 +3018,7 @@ struct go2sim {
   Model hm;                 // host copy of the model
   Model* dm = nullptr;      // device copy
   ModelS* dms = nullptr;    // device copy of the compact tables (staged into LDS by the team kernels)
-  Pool P = {nullptr, nullptr, 0};
+  Pool P = {nullptr, nullptr, 0, nullptr, nullptr};
   DCfg hcfg; DCfg* dcfg = nullptr; bool cfg_set = false;
   Glob* dglob = nullptr; Acc* dacc = nullptr; int* derr = nullptr;
   GjkScratch* gjk_scratch = nullptr;        // working memory of the GJK/EPA fallback: one block per (env, narrow-phase lane)
@@ -3508,6 +3118,10 @@ int go2sim_create(const void* blob, size_t nbytes, int n_envs, int device, uint6
   h->P.B = n_envs;
   HIPCHK(hipMemset(h->P.f, 0, nf * sizeof(float)));
   HIPCHK(hipMemset(h->P.i, 0, ni * sizeof(int)));
+  HIPCHK(hipMalloc((void**)&h->P.fa, (size_t)ASTRIDE * n_envs * sizeof(float)));      // AoS records of the physics-internal arrays
+  HIPCHK(hipMalloc((void**)&h->P.ia, (size_t)AISTRIDE * n_envs * sizeof(int)));
+  HIPCHK(hipMemset(h->P.fa, 0, (size_t)ASTRIDE * n_envs * sizeof(float)));
+  HIPCHK(hipMemset(h->P.ia, 0, (size_t)AISTRIDE * n_envs * sizeof(int)));
   HIPCHK(hipMalloc((void**)&h->dm, sizeof(Model)));
   HIPCHK(hipMemcpy(h->dm, &h->hm, sizeof(Model), hipMemcpyHostToDevice));
   {
@@ -3530,6 +3144,7 @@ int go2sim_create(const void* blob, size_t nbytes, int n_envs, int device, uint6
   HIPCHK(hipMemset(h->dacc, 0, sizeof(Acc)));
   memset(&h->hcfg, 0, sizeof(DCfg));
   hipLaunchKernelGGL(k_init_state, grid_for(n_envs), dim3(WG), 0, 0, h->P, h->dm, 0);
+  launch_fk_team(h, 0, 1, nullptr);
   HIPCHK(hipGetLastError());
   HIPCHK(hipDeviceSynchronize());
   *out = h;
@@ -3541,7 +3156,7 @@ int go2sim_destroy(go2sim_t* h) {
   (void)hipSetDevice(h->device);
   (void)hipDeviceSynchronize();
   if (h->ev_created) for (int i = 0; i < TIMING_RING; ++i) { (void)hipEventDestroy(h->ev0[i]); (void)hipEventDestroy(h->ev1[i]); }
-  (void)hipFree(h->P.f); (void)hipFree(h->P.i); (void)hipFree(h->dm); (void)hipFree(h->dcfg); (void)hipFree(h->dglob); (void)hipFree(h->dacc); (void)hipFree(h->derr); (void)hipFree(h->solver_ovf); (void)hipFree(h->gjk_scratch); (void)hipFree(h->dms);
+  (void)hipFree(h->P.f); (void)hipFree(h->P.i); (void)hipFree(h->P.fa); (void)hipFree(h->P.ia); (void)hipFree(h->dm); (void)hipFree(h->dcfg); (void)hipFree(h->dglob); (void)hipFree(h->dacc); (void)hipFree(h->derr); (void)hipFree(h->solver_ovf); (void)hipFree(h->gjk_scratch); (void)hipFree(h->dms);
   delete h;
   return GO2SIM_E_OK;
 }
@@ -3553,6 +3168,7 @@ int go2sim_scene_reset(go2sim_t* h, void* stream) {
   ScopedTimer t(h, s, T_MISC);
   hipLaunchKernelGGL(k_scene_reset_clear, grid_for(h->B), dim3(WG), 0, s, h->P);
   hipLaunchKernelGGL(k_init_state, grid_for(h->B), dim3(WG), 0, s, h->P, h->dm, 1);
+  launch_fk_team(h, s, 1, nullptr);
   HIPCHK(hipGetLastError());
   return GO2SIM_E_OK;
 }
@@ -3579,13 +3195,14 @@ int go2sim_forward_kinematics(go2sim_t* h, void* stream) {
   return GO2SIM_E_OK;
 }
 
-static int field_lookup(int field, int* k, int* is_int, int* off) {
-  int kk = -1, ii = 0, oo = 0;
+// field -> (components, int?, offset, AoS?)
+static int field_lookup(int field, int* k, int* is_int, int* off, int* is_aos = nullptr) {
+  int kk = -1, ii = 0, oo = 0, aa = 0;
   switch (field) {
     case GO2SIM_F_QPOS: kk = NQ; oo = FO(qpos); break;
     case GO2SIM_F_VEL: kk = ND; oo = FO(vel); break;
-    case GO2SIM_F_ACC: kk = ND; oo = FO(acc); break;
-    case GO2SIM_F_QACC_WS: kk = ND; oo = FO(qacc_ws); break;
+    case GO2SIM_F_ACC: kk = ND; oo = AO(acc); aa = 1; break;
+    case GO2SIM_F_QACC_WS: kk = ND; oo = AO(qacc_ws); aa = 1; break;
     case GO2SIM_F_CTRL_FORCE: kk = ND; oo = FO(ctrl_force); break;
     case GO2SIM_F_EXT_FORCE: kk = NL * 6; oo = FO(ext); break;
     case GO2SIM_F_MASS_SHIFT: kk = NL; oo = FO(mass_shift); break;
@@ -3597,24 +3214,24 @@ static int field_lookup(int field, int* k, int* is_int, int* off) {
     case GO2SIM_F_LINK_CDANG: kk = NL * 3; oo = FO(cd_ang); break;
     case GO2SIM_F_ROOT_COM: kk = 3; oo = FO(root_com) + 3; break;
     case GO2SIM_F_CONTACT_FORCE: kk = NL * 3; oo = FO(contact_force); break;
-    case GO2SIM_F_MASS_MAT: kk = ND * ND; oo = FO(mass_mat); break;
-    case GO2SIM_F_FORCE: kk = ND; oo = FO(qf_smooth); break;
-    case GO2SIM_F_ACC_SMOOTH: kk = ND; oo = FO(acc_smooth); break;
-    case GO2SIM_F_CONTACT_POS: kk = MAXC * 3; oo = FO(c_pos); break;
-    case GO2SIM_F_CONTACT_NORMAL: kk = MAXC * 3; oo = FO(c_normal); break;
-    case GO2SIM_F_CONTACT_PEN: kk = MAXC; oo = FO(c_pen); break;
+    case GO2SIM_F_MASS_MAT: kk = ND * ND; oo = AO(mass_mat); aa = 1; break;
+    case GO2SIM_F_FORCE: kk = ND; oo = AO(qf_smooth); aa = 1; break;
+    case GO2SIM_F_ACC_SMOOTH: kk = ND; oo = AO(acc_smooth); aa = 1; break;
+    case GO2SIM_F_CONTACT_POS: kk = MAXC * 3; oo = AO(c_pos); aa = 1; break;
+    case GO2SIM_F_CONTACT_NORMAL: kk = MAXC * 3; oo = AO(c_normal); aa = 1; break;
+    case GO2SIM_F_CONTACT_PEN: kk = MAXC; oo = AO(c_pen); aa = 1; break;
     case GO2SIM_F_NORMAL_CACHE: kk = NPAIR * 3; oo = FO(normal_cache); break;
-    case GO2SIM_F_SORT_VALUE: kk = 2 * NG; oo = FO(sort_value); break;
+    case GO2SIM_F_SORT_VALUE: kk = 2 * NG; oo = AO(sort_value); aa = 1; break;
     case GO2SIM_F_GEOM_FRICTION: kk = NG; oo = FO(geom_friction); break;
-    case GO2SIM_F_EFC_FORCE: kk = MAXR; oo = FO(efc_force); break;
-    case GO2SIM_F_QFRC_CONSTRAINT: kk = ND; oo = FO(qfrc_constraint); break;
+    case GO2SIM_F_EFC_FORCE: kk = MAXR; oo = AO(efc_force); aa = 1; break;
+    case GO2SIM_F_QFRC_CONSTRAINT: kk = ND; oo = AO(qfrc_constraint); aa = 1; break;
     case GO2SIM_I_N_CONTACTS: kk = 1; ii = 1; oo = IO(n_contacts); break;
-    case GO2SIM_I_CONTACT_GEOMS: kk = 2 * MAXC; ii = 1; oo = IO(c_geom); break;
+    case GO2SIM_I_CONTACT_GEOMS: kk = 2 * MAXC; ii = 1; oo = AIO(c_geom); aa = 1; break;
     case GO2SIM_I_N_CONSTRAINTS: kk = 1; ii = 1; oo = IO(n_con); break;
     case GO2SIM_I_ERRNO: kk = 1; ii = 1; oo = IO(err); break;
     case GO2SIM_I_IS_WARMSTART: kk = 1; ii = 1; oo = IO(is_warmstart); break;
     case GO2SIM_I_FIRST_TIME: kk = 1; ii = 1; oo = IO(first_time); break;
-    case GO2SIM_I_SORT_IG: kk = 2 * NG; ii = 1; oo = IO(sort_ig); break;
+    case GO2SIM_I_SORT_IG: kk = 2 * NG; ii = 1; oo = AIO(sort_ig); aa = 1; break;
     case GO2SIM_I_N_BROAD: kk = 1; ii = 1; oo = IO(n_broad); break;
     case GO2SIM_I_SOLVER_ITERS: kk = 1; ii = 1; oo = IO(solver_iters); break;
     case GO2SIM_I_CTRL_MODE: kk = ND; ii = 1; oo = IO(ctrl_mode); break;
@@ -3623,25 +3240,44 @@ static int field_lookup(int field, int* k, int* is_int, int* off) {
   if (k) *k = kk;
   if (is_int) *is_int = ii;
   if (off) *off = oo;
+  if (is_aos) *is_aos = aa;
   return GO2SIM_E_OK;
 }
 int go2sim_field_size(int field, int* k, int* is_int) { return field_lookup(field, k, is_int, nullptr); }
+// zero-copy view: only the fields that live in the SoA pool ([k][n_envs]); the physics-internal arrays are kept as per-env records
+// (use go2sim_get_field / go2sim_set_field for those)
 int go2sim_field_ptr(go2sim_t* h, int field, void** ptr_out) {
-  int k, ii, off;
-  if (!h || !ptr_out || field_lookup(field, &k, &ii, &off)) return GO2SIM_E_BADARG;
+  int k, ii, off, aa;
+  if (!h || !ptr_out || field_lookup(field, &k, &ii, &off, &aa) || aa) return GO2SIM_E_BADARG;
   *ptr_out = ii ? (void*)(h->P.i + (size_t)off * h->B) : (void*)(h->P.f + (size_t)off * h->B);
   return GO2SIM_E_OK;
 }
 int go2sim_get_field(go2sim_t* h, int field, void* dst, void* stream) {
-  int k, ii, off; void* p;
-  if (!h || !dst || field_lookup(field, &k, &ii, &off) || go2sim_field_ptr(h, field, &p)) return GO2SIM_E_BADARG;
-  HIPCHK(hipMemcpyAsync(dst, p, (size_t)k * h->B * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  int k, ii, off, aa;
+  if (!h || !dst || field_lookup(field, &k, &ii, &off, &aa)) return GO2SIM_E_BADARG;
+  hipStream_t s = (hipStream_t)stream;
+  if (aa) {
+    const int* rec = ii ? h->P.ia : (const int*)h->P.fa;
+    hipLaunchKernelGGL(k_aos_to_rows, dim3((k * h->B + 255) / 256), dim3(256), 0, s, rec, ii ? AISTRIDE : ASTRIDE, off, k, h->B, (int*)dst);
+    HIPCHK(hipGetLastError());
+  } else {
+    void* p = ii ? (void*)(h->P.i + (size_t)off * h->B) : (void*)(h->P.f + (size_t)off * h->B);
+    HIPCHK(hipMemcpyAsync(dst, p, (size_t)k * h->B * 4, hipMemcpyDeviceToDevice, s));
+  }
   return GO2SIM_E_OK;
 }
 int go2sim_set_field(go2sim_t* h, int field, const void* src, void* stream) {
-  int k, ii, off; void* p;
-  if (!h || !src || field_lookup(field, &k, &ii, &off) || go2sim_field_ptr(h, field, &p)) return GO2SIM_E_BADARG;
-  HIPCHK(hipMemcpyAsync(p, src, (size_t)k * h->B * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  int k, ii, off, aa;
+  if (!h || !src || field_lookup(field, &k, &ii, &off, &aa)) return GO2SIM_E_BADARG;
+  hipStream_t s = (hipStream_t)stream;
+  if (aa) {
+    int* rec = ii ? h->P.ia : (int*)h->P.fa;
+    hipLaunchKernelGGL(k_rows_to_aos, dim3((k * h->B + 255) / 256), dim3(256), 0, s, (const int*)src, rec, ii ? AISTRIDE : ASTRIDE, off, k, h->B);
+    HIPCHK(hipGetLastError());
+  } else {
+    void* p = ii ? (void*)(h->P.i + (size_t)off * h->B) : (void*)(h->P.f + (size_t)off * h->B);
+    HIPCHK(hipMemcpyAsync(p, src, (size_t)k * h->B * 4, hipMemcpyDeviceToDevice, s));
+  }
   return GO2SIM_E_OK;
 }
 int go2sim_reset_caches(go2sim_t* h, const int* envs_idx, int n_sel, void* stream) {
