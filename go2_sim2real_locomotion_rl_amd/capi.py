@@ -175,6 +175,13 @@ class Go2Sim:
     def set_friction(self, mu, stream=None):
         self._call("set_friction", ctypes.c_float(mu), _ptr(stream))
 
+    def set_terrain(self, hf_int16, horizontal_scale, vertical_scale, origin, stream=None):
+        hf = np.ascontiguousarray(hf_int16, dtype=np.int16)
+        org = np.ascontiguousarray(origin, dtype=np.float32)
+        self._terrain_keepalive = (hf, org)
+        self._call("set_terrain", _ptr(hf), ctypes.c_int(hf.shape[0]), ctypes.c_int(hf.shape[1]), ctypes.c_float(horizontal_scale),
+                   ctypes.c_float(vertical_scale), _ptr(org), _ptr(stream))
+
     def set_dof_gains(self, dof, kp, kv, flo, fhi):
         self._call("set_dof_gains", ctypes.c_int(dof), ctypes.c_float(kp), ctypes.c_float(kv), ctypes.c_float(flo), ctypes.c_float(fhi))
 

@@ -347,3 +347,52 @@ def flatten_base_cfg(num_envs, env_cfg, obs_cfg, reward_cfg, command_cfg, *, mod
     i[I("GLOBAL_DR_INTERVAL")] = 1 << 30
     i[I("FREEZE_CURRICULUM")] = 1
     return f, i, names
+
+
+# ---------------------------------------------------------------------------------------------
+# stair terrain (go2_env_stair.py:47-186): difficulty rows along y, repeated up / down flights along x
+# ---------------------------------------------------------------------------------------------
+def get_stair_terrain_cfg():
+    """`terrain` block of go2_train_stair.py:97-119."""
+    return {"enabled": True, "horizontal_scale": 0.05, "vertical_scale": 0.005, "num_difficulty_rows": 13, "row_width_m": 6.0,
+            "step_depth_m": 0.39, "num_steps": 6, "num_flights": 4, "flat_before_m": 2.0, "flat_top_m": 1.5, "flat_gap_m": 1.5,
+            "flat_after_m": 2.0, "step_height_min": 0.02, "step_height_max": 0.15}
+
+
+def build_stair_terrain(terrain_cfg):
+    """Heightfield (int16 [x cells, y cells]) and placement metadata, as go2_env_stair.py:47-186 builds them."""
+    g = terrain_cfg.get
+    h_scale, v_scale = g("horizontal_scale", 0.05), g("vertical_scale", 0.005)
+    num_rows, row_width_m = g("num_difficulty_rows", 10), g("row_width_m", 6.0)
+    num_steps, num_flights = g("num_steps", 6), g("num_flights", 4)
+    cells = lambda metres: max(1, int(round(metres / h_scale)))
+    step_depth, flat_before, flat_top = cells(g("step_depth_m", 0.30)), cells(g("flat_before_m", 2.0)), cells(g("flat_top_m", 1.5))
+    flat_gap, flat_after, row_width = cells(g("flat_gap_m", 1.5)), cells(g("flat_after_m", 2.0)), cells(row_width_m)
+    stair_section = num_steps * step_depth
+    total_x = flat_before + num_flights * (2 * stair_section + flat_top + flat_gap) + flat_after
+    total_y = num_rows * row_width
+    step_heights_m = np.linspace(g("step_height_min", 0.02), g("step_height_max", 0.15), num_rows)
+    step_units = np.round(step_heights_m / v_scale).astype(np.int16)
+    hf = np.zeros((total_x, total_y), dtype=np.int16)
+    centers = []
+    for row in range(num_rows):
+        y0, y1, sh = row * row_width, (row + 1) * row_width, step_units[row]
+        x = flat_before
+        for _ in range(num_flights):
+            for s in range(num_steps):
+                hf[x:x + step_depth, y0:y1] = (s + 1) * sh
+                x += step_depth
+            top = num_steps * sh
+            hf[x:x + flat_top, y0:y1] = top
+            x += flat_top
+            for s in range(num_steps):
+                hf[x:x + step_depth, y0:y1] = top - (s + 1) * sh
+                x += step_depth
+            x += flat_gap
+        centers.append((flat_before * h_scale * 0.5, (y0 + row_width / 2.0) * h_scale, 0.0))
+    origin = (0.0, -total_y * h_scale / 2.0, 0.0)
+    info = {"heightfield": hf, "horizontal_scale": h_scale, "vertical_scale": v_scale, "terrain_origin": origin,
+            "num_difficulty_rows": num_rows, "row_centers": [(cx + origin[0], cy + origin[1], cz + origin[2]) for cx, cy, cz in centers],
+            "step_heights_m": step_heights_m.tolist(), "total_x_m": total_x * h_scale, "total_y_m": total_y * h_scale,
+            "num_flights": num_flights, "num_steps": num_steps, "step_depth_m": g("step_depth_m", 0.30)}
+    return hf, info

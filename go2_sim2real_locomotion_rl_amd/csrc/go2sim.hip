@@ -23,6 +23,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <vector>
 
 #include "../../include/go2sim.h"
 #include "../../include/go2sim_detmath.h"
@@ -36,7 +37,7 @@ namespace {
 constexpr int NL = GO2SIM_NL, ND = GO2SIM_ND, NQ = GO2SIM_NQ, NG = GO2SIM_NG, NJ = GO2SIM_NJ;
 constexpr int NPAIR = GO2SIM_NPAIR_MAX, MAXC = GO2SIM_MAX_CONTACTS, MAXB = GO2SIM_MAX_BROAD, MAXR = GO2SIM_MAX_ROWS;
 constexpr int JOINT_FIXED = 0, JOINT_REVOLUTE = 1, JOINT_FREE = 4;
-constexpr int GEOM_SPHERE = 1, GEOM_CYLINDER = 3, GEOM_BOX = 5;
+constexpr int GEOM_SPHERE = 1, GEOM_CYLINDER = 3, GEOM_BOX = 5, GEOM_TERRAIN = 7;
 constexpr int CTRL_FORCE = 0, CTRL_VELOCITY = 1, CTRL_POSITION = 2;
 constexpr int NA = 16, NM = 12, NOBS_MAX = 64, NPRIV_MAX = 128, NREW = 32;
 constexpr int WG = 64;  // one wavefront per workgroup
@@ -53,6 +54,7 @@ DEV float fmx(float a, float b) { return (a < b) ? b : a; }   // std::max semant
 DEV int imn(int a, int b) { return (b < a) ? b : a; }
 DEV int imx(int a, int b) { return (a < b) ? b : a; }
 DEV V3 v3(float x, float y, float z) { V3 r = {x, y, z}; return r; }
+static inline V3 v3h(float x, float y, float z) { V3 r = {x, y, z}; return r; }   // host-side constructor
 DEV V3 operator+(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
 DEV V3 operator-(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
 DEV V3 operator-(V3 a) { return v3(-a.x, -a.y, -a.z); }
@@ -238,12 +240,15 @@ struct Model {
   Link links[NL]; Joint joints[NJ]; Dof dofs[ND]; Geom geoms[NG]; Entity entities[2];
   float qpos0[NQ]; float mass_parent_mask[ND][ND]; int pair_idx[NG][NG]; int theta_to_ring[180];
   int pair_list[NPAIR];   // derived: valid pair p -> geom_a | geom_b << 8 (a < b)
+  // heightfield terrain replacing the ground slab (go2sim_set_terrain; collider.py:374-394); hf is a device pointer
+  int terrain_enabled, terrain_rows, terrain_cols; float terrain_hs; float terrain_xyz_maxmin[6]; const float* terrain_hf;
   // derived tree tables: links grouped by depth, children of every link in DESCENDING index order (the order in which the
   // reference's leaf->root loops add them to the parent), link of every dof
   int n_levels, level_start[NL + 1], level_links[NL], child_start[NL + 1], child_list[NL], dof_link[ND];
 };
 
 bool parse_model(const void* blob, size_t nbytes, Model& m) {
+  m.terrain_enabled = 0; m.terrain_rows = m.terrain_cols = 0; m.terrain_hs = 0.0f; m.terrain_hf = nullptr;
   if (nbytes < 128) return false;
   const int32_t* H = (const int32_t*)blob;
   if (H[0] != GO2SIM_MODEL_MAGIC || H[1] != GO2SIM_MODEL_VERSION) return false;
@@ -1116,8 +1121,18 @@ DEV V3 support_cylinder_local(const Model& m, const Geom& G, V3 d_mesh, int* vid
   return v;
 }
 // support_driver, collider/mpr.py:146-176
-DEV V3 support_driver(const Model& m, V3 direction, int i_g, V3 pos, Q4 quat) {
+// _func_support_prism, support_field.py:262-280: the terrain geom is represented by the current 6-vertex prism
+DEV V3 support_prism(const V3* prism, V3 d) {
+  int istart = 3;
+  if (d.z < 0) istart = 0;
+  int ibest = istart;
+  float best = dot(prism[istart], d);
+  for (int i = istart + 1; i < istart + 3; ++i) { float dt_ = dot(prism[i], d); if (dt_ > best) { ibest = i; best = dt_; } }
+  return prism[ibest];
+}
+DEV V3 support_driver(const Model& m, V3 direction, int i_g, V3 pos, Q4 quat, const V3* prism = nullptr) {
   const Geom& G = m.geoms[i_g];
+  if (G.type == GEOM_TERRAIN) return support_prism(prism, direction);
   if (G.type == GEOM_SPHERE) {
     return pos + direction * G.data[0];
   } else if (G.type == GEOM_BOX) {
@@ -1131,11 +1146,11 @@ DEV V3 support_driver(const Model& m, V3 direction, int i_g, V3 pos, Q4 quat) {
     return transform_by_trans_quat(v_, pos, quat);
   }
 }
-struct Pair { int i_ga, i_gb; V3 pos_a; Q4 quat_a; V3 pos_b; Q4 quat_b; };
+struct Pair { int i_ga, i_gb; V3 pos_a; Q4 quat_a; V3 pos_b; Q4 quat_b; const V3* prism; };
 // compute_support, collider/mpr.py:179-202
 DEVN void compute_support(const Model& m, V3 direction, const Pair& pr, V3& v, V3& v1, V3& v2) {
   v1 = support_driver(m, direction, pr.i_ga, pr.pos_a, pr.quat_a);
-  v2 = support_driver(m, -direction, pr.i_gb, pr.pos_b, pr.quat_b);
+  v2 = support_driver(m, -direction, pr.i_gb, pr.pos_b, pr.quat_b, pr.prism);
   v = v1 - v2;
 }
 
@@ -1359,10 +1374,9 @@ DEV void guess_geoms_center(const Model& m, const Pair& pr, V3 normal_ws, V3& ce
   }
 }
 // func_mpr_contact -> func_mpr_contact_from_centers, mpr.py:686-819
-DEVN void mpr_contact(const Model& m, const Pair& pr, V3 normal_ws, bool& is_col, V3& normal, float& penetration, V3& pos) {
+// func_mpr_contact_from_centers, mpr.py:686-760
+DEVN void mpr_contact_from_centers(const Model& m, const Pair& pr, V3 center_a, V3 center_b, bool& is_col, V3& normal, float& penetration, V3& pos) {
   Simplex s;
-  V3 center_a, center_b;
-  guess_geoms_center(m, pr, normal_ws, center_a, center_b);
   int res = mpr_discover_portal(m, s, pr, center_a, center_b);
   is_col = false; pos = v3(0, 0, 0); normal = v3(0, 0, 0); penetration = 0.0f;
   if (res == 1) {
@@ -1373,6 +1387,11 @@ DEVN void mpr_contact(const Model& m, const Pair& pr, V3 normal_ws, bool& is_col
     res = mpr_refine_portal(m, s, pr);
     if (res >= 0) mpr_find_penetration(m, s, pr, is_col, normal, penetration, pos);
   }
+}
+DEV void mpr_contact(const Model& m, const Pair& pr, V3 normal_ws, bool& is_col, V3& normal, float& penetration, V3& pos) {
+  V3 center_a, center_b;
+  guess_geoms_center(m, pr, normal_ws, center_a, center_b);
+  mpr_contact_from_centers(m, pr, center_a, center_b, is_col, normal, penetration, pos);
 }
 
 // func_compute_tolerance, contact.py:264-283
@@ -1443,7 +1462,7 @@ DEV void convex_convex_contact_staged(const Model& m, const E& e, int i_ga, int 
   bool multi_contact = (type_a != GEOM_SPHERE) && (type_b != GEOM_SPHERE);
   float tolerance = compute_tolerance(m, i_ga, i_gb, m.mc_tolerance);
   V3 ga_pos_o = e.g_pos()[i_ga], gb_pos_o = e.g_pos()[i_gb]; Q4 ga_quat_o = e.g_quat()[i_ga], gb_quat_o = e.g_quat()[i_gb];
-  Pair pr; pr.i_ga = i_ga; pr.i_gb = i_gb; pr.pos_a = ga_pos_o; pr.quat_a = ga_quat_o; pr.pos_b = gb_pos_o; pr.quat_b = gb_quat_o;
+  Pair pr; pr.i_ga = i_ga; pr.i_gb = i_gb; pr.pos_a = ga_pos_o; pr.quat_a = ga_quat_o; pr.pos_b = gb_pos_o; pr.quat_b = gb_quat_o; pr.prism = nullptr;
   bool is_col_0 = false; V3 normal_0 = v3(0, 0, 0), contact_pos_0 = v3(0, 0, 0);
   bool is_col = false; float penetration = 0.0f; V3 normal = v3(0, 0, 0), contact_pos = v3(0, 0, 0);
   V3 axis_0 = v3(0, 0, 0), axis_1 = v3(0, 0, 0); Q4 qrot = q4(0, 0, 0, 0);
@@ -1508,6 +1527,71 @@ DEV void convex_convex_contact_staged(const Model& m, const E& e, int i_ga, int 
         stage_contact(cs, normal, contact_pos, penetration);
       }
     }
+  }
+}
+
+// func_contact_mpr_terrain, narrowphase.py:345-490: geom i_ga against the heightfield cells under its bounding box; contacts are staged
+DEV void contact_mpr_terrain_staged(const Model& m, const E& e, int i_ga, int i_gb, ContactStage& cs) {
+  V3 ga_pos = e.g_pos()[i_ga], gb_pos = e.g_pos()[i_gb]; Q4 ga_quat = e.g_quat()[i_ga], gb_quat = e.g_quat()[i_gb];
+  const float margin = 0.0f;
+  bool is_return = false;
+  float tolerance = compute_tolerance(m, i_ga, i_gb, m.mc_tolerance);
+  V3 prism[6]; float xyz_max_min[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) prism[i] = v3(0, 0, 0);
+  Pair pr; pr.i_ga = i_ga; pr.i_gb = i_gb; pr.prism = prism;
+  transform_pos_quat_by_trans_quat(ga_pos - gb_pos, ga_quat, v3(0, 0, 0), inv_quat(gb_quat), pr.pos_a, pr.quat_a);
+  pr.pos_b = v3(0, 0, 0); pr.quat_b = qident();
+  V3 center_a = transform_by_trans_quat(m.geoms[i_ga].center, pr.pos_a, pr.quat_a);
+  for (int i_axis = 0; i_axis < 3; ++i_axis)
+    for (int i_m = 0; i_m < 2; ++i_m) {
+      V3 direction = v3(0, 0, 0);
+      vset(direction, i_axis, (i_m == 0) ? 1.0f : -1.0f);
+      V3 v1 = support_driver(m, direction, i_ga, pr.pos_a, pr.quat_a);
+      xyz_max_min[3 * i_m + i_axis] = vget(v1, i_axis);
+    }
+  const float* tmm = m.terrain_xyz_maxmin;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    prism[i].z = tmm[5];
+    if (tmm[i] < xyz_max_min[i + 3] - margin || tmm[i + 3] > xyz_max_min[i] + margin) is_return = true;
+  }
+  if (is_return) return;
+  const float sh = m.terrain_hs;
+  int r_min = (int)dm_floor((xyz_max_min[3] - tmm[3]) / sh);
+  int r_max = (int)dm_ceil((xyz_max_min[0] - tmm[3]) / sh);
+  int c_min = (int)dm_floor((xyz_max_min[4] - tmm[4]) / sh);
+  int c_max = (int)dm_ceil((xyz_max_min[1] - tmm[4]) / sh);
+  r_min = imx(0, r_min); c_min = imx(0, c_min);
+  r_max = imn(m.terrain_rows - 1, r_max); c_max = imn(m.terrain_cols - 1, c_max);
+  for (int r = r_min; r < r_max; ++r) {
+    int nvert = 0;
+    for (int c = c_min; c < c_max + 1; ++c)
+      for (int i = 0; i < 2; ++i)
+        if (cs.n < m.n_contacts_per_pair) {
+          nvert = nvert + 1;
+          float x = sh * (float)(r + i) + tmm[3], y = sh * (float)c + tmm[4], z = m.terrain_hf[(size_t)(r + i) * m.terrain_cols + c] + margin;
+          prism[0] = prism[1]; prism[1] = prism[2]; prism[3] = prism[4]; prism[4] = prism[5];            // func_add_prism_vert :493-512
+          prism[2].x = x; prism[5].x = x; prism[2].y = y; prism[5].y = y; prism[5].z = z;
+          if (nvert > 2 && (prism[3].z >= xyz_max_min[5] || prism[4].z >= xyz_max_min[5] || prism[5].z >= xyz_max_min[5])) {
+            V3 center_b = v3(0, 0, 0);
+            for (int i_p = 0; i_p < 6; ++i_p) center_b = center_b + prism[i_p];
+            center_b = center_b / 6.0f;
+            bool is_col; V3 normal, contact_pos; float penetration;
+            mpr_contact_from_centers(m, pr, center_a, center_b, is_col, normal, penetration, contact_pos);
+            if (is_col) {
+              normal = transform_by_quat(normal, gb_quat);
+              contact_pos = transform_by_quat(contact_pos, gb_quat);
+              contact_pos = contact_pos + gb_pos;
+              bool valid = true;
+              for (int j = 0; j < cs.n; ++j) {
+                const float* prev = cs.st + 7 * (cs.n - j - 1);
+                if (norm(contact_pos - v3(prev[3], prev[4], prev[5])) < tolerance) { valid = false; break; }
+              }
+              if (valid) stage_contact(cs, normal, contact_pos, penetration);
+            }
+          }
+        }
   }
 }
 
@@ -1610,9 +1694,11 @@ __global__ __launch_bounds__(64) void k_collide_team(Pool P, const Model* __rest
   team_sync();
   for (int c = tl; c < n_broad; c += T) { int pk = s->pair_sorted[c]; e.broad()[2 * c] = pk & 0xff; e.broad()[2 * c + 1] = pk >> 8; }
   PH(32)
-  // ---- func_narrow_phase_convex_vs_convex, narrowphase.py:964-1068: one lane per pair, ordered compaction ----
+  // ---- func_narrow_phase_convex_vs_convex (narrowphase.py:964-1068), then func_narrow_phase_any_vs_terrain (:1197-1244): one lane per
+  //      pair, ordered compaction; the terrain pass appends after all convex-convex contacts, as the two reference kernels do ----
   int nc_run = 0;
   const int n_np_iter = (n_broad + T - 1) / T;
+  for (int pass = 0; pass < (m.terrain_enabled ? 2 : 1); ++pass)
   for (int it = 0; it < n_np_iter; ++it) {
     int ip = it * T + tl;
     ContactStage cs; cs.st = &s->stage[tl][0][0]; cs.n = 0;
@@ -1621,7 +1707,9 @@ __global__ __launch_bounds__(64) void k_collide_team(Pool P, const Model* __rest
       int pk = s->pair_sorted[ip];
       i_ga = pk & 0xff; i_gb = pk >> 8;
       if (m.geoms[i_ga].type > m.geoms[i_gb].type) { int t = i_ga; i_ga = i_gb; i_gb = t; }
-      convex_convex_contact_staged(m, e, i_ga, i_gb, cs, &gjk_scratch[(size_t)b * T + tl]);
+      const bool with_terrain = m.geoms[i_gb].type == GEOM_TERRAIN;
+      if (pass == 0 && !with_terrain) convex_convex_contact_staged(m, e, i_ga, i_gb, cs, &gjk_scratch[(size_t)b * T + tl]);
+      if (pass == 1 && with_terrain) contact_mpr_terrain_staged(m, e, i_ga, i_gb, cs);
     }
     s->cnt[tl] = cs.n;
     team_sync();
@@ -3021,6 +3109,7 @@ struct go2sim {
   Pool P = {nullptr, nullptr, 0, nullptr, nullptr};
   DCfg hcfg; DCfg* dcfg = nullptr; bool cfg_set = false;
   Glob* dglob = nullptr; Acc* dacc = nullptr; int* derr = nullptr;
+  float* terrain_hf = nullptr;              // device copy of the heightfield in metres (go2sim_set_terrain)
   GjkScratch* gjk_scratch = nullptr;        // working memory of the GJK/EPA fallback: one block per (env, narrow-phase lane)
   SolverData<MAXR>* solver_ovf = nullptr;   // per-env global scratch for solves that do not fit in LDS (> RL rows)
   int dyn_team = 16;                        // lanes per environment in k_dynamics_team / k_integrate_fk_team / k_fk_team
@@ -3156,7 +3245,7 @@ int go2sim_destroy(go2sim_t* h) {
   (void)hipSetDevice(h->device);
   (void)hipDeviceSynchronize();
   if (h->ev_created) for (int i = 0; i < TIMING_RING; ++i) { (void)hipEventDestroy(h->ev0[i]); (void)hipEventDestroy(h->ev1[i]); }
-  (void)hipFree(h->P.f); (void)hipFree(h->P.i); (void)hipFree(h->P.fa); (void)hipFree(h->P.ia); (void)hipFree(h->dm); (void)hipFree(h->dcfg); (void)hipFree(h->dglob); (void)hipFree(h->dacc); (void)hipFree(h->derr); (void)hipFree(h->solver_ovf); (void)hipFree(h->gjk_scratch); (void)hipFree(h->dms);
+  (void)hipFree(h->P.f); (void)hipFree(h->P.i); (void)hipFree(h->P.fa); (void)hipFree(h->P.ia); (void)hipFree(h->dm); (void)hipFree(h->dcfg); (void)hipFree(h->dglob); (void)hipFree(h->dacc); (void)hipFree(h->derr); (void)hipFree(h->solver_ovf); (void)hipFree(h->gjk_scratch); if (h->terrain_hf) (void)hipFree(h->terrain_hf); (void)hipFree(h->dms);
   delete h;
   return GO2SIM_E_OK;
 }
@@ -3294,6 +3383,42 @@ int go2sim_set_friction(go2sim_t* h, float mu, void* stream) {
   hipLaunchKernelGGL(k_set_friction, grid_for(h->B), dim3(WG), 0, s, h->P, mu);
   HIPCHK(hipMemcpyAsync((char*)h->dglob + offsetof(Glob, friction), &mu, sizeof(float), hipMemcpyHostToDevice, s));
   HIPCHK(hipStreamSynchronize(s));  // `mu` lives on the caller's stack
+  return GO2SIM_E_OK;
+}
+__global__ void k_set_link0_pose(Pool P, V3 pos) {
+  int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= P.B) return;
+  E e(P, b);
+  e.l_pos()[0] = pos; e.l_quat()[0] = qident();
+  e.first_time()[0] = 1; e.is_warmstart()[0] = 0;
+  auto nc = e.normal_cache();
+  for (int p = 0; p < NPAIR; ++p) nc[p] = v3(0, 0, 0);
+}
+int go2sim_set_terrain(go2sim_t* h, const int16_t* hf, int rows, int cols, float horizontal_scale, float vertical_scale, const float* origin, void* stream) {
+  if (!h || !hf || rows < 2 || cols < 2 || !origin || !(horizontal_scale > 0.0f)) return GO2SIM_E_BADARG;
+  hipStream_t s = (hipStream_t)stream;
+  HIPCHK(hipStreamSynchronize(s));
+  Model& m = h->hm;
+  std::vector<float> hfm((size_t)rows * cols);
+  float hmax = -1e30f, hmin = 1e30f;
+  for (size_t k = 0; k < hfm.size(); ++k) { float v = (float)hf[k] * vertical_scale; hfm[k] = v; hmax = (hmax < v) ? v : hmax; hmin = (v < hmin) ? v : hmin; }
+  if (h->terrain_hf) (void)hipFree(h->terrain_hf);
+  HIPCHK(hipMalloc((void**)&h->terrain_hf, hfm.size() * sizeof(float)));
+  HIPCHK(hipMemcpy(h->terrain_hf, hfm.data(), hfm.size() * sizeof(float), hipMemcpyHostToDevice));
+  m.terrain_enabled = 1; m.terrain_rows = rows; m.terrain_cols = cols; m.terrain_hs = horizontal_scale; m.terrain_hf = h->terrain_hf;
+  m.terrain_xyz_maxmin[0] = (float)rows * horizontal_scale; m.terrain_xyz_maxmin[1] = (float)cols * horizontal_scale; m.terrain_xyz_maxmin[2] = hmax;
+  m.terrain_xyz_maxmin[3] = 0.0f; m.terrain_xyz_maxmin[4] = 0.0f; m.terrain_xyz_maxmin[5] = hmin - 1.0f;
+  Geom& G = m.geoms[0];
+  G.type = GEOM_TERRAIN; G.pos = v3h(0, 0, 0); G.quat = {1.0f, 0.0f, 0.0f, 0.0f}; G.center = v3h(0, 0, 0);
+  float x1 = (float)(rows - 1) * horizontal_scale, y1 = (float)(cols - 1) * horizontal_scale, z0 = hmin - 1.0f, z1 = hmax;
+  for (int c = 0; c < 8; ++c) G.aabb[c] = v3h((c & 4) ? x1 : 0.0f, (c & 2) ? y1 : 0.0f, (c & 1) ? z1 : z0);
+  m.links[0].pos = v3h(origin[0], origin[1], origin[2]); m.links[0].quat = {1.0f, 0.0f, 0.0f, 0.0f};
+  HIPCHK(hipMemcpy(h->dm, &h->hm, sizeof(Model), hipMemcpyHostToDevice));
+  { ModelS hs; if (!build_model_s(h->hm, hs)) return GO2SIM_E_BADMODEL; HIPCHK(hipMemcpy(h->dms, &hs, sizeof(ModelS), hipMemcpyHostToDevice)); }
+  hipLaunchKernelGGL(k_set_link0_pose, dim3((h->B + 255) / 256), dim3(256), 0, s, h->P, m.links[0].pos);
+  launch_fk_team(h, s, 1, nullptr);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(s));
   return GO2SIM_E_OK;
 }
 int go2sim_set_dof_gains(go2sim_t* h, int d, float kp, float kv, float flo, float fhi) {

@@ -278,6 +278,12 @@ int go2sim_reset_caches(go2sim_t* h, const int* envs_idx_dev, int n_sel, void* s
 /* RigidEntity.set_friction on ground + robot: geoms_info.friction = mu for every geom
  * (rigid_entity.py:3189, rigid_geom.py:327-336). */
 int go2sim_set_friction(go2sim_t* h, float mu, void* stream);
+/* gs.morphs.Terrain(height_field=hf, horizontal_scale=, vertical_scale=, pos=origin) in place of the plane entity
+ * (go2_env_stair.py:424-433; rigid_entity.py:505-552; collider.py:374-394): geom 0 becomes a GEOM_TYPE.TERRAIN heightfield whose cells are
+ * collided as 6-vertex prisms (narrowphase.py:345-512).  `hf_host` is a HOST pointer to int16[rows][cols] (heights = hf * vertical_scale);
+ * origin = world position of cell (0, 0).  Resets the collision caches and refreshes the kinematics. */
+int go2sim_set_terrain(go2sim_t* h, const int16_t* hf_host, int rows, int cols, float horizontal_scale, float vertical_scale,
+                       const float* origin3_host, void* stream);
 /* dofs_info.kp / kv / force_range for one dof (rigid_solver.py:2270-2292); host values. */
 int go2sim_set_dof_gains(go2sim_t* h, int dof_idx, float kp, float kv, float force_lo, float force_hi);
 /* RigidSolver.check_errno (rigid_solver.py:1189-1213): OR-reduction of errno over envs, written to a

@@ -33,7 +33,7 @@ typedef float real;
 constexpr int NL = GO2SIM_NL, ND = GO2SIM_ND, NQ = GO2SIM_NQ, NG = GO2SIM_NG, NJ = GO2SIM_NJ;
 constexpr int NPAIR = GO2SIM_NPAIR_MAX, MAXC = GO2SIM_MAX_CONTACTS, MAXB = GO2SIM_MAX_BROAD, MAXR = GO2SIM_MAX_ROWS;
 constexpr int JOINT_FIXED = 0, JOINT_REVOLUTE = 1, JOINT_FREE = 4;
-constexpr int GEOM_SPHERE = 1, GEOM_CYLINDER = 3, GEOM_BOX = 5;
+constexpr int GEOM_SPHERE = 1, GEOM_CYLINDER = 3, GEOM_BOX = 5, GEOM_TERRAIN = 7;
 constexpr int CTRL_FORCE = 0, CTRL_VELOCITY = 1, CTRL_POSITION = 2;
 
 // ---------------------------------------------------------------------------------------------
@@ -229,9 +229,12 @@ struct Model {
       ccd_eps, ccd_tolerance;
   Link links[NL]; Joint joints[NJ]; Dof dofs[ND]; Geom geoms[NG]; Entity entities[2];
   real qpos0[NQ]; real mass_parent_mask[ND][ND]; int pair_idx[NG][NG]; int theta_to_ring[180];
+  // heightfield terrain replacing the ground slab (go2sim_cpu_set_terrain; collider.py:374-394)
+  int terrain_enabled, terrain_rows, terrain_cols; real terrain_hs; real terrain_xyz_maxmin[6]; std::vector<real> terrain_hf;
 };
 
 bool parse_model(const void* blob, size_t nbytes, Model& m) {
+  m.terrain_enabled = 0; m.terrain_rows = m.terrain_cols = 0; m.terrain_hs = 0.0f;
   if (nbytes < 128) return false;
   const int32_t* H = (const int32_t*)blob;
   if (H[0] != GO2SIM_MODEL_MAGIC || H[1] != GO2SIM_MODEL_VERSION) return false;
@@ -336,6 +339,7 @@ struct Env {
   int n_broad; int broad[MAXB][2];
   int n_contacts; Contact contacts[MAXC];
   V3 mpr_v[4], mpr_v1[4], mpr_v2[4];
+  V3 prism[6]; real xyz_max_min[6];   // collider_state.prism / xyz_max_min of the terrain narrow phase
   int gjk_fallback_count;  // number of pairs that switched from MPR to the safe GJK + EPA
   // constraints
   int n_con;
@@ -809,9 +813,20 @@ V3 support_cylinder_local(const Model& m, const Geom& G, V3 d_mesh, int* vid_out
   if (vid_out) *vid_out = vid;
   return v;
 }
-// support_driver, collider/mpr.py:146-176 (sphere / box / table-driven mesh)
+// _func_support_prism, support_field.py:262-280: the terrain geom is represented by the current 6-vertex prism
+static thread_local const V3* g_prism = nullptr;
+inline V3 support_prism(const V3* prism, V3 d) {
+  int istart = 3;
+  if (d.z < 0) istart = 0;
+  int ibest = istart;
+  real best = dot(prism[istart], d);
+  for (int i = istart + 1; i < istart + 3; ++i) { real dt_ = dot(prism[i], d); if (dt_ > best) { ibest = i; best = dt_; } }
+  return prism[ibest];
+}
+// support_driver, collider/mpr.py:146-176 (sphere / box / table-driven mesh / terrain prism)
 V3 support_driver(const Model& m, V3 direction, int i_g, V3 pos, Q4 quat) {
   const Geom& G = m.geoms[i_g];
+  if (G.type == GEOM_TERRAIN) return support_prism(g_prism, direction);
   if (G.type == GEOM_SPHERE) {                                   // support_field.py:183-206
     return pos + direction * G.data[0];
   } else if (G.type == GEOM_BOX) {                               // support_field.py:285-306
@@ -1045,10 +1060,17 @@ void guess_geoms_center(const Model& m, int i_ga, int i_gb, V3 pos_a, Q4 quat_a,
   }
 }
 // func_mpr_contact -> func_mpr_contact_from_centers, mpr.py:686-819
+// func_mpr_contact_from_centers, mpr.py:686-760
+void mpr_contact_from_centers(const Model& m, Env& e, int i_ga, int i_gb, V3 center_a, V3 center_b, V3 pos_a, Q4 quat_a, V3 pos_b, Q4 quat_b, bool& is_col,
+                              V3& normal, real& penetration, V3& pos);
 void mpr_contact(const Model& m, Env& e, int i_ga, int i_gb, V3 normal_ws, V3 pos_a, Q4 quat_a, V3 pos_b, Q4 quat_b, bool& is_col, V3& normal,
                  real& penetration, V3& pos) {
   V3 center_a, center_b;
   guess_geoms_center(m, i_ga, i_gb, pos_a, quat_a, pos_b, quat_b, normal_ws, center_a, center_b);
+  mpr_contact_from_centers(m, e, i_ga, i_gb, center_a, center_b, pos_a, quat_a, pos_b, quat_b, is_col, normal, penetration, pos);
+}
+void mpr_contact_from_centers(const Model& m, Env& e, int i_ga, int i_gb, V3 center_a, V3 center_b, V3 pos_a, Q4 quat_a, V3 pos_b, Q4 quat_b, bool& is_col,
+                              V3& normal, real& penetration, V3& pos) {
   int res = mpr_discover_portal(m, e, i_ga, i_gb, center_a, center_b, pos_a, quat_a, pos_b, quat_b);
   is_col = false; pos = v3(0, 0, 0); normal = v3(0, 0, 0); penetration = 0.0f;
   if (res == 1) {                                                // mpr_find_penetr_touch
@@ -1190,12 +1212,85 @@ void convex_convex_contact(const Model& m, Env& e, int i_ga, int i_gb) {
   }
 }
 
-// func_narrow_phase_convex_vs_convex, narrowphase.py:964-1068
+// func_add_prism_vert, narrowphase.py:493-512
+inline void add_prism_vert(Env& e, real x, real y, real z) {
+  e.prism[0] = e.prism[1]; e.prism[1] = e.prism[2]; e.prism[3] = e.prism[4]; e.prism[4] = e.prism[5];
+  e.prism[2].x = x; e.prism[5].x = x; e.prism[2].y = y; e.prism[5].y = y; e.prism[5].z = z;
+}
+// func_contact_mpr_terrain, narrowphase.py:345-490: geom i_ga against the heightfield cells under its bounding box
+void contact_mpr_terrain(const Model& m, Env& e, int i_ga, int i_gb) {
+  V3 ga_pos = e.g_pos[i_ga], gb_pos = e.g_pos[i_gb]; Q4 ga_quat = e.g_quat[i_ga], gb_quat = e.g_quat[i_gb];
+  const real margin = 0.0f;
+  bool is_return = false;
+  real tolerance = compute_tolerance(m, i_ga, i_gb, m.mc_tolerance);
+  V3 ga_pos_t; Q4 ga_quat_t;
+  transform_pos_quat_by_trans_quat(ga_pos - gb_pos, ga_quat, v3(0, 0, 0), inv_quat(gb_quat), ga_pos_t, ga_quat_t);
+  V3 gb_pos_t = v3(0, 0, 0); Q4 gb_quat_t = q4(1, 0, 0, 0);
+  V3 center_a = transform_by_trans_quat(m.geoms[i_ga].center, ga_pos_t, ga_quat_t);
+  for (int i_axis = 0; i_axis < 3; ++i_axis)
+    for (int i_m = 0; i_m < 2; ++i_m) {
+      V3 direction = v3(0, 0, 0);
+      vset(direction, i_axis, (i_m == 0) ? 1.0f : -1.0f);
+      V3 v1 = support_driver(m, direction, i_ga, ga_pos_t, ga_quat_t);
+      e.xyz_max_min[3 * i_m + i_axis] = vget(v1, i_axis);
+    }
+  const real* tmm = m.terrain_xyz_maxmin;
+  for (int i = 0; i < 3; ++i) {
+    e.prism[i].z = tmm[5];
+    if (tmm[i] < e.xyz_max_min[i + 3] - margin || tmm[i + 3] > e.xyz_max_min[i] + margin) is_return = true;
+  }
+  if (is_return) return;
+  const real sh = m.terrain_hs;
+  int r_min = (int)dm_floor((e.xyz_max_min[3] - tmm[3]) / sh);
+  int r_max = (int)dm_ceil((e.xyz_max_min[0] - tmm[3]) / sh);
+  int c_min = (int)dm_floor((e.xyz_max_min[4] - tmm[4]) / sh);
+  int c_max = (int)dm_ceil((e.xyz_max_min[1] - tmm[4]) / sh);
+  r_min = std::max(0, r_min); c_min = std::max(0, c_min);
+  r_max = std::min(m.terrain_rows - 1, r_max); c_max = std::min(m.terrain_cols - 1, c_max);
+  int n_con = 0;
+  g_prism = e.prism;
+  for (int r = r_min; r < r_max; ++r) {
+    int nvert = 0;
+    for (int c = c_min; c < c_max + 1; ++c)
+      for (int i = 0; i < 2; ++i)
+        if (n_con < m.n_contacts_per_pair) {
+          nvert = nvert + 1;
+          add_prism_vert(e, sh * (real)(r + i) + tmm[3], sh * (real)c + tmm[4], m.terrain_hf[(size_t)(r + i) * m.terrain_cols + c] + margin);
+          if (nvert > 2 && (e.prism[3].z >= e.xyz_max_min[5] || e.prism[4].z >= e.xyz_max_min[5] || e.prism[5].z >= e.xyz_max_min[5])) {
+            V3 center_b = v3(0, 0, 0);
+            for (int i_p = 0; i_p < 6; ++i_p) center_b = center_b + e.prism[i_p];
+            center_b = center_b / 6.0f;
+            bool is_col; V3 normal, contact_pos; real penetration;
+            mpr_contact_from_centers(m, e, i_ga, i_gb, center_a, center_b, ga_pos_t, ga_quat_t, gb_pos_t, gb_quat_t, is_col, normal, penetration, contact_pos);
+            if (is_col) {
+              normal = transform_by_quat(normal, gb_quat);
+              contact_pos = transform_by_quat(contact_pos, gb_quat);
+              contact_pos = contact_pos + gb_pos;
+              bool valid = true;
+              int i_c = e.n_contacts;
+              for (int j = 0; j < n_con; ++j)
+                if (norm(contact_pos - e.contacts[i_c - j - 1].pos) < tolerance) { valid = false; break; }
+              if (valid) { add_contact(m, e, i_ga, i_gb, normal, contact_pos, penetration); n_con = n_con + 1; }
+            }
+          }
+        }
+  }
+  g_prism = nullptr;
+}
+
+// func_narrow_phase_convex_vs_convex (narrowphase.py:964-1068) then func_narrow_phase_any_vs_terrain (:1197-1244), collider.py:436-528
 void narrow_phase(const Model& m, Env& e) {
   for (int i_pair = 0; i_pair < e.n_broad; ++i_pair) {
     int i_ga = e.broad[i_pair][0], i_gb = e.broad[i_pair][1];
     if (m.geoms[i_ga].type > m.geoms[i_gb].type) std::swap(i_ga, i_gb);
+    if (m.geoms[i_gb].type == GEOM_TERRAIN) continue;
     convex_convex_contact(m, e, i_ga, i_gb);
+  }
+  if (!m.terrain_enabled) return;
+  for (int i_pair = 0; i_pair < e.n_broad; ++i_pair) {
+    int i_ga = e.broad[i_pair][0], i_gb = e.broad[i_pair][1];
+    if (m.geoms[i_ga].type == GEOM_TERRAIN) std::swap(i_ga, i_gb);
+    if (m.geoms[i_gb].type == GEOM_TERRAIN) contact_mpr_terrain(m, e, i_ga, i_gb);
   }
 }
 
@@ -2578,6 +2673,33 @@ int go2sim_cpu_env_set_level(go2sim* h, float level, void*) {
 }
 int go2sim_cpu_enable_timing(go2sim*, int) { return GO2SIM_E_BADARG; }
 int go2sim_cpu_read_timing(go2sim*, float*, int*, int) { return GO2SIM_E_BADARG; }
+
+// Terrain morph (rigid_entity.py:505-552, utils/terrain.py:228-330, collider.py:374-394): the ground slab becomes a heightfield geom
+int go2sim_cpu_set_terrain(go2sim* h, const int16_t* hf, int rows, int cols, float horizontal_scale, float vertical_scale, const float* origin, void*) {
+  if (!h || !hf || rows < 2 || cols < 2 || !origin || !(horizontal_scale > 0.0f)) return GO2SIM_E_BADARG;
+  Model& m = h->m;
+  m.terrain_enabled = 1; m.terrain_rows = rows; m.terrain_cols = cols; m.terrain_hs = horizontal_scale;
+  m.terrain_hf.resize((size_t)rows * cols);
+  real hmax = -1e30f, hmin = 1e30f;
+  for (size_t k = 0; k < (size_t)rows * cols; ++k) { real v = (real)hf[k] * vertical_scale; m.terrain_hf[k] = v; hmax = std::max(hmax, v); hmin = std::min(hmin, v); }
+  m.terrain_xyz_maxmin[0] = (real)rows * horizontal_scale; m.terrain_xyz_maxmin[1] = (real)cols * horizontal_scale; m.terrain_xyz_maxmin[2] = hmax;
+  m.terrain_xyz_maxmin[3] = 0.0f; m.terrain_xyz_maxmin[4] = 0.0f; m.terrain_xyz_maxmin[5] = hmin - 1.0f;
+  Geom& G = m.geoms[0];
+  G.type = GEOM_TERRAIN; G.pos = v3(0, 0, 0); G.quat = q4(1, 0, 0, 0); G.center = v3(0, 0, 0);
+  real x1 = (real)(rows - 1) * horizontal_scale, y1 = (real)(cols - 1) * horizontal_scale, z0 = hmin - 1.0f, z1 = hmax;
+  for (int c = 0; c < 8; ++c) G.aabb[c] = v3((c & 4) ? x1 : 0.0f, (c & 2) ? y1 : 0.0f, (c & 1) ? z1 : z0);
+  m.links[0].pos = v3(origin[0], origin[1], origin[2]); m.links[0].quat = q4(1, 0, 0, 0);
+#pragma omp parallel for schedule(static)
+  for (int b = 0; b < h->B; ++b) {
+    Env& e = h->envs[b];
+    e.l_pos[0] = m.links[0].pos; e.l_quat[0] = m.links[0].quat;
+    e.first_time = 1; e.is_warmstart = 0;
+    for (int p = 0; p < NPAIR; ++p) e.normal_cache[p] = v3(0, 0, 0);
+    update_cartesian_space(m, e, true);
+    forward_velocity(m, e);
+  }
+  return GO2SIM_E_OK;
+}
 
 // extra oracle-only diagnostics
 // one narrow-phase query on explicit poses: which = 0 -> MPR (cold start), 1 -> safe GJK + EPA.  out = {is_col, penetration, normal[3], pos[3]}
