@@ -59,7 +59,7 @@ class EnvGlobals(ctypes.Structure):
         ("friction", ctypes.c_float), ("mass_shift", ctypes.c_float), ("com_shift", ctypes.c_float * 3),
         ("leg_mass_shift", ctypes.c_float * 4), ("action_write_idx", ctypes.c_int), ("step_count", ctypes.c_uint),
         ("reset_calls", ctypes.c_uint), ("last_reset_count", ctypes.c_int), ("last_episode_rew", ctypes.c_float * 32),
-        ("n_reset_now", ctypes.c_int), ("ep_acc", ctypes.c_float * 32), ("t_sample", ctypes.c_float),
+        ("n_reset_now", ctypes.c_int), ("ep_acc", ctypes.c_float * 32), ("t_sample", ctypes.c_float), ("terrain_mean_row", ctypes.c_float), ("terrain_row_sum", ctypes.c_int),
     ]
 
     def as_dict(self):

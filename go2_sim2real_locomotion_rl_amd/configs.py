@@ -20,6 +20,7 @@ REWARD_IDS = {
     "feet_air_time": "GO2SIM_R_FEET_AIR_TIME", "foot_slip": "GO2SIM_R_FOOT_SLIP", "foot_clearance": "GO2SIM_R_FOOT_CLEARANCE",
     "joint_tracking": "GO2SIM_R_JOINT_TRACKING", "energy": "GO2SIM_R_ENERGY", "torque_load": "GO2SIM_R_TORQUE_LOAD",
     "stand_still": "GO2SIM_R_STAND_STILL", "stand_still_vel": "GO2SIM_R_STAND_STILL_VEL", "feet_stance": "GO2SIM_R_FEET_STANCE",
+    "orientation_roll_only": "GO2SIM_R_ORIENTATION_ROLL_ONLY", "forward_progress": "GO2SIM_R_FORWARD_PROGRESS",   # go2_env_stair.py
 }
 
 
@@ -232,6 +233,34 @@ def flatten_walk_cfg(num_envs, env_cfg, obs_cfg, reward_cfg, command_cfg, *, mod
     i[I("PUSH_LINK")] = robot_links[1]  # `self.robot.links[1].idx` (go2_env_walk.py:339-342): first depth-1 link, not the base
     i[I("PER_ENV_GLOBAL_DR")] = int(per_env_global_dr)
     i[I("FREEZE_CURRICULUM")] = int(freeze_curriculum)
+
+    # ---- stair env extras (go2_env_stair.py:352-398, 972-988, 1615-1626) ----
+    f[F("LIN_VEL_Z_DEADZONE")] = float(reward_cfg.get("lin_vel_z_deadzone", 0.0))
+    dr_sched = env_cfg.get("dr_schedule", None)
+    i[I("DR_SCHEDULE")] = int(dr_sched is not None)
+    if dr_sched is not None:
+        f[F("DR_PHASE1_LEVEL")], f[F("DR_TERRAIN_GATE")] = dr_sched.get("phase1_level", 0.15), dr_sched.get("terrain_gate", 0.50)
+    tcfg = env_cfg.get("terrain", None)
+    if tcfg is not None and tcfg.get("enabled", False):
+        import torch
+
+        _, info = build_stair_terrain(tcfg)
+        n_rows = info["num_difficulty_rows"]
+        if n_rows > 16:
+            raise NotImplementedError("at most 16 difficulty rows")
+        i[I("USE_TERRAIN")], i[I("N_TERRAIN_ROWS")] = 1, n_rows
+        f[F("TERRAIN_ORIGIN_X")], f[F("TERRAIN_ORIGIN_Y")] = info["terrain_origin"][0], info["terrain_origin"][1]
+        f[F("TERRAIN_H_SCALE")] = info["horizontal_scale"]
+        f[F("ROW_CENTER0"):F("ROW_CENTER0") + 3 * n_rows] = np.asarray(info["row_centers"], np.float32).reshape(-1)
+        hs = tcfg.get("height_scan", {})
+        nx, ny = int(hs.get("num_x", 11)), int(hs.get("num_y", 7))
+        if nx * ny > 80:
+            raise NotImplementedError("height scan grids of at most 80 points")
+        xr, yr = hs.get("x_range", [-0.5, 0.5]), hs.get("y_range", [-0.3, 0.3])
+        gx, gy = torch.meshgrid(torch.linspace(float(xr[0]), float(xr[1]), nx), torch.linspace(float(yr[0]), float(yr[1]), ny), indexing="ij")
+        i[I("SCAN_N")] = nx * ny
+        f[F("SCAN_X0"):F("SCAN_X0") + nx * ny] = gx.reshape(-1).numpy()
+        f[F("SCAN_Y0"):F("SCAN_Y0") + nx * ny] = gy.reshape(-1).numpy()
     return f, i, names
 
 
@@ -396,3 +425,25 @@ def build_stair_terrain(terrain_cfg):
             "step_heights_m": step_heights_m.tolist(), "total_x_m": total_x * h_scale, "total_y_m": total_y * h_scale,
             "num_flights": num_flights, "num_steps": num_steps, "step_depth_m": g("step_depth_m", 0.30)}
     return hf, info
+
+
+def get_stair_cfgs():
+    """go2_train_stair.py:84-372 (values transcribed): the walk configuration plus the stair terrain, the terrain-relative rewards, the
+    two-phase DR schedule and the 182-wide privileged observation (49 + 55 + terrain row + 77 height-scan points)."""
+    env_cfg, obs_cfg, reward_cfg, command_cfg = get_walk_cfgs()
+    terrain = get_stair_terrain_cfg()
+    terrain["height_scan"] = {"num_x": 11, "num_y": 7, "x_range": [-0.5, 0.5], "y_range": [-0.3, 0.3]}
+    env_cfg["curriculum"].update({"level_init": 0.65, "ready_timeout_rate": 0.60, "ready_tracking": 0.45, "ready_fall_rate": 0.35, "ready_streak": 5,
+                                  "hard_fall_rate": 0.40, "hard_streak": 2, "step_up": 0.01, "step_down": 0.03, "cooldown_updates": 5,
+                                  "push_start": 0.3})
+    env_cfg.update({"episode_length_s": 25.0, "terrain": terrain, "dr_schedule": {"phase1_level": 0.15, "terrain_gate": 0.50}})
+    obs_cfg["num_privileged_obs"] = obs_cfg["num_obs"] + 55 + 1 + 77
+    reward_cfg.update({"feet_height_target": 0.17, "lin_vel_z_deadzone": 0.15})
+    reward_cfg["reward_scales"] = {
+        "tracking_lin_vel": 1.5, "tracking_ang_vel": 0.8, "forward_progress": 0.4, "lin_vel_z": -1.0, "base_height": -0.1, "action_rate": -0.01,
+        "similar_to_default": -0.05, "orientation_roll_only": -5.0, "dof_acc": -2.5e-7, "dof_vel": -5e-4, "ang_vel_xy": -0.05,
+        "feet_air_time": 0.2, "foot_slip": -0.15, "foot_clearance": -0.5, "joint_tracking": -0.1, "energy": 0.0, "torque_load": 0.0,
+        "stand_still": -0.5, "stand_still_vel": -2.0, "feet_stance": -0.3}
+    command_cfg.update({"lin_vel_x_range": [0.3, 0.8], "lin_vel_y_range": [0.0, 0.0], "ang_vel_range": [0.0, 0.0], "cmd_curriculum": False,
+                        "rel_standing_envs": 0.05})
+    return env_cfg, obs_cfg, reward_cfg, command_cfg

@@ -39,7 +39,7 @@ constexpr int NPAIR = GO2SIM_NPAIR_MAX, MAXC = GO2SIM_MAX_CONTACTS, MAXB = GO2SI
 constexpr int JOINT_FIXED = 0, JOINT_REVOLUTE = 1, JOINT_FREE = 4;
 constexpr int GEOM_SPHERE = 1, GEOM_CYLINDER = 3, GEOM_BOX = 5, GEOM_TERRAIN = 7;
 constexpr int CTRL_FORCE = 0, CTRL_VELOCITY = 1, CTRL_POSITION = 2;
-constexpr int NA = 16, NM = 12, NOBS_MAX = 64, NPRIV_MAX = 128, NREW = 32;
+constexpr int NA = 16, NM = 12, NOBS_MAX = 64, NPRIV_MAX = 192, NREW = 32;
 constexpr int WG = 64;  // one wavefront per workgroup
 
 // ---------------------------------------------------------------------------------------------
@@ -449,12 +449,12 @@ DEV void load_model_s(ModelS* dst, const ModelS* __restrict__ src) {
   X(e_dof_pos, NM) X(e_dof_vel, NM) X(last_dof_vel, NM) X(torque, NM) X(base_pos, 3) X(base_quat, 4) X(base_lin_vel, 3) \
   X(base_ang_vel, 3) X(projected_gravity, 3) X(base_euler, 3) X(commands, 3) X(time_out, 1) X(kp_factors, NM)          \
   X(kd_factors, NM) X(motor_strength, NM) X(gravity_offset, 3) X(current_push_force, 3) X(push_stored_force, 3)       \
-  X(feet_air_time, 4) X(base_vel_world, 3) X(episode_sums, NREW) X(rew_terms, NREW) X(rew, 1) X(obs, NOBS_MAX) X(priv, NPRIV_MAX)
+  X(feet_air_time, 4) X(base_vel_world, 3) X(last_base_pos_x, 1) X(episode_sums, NREW) X(rew_terms, NREW) X(rew, 1) X(obs, NOBS_MAX) X(priv, NPRIV_MAX)
 
 #define GO2SIM_INT_FIELDS(X)                                                                                         \
   X(n_contacts, 1) X(n_con, 1) X(err, 1) X(is_warmstart, 1) X(first_time, 1) X(n_broad, 1) X(solver_iters, 1) X(ctrl_mode, ND) \
   X(gjk_fallback, 1) X(delay_steps, 1) X(episode_length, 1) X(reset_buf, 1) X(push_remaining, 1) X(foot_contact, 4)    \
-  X(last_foot_contact, 4)
+  X(last_foot_contact, 4) X(terrain_row, 1) X(terrain_key, 1)
 
 #define GO2SIM_AOS_FLOAT_FIELDS(X)                                                                                   \
   X(acc, ND) X(qacc_ws, ND) X(force, ND) X(qf_smooth, ND) X(acc_smooth, ND) X(qfrc_constraint, ND) X(mass_mat, ND * ND)  \
@@ -556,10 +556,10 @@ struct E {
   FA(geom_friction) FA3(normal_cache) FA3(l_pos) FA4(l_quat) FA3(root_com) FA(dof_pos) FA3(cd_vel) FA3(cd_ang) FA3(contact_force)
   FA(actions) FA(last_actions) FA(applied_actions) FA2(action_history, NA) FA(target_dof_pos) FA(e_dof_pos) FA(e_dof_vel) FA(last_dof_vel)
   FA(torque) FA(base_pos) FA(base_quat) FA(base_lin_vel) FA(base_ang_vel) FA(projected_gravity) FA(base_euler) FA(commands) FA(time_out)
-  FA(kp_factors) FA(kd_factors) FA(motor_strength) FA(gravity_offset) FA(current_push_force) FA(push_stored_force) FA(feet_air_time) FA(base_vel_world)
+  FA(kp_factors) FA(kd_factors) FA(motor_strength) FA(gravity_offset) FA(current_push_force) FA(push_stored_force) FA(feet_air_time) FA(base_vel_world) FA(last_base_pos_x)
   FA(episode_sums) FA(rew_terms) FA(rew) FA(obs) FA(priv)
   IA(n_contacts) IA(n_con) IA(err) IA(is_warmstart) IA(first_time) IA(n_broad) IA(solver_iters) IA(ctrl_mode)
-  IA(gjk_fallback) IA(delay_steps) IA(episode_length) IA(reset_buf) IA(push_remaining) IA(foot_contact) IA(last_foot_contact)
+  IA(gjk_fallback) IA(delay_steps) IA(episode_length) IA(reset_buf) IA(push_remaining) IA(foot_contact) IA(last_foot_contact) IA(terrain_row) IA(terrain_key)
   AA(acc) AA(qacc_ws) AA(force) AA(qf_smooth) AA(acc_smooth) AA(qfrc_constraint) AA2(mass_mat, ND) AA3(cdof_ang) AA3(cdof_vel) AA3(cdofd_ang)
   AA3(cdofd_vel) AA9(cinr_inertial) AA3(cinr_pos) AA(cinr_mass) AA3(i_pos) AA4(i_quat) AA3(g_pos) AA4(g_quat) AA(sort_value) AA3(c_pos) AA3(c_normal)
   AA(c_pen) AA(c_friction) AA2(c_sol, 7) AA3(c_force) AA(efc_force)
@@ -2329,7 +2329,7 @@ struct DCfg { float f[GO2SIM_FC_COUNT]; int i[GO2SIM_IC_COUNT]; };
 struct Acc { double timeouts, tracking, ep[NREW]; int n_reset_now; int pad; };
 typedef go2sim_env_globals_t Glob;
 
-enum { RNG_ACTION_NOISE = 1, RNG_PUSH = 2, RNG_CMD = 3, RNG_OBS_NOISE = 4, RNG_RESET_DR = 5, RNG_GLOBAL_DR = 6, RNG_RESET_CMD = 7, RNG_RESET_POSE = 8 };
+enum { RNG_ACTION_NOISE = 1, RNG_PUSH = 2, RNG_CMD = 3, RNG_OBS_NOISE = 4, RNG_RESET_DR = 5, RNG_GLOBAL_DR = 6, RNG_RESET_CMD = 7, RNG_RESET_POSE = 8, RNG_TERRAIN_ROW = 9, RNG_TERRAIN_PERM = 10 };
 DEV dm_u4 rng4(uint64_t seed, uint32_t purpose, uint32_t env, uint32_t step, uint32_t idx) {
   return dm_philox(env, step, purpose, idx, (uint32_t)seed, (uint32_t)(seed >> 32));
 }
@@ -2372,8 +2372,27 @@ DEV V3 tc_quat_to_xyz_rpy_deg(Q4 q, float eps) {                   // geom.py:71
 }
 
 // Go2Env._apply_curriculum_level, go2_env_walk.py:628-686 (python float64 arithmetic)
+// _get_dr_level, go2_env_stair.py:972-988 (two-phase DR schedule coupled to the terrain level)
+__host__ __device__ inline double dr_level(const DCfg& c, double terrain_level) {
+  if (!c.i[GO2SIM_IC_DR_SCHEDULE]) return terrain_level;
+  double gate = c.f[GO2SIM_FC_DR_TERRAIN_GATE], p1 = c.f[GO2SIM_FC_DR_PHASE1_LEVEL];
+  if (terrain_level < gate) return p1;
+  double den = 1.0 - gate; if (den < 1e-6) den = 1e-6;
+  double progress = clamp01d((terrain_level - gate) / den);
+  return lerpd(p1, 1.0, progress);
+}
+// heightfield lookup of the env code (_get_terrain_height, go2_env_stair.py:758-770): truncation toward zero, then clamping
+DEV float terrain_height(const Model& m, const DCfg& c, float x, float y) {
+  if (!c.i[GO2SIM_IC_USE_TERRAIN] || !m.terrain_enabled) return 0.0f;
+  long long col = (long long)((x - c.f[GO2SIM_FC_TERRAIN_ORIGIN_X]) / c.f[GO2SIM_FC_TERRAIN_H_SCALE]);
+  long long row = (long long)((y - c.f[GO2SIM_FC_TERRAIN_ORIGIN_Y]) / c.f[GO2SIM_FC_TERRAIN_H_SCALE]);
+  col = col < 0 ? 0 : (col > m.terrain_rows - 1 ? m.terrain_rows - 1 : col);
+  row = row < 0 ? 0 : (row > m.terrain_cols - 1 ? m.terrain_cols - 1 : row);
+  return m.terrain_hf[(size_t)col * m.terrain_cols + row];
+}
 __host__ __device__ inline void apply_curriculum_level(const DCfg& c, Glob& g) {
-  double lvl = c.i[GO2SIM_IC_CURR_ENABLED] ? (double)g.level : 1.0;
+  double lvl_terrain = c.i[GO2SIM_IC_CURR_ENABLED] ? (double)g.level : 1.0;
+  double lvl = dr_level(c, lvl_terrain);   // noise / pushes / delay follow the DR level; the command ranges follow the curriculum level
   g.obs_noise_level_cur = (float)lerpd(0.0, c.i[GO2SIM_IC_HAS_OBS_NOISE] ? c.f[GO2SIM_FC_OBS_NOISE_LEVEL_MAX] : 0.0, lvl);
   g.action_noise_std_cur = (float)lerpd(0.0, c.f[GO2SIM_FC_ACTION_NOISE_STD_MAX], lvl);
   double dt = c.f[GO2SIM_FC_DT];
@@ -2396,7 +2415,7 @@ __host__ __device__ inline void apply_curriculum_level(const DCfg& c, Glob& g) {
     }
   }
   g.delay_max_cur = (int)rint(lerpd((double)c.i[GO2SIM_IC_DELAY_EASY_MAX], (double)c.i[GO2SIM_IC_MAX_DELAY], lvl));
-  double frac = c.i[GO2SIM_IC_CMD_CURRICULUM] ? lerpd(c.f[GO2SIM_FC_CMD_START_FRAC], 1.0, lvl) : 1.0;
+  double frac = c.i[GO2SIM_IC_CMD_CURRICULUM] ? lerpd(c.f[GO2SIM_FC_CMD_START_FRAC], 1.0, lvl_terrain) : 1.0;
   {
     double lo = c.f[GO2SIM_FC_CMD_X_LO], hi = c.f[GO2SIM_FC_CMD_X_HI], center = (lo + hi) / 2.0, half = (hi - lo) / 2.0;
     g.cmd_x_lo = (float)(center - half * frac); g.cmd_x_hi = (float)(center + half * frac);
@@ -2534,7 +2553,7 @@ __global__ __launch_bounds__(WG) void k_env_pre(Pool P, const Model* __restrict_
   }
 }
 
-struct RewCtx { float link_vel_xy[8], foot_z[4]; float vel_world[3]; int was_reset; };
+struct RewCtx { float link_vel_xy[8], foot_z[4], foot_xy[8]; float vel_world[3]; int was_reset; };
 // reward terms, go2_env_walk.py:1251-1366
 DEV float reward_term(const Model& m, const DCfg& c, const E& e, int id, const RewCtx& rc) {
   const float dt = c.f[GO2SIM_FC_DT];
@@ -2546,10 +2565,19 @@ DEV float reward_term(const Model& m, const DCfg& c, const E& e, int id, const R
   switch (id) {
     case GO2SIM_R_TRACKING_LIN_VEL: { float d0 = c0 - blv[0], d1 = c1 - blv[1]; return dm_exp(-(d0 * d0 + d1 * d1) / c.f[GO2SIM_FC_TRACKING_SIGMA]); }
     case GO2SIM_R_TRACKING_ANG_VEL: { float d = c2 - bav[2]; return dm_exp(-(d * d) / c.f[GO2SIM_FC_TRACKING_SIGMA]); }
-    case GO2SIM_R_LIN_VEL_Z: { float v = blv[2]; return v * v; }
+    case GO2SIM_R_LIN_VEL_Z: {                                       // go2_env_stair.py:1615-1626 (deadzone 0 = walk env)
+      float v = blv[2], dz = c.f[GO2SIM_FC_LIN_VEL_Z_DEADZONE];
+      if (dz > 0.0f) { float ex = fmx(dm_abs(v) - dz, 0.0f); return ex * ex; }
+      return v * v;
+    }
     case GO2SIM_R_ACTION_RATE: { float s = 0.0f; auto la = e.last_actions(); auto a = e.actions(); for (int i = 0; i < c.i[GO2SIM_IC_NUM_ACTIONS]; ++i) { float d = la[i] - a[i]; s = s + d * d; } return s; }
     case GO2SIM_R_SIMILAR_TO_DEFAULT: { float s = 0.0f; for (int i = 0; i < NM; ++i) s = s + dm_abs(dof_pos[i] - c.f[GO2SIM_FC_DEFAULT_DOF_POS0 + i]); return s; }
-    case GO2SIM_R_BASE_HEIGHT: { float d = e.base_pos()[2] - c.f[GO2SIM_FC_BASE_HEIGHT_TARGET]; return d * d; }
+    case GO2SIM_R_BASE_HEIGHT: {                                     // go2_env_stair.py:1634-1648: height above the local terrain
+      auto bp = e.base_pos();
+      float hgt = bp[2];
+      if (c.i[GO2SIM_IC_USE_TERRAIN]) hgt = bp[2] - terrain_height(m, c, bp[0], bp[1]);
+      float d = hgt - c.f[GO2SIM_FC_BASE_HEIGHT_TARGET]; return d * d;
+    }
     case GO2SIM_R_DOF_ACC: { float s = 0.0f; auto ldv = e.last_dof_vel(); for (int i = 0; i < NM; ++i) { float a = (dof_vel[i] - ldv[i]) / dt; s = s + a * a; } return s; }
     case GO2SIM_R_DOF_VEL: { float s = 0.0f; for (int i = 0; i < NM; ++i) { float v = dof_vel[i]; s = s + v * v; } return s; }
     case GO2SIM_R_ORIENTATION_PENALTY: { auto pg = e.projected_gravity(); float a = pg[0], b2 = pg[1]; return a * a + b2 * b2; }
@@ -2579,7 +2607,9 @@ DEV float reward_term(const Model& m, const DCfg& c, const E& e, int id, const R
       for (int i = 0; i < 4; ++i) {
         float vx = rc.link_vel_xy[2 * i], vy = rc.link_vel_xy[2 * i + 1];
         float vn = dm_sqrt(vx * vx + vy * vy);
-        float he = c.f[GO2SIM_FC_FEET_HEIGHT_TARGET] - rc.foot_z[i]; he = he * he;
+        float fz = rc.foot_z[i];
+        if (c.i[GO2SIM_IC_USE_TERRAIN]) fz = rc.foot_z[i] - terrain_height(m, c, rc.foot_xy[2 * i], rc.foot_xy[2 * i + 1]);   // go2_env_stair.py:1742-1747
+        float he = c.f[GO2SIM_FC_FEET_HEIGHT_TARGET] - fz; he = he * he;
         pen = pen + (fc[i] ? 0.0f : 1.0f) * he * vn;
       }
       return pen * moving;
@@ -2625,6 +2655,9 @@ DEV float reward_term(const Model& m, const DCfg& c, const E& e, int id, const R
     }
     case GO2SIM_R_CROUCH_PROGRESS: return fmx(0.35f - e.base_pos()[2], 0.0f);
     case GO2SIM_R_CROUCH_SPEED: return -(blv[2] * blv[2]);
+    // ---- go2_env_stair.py:1659-1771 ----
+    case GO2SIM_R_ORIENTATION_ROLL_ONLY: { float gy = e.projected_gravity()[1]; return gy * gy; }
+    case GO2SIM_R_FORWARD_PROGRESS: { auto lx = e.last_base_pos_x(); float bx = e.base_pos()[0]; float dx = bx - lx[0]; lx[0] = bx; return dx; }   // mutates _last_base_pos_x
   }
   return 0.0f;
 }
@@ -2671,7 +2704,7 @@ __global__ __launch_bounds__(WG) void k_env_post_a(Pool P, const Model* __restri
     fc[i] = dm_abs(cf.z) > c.f[GO2SIM_FC_FOOT_CONTACT_THRESHOLD];
     V3 lp = e.l_pos()[l];
     V3 lv = (V3)e.cd_vel()[l] + cross((V3)e.cd_ang()[l], lp - rcom);
-    rc.link_vel_xy[2 * i] = lv.x; rc.link_vel_xy[2 * i + 1] = lv.y; rc.foot_z[i] = lp.z;
+    rc.link_vel_xy[2 * i] = lv.x; rc.link_vel_xy[2 * i + 1] = lv.y; rc.foot_z[i] = lp.z; rc.foot_xy[2 * i] = lp.x; rc.foot_xy[2 * i + 1] = lp.y;
   }
   auto cmd = e.commands();
   if (ep_len % c.i[GO2SIM_IC_RESAMPLE_STEPS] == 0) {
@@ -2763,7 +2796,8 @@ __global__ void k_env_globals(const DCfg* __restrict__ cp, Glob* gp, Acc* acc, u
     dm_u4 r1 = rng4(seed, RNG_GLOBAL_DR, 0xffffffffu, g.reset_calls, 1);
     dm_u4 r2 = rng4(seed, RNG_GLOBAL_DR, 0xffffffffu, g.reset_calls, 2);
     double t;
-    if (!c.i[GO2SIM_IC_CURR_ENABLED]) t = 1.0;
+    if (c.i[GO2SIM_IC_DR_SCHEDULE]) t = dr_level(c, c.i[GO2SIM_IC_CURR_ENABLED] ? (double)g.level : 1.0);   // go2_env_stair.py:1506-1507
+    else if (!c.i[GO2SIM_IC_CURR_ENABLED]) t = 1.0;
     else if (dm_u01(r0.v[0]) < c.f[GO2SIM_FC_CURR_MIX_PROB_CURRENT]) t = clamp01d(g.level);
     else {
       double hi = (double)g.level < (double)c.f[GO2SIM_FC_CURR_MIX_LEVEL_HIGH] ? (double)g.level : (double)c.f[GO2SIM_FC_CURR_MIX_LEVEL_HIGH];
@@ -2785,6 +2819,7 @@ __global__ void k_env_globals(const DCfg* __restrict__ cp, Glob* gp, Acc* acc, u
     if (c.i[GO2SIM_IC_HAS_LEGM_DR])
       for (int k = 0; k < 4; ++k) g.leg_mass_shift[k] = rand_float(lerp_lo(c, GO2SIM_FC_LEGM_EASY_LO, ts), lerp_hi(c, GO2SIM_FC_LEGM_EASY_LO, ts), r2.v[k]);
     g.last_reset_count = n;
+    g.terrain_row_sum = 0;   // accumulated by k_env_terrain_rows
     for (int k = 0; k < NREW; ++k)
       g.last_episode_rew[k] = (c.i[GO2SIM_IC_ENV_KIND] == 1) ? (float)((double)(float)(acc->ep[k] / (double)n) / (double)c.f[GO2SIM_FC_EPISODE_LENGTH_S]) : (float)(acc->ep[k] / (double)n);
     g.reset_calls += 1;
@@ -2828,6 +2863,13 @@ DEV void env_reset_one(const Model& m, const DCfg& c, const Glob& g, const E& e,
   { auto ncache = e.normal_cache(); for (int p = 0; p < NPAIR; ++p) ncache[p] = v3(0, 0, 0); }
   float bpx = c.f[GO2SIM_FC_BASE_INIT_POS0], bpy = c.f[GO2SIM_FC_BASE_INIT_POS0 + 1], bpz = c.f[GO2SIM_FC_BASE_INIT_POS0 + 2];
   float bq[4] = {c.f[GO2SIM_FC_BASE_INIT_QUAT0], c.f[GO2SIM_FC_BASE_INIT_QUAT0 + 1], c.f[GO2SIM_FC_BASE_INIT_QUAT0 + 2], c.f[GO2SIM_FC_BASE_INIT_QUAT0 + 3]};
+  if (c.i[GO2SIM_IC_USE_TERRAIN]) {                                    // _get_terrain_spawn_pos, go2_env_stair.py:856-871, :1531-1540
+    const float* rcn = &c.f[GO2SIM_FC_ROW_CENTER0 + 3 * e.terrain_row()[0]];
+    float init_z = c.f[GO2SIM_FC_BASE_INIT_POS0 + 2];
+    float spawn_z = rcn[2] + init_z;
+    bpx = rcn[0]; bpy = rcn[1]; bpz = spawn_z;
+    if (c.i[GO2SIM_IC_HAS_INIT_Z]) bpz = ((spawn_z + rand_float(c.f[GO2SIM_FC_INIT_Z_LO], c.f[GO2SIM_FC_INIT_Z_HI], rp.v[0])) - init_z) + init_z;
+  } else
   if (c.i[GO2SIM_IC_HAS_INIT_Z]) bpz = rand_float(c.f[GO2SIM_FC_INIT_Z_LO], c.f[GO2SIM_FC_INIT_Z_HI], rp.v[0]);
   if (c.i[GO2SIM_IC_HAS_INIT_EULER]) {                                 // euler_to_quat_wxyz, go2_env_walk.py:16-25
     const float D2R = 0.017453292519943295f;
@@ -2847,6 +2889,7 @@ DEV void env_reset_one(const Model& m, const DCfg& c, const Glob& g, const E& e,
   auto la = e.last_actions(); auto aa = e.applied_actions(); auto hist = e.action_history();
   for (int i = 0; i < NA; ++i) { la[i] = 0.0f; aa[i] = 0.0f; hist[0][i] = 0.0f; hist[1][i] = 0.0f; }
   { auto ldv = e.last_dof_vel(); for (int i = 0; i < NM; ++i) ldv[i] = 0.0f; }
+  e.last_base_pos_x()[0] = bpx;                                       // go2_env_stair.py:1557
   { auto psf = e.push_stored_force(); for (int k = 0; k < 3; ++k) psf[k] = 0.0f; }
   e.push_remaining()[0] = 0;
   { auto fat = e.feet_air_time(); auto fc = e.foot_contact(); auto lfc = e.last_foot_contact(); for (int i = 0; i < 4; ++i) { fat[i] = 0.0f; fc[i] = 0; lfc[i] = 0; } }
@@ -2871,6 +2914,42 @@ DEV void reset_tail(const Model& m, const DCfg& c, const Glob& g, const E& e, in
   if (c.i[GO2SIM_IC_HAS_COM_DR]) e.com_shift()[bl] = v3(g.com_shift[0], g.com_shift[1], g.com_shift[2]);
   if (c.i[GO2SIM_IC_HAS_LEGM_DR]) for (int k = 0; k < 4; ++k) e.mass_shift()[c.i[GO2SIM_IC_HIP_LINK0 + k]] = g.leg_mass_shift[k];
   // the full-batch FK refresh follows as k_fk_team gated on g.n_reset_now (launch_fk_team)
+}
+
+// _assign_terrain_rows, go2_env_stair.py:809-854: 40 % of the reset envs on the frontier row, 30 % just below it, 30 % on easy rows,
+// shuffled.  The shuffle is the rank of a per-env Philox key; the j-th reset env (env order) receives rows[perm[j]].  One thread per env;
+// a reset env scans the batch once (keys of the other reset envs are recomputed on the fly).  Gated on g.n_reset_now.
+__global__ __launch_bounds__(256) void k_env_terrain_rows(Pool P, const DCfg* __restrict__ cp, Glob* gp, uint64_t seed) {
+  const DCfg& c = *cp; Glob& g = *gp;
+  if (!c.i[GO2SIM_IC_USE_TERRAIN] || g.n_reset_now <= 0) return;
+  int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= P.B) return;
+  E e(P, b);
+  if (!e.reset_buf()[0]) return;
+  const int n_rows = c.i[GO2SIM_IC_N_TERRAIN_ROWS];
+  const uint32_t rc = g.reset_calls - 1;
+  const int n = g.n_reset_now;
+  int row = e.terrain_row()[0];
+  if (n_rows > 1) {
+    double level = c.i[GO2SIM_IC_CURR_ENABLED] ? (double)g.level : 1.0;
+    int max_row = (int)(level * (double)(n_rows - 1));
+    max_row = imx(0, imn(max_row, n_rows - 1));
+    int n_frontier = (int)((double)n * 0.40), n_near = (int)((double)n * 0.30);
+    const unsigned kj = rng4(seed, RNG_TERRAIN_PERM, b, rc, 0).v[0];
+    int p = 0;
+    const int* rb = P.i + (size_t)IO(reset_buf) * P.B;
+    for (int b2 = 0; b2 < P.B; ++b2) {
+      if (!rb[b2] || b2 == b) continue;
+      unsigned k2 = rng4(seed, RNG_TERRAIN_PERM, b2, rc, 0).v[0];
+      p += (k2 < kj) || (k2 == kj && b2 < b);
+    }
+    dm_u4 r = rng4(seed, RNG_TERRAIN_ROW, (uint32_t)p, rc, 0);
+    if (p < n_frontier) row = max_row;
+    else if (p < n_frontier + n_near) row = (max_row >= 2) ? rand_int(imx(0, max_row - 2), imx(0, max_row - 1), r.v[0]) : max_row;
+    else row = rand_int(0, (max_row >= 3) ? max_row - 3 : 0, r.v[1]);
+    e.terrain_row()[0] = row;
+  }
+  atomicAdd(&g.terrain_row_sum, row);
 }
 
 __global__ __launch_bounds__(WG) void k_env_reset_tail(Pool P, const Model* __restrict__ mp, const DCfg* __restrict__ cp, const Glob* __restrict__ gp, uint64_t seed) {
@@ -2985,6 +3064,18 @@ __global__ __launch_bounds__(64) void k_env_post_b_team(Pool P, const Model* __r
     else if (j < 51) v = gload(e, FO(gravity_offset), j - 48);
     else if (j < 54) v = gload(e, FO(current_push_force), j - 51);
     else if (j < 55) { write = c.i[GO2SIM_IC_MAX_DELAY] > 0; v = write ? (float)e.delay_steps()[0] / (float)c.i[GO2SIM_IC_MAX_DELAY] : gload(e, FO(priv), i); }
+    else if (c.i[GO2SIM_IC_USE_TERRAIN] && j == 55) v = (float)e.terrain_row()[0] / (float)imx(1, c.i[GO2SIM_IC_N_TERRAIN_ROWS] - 1);   // go2_env_stair.py:1466-1472
+    else if (c.i[GO2SIM_IC_USE_TERRAIN] && j - 56 < c.i[GO2SIM_IC_SCAN_N] && 56 + c.i[GO2SIM_IC_SCAN_N] <= npriv - nobs) {        // _compute_height_scan :772-803
+      auto bq = e.base_quat(); auto bp = e.base_pos();
+      float qw = bq[0], qx = bq[1], qy = bq[2], qz = bq[3];
+      float yaw = dm_atan2(2.0f * (qw * qz + qx * qy), 1.0f - 2.0f * (qy * qy + qz * qz));
+      float sy, cy;
+      dm_sincos(yaw, &sy, &cy);
+      float lx = c.f[GO2SIM_FC_SCAN_X0 + j - 56], ly = c.f[GO2SIM_FC_SCAN_Y0 + j - 56];
+      float wx = bp[0] + cy * lx - sy * ly;
+      float wy = bp[1] + sy * lx + cy * ly;
+      v = terrain_height(m, c, wx, wy) - bp[2];
+    }
     else v = 0.0f;
     if (write) gstore(e, FO(priv), i, v);
     if (priv_out) priv_out[(size_t)b * npriv + i] = v;
@@ -3485,6 +3576,7 @@ int go2sim_env_step(go2sim_t* h, const float* actions, float* obs, float* priv, 
     ScopedTimer t(h, s, T_ENV_POST);
     hipLaunchKernelGGL(k_env_post_a, g, b, 0, s, h->P, h->dm, h->dcfg, h->dglob, h->dacc, h->seed, h->step_count);
     hipLaunchKernelGGL(k_env_globals, dim3(1), dim3(1), 0, s, h->dcfg, h->dglob, h->dacc, h->seed, 1);
+    if (h->hcfg.i[GO2SIM_IC_USE_TERRAIN]) hipLaunchKernelGGL(k_env_terrain_rows, dim3((h->B + 255) / 256), dim3(256), 0, s, h->P, h->dcfg, h->dglob, h->seed);
     hipLaunchKernelGGL(k_env_post_b_team<16>, dim3((h->B + 3) / 4), dim3(64), 0, s, h->P, h->dm, h->dcfg, h->dglob, h->seed, h->step_count, obs, priv, rew, reset, timeout);
     launch_fk_team(h, s, 1, &h->dglob->n_reset_now);
   }
@@ -3501,6 +3593,7 @@ int go2sim_env_reset(go2sim_t* h, void* stream) {
   HIPCHK(hipMemsetAsync(h->dacc, 0, sizeof(Acc), s));
   hipLaunchKernelGGL(k_env_mark_all, g, b, 0, s, h->P, h->dcfg, h->dacc);
   hipLaunchKernelGGL(k_env_globals, dim3(1), dim3(1), 0, s, h->dcfg, h->dglob, h->dacc, h->seed, 0);
+  if (h->hcfg.i[GO2SIM_IC_USE_TERRAIN]) hipLaunchKernelGGL(k_env_terrain_rows, dim3((h->B + 255) / 256), dim3(256), 0, s, h->P, h->dcfg, h->dglob, h->seed);
   hipLaunchKernelGGL(k_env_reset_tail, g, b, 0, s, h->P, h->dm, h->dcfg, h->dglob, h->seed);
   launch_fk_team(h, s, 1, &h->dglob->n_reset_now);
   HIPCHK(hipGetLastError());
@@ -3526,6 +3619,7 @@ int go2sim_env_get(go2sim_t* h, int buf, void* dst, void* stream) {
     case GO2SIM_EB_FEET_AIR_TIME: k = 4; src = F + FO(feet_air_time) * B; break;
     case GO2SIM_EB_REW_TERMS: k = NREW; src = F + FO(rew_terms) * B; break;
     case GO2SIM_EB_TORQUE: k = 12; src = F + FO(torque) * B; break;
+    case GO2SIM_EB_TERRAIN_ROW: k = 1; src = I + IO(terrain_row) * B; break;
     default: return GO2SIM_E_BADARG;
   }
   int n = k * h->B;
@@ -3551,6 +3645,7 @@ int go2sim_env_globals(go2sim_t* h, go2sim_env_globals_t* out, void* stream) {
   HIPCHK(hipMemcpyAsync(out, h->dglob, sizeof(Glob), hipMemcpyDeviceToHost, s));
   HIPCHK(hipStreamSynchronize(s));
   out->step_count = h->step_count; out->action_write_idx = h->action_write_idx;
+  out->terrain_mean_row = out->last_reset_count > 0 ? (float)((double)out->terrain_row_sum / (double)out->last_reset_count) : 0.0f;
   return GO2SIM_E_OK;
 }
 int go2sim_env_globals_ptr(go2sim_t* h, void** ptr_out) {

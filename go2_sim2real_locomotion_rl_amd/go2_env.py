@@ -22,7 +22,7 @@ import math
 import torch
 
 from .capi import C, EnvGlobals, Go2Sim, Go2SimError, load_hip_lib
-from .configs import flatten_base_cfg, flatten_walk_cfg
+from .configs import build_stair_terrain, flatten_base_cfg, flatten_walk_cfg
 from .model_blob import pack_model
 
 _DEVICE = None
@@ -89,14 +89,20 @@ class Go2Env:
         else:
             fcfg, icfg, self._reward_names = flatten_walk_cfg(num_envs, env_cfg, obs_cfg, reward_cfg, command_cfg,
                                                               freeze_curriculum=freeze_curriculum)
-            if self.num_obs != 49 or self.num_privileged_obs not in (None, 104) or self.num_actions != 16:
-                raise Go2SimError("go2sim implements the walk layout (16 actions, 49 / 104 obs; go2_train_walk.py:300-320) and the base layout "
-                                  "(12 actions, 45 obs; go2_train_crouch.py / go2_train_jump.py)")
+            if self.num_obs != 49 or self.num_privileged_obs not in (None, 104, 182) or self.num_actions != 16:
+                raise Go2SimError("go2sim implements the walk layout (16 actions, 49 / 104 obs; go2_train_walk.py:300-320), the stair layout "
+                                  "(49 / 182 obs; go2_train_stair.py:282-300) and the base layout (12 actions, 45 obs; go2_train_crouch.py / "
+                                  "go2_train_jump.py)")
+            terrain_cfg = env_cfg.get("terrain", None)
+            if terrain_cfg is not None and terrain_cfg.get("enabled", False):     # go2_env_stair.py:352-433: gs.morphs.Terrain instead of the plane
+                hf, info = build_stair_terrain(terrain_cfg)
+                self._terrain_info = info
+                self._sim.set_terrain(hf, info["horizontal_scale"], info["vertical_scale"], info["terrain_origin"])
         self._sim.env_configure(fcfg, icfg)
 
         B, dev = num_envs, self.device
         self.obs_buf = torch.zeros(B, self.num_obs, device=dev)
-        self.privileged_obs_buf = torch.zeros(B, 45 if self.is_base_env else 104, device=dev)
+        self.privileged_obs_buf = torch.zeros(B, 45 if self.is_base_env else (self.num_privileged_obs or 104), device=dev)
         self.rew_buf = torch.zeros(B, device=dev)
         self.reset_buf = torch.zeros(B, dtype=torch.uint8, device=dev)
         self._time_outs = torch.zeros(B, device=dev)

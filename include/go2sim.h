@@ -164,7 +164,13 @@ enum go2sim_fcfg {
   GO2SIM_FC_CURR_MIX_PROB_CURRENT, GO2SIM_FC_CURR_MIX_LEVEL_LOW, GO2SIM_FC_CURR_MIX_LEVEL_HIGH,
   /* base env (go2_env_base.py): episode-log normalisation and jump rewards */
   GO2SIM_FC_EPISODE_LENGTH_S, GO2SIM_FC_JUMP_APEX_HEIGHT, GO2SIM_FC_JUMP_APEX_SIGMA,
-  GO2SIM_FC_COUNT
+  /* stair env (go2_env_stair.py): terrain-relative rewards, two-phase DR schedule, spawn rows, height scan */
+  GO2SIM_FC_LIN_VEL_Z_DEADZONE, GO2SIM_FC_DR_PHASE1_LEVEL, GO2SIM_FC_DR_TERRAIN_GATE,
+  GO2SIM_FC_TERRAIN_ORIGIN_X, GO2SIM_FC_TERRAIN_ORIGIN_Y, GO2SIM_FC_TERRAIN_H_SCALE,
+  GO2SIM_FC_ROW_CENTER0,                                   /* 16 x (x, y, z) spawn centres of the difficulty rows */
+  GO2SIM_FC_SCAN_X0 = GO2SIM_FC_ROW_CENTER0 + 48,          /* 80 body-frame x offsets of the height-scan grid (row-major nx x ny) */
+  GO2SIM_FC_SCAN_Y0 = GO2SIM_FC_SCAN_X0 + 80,              /* 80 body-frame y offsets */
+  GO2SIM_FC_COUNT = GO2SIM_FC_SCAN_Y0 + 80
 };
 enum go2sim_icfg {
   GO2SIM_IC_ENV_KIND = 0, /* 0 = walk (go2_env_walk.py), 1 = base (go2_env_base.py: crouch / jump; engine PD, reset before reward, 45 obs) */
@@ -186,6 +192,10 @@ enum go2sim_icfg {
   GO2SIM_IC_CURR_UPDATE_EVERY, GO2SIM_IC_GLOBAL_DR_INTERVAL,
   GO2SIM_IC_PER_ENV_GLOBAL_DR, /* 0 = reference behaviour (one value for all envs), 1 = per-env draws */
   GO2SIM_IC_FREEZE_CURRICULUM, /* 1 = keep the level fixed (bench protocol) */
+  /* stair env (go2_env_stair.py) */
+  GO2SIM_IC_USE_TERRAIN,       /* terrain-relative rewards, spawn rows, terrain_row + height scan in the privileged obs */
+  GO2SIM_IC_DR_SCHEDULE,       /* 1 = two-phase DR level (_get_dr_level :972-988) and t_sample = dr level (:1507) */
+  GO2SIM_IC_N_TERRAIN_ROWS, GO2SIM_IC_SCAN_N,
   GO2SIM_IC_COUNT
 };
 /* reward terms of go2_env_walk.py:1251-1366 */
@@ -199,6 +209,8 @@ enum go2sim_reward {
   GO2SIM_R_JUMP_IMPULSE, GO2SIM_R_JUMP_APEX, GO2SIM_R_XY_STABILITY, GO2SIM_R_ORIENTATION, GO2SIM_R_NO_SHAKE, GO2SIM_R_CROUCH,
   GO2SIM_R_CROUCH_2, GO2SIM_R_GROUND_PENALTY, GO2SIM_R_CROUCH_TARGET, GO2SIM_R_NO_FALL, GO2SIM_R_Y_STABILITY, GO2SIM_R_TORQUE_LOAD_BASE,
   GO2SIM_R_CROUCH_PROGRESS, GO2SIM_R_CROUCH_SPEED,
+  /* additional terms of go2_env_stair.py:1659-1771 */
+  GO2SIM_R_ORIENTATION_ROLL_ONLY, GO2SIM_R_FORWARD_PROGRESS,
   GO2SIM_R_COUNT
 };
 
@@ -219,6 +231,7 @@ enum go2sim_env_buf {
   GO2SIM_EB_FEET_AIR_TIME,    /* f32 k=4  */
   GO2SIM_EB_REW_TERMS,        /* f32 k=32 per-term reward of the last step (already x scale) */
   GO2SIM_EB_TORQUE,           /* f32 k=12 last commanded torque */
+  GO2SIM_EB_TERRAIN_ROW,      /* i32 k=1  difficulty row of the env (go2_env_stair.py:_env_terrain_row) */
   GO2SIM_EB_COUNT
 };
 
@@ -240,6 +253,9 @@ typedef struct go2sim_env_globals {
   int   last_reset_count; float last_episode_rew[32];
   int   n_reset_now; float ep_acc[32]; /* scratch accumulators */
   float t_sample;
+  float terrain_mean_row;      /* extras["episode"]["terrain_mean_row"] of the last reset call (go2_env_stair.py:1588-1590);
+                                  filled by go2sim_env_globals() from terrain_row_sum / last_reset_count */
+  int   terrain_row_sum;
 } go2sim_env_globals_t;
 
 typedef struct go2sim go2sim_t;

@@ -1749,7 +1749,7 @@ void substep(const Model& m, Env& e) {
 // ---------------------------------------------------------------------------------------------
 // Go2Env (walk)  -- examples/locomotion/final/go2_env_walk.py
 // ---------------------------------------------------------------------------------------------
-constexpr int NA = 16, NM = 12, NOBS_MAX = 64, NPRIV_MAX = 128, NREW = 32;
+constexpr int NA = 16, NM = 12, NOBS_MAX = 64, NPRIV_MAX = 192, NREW = 32;
 
 struct EnvBuf {
   real actions[NA], last_actions[NA], applied_actions[NA], action_history[2][NA]; int delay_steps;
@@ -1757,6 +1757,7 @@ struct EnvBuf {
   real base_pos[3], base_quat[4], base_lin_vel[3], base_ang_vel[3], projected_gravity[3], base_euler[3];
   real commands[3]; int episode_length, reset_buf; real time_out;
   real base_vel_world[3];   // robot.get_vel() (world frame), used by the base-env rewards
+  int terrain_row; real last_base_pos_x; unsigned terrain_key;   // go2_env_stair.py: _env_terrain_row, _last_base_pos_x; key of the row shuffle
   real kp_factors[NM], kd_factors[NM], motor_strength[NM], gravity_offset[3], current_push_force[3];
   real push_stored_force[3]; int push_remaining;
   int foot_contact[4], last_foot_contact[4]; real feet_air_time[4];
@@ -1821,14 +1822,32 @@ namespace {
 inline dm_u4 rng4(const go2sim* h, uint32_t purpose, uint32_t env, uint32_t step, uint32_t idx) {
   return dm_philox(env, step, purpose, idx, (uint32_t)h->seed, (uint32_t)(h->seed >> 32));
 }
-enum { RNG_ACTION_NOISE = 1, RNG_PUSH = 2, RNG_CMD = 3, RNG_OBS_NOISE = 4, RNG_RESET_DR = 5, RNG_GLOBAL_DR = 6, RNG_RESET_CMD = 7, RNG_RESET_POSE = 8 };
+enum { RNG_ACTION_NOISE = 1, RNG_PUSH = 2, RNG_CMD = 3, RNG_OBS_NOISE = 4, RNG_RESET_DR = 5, RNG_GLOBAL_DR = 6, RNG_RESET_CMD = 7, RNG_RESET_POSE = 8, RNG_TERRAIN_ROW = 9, RNG_TERRAIN_PERM = 10 };
 inline real rand_float(real lower, real upper, uint32_t r) { return (upper - lower) * dm_u01(r) + lower; }   // gs_rand_float, go2_env_walk.py:7-8
 inline int rand_int(int lower, int upper, uint32_t r) { return lower + (int)(r % (uint32_t)(upper - lower + 1)); }   // gs_rand_int, :11-13
 
 // Go2Env._apply_curriculum_level, go2_env_walk.py:628-686 (python float64 arithmetic)
+// _get_dr_level, go2_env_stair.py:972-988 (two-phase DR schedule coupled to the terrain level)
+inline double dr_level(const Cfg& c, double terrain_level) {
+  if (!c.i[GO2SIM_IC_DR_SCHEDULE]) return terrain_level;
+  double gate = c.f[GO2SIM_FC_DR_TERRAIN_GATE], p1 = c.f[GO2SIM_FC_DR_PHASE1_LEVEL];
+  if (terrain_level < gate) return p1;
+  double progress = clamp01d((terrain_level - gate) / std::max(1e-6, 1.0 - gate));
+  return lerpd(p1, 1.0, progress);
+}
+// heightfield lookup of the env code (_get_terrain_height, go2_env_stair.py:758-770): truncation toward zero, then clamping
+inline real terrain_height(const go2sim* h, real x, real y) {
+  const Model& m = h->m; const Cfg& c = h->cfg;
+  if (!c.i[GO2SIM_IC_USE_TERRAIN] || !m.terrain_enabled) return 0.0f;
+  long col = (long)((x - c.f[GO2SIM_FC_TERRAIN_ORIGIN_X]) / c.f[GO2SIM_FC_TERRAIN_H_SCALE]);
+  long row = (long)((y - c.f[GO2SIM_FC_TERRAIN_ORIGIN_Y]) / c.f[GO2SIM_FC_TERRAIN_H_SCALE]);
+  col = std::min(std::max(col, 0L), (long)m.terrain_rows - 1); row = std::min(std::max(row, 0L), (long)m.terrain_cols - 1);
+  return m.terrain_hf[(size_t)col * m.terrain_cols + row];
+}
 void apply_curriculum_level(go2sim* h) {
   const Cfg& c = h->cfg; go2sim_env_globals_t& g = h->g;
-  double lvl = c.i[GO2SIM_IC_CURR_ENABLED] ? (double)g.level : 1.0;
+  double lvl_terrain = c.i[GO2SIM_IC_CURR_ENABLED] ? (double)g.level : 1.0;
+  double lvl = dr_level(c, lvl_terrain);   // noise / pushes / delay follow the DR level; the command ranges follow the curriculum level
   g.obs_noise_level_cur = (float)lerpd(0.0, c.i[GO2SIM_IC_HAS_OBS_NOISE] ? c.f[GO2SIM_FC_OBS_NOISE_LEVEL_MAX] : 0.0, lvl);
   g.action_noise_std_cur = (float)lerpd(0.0, c.f[GO2SIM_FC_ACTION_NOISE_STD_MAX], lvl);
   double dt = c.f[GO2SIM_FC_DT];
@@ -1849,7 +1868,7 @@ void apply_curriculum_level(go2sim* h) {
     }
   }
   g.delay_max_cur = (int)nearbyint(lerpd((double)c.i[GO2SIM_IC_DELAY_EASY_MAX], (double)c.i[GO2SIM_IC_MAX_DELAY], lvl));
-  double frac = c.i[GO2SIM_IC_CMD_CURRICULUM] ? lerpd(c.f[GO2SIM_FC_CMD_START_FRAC], 1.0, lvl) : 1.0;
+  double frac = c.i[GO2SIM_IC_CMD_CURRICULUM] ? lerpd(c.f[GO2SIM_FC_CMD_START_FRAC], 1.0, lvl_terrain) : 1.0;
   const int lo_idx[3] = {GO2SIM_FC_CMD_X_LO, GO2SIM_FC_CMD_Y_LO, GO2SIM_FC_CMD_YAW_LO};
   float* out[3][2] = {{&g.cmd_x_lo, &g.cmd_x_hi}, {&g.cmd_y_lo, &g.cmd_y_hi}, {&g.cmd_yaw_lo, &g.cmd_yaw_hi}};
   for (int k = 0; k < 3; ++k) {
@@ -1970,7 +1989,7 @@ void env_pre(go2sim* h, int b, const real* actions) {
 
 inline real fmaxr(real a, real b) { return (a < b) ? b : a; }   // torch.clamp(min=) on non-NaN input
 inline real fminr(real a, real b) { return (b < a) ? b : a; }
-inline real reward_term(const go2sim* h, int b, int id, const real* link_vel_xy /*[4][2]*/, const real* foot_z) {
+inline real reward_term(const go2sim* h, int b, int id, const real* link_vel_xy /*[4][2]*/, const real* foot_z, const real* foot_xy = nullptr /*[4][2]*/) {
   const Cfg& c = h->cfg; const Env& e = h->envs[b]; EnvBuf& x = const_cast<EnvBuf&>(h->eb[b]);
   const real dt = c.f[GO2SIM_FC_DT];
   real cmd_norm = dm_sqrt(x.commands[0] * x.commands[0] + x.commands[1] * x.commands[1] + x.commands[2] * x.commands[2]);
@@ -1982,10 +2001,18 @@ inline real reward_term(const go2sim* h, int b, int id, const real* link_vel_xy 
       return dm_exp(-(d0 * d0 + d1 * d1) / c.f[GO2SIM_FC_TRACKING_SIGMA]);
     }
     case GO2SIM_R_TRACKING_ANG_VEL: { real d = x.commands[2] - x.base_ang_vel[2]; return dm_exp(-(d * d) / c.f[GO2SIM_FC_TRACKING_SIGMA]); }
-    case GO2SIM_R_LIN_VEL_Z: return x.base_lin_vel[2] * x.base_lin_vel[2];
+    case GO2SIM_R_LIN_VEL_Z: {                                                           // go2_env_stair.py:1615-1626 (deadzone 0 = walk env)
+      real dz = c.f[GO2SIM_FC_LIN_VEL_Z_DEADZONE];
+      if (dz > 0.0f) { real ex = fmaxr(dm_abs(x.base_lin_vel[2]) - dz, 0.0f); return ex * ex; }
+      return x.base_lin_vel[2] * x.base_lin_vel[2];
+    }
     case GO2SIM_R_ACTION_RATE: { real s = 0.0f; for (int i = 0; i < c.i[GO2SIM_IC_NUM_ACTIONS]; ++i) { real d = x.last_actions[i] - x.actions[i]; s = s + d * d; } return s; }
     case GO2SIM_R_SIMILAR_TO_DEFAULT: { real s = 0.0f; for (int i = 0; i < NM; ++i) s = s + dm_abs(x.dof_pos[i] - c.f[GO2SIM_FC_DEFAULT_DOF_POS0 + i]); return s; }
-    case GO2SIM_R_BASE_HEIGHT: { real d = x.base_pos[2] - c.f[GO2SIM_FC_BASE_HEIGHT_TARGET]; return d * d; }
+    case GO2SIM_R_BASE_HEIGHT: {                                                         // go2_env_stair.py:1634-1648: height above the local terrain
+      real hgt = x.base_pos[2];
+      if (c.i[GO2SIM_IC_USE_TERRAIN]) hgt = x.base_pos[2] - terrain_height(h, x.base_pos[0], x.base_pos[1]);
+      real d = hgt - c.f[GO2SIM_FC_BASE_HEIGHT_TARGET]; return d * d;
+    }
     case GO2SIM_R_DOF_ACC: { real s = 0.0f; for (int i = 0; i < NM; ++i) { real a = (x.dof_vel[i] - x.last_dof_vel[i]) / dt; s = s + a * a; } return s; }
     case GO2SIM_R_DOF_VEL: { real s = 0.0f; for (int i = 0; i < NM; ++i) s = s + x.dof_vel[i] * x.dof_vel[i]; return s; }
     case GO2SIM_R_ORIENTATION_PENALTY: return x.projected_gravity[0] * x.projected_gravity[0] + x.projected_gravity[1] * x.projected_gravity[1];
@@ -2019,7 +2046,9 @@ inline real reward_term(const go2sim* h, int b, int id, const real* link_vel_xy 
       for (int i = 0; i < 4; ++i) {
         real vx = link_vel_xy[2 * i], vy = link_vel_xy[2 * i + 1];
         real vn = dm_sqrt(vx * vx + vy * vy);
-        real he = c.f[GO2SIM_FC_FEET_HEIGHT_TARGET] - foot_z[i]; he = he * he;
+        real fz = foot_z[i];
+        if (c.i[GO2SIM_IC_USE_TERRAIN]) fz = foot_z[i] - terrain_height(h, foot_xy[2 * i], foot_xy[2 * i + 1]);   // go2_env_stair.py:1742-1747
+        real he = c.f[GO2SIM_FC_FEET_HEIGHT_TARGET] - fz; he = he * he;
         pen = pen + (x.foot_contact[i] ? 0.0f : 1.0f) * he * vn;
       }
       return pen * moving;
@@ -2061,6 +2090,9 @@ inline real reward_term(const go2sim* h, int b, int id, const real* link_vel_xy 
     }
     case GO2SIM_R_CROUCH_PROGRESS: return fmaxr(0.35f - x.base_pos[2], 0.0f);
     case GO2SIM_R_CROUCH_SPEED: return -(x.base_lin_vel[2] * x.base_lin_vel[2]);
+    // ---- go2_env_stair.py:1659-1771 ----
+    case GO2SIM_R_ORIENTATION_ROLL_ONLY: return x.projected_gravity[1] * x.projected_gravity[1];
+    case GO2SIM_R_FORWARD_PROGRESS: { real dx = x.base_pos[0] - x.last_base_pos_x; x.last_base_pos_x = x.base_pos[0]; return dx; }   // mutates _last_base_pos_x
   }
   return 0.0f;
 }
@@ -2086,13 +2118,13 @@ void env_post_a(go2sim* h, int b) {
   x.base_ang_vel[0] = bav.x; x.base_ang_vel[1] = bav.y; x.base_ang_vel[2] = bav.z;
   x.projected_gravity[0] = pg.x; x.projected_gravity[1] = pg.y; x.projected_gravity[2] = pg.z;
   for (int i = 0; i < NM; ++i) { int d = c.i[GO2SIM_IC_MOTOR_DOF0 + i]; x.dof_pos[i] = e.dof_pos[d]; x.dof_vel[i] = e.vel[d]; }
-  real link_vel_xy[8], foot_z[4];
+  real link_vel_xy[8], foot_z[4], foot_xy[8];
   for (int i = 0; i < 4; ++i) {                                                         // _update_foot_contacts :599-605
     int l = c.i[GO2SIM_IC_FOOT_LINK0 + i];
     x.last_foot_contact[i] = x.foot_contact[i];
     x.foot_contact[i] = dm_abs(e.contact_force[l].z) > c.f[GO2SIM_FC_FOOT_CONTACT_THRESHOLD];
     V3 lv = e.cd_vel[l] + cross(e.cd_ang[l], e.l_pos[l] - e.root_com[l]);
-    link_vel_xy[2 * i] = lv.x; link_vel_xy[2 * i + 1] = lv.y; foot_z[i] = e.l_pos[l].z;
+    link_vel_xy[2 * i] = lv.x; link_vel_xy[2 * i + 1] = lv.y; foot_z[i] = e.l_pos[l].z; foot_xy[2 * i] = e.l_pos[l].x; foot_xy[2 * i + 1] = e.l_pos[l].y;
   }
   if (x.episode_length % c.i[GO2SIM_IC_RESAMPLE_STEPS] == 0) {                          // _resample_commands :927-963
     dm_u4 r = rng4(h, RNG_CMD, b, g.step_count, 0);
@@ -2112,7 +2144,7 @@ void env_post_a(go2sim* h, int b) {
   if (c.i[GO2SIM_IC_ENV_KIND] == 1) return;                                              // base env: rewards follow the reset (go2_env_base.py:165-172)
   x.rew = 0.0f;                                                                          // :1072-1077
   for (int k = 0; k < c.i[GO2SIM_IC_N_REWARDS]; ++k) {
-    real r = reward_term(h, b, c.i[GO2SIM_IC_REWARD_ID0 + k], link_vel_xy, foot_z) * c.f[GO2SIM_FC_REWARD_SCALE0 + k];
+    real r = reward_term(h, b, c.i[GO2SIM_IC_REWARD_ID0 + k], link_vel_xy, foot_z, foot_xy) * c.f[GO2SIM_FC_REWARD_SCALE0 + k];
     x.rew_terms[k] = r;
     x.rew = x.rew + r;
     x.episode_sums[k] = x.episode_sums[k] + r;
@@ -2156,7 +2188,8 @@ void env_globals_update(go2sim* h, bool count_push) {
     dm_u4 r1 = rng4(h, RNG_GLOBAL_DR, 0xffffffffu, g.reset_calls, 1);
     dm_u4 r2 = rng4(h, RNG_GLOBAL_DR, 0xffffffffu, g.reset_calls, 2);
     double t;                                                                             // CurriculumManager.sample_level :85-93
-    if (!c.i[GO2SIM_IC_CURR_ENABLED]) t = 1.0;
+    if (c.i[GO2SIM_IC_DR_SCHEDULE]) t = dr_level(c, c.i[GO2SIM_IC_CURR_ENABLED] ? (double)g.level : 1.0);   // go2_env_stair.py:1506-1507
+    else if (!c.i[GO2SIM_IC_CURR_ENABLED]) t = 1.0;
     else if (dm_u01(r0.v[0]) < c.f[GO2SIM_FC_CURR_MIX_PROB_CURRENT]) t = clamp01d(g.level);
     else {
       double hi = std::min((double)g.level, (double)c.f[GO2SIM_FC_CURR_MIX_LEVEL_HIGH]);
@@ -2219,6 +2252,13 @@ void env_reset_one(go2sim* h, int b) {
   for (int p = 0; p < NPAIR; ++p) e.normal_cache[p] = v3(0, 0, 0);
   x.base_pos[0] = c.f[GO2SIM_FC_BASE_INIT_POS0]; x.base_pos[1] = c.f[GO2SIM_FC_BASE_INIT_POS0 + 1]; x.base_pos[2] = c.f[GO2SIM_FC_BASE_INIT_POS0 + 2];
   for (int k = 0; k < 4; ++k) x.base_quat[k] = c.f[GO2SIM_FC_BASE_INIT_QUAT0 + k];
+  if (c.i[GO2SIM_IC_USE_TERRAIN]) {                                                         // _get_terrain_spawn_pos, go2_env_stair.py:856-871, :1531-1540
+    const float* rcn = &c.f[GO2SIM_FC_ROW_CENTER0 + 3 * x.terrain_row];
+    real init_z = c.f[GO2SIM_FC_BASE_INIT_POS0 + 2];
+    real spawn_z = rcn[2] + init_z;
+    x.base_pos[0] = rcn[0]; x.base_pos[1] = rcn[1]; x.base_pos[2] = spawn_z;
+    if (c.i[GO2SIM_IC_HAS_INIT_Z]) x.base_pos[2] = ((spawn_z + rand_float(c.f[GO2SIM_FC_INIT_Z_LO], c.f[GO2SIM_FC_INIT_Z_HI], rp.v[0])) - init_z) + init_z;
+  } else
   if (c.i[GO2SIM_IC_HAS_INIT_Z]) x.base_pos[2] = rand_float(c.f[GO2SIM_FC_INIT_Z_LO], c.f[GO2SIM_FC_INIT_Z_HI], rp.v[0]);
   if (c.i[GO2SIM_IC_HAS_INIT_EULER]) {                                                     // :1191-1199, euler_to_quat_wxyz :16-25
     const real D2R = 0.017453292519943295f;
@@ -2234,6 +2274,7 @@ void env_reset_one(go2sim* h, int b) {
   for (int k = 0; k < 3; ++k) { x.base_lin_vel[k] = 0.0f; x.base_ang_vel[k] = 0.0f; }
   for (int i = 0; i < NA; ++i) { x.last_actions[i] = 0.0f; x.applied_actions[i] = 0.0f; x.action_history[0][i] = 0.0f; x.action_history[1][i] = 0.0f; }
   for (int i = 0; i < NM; ++i) x.last_dof_vel[i] = 0.0f;
+  x.last_base_pos_x = x.base_pos[0];                                                       // go2_env_stair.py:1557
   for (int k = 0; k < 3; ++k) x.push_stored_force[k] = 0.0f;
   x.push_remaining = 0;
   for (int i = 0; i < 4; ++i) { x.feet_air_time[i] = 0.0f; x.foot_contact[i] = 0; x.last_foot_contact[i] = 0; }
@@ -2337,6 +2378,23 @@ void env_post_b(go2sim* h, int b, real* obs, real* priv) {
   idx += 3;
   if (c.i[GO2SIM_IC_MAX_DELAY] > 0) p[idx] = (real)x.delay_steps / (real)c.i[GO2SIM_IC_MAX_DELAY];
   idx += 1;
+  if (c.i[GO2SIM_IC_USE_TERRAIN]) {                                                         // go2_env_stair.py:1466-1480
+    if (idx < npriv) { p[idx] = (real)x.terrain_row / (real)std::max(1, c.i[GO2SIM_IC_N_TERRAIN_ROWS] - 1); idx += 1; }
+    const int scan_n = c.i[GO2SIM_IC_SCAN_N];
+    if (scan_n > 0 && idx + scan_n <= npriv) {                                                // _compute_height_scan :772-803
+      real qw = x.base_quat[0], qx = x.base_quat[1], qy = x.base_quat[2], qz = x.base_quat[3];
+      real yaw = dm_atan2(2.0f * (qw * qz + qx * qy), 1.0f - 2.0f * (qy * qy + qz * qz));
+      real sy, cy;
+      dm_sincos(yaw, &sy, &cy);
+      for (int k = 0; k < scan_n; ++k) {
+        real lx = c.f[GO2SIM_FC_SCAN_X0 + k], ly = c.f[GO2SIM_FC_SCAN_Y0 + k];
+        real wx = x.base_pos[0] + cy * lx - sy * ly;
+        real wy = x.base_pos[1] + sy * lx + cy * ly;
+        p[idx + k] = terrain_height(h, wx, wy) - x.base_pos[2];
+      }
+      idx += scan_n;
+    }
+  }
   for (int i = idx; i < npriv; ++i) p[i] = 0.0f;
   for (int i = 0; i < na; ++i) x.last_actions[i] = x.actions[i];                            // :1103-1104
   for (int i = 0; i < NM; ++i) x.last_dof_vel[i] = x.dof_vel[i];
@@ -2573,6 +2631,41 @@ int go2sim_cpu_env_configure(go2sim* h, const float* f, int nf, const int* i, in
   return GO2SIM_E_OK;
 }
 
+// _assign_terrain_rows, go2_env_stair.py:809-854: 40 % of the reset envs on the frontier row, 30 % just below it, 30 % on easy rows,
+// shuffled.  The shuffle is the rank of a per-env Philox key; the j-th reset env (env order) receives rows[perm[j]].
+static void assign_terrain_rows(go2sim* h) {
+  const Cfg& c = h->cfg; go2sim_env_globals_t& g = h->g;
+  const int n_rows = c.i[GO2SIM_IC_N_TERRAIN_ROWS];
+  uint32_t rc = g.reset_calls - 1;
+  std::vector<int> idx;
+  for (int b = 0; b < h->B; ++b) if (h->eb[b].reset_buf) idx.push_back(b);
+  const int n = (int)idx.size();
+  double mean_row = 0.0;
+  if (n_rows > 1) {
+    double level = c.i[GO2SIM_IC_CURR_ENABLED] ? (double)g.level : 1.0;
+    int max_row = (int)(level * (double)(n_rows - 1));
+    max_row = std::max(0, std::min(max_row, n_rows - 1));
+    int n_frontier = (int)((double)n * 0.40), n_near = (int)((double)n * 0.30);
+    for (int j = 0; j < n; ++j) h->eb[idx[j]].terrain_key = rng4(h, RNG_TERRAIN_PERM, idx[j], rc, 0).v[0];
+    for (int j = 0; j < n; ++j) {
+      unsigned kj = h->eb[idx[j]].terrain_key;
+      int p = 0;
+      for (int j2 = 0; j2 < n; ++j2) { unsigned k2 = h->eb[idx[j2]].terrain_key; p += (k2 < kj) || (k2 == kj && j2 < j); }
+      dm_u4 r = rng4(h, RNG_TERRAIN_ROW, (uint32_t)p, rc, 0);
+      int row;
+      if (p < n_frontier) row = max_row;
+      else if (p < n_frontier + n_near) row = (max_row >= 2) ? rand_int(std::max(0, max_row - 2), std::max(0, max_row - 1), r.v[0]) : max_row;
+      else row = rand_int(0, (max_row >= 3) ? max_row - 3 : 0, r.v[1]);
+      h->eb[idx[j]].terrain_row = row;
+    }
+  }
+  int row_sum = 0;
+  for (int j = 0; j < n; ++j) row_sum += h->eb[idx[j]].terrain_row;
+  (void)mean_row;
+  g.terrain_row_sum = row_sum;
+  g.terrain_mean_row = n > 0 ? (float)((double)row_sum / (double)n) : 0.0f;
+}
+
 static void reset_call(go2sim* h, bool count_push) {
   h->acc_timeouts = 0.0; h->acc_tracking = 0.0;
   for (int k = 0; k < NREW; ++k) h->acc_ep[k] = 0.0;
@@ -2580,6 +2673,7 @@ static void reset_call(go2sim* h, bool count_push) {
   for (int b = 0; b < h->B; ++b) if (h->eb[b].reset_buf) env_reset_stats(h, b);
   bool any = h->g.n_reset_now > 0;
   env_globals_update(h, count_push);
+  if (any && h->cfg.i[GO2SIM_IC_USE_TERRAIN]) assign_terrain_rows(h);
   if (any) {
 #pragma omp parallel for schedule(static)
     for (int b = 0; b < h->B; ++b) {
@@ -2640,6 +2734,7 @@ int go2sim_cpu_env_get(go2sim* h, int buf, void* dst, void*) {
       case GO2SIM_EB_FEET_AIR_TIME: memcpy(f + 4 * b, x.feet_air_time, 16); break;
       case GO2SIM_EB_REW_TERMS: memcpy(f + NREW * b, x.rew_terms, 4 * NREW); break;
       case GO2SIM_EB_TORQUE: memcpy(f + 12 * b, x.torque, 48); break;
+      case GO2SIM_EB_TERRAIN_ROW: ip[b] = x.terrain_row; break;
       default: return GO2SIM_E_BADARG;
     }
   }

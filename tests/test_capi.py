@@ -10,7 +10,7 @@ from go2_sim2real_locomotion_rl_amd import capi
 def test_header_enums_parsed():
     C = capi.C
     assert C["GO2SIM_NL"] == 14 and C["GO2SIM_ND"] == 18 and C["GO2SIM_NQ"] == 19 and C["GO2SIM_NG"] == 28
-    assert C["GO2SIM_R_COUNT"] == 33 and C["GO2SIM_R_FEET_STANCE"] == 18  # 19 walk terms + 14 base-env terms
+    assert C["GO2SIM_R_COUNT"] == 35 and C["GO2SIM_R_FEET_STANCE"] == 18  # 19 walk + 14 base-env + 2 stair-env terms
     assert C["GO2SIM_FC_DEFAULT_DOF_POS0"] == C["GO2SIM_FC_TORQUE_LIMIT0"] + 12
     assert C["GO2SIM_IC_COUNT"] > C["GO2SIM_IC_FREEZE_CURRICULUM"]
     assert len(capi.DECLARED_FUNCS) >= 25

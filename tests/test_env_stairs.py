@@ -1,0 +1,103 @@
+"""Stair env (go2_env_stair.py; BASELINE configs[2]): terrain rows, spawn, terrain-relative rewards, height scan -- on the CPU oracle,
+recomputed independently in numpy; GPU-vs-oracle parity (tolerance 0)."""
+import numpy as np
+import pytest
+
+from go2_sim2real_locomotion_rl_amd.configs import build_stair_terrain, get_stair_cfgs
+from util import CpuEnv, GpuEnv, bits_equal, make_actions
+
+DT = 0.02
+
+
+@pytest.fixture(scope="module")
+def terrain():
+    hf, info = build_stair_terrain(get_stair_cfgs()[0]["terrain"])
+    return hf.astype(np.float32) * np.float32(info["vertical_scale"]), info
+
+
+def _height(hfm, x, y):
+    col = np.clip(np.trunc((x - 0.0) / np.float32(0.05)).astype(np.int64), 0, hfm.shape[0] - 1)
+    row = np.clip(np.trunc((y + 39.0) / np.float32(0.05)).astype(np.int64), 0, hfm.shape[1] - 1)
+    return hfm[col, row]
+
+
+def test_rows_spawn_scan_and_terrain_rewards(oracle_lib, blob, terrain):
+    hfm, info = terrain
+    B = 200
+    env = CpuEnv(oracle_lib, blob, B, seed=5, task="stairs")
+    env.reset()
+    g = env.sim.env_globals()
+    rows = env.env_buf("TERRAIN_ROW", 1, np.int32)[:, 0]
+    # _assign_terrain_rows: level_init 0.65 -> frontier row 7; 40 % frontier, 30 % rows 5-6, 30 % rows 0-4
+    assert g.level == pytest.approx(0.65) and rows.max() == 7
+    assert (rows == 7).sum() == int(B * 0.4) and ((rows == 5) | (rows == 6)).sum() == int(B * 0.3) and (rows <= 4).sum() == B - int(B * 0.4) - int(B * 0.3)
+    assert g.terrain_mean_row == pytest.approx(rows.mean(), abs=1e-5) and g.t_sample == pytest.approx(0.15 + 0.85 * 0.3, abs=1e-6)
+    bp = env.env_buf("BASE_POS", 3)
+    centers = np.asarray(info["row_centers"], np.float32)
+    assert np.allclose(bp[:, :2], centers[rows, :2]) and ((bp[:, 2] > 0.42 + 0.38 - 1e-5) & (bp[:, 2] < 0.42 + 0.45 + 1e-5)).all()
+    names = env.reward_names
+    acts = make_actions(60, B, seed=2, kind="0.3")
+    last_x = bp[:, 0].copy()
+    for s, a in enumerate(acts):
+        obs, priv, rew, rst, to = env.step(a)
+        bp, bq = env.env_buf("BASE_POS", 3), env.env_buf("BASE_QUAT", 4)
+        terms = env.env_buf("REW_TERMS", 32)
+        was = rst.astype(bool)
+        # privileged tail: terrain row + height scan of the (post-reset) base pose
+        rows = env.env_buf("TERRAIN_ROW", 1, np.int32)[:, 0]
+        assert np.allclose(priv[:, 104], rows / 12.0, atol=1e-6)
+        qw, qx, qy, qz = bq.T
+        yaw = np.arctan2(2 * (qw * qz + qx * qy), 1 - 2 * (qy * qy + qz * qz))
+        lx, ly = np.meshgrid(np.linspace(-0.5, 0.5, 11, dtype=np.float32), np.linspace(-0.3, 0.3, 7, dtype=np.float32), indexing="ij")
+        lx, ly = lx.reshape(-1), ly.reshape(-1)
+        wx = bp[:, :1] + np.cos(yaw)[:, None] * lx - np.sin(yaw)[:, None] * ly
+        wy = bp[:, 1:2] + np.sin(yaw)[:, None] * lx + np.cos(yaw)[:, None] * ly
+        want = _height(hfm, wx.astype(np.float32), wy.astype(np.float32)) - bp[:, 2:3]
+        # grid points within 1e-4 of a cell edge may fall in the neighbouring cell: compare with the cell-edge tolerant criterion
+        diff = np.abs(priv[:, 105:182] - want)
+        frac = np.minimum(np.mod(wx / 0.05, 1.0), np.mod((wy + 39.0) / 0.05, 1.0))
+        assert ((diff < 1e-5) | (frac < 2e-3) | (frac > 1 - 2e-3)).all()
+        # rewards are evaluated BEFORE the reset in this env: check the non-reset envs (their buffers are unchanged)
+        ok = ~was
+        k = names.index("forward_progress")
+        assert np.allclose(terms[ok, k], (bp[ok, 0] - last_x[ok]) * np.float32(0.4 * DT), atol=1e-6)
+        k = names.index("base_height")
+        assert np.allclose(terms[ok, k], (bp[ok, 2] - _height(hfm, bp[ok, 0], bp[ok, 1]) - np.float32(0.3)) ** 2 * np.float32(-0.1 * DT), rtol=2e-5, atol=1e-7)
+        k = names.index("orientation_roll_only")
+        assert np.allclose(terms[ok, k], env.env_buf("PROJECTED_GRAVITY", 3)[ok, 1] ** 2 * np.float32(-5.0 * DT), rtol=2e-5, atol=1e-7)
+        k = names.index("lin_vel_z")
+        vz = env.env_buf("BASE_LIN_VEL", 3)[ok, 2]
+        assert np.allclose(terms[ok, k], np.maximum(np.abs(vz) - np.float32(0.15), 0) ** 2 * np.float32(-1.0 * DT), rtol=2e-5, atol=1e-7)
+        last_x = bp[:, 0].copy()
+    assert env.sim.check_errno() == 0
+
+
+def test_walk_env_unchanged_by_stair_extensions(oracle_lib, blob):
+    """USE_TERRAIN = 0 (walk cfg): the golden walk trajectory already pins this; here only the flags."""
+    env = CpuEnv(oracle_lib, blob, 4, seed=1)
+    from go2_sim2real_locomotion_rl_amd.capi import C
+    assert env.icfg[C["GO2SIM_IC_USE_TERRAIN"]] == 0 and env.icfg[C["GO2SIM_IC_DR_SCHEDULE"]] == 0 and env.fcfg[C["GO2SIM_FC_LIN_VEL_Z_DEADZONE"]] == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_envs,steps,kind,seed", [(96, 120, "mixed", 6), (33, 60, "0.5", 2)])
+def test_stair_env_bit_exact(oracle_lib, hip_lib, blob, n_envs, steps, kind, seed):
+    from test_parity_gpu import _compare_fields, _compare_globals
+
+    cpu, gpu = CpuEnv(oracle_lib, blob, n_envs, seed=seed, task="stairs"), GpuEnv(hip_lib, blob, n_envs, seed=seed, task="stairs")
+    cpu.reset(); gpu.reset()
+    assert np.array_equal(cpu.env_buf("TERRAIN_ROW", 1, np.int32), gpu.env_buf("TERRAIN_ROW", 1, np.int32))
+    acts = make_actions(steps, n_envs, seed=seed, kind=kind)
+    n_resets = 0
+    for s, a in enumerate(acts):
+        oc, pc, rc, dc, tc = cpu.step(a)
+        og, pg, rg, dg, tg = gpu.step(a)
+        assert np.array_equal(dc, dg), f"done mask differs at step {s}"
+        assert bits_equal(oc, og) and bits_equal(pc, pg), f"observations differ at step {s}"
+        assert bits_equal(rc, rg) and bits_equal(cpu.env_buf("REW_TERMS", 32), gpu.env_buf("REW_TERMS", 32)), f"rewards differ at step {s}"
+        assert np.array_equal(cpu.env_buf("TERRAIN_ROW", 1, np.int32), gpu.env_buf("TERRAIN_ROW", 1, np.int32))
+        n_resets += int(dc.sum())
+    _compare_fields(cpu, gpu, "final")
+    _compare_globals(cpu, gpu)
+    if kind == "mixed":
+        assert n_resets > 0
