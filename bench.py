@@ -32,13 +32,15 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from go2_sim2real_locomotion_rl_amd.capi import C, Go2Sim, load_hip_lib  # noqa: E402
-from go2_sim2real_locomotion_rl_amd.configs import flatten_walk_cfg, get_walk_cfgs  # noqa: E402
+from go2_sim2real_locomotion_rl_amd.configs import build_stair_terrain, flatten_walk_cfg, get_stair_cfgs, get_walk_cfgs  # noqa: E402
 from go2_sim2real_locomotion_rl_amd.model_blob import pack_model  # noqa: E402
 
 ENVS_PER_GPU = 4096
 ALGO_BYTES_WALK = 5701  # algorithmic HBM bytes per env-step, SURVEY.md section 8(d)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 ROLLOUT_LEN = 24  # num_steps_per_env, go2_train_walk.py:60
+NPRIV = {"walk": 104, "stairs": 182}
+WORKLOAD = "walk"
 KERNEL_CLASSES = ["k_dynamics", "k_collide", "k_constraint_solve", "k_integrate_fk", "k_env_pre", "k_env_post(a+globals+b)", "misc", "env_step_total"]
 
 
@@ -66,16 +68,26 @@ def pmc_traffic_bytes(kernel, n_envs):
     return None if rec is None else int((2 * rec["fetch_size_kb"] + rec["write_size_kb"]) * 1000)
 
 
+def make_sim(lib, n_envs, device_index, seed, workload):
+    """Configured handle: walk (flat plane) or stairs (go2_train_stair.py terrain + cfg), curriculum frozen at its initial level."""
+    sim = Go2Sim(lib, pack_model(), n_envs, device_index, seed)
+    cfgs = get_stair_cfgs() if workload == "stairs" else get_walk_cfgs()
+    if workload == "stairs":
+        hf, info = build_stair_terrain(cfgs[0]["terrain"])
+        sim.set_terrain(hf, info["horizontal_scale"], info["vertical_scale"], info["terrain_origin"])
+    f, i, _ = flatten_walk_cfg(n_envs, *cfgs, freeze_curriculum=True)
+    sim.env_configure(f, i)
+    sim.env_reset()
+    return sim
+
+
 def cpu_baseline(n_envs, steps, warmup):
     from go2_sim2real_locomotion_rl_amd.capi import load_cpu_oracle_lib
 
     lib = load_cpu_oracle_lib()
-    sim = Go2Sim(lib, pack_model(), n_envs, 0, 1)
-    f, i, _ = flatten_walk_cfg(n_envs, *get_walk_cfgs(), freeze_curriculum=True)
-    sim.env_configure(f, i)
-    sim.env_reset()
+    sim = make_sim(lib, n_envs, 0, 1, WORKLOAD)
     act = make_actions(steps + warmup, n_envs, torch.device("cpu")).numpy()
-    obs = np.zeros((n_envs, 49), np.float32); priv = np.zeros((n_envs, 104), np.float32)
+    obs = np.zeros((n_envs, 49), np.float32); priv = np.zeros((n_envs, NPRIV[WORKLOAD]), np.float32)
     rew = np.zeros(n_envs, np.float32); rst = np.zeros(n_envs, np.uint8); to = np.zeros(n_envs, np.float32)
     for s in range(warmup):
         sim.env_step(act[s], obs, priv, rew, rst, to)
@@ -92,6 +104,8 @@ def main():
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
+    ap.add_argument("--workload", choices=["walk", "stairs"], default="walk",
+                    help="walk = BASELINE configs[1] (the headline metric); stairs = configs[2] (heightfield terrain, reported for information)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile-pass", action="store_true")
     args = ap.parse_args()
@@ -122,14 +136,13 @@ def main():
         dist = dist_mod
     coll_device = torch.device("cpu") if rehearsal else device
 
+    global WORKLOAD
+    WORKLOAD = args.workload
     B = args.envs_per_gpu
-    sim = Go2Sim(load_hip_lib(), pack_model(), B, local_rank, 1 + rank)
-    f, i, _ = flatten_walk_cfg(B, *get_walk_cfgs(), freeze_curriculum=True)
-    sim.env_configure(f, i)
-    sim.env_reset()
+    sim = make_sim(load_hip_lib(), B, local_rank, 1 + rank, WORKLOAD)
     K, W = args.steps, args.warmup
     actions = make_actions(K + W, B, device)
-    obs = torch.zeros(B, 49, device=device); priv = torch.zeros(B, 104, device=device)
+    obs = torch.zeros(B, 49, device=device); priv = torch.zeros(B, NPRIV[WORKLOAD], device=device)
     rew = torch.zeros(B, device=device); rst = torch.zeros(B, dtype=torch.uint8, device=device); to = torch.zeros(B, device=device)
     stats = torch.zeros(3, device=device)
     gathered = torch.zeros(3 * world, device=coll_device) if world > 1 else None
@@ -168,9 +181,7 @@ def main():
     # recorded around every kernel launch on the launch stream.  Kept out of the timed region so `value` carries no event overhead.
     roofline = None
     if not args.no_profile_pass:
-        sim2 = Go2Sim(load_hip_lib(), pack_model(), B, local_rank, 1 + rank)
-        sim2.env_configure(f, i)
-        sim2.env_reset()
+        sim2 = make_sim(load_hip_lib(), B, local_rank, 1 + rank, WORKLOAD)
         sim2.enable_timing(True)
         sim2.read_timing(reset=True)
         for s in range(W):
@@ -192,7 +203,7 @@ def main():
         achieved = ALGO_BYTES_WALK * units / (per_launch[dom] * 1e-3) / 1e9 if per_launch[dom] > 0 else 0.0
         roofline = {
             "bound": "hbm", "kernel": KERNEL_CLASSES[dom], "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic_bytes(KERNEL_CLASSES[dom], B),
+            "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic_bytes(KERNEL_CLASSES[dom], B) if WORKLOAD == "walk" else None,
             "avg_launch_ms": round(per_launch[dom], 4), "avg_launch_ms_incl_warmup": round(per_launch_all[dom], 4),
             "launches_timed": cnt[dom], "algo_bytes_per_env_step": ALGO_BYTES_WALK, "units_per_launch_env_steps": units,
             "ms_per_step_by_kernel": {KERNEL_CLASSES[k]: round(per_step[k], 4) for k in range(8)},
@@ -212,7 +223,9 @@ def main():
             "metric": "env-steps/sec (all envs) Go2 walk 4096 envs; 1/2/4/8-GPU scaling", "value": round(value, 1), "unit": "env-steps/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(elapsed / K * 1e3, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "Go2 walk flat-plane, num_envs=4096 per GPU, 2 substeps x dt 0.01, action set C (open-loop sine gait), curriculum frozen at level 0.10",
+            "config": {"workload": ("Go2 walk flat-plane, num_envs=4096 per GPU, 2 substeps x dt 0.01, action set C (open-loop sine gait), curriculum frozen at level 0.10"
+                                    if WORKLOAD == "walk" else
+                                    "Go2 stairs heightfield terrain (BASELINE configs[2], NOT the headline metric), num_envs per GPU as given, action set C, curriculum frozen at level 0.65"),
                        "envs_per_gpu": B, "total_envs": total_envs, "parallelism": f"env-shard x{world}", "errno": errno},
             "roofline": roofline, "cpu_baseline": cpu,
         }

@@ -1765,7 +1765,8 @@ DEVN int update_bracket(LsPoint& p, const float alphas[3], const float costs[3],
 // results are bit-identical to the one-lane-per-env formulation and to the CPU oracle.
 // Environments with more than RL rows fall back to the same code on a per-env global scratch block.
 // ---------------------------------------------------------------------------------------------
-constexpr int RL = 32;  // constraint rows held in LDS (8 contacts); typical walking uses 16; more rows take the global-scratch path
+constexpr int RL = 32;        // constraint rows held in LDS on flat ground (8 contacts; typical walking uses 16)
+constexpr int RL_TERRAIN = 96;  // ... and on heightfield terrain (several prism contacts per foot / shank): one env per wavefront
 constexpr int DS = 20;  // padded stride of dof-indexed rows in the solver working set (16-byte aligned rows => wide LDS accesses)
 
 template <int R>
@@ -2275,10 +2276,10 @@ DEVN void ts_solve_overflow(const MT& m, const E& e, SolverData<MAXR>* s, int tl
   ts_commit<T>(m, e, s, tl, nc, n_con, iters);
 }
 
-template <int T>
+template <int T, int RLN>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_constraint_solve_team(Pool P, const Model* __restrict__ gm, const ModelS* __restrict__ mp, SolverData<MAXR>* __restrict__ overflow) {
   constexpr int EPW = 64 / T;
-  __shared__ SolverData<RL> lds[EPW];
+  __shared__ SolverData<RLN> lds[EPW];
   __shared__ LinkS lnk[NL];
   __shared__ unsigned char tri_i[NTRI + 1], tri_j[NTRI + 1];
   {
@@ -2301,8 +2302,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     if (fmn(q - m.dofs[Jt.dof_start].limit[0], m.dofs[Jt.dof_start].limit[1] - q) < 0) n_lim++;
   }
   const int n_con = 4 * nc + n_lim;
-  if (n_con <= RL) {
-    SolverData<RL>* s = &lds[slot];
+  if (n_con <= RLN) {
+    SolverData<RLN>* s = &lds[slot];
     int iters = ts_solve<T>(m, e, s, tl, nc, n_con);
     PH_BEGIN
     ts_commit<T>(m, e, s, tl, nc, n_con, iters);
@@ -3263,11 +3264,16 @@ static int launch_substep(go2sim* h, hipStream_t s) {
   }
   {
     ScopedTimer t(h, s, T_SOLVE);
-    const int T = h->solver_team;
-    dim3 gs((h->B + 64 / T - 1) / (64 / T));
-    if (T == 16) hipLaunchKernelGGL(k_constraint_solve_team<16>, gs, b, 0, s, h->P, h->dm, h->dms, h->solver_ovf);
-    else if (T == 32) hipLaunchKernelGGL(k_constraint_solve_team<32>, gs, b, 0, s, h->P, h->dm, h->dms, h->solver_ovf);
-    else hipLaunchKernelGGL(k_constraint_solve_team<64>, gs, b, 0, s, h->P, h->dm, h->dms, h->solver_ovf);
+    // flat ground: 32 lanes per env and 32 LDS rows; heightfield terrain (many more contacts): one env per wavefront with 96 LDS rows
+    if (h->hm.terrain_enabled) {
+      hipLaunchKernelGGL((k_constraint_solve_team<64, RL_TERRAIN>), dim3(h->B), b, 0, s, h->P, h->dm, h->dms, h->solver_ovf);
+    } else {
+      const int T = h->solver_team;
+      dim3 gs((h->B + 64 / T - 1) / (64 / T));
+      if (T == 16) hipLaunchKernelGGL((k_constraint_solve_team<16, RL>), gs, b, 0, s, h->P, h->dm, h->dms, h->solver_ovf);
+      else if (T == 32) hipLaunchKernelGGL((k_constraint_solve_team<32, RL>), gs, b, 0, s, h->P, h->dm, h->dms, h->solver_ovf);
+      else hipLaunchKernelGGL((k_constraint_solve_team<64, RL>), gs, b, 0, s, h->P, h->dm, h->dms, h->solver_ovf);
+    }
   }
   {
     ScopedTimer t(h, s, T_INTEGRATE);
