@@ -3411,6 +3411,9 @@ static int field_lookup(int field, int* k, int* is_int, int* off, int* is_aos = 
     case GO2SIM_F_GEOM_FRICTION: kk = NG; oo = FO(geom_friction); break;
     case GO2SIM_F_EFC_FORCE: kk = MAXR; oo = AO(efc_force); aa = 1; break;
     case GO2SIM_F_QFRC_CONSTRAINT: kk = ND; oo = AO(qfrc_constraint); aa = 1; break;
+    case GO2SIM_F_CTRL_POS: kk = ND; oo = FO(ctrl_pos); break;
+    case GO2SIM_F_CTRL_VEL: kk = ND; oo = FO(ctrl_vel); break;
+    case GO2SIM_F_DOF_POS: kk = ND; oo = FO(dof_pos); break;
     case GO2SIM_I_N_CONTACTS: kk = 1; ii = 1; oo = IO(n_contacts); break;
     case GO2SIM_I_CONTACT_GEOMS: kk = 2 * MAXC; ii = 1; oo = AIO(c_geom); aa = 1; break;
     case GO2SIM_I_N_CONSTRAINTS: kk = 1; ii = 1; oo = IO(n_con); break;

@@ -104,6 +104,9 @@ enum go2sim_field {
   GO2SIM_F_GEOM_FRICTION = 23,/* f32 k=28  geoms_info.friction (global in the reference)*/
   GO2SIM_F_EFC_FORCE = 24,    /* f32 k=GO2SIM_MAX_ROWS constraint_state.efc_force       */
   GO2SIM_F_QFRC_CONSTRAINT = 25, /* f32 k=18                                            */
+  GO2SIM_F_CTRL_POS = 26,     /* f32 k=18  dofs_state.ctrl_pos (control_dofs_position)    */
+  GO2SIM_F_CTRL_VEL = 27,     /* f32 k=18  dofs_state.ctrl_vel                          */
+  GO2SIM_F_DOF_POS = 28,      /* f32 k=18  dofs_state.pos (qpos - qpos0 per dof; FK output) */
   /* int32 fields */
   GO2SIM_I_N_CONTACTS = 64,   /* i32 k=1   collider_state.n_contacts                    */
   GO2SIM_I_CONTACT_GEOMS = 65,/* i32 k=300 contact_data.geom_a, geom_b (150 + 150)      */

@@ -2479,7 +2479,7 @@ int go2sim_cpu_field_size(int field, int* k, int* is_int) {
   switch (field) {
     case GO2SIM_F_QPOS: kk = NQ; break;
     case GO2SIM_F_VEL: case GO2SIM_F_ACC: case GO2SIM_F_QACC_WS: case GO2SIM_F_CTRL_FORCE: case GO2SIM_F_FORCE: case GO2SIM_F_ACC_SMOOTH:
-    case GO2SIM_F_QFRC_CONSTRAINT: kk = ND; break;
+    case GO2SIM_F_QFRC_CONSTRAINT: case GO2SIM_F_CTRL_POS: case GO2SIM_F_CTRL_VEL: case GO2SIM_F_DOF_POS: kk = ND; break;
     case GO2SIM_F_EXT_FORCE: kk = NL * 6; break;
     case GO2SIM_F_MASS_SHIFT: kk = NL; break;
     case GO2SIM_F_COM_SHIFT: case GO2SIM_F_LINK_POS: case GO2SIM_F_LINK_CDVEL: case GO2SIM_F_LINK_CDANG: case GO2SIM_F_CONTACT_FORCE: kk = NL * 3; break;
@@ -2530,6 +2530,9 @@ void* field_elem(Env& e, int field, int j) {
     case GO2SIM_F_FORCE: return &e.qf_smooth[j];
     case GO2SIM_F_ACC_SMOOTH: return &e.acc_smooth[j];
     case GO2SIM_F_QFRC_CONSTRAINT: return &e.qfrc_constraint[j];
+    case GO2SIM_F_CTRL_POS: return &e.ctrl_pos[j];
+    case GO2SIM_F_CTRL_VEL: return &e.ctrl_vel[j];
+    case GO2SIM_F_DOF_POS: return &e.dof_pos[j];
     case GO2SIM_F_CONTACT_POS: return ((real*)&e.contacts[j / 3].pos) + j % 3;
     case GO2SIM_F_CONTACT_NORMAL: return ((real*)&e.contacts[j / 3].normal) + j % 3;
     case GO2SIM_F_CONTACT_PEN: return &e.contacts[j].penetration;

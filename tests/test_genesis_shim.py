@@ -1,0 +1,83 @@
+"""The Genesis-shaped `gs` surface (genesis_shim.py): a transcription-free re-play of go2_env_base.py's step written against
+gs.Scene / RigidEntity accessors must reproduce the fused env path (same physics, torch arithmetic for the env logic)."""
+import numpy as np
+import pytest
+import torch
+
+import go2_sim2real_locomotion_rl_amd.genesis_shim as gs
+from go2_sim2real_locomotion_rl_amd.configs import get_jump_cfgs
+from util import CpuEnv, make_actions
+
+
+def _build(oracle_lib, B, env_cfg):
+    gs.init(backend=gs.cpu, precision="32", seed=3, _backend_lib=oracle_lib)
+    scene = gs.Scene(sim_options=gs.options.SimOptions(dt=0.02, substeps=2),
+                     rigid_options=gs.options.RigidOptions(dt=0.02, constraint_solver=gs.constraint_solver.Newton, enable_collision=True,
+                                                           enable_joint_limit=True, max_collision_pairs=30), show_viewer=False)
+    scene.add_entity(gs.morphs.URDF(file="urdf/plane/plane.urdf", fixed=True))
+    robot = scene.add_entity(gs.morphs.URDF(file="urdf/go2/urdf/go2.urdf", pos=np.array(env_cfg["base_init_pos"]), quat=np.array(env_cfg["base_init_quat"])))
+    scene.build(n_envs=B)
+    return scene, robot
+
+
+def test_base_env_step_through_the_gs_surface(oracle_lib, blob):
+    B, steps = 6, 40
+    env_cfg, obs_cfg, reward_cfg, command_cfg = get_jump_cfgs()
+    scene, robot = _build(oracle_lib, B, env_cfg)
+    motors = [robot.get_joint(n).dof_start for n in env_cfg["joint_names"]]
+    assert motors == [7, 11, 15, 6, 10, 14, 9, 13, 17, 8, 12, 16]
+    robot.set_dofs_kp([env_cfg["kp"]] * 12, motors); robot.set_dofs_kv([env_cfg["kd"]] * 12, motors)
+    default = torch.tensor([env_cfg["default_joint_angles"][n] for n in env_cfg["joint_names"]])
+    all_envs = torch.arange(B)
+    # reset_idx of go2_env_base.py:201-239
+    robot.set_dofs_position(position=default.repeat(B, 1), dofs_idx_local=motors, zero_velocity=True, envs_idx=all_envs)
+    robot.set_pos(torch.tensor(env_cfg["base_init_pos"]).repeat(B, 1), zero_velocity=False, envs_idx=all_envs)
+    robot.set_quat(torch.tensor(env_cfg["base_init_quat"]).repeat(B, 1), zero_velocity=False, envs_idx=all_envs)
+    robot.zero_all_dofs_velocity(all_envs)
+
+    fused = CpuEnv(oracle_lib, blob, B, seed=3, task="jump")
+    fused.reset()
+    inv_init = gs.inv_quat(torch.tensor(env_cfg["base_init_quat"]))
+    acts = make_actions(steps, B, seed=9, kind="0.2", n_act=12)
+    last = torch.zeros(B, 12)
+    sc = obs_cfg["obs_scales"]
+    for s, a in enumerate(acts):
+        actions = torch.from_numpy(a)
+        target = last * env_cfg["action_scale"] + default                      # simulate_action_latency: exec_actions = last_actions
+        robot.control_dofs_position(target, motors)
+        scene.step()
+        base_quat = robot.get_quat()
+        inv_base_quat = gs.inv_quat(base_quat)
+        base_lin_vel = gs.transform_by_quat(robot.get_vel(), inv_base_quat)
+        base_ang_vel = gs.transform_by_quat(robot.get_ang(), inv_base_quat)
+        gravity = gs.transform_by_quat(torch.tensor([0.0, 0.0, -1.0]).repeat(B, 1), inv_base_quat)
+        dof_pos, dof_vel = robot.get_dofs_position(motors), robot.get_dofs_velocity(motors)
+        obs = torch.cat([base_ang_vel * sc["ang_vel"], gravity, torch.zeros(B, 3), (dof_pos - default) * sc["dof_pos"], dof_vel * sc["dof_vel"], actions], dim=-1)
+        fo, _, frew, frst, _ = fused.step(a)
+        assert frst.sum() == 0
+        assert np.allclose(obs.numpy(), fo, atol=2e-5), f"step {s}: max diff {np.abs(obs.numpy() - fo).max()}"
+        assert np.allclose(robot.get_pos().numpy(), fused.env_buf("BASE_POS", 3), atol=1e-6)
+        assert np.allclose(base_lin_vel.numpy(), fused.env_buf("BASE_LIN_VEL", 3), atol=2e-5)
+        last = actions
+    # contact forces / link kinematics / control force accessors
+    cf = robot.get_links_net_contact_force()
+    assert cf.shape == (B, 13, 3) and (cf[:, :, 2].sum(1) > 20.0).all()          # the moving robot is carried by its feet
+    assert robot.get_links_pos().shape == (B, 13, 3) and robot.get_links_vel().shape == (B, 13, 3)
+    tau = robot.get_dofs_control_force(motors)
+    assert tau.shape == (B, 12) and float(tau.abs().max()) <= 45.0 + 1e-4
+    scene.rigid_solver.check_errno()
+
+
+def test_external_force_and_dr_hooks(oracle_lib):
+    env_cfg = get_jump_cfgs()[0]
+    scene, robot = _build(oracle_lib, 3, env_cfg)
+    z0 = robot.get_pos()[:, 2].clone()
+    for _ in range(5):                                                           # a strong upward push on the base of env 1 only
+        scene.rigid_solver.apply_links_external_force(torch.tensor([[[0.0, 0.0, 400.0]]]), [robot.get_link("base").idx], envs_idx=[1])
+        scene.step()
+    z = robot.get_pos()[:, 2]
+    assert z[1] > z[0] + 0.01 and abs(float(z[0] - z[2])) < 1e-6 and z0.shape == (3,)
+    robot.set_mass_shift(torch.tensor([[2.0]]).repeat(3, 1), [0]); robot.set_COM_shift(torch.zeros(3, 1, 3), [0]); robot.set_friction(0.7)
+    scene.step()
+    with pytest.raises(gs.GenesisException):
+        robot.get_joint("no_such_joint")
