@@ -215,3 +215,31 @@ def test_go2env_class_base_family(hip_lib, blob):
     obs, rew, reset, extras = env.step(torch.zeros(16, 12, device=env.device))
     assert obs.shape == (16, 45) and extras["observations"]["critic"] is obs and env.get_privileged_observations() is None
     assert set(extras["episode"]) == {"rew_" + n for n in env.reward_scales}
+
+
+def test_gs_surface_on_hip_backend(oracle_lib):
+    """The gs shim drives the HIP library by default; its accessor results equal the oracle-backed shim on the same script."""
+    import torch
+
+    import go2_sim2real_locomotion_rl_amd.genesis_shim as gs
+    from go2_sim2real_locomotion_rl_amd.configs import get_jump_cfgs
+
+    env_cfg = get_jump_cfgs()[0]
+    res = []
+    for backend_lib in (None, oracle_lib):
+        gs.init(backend=gs.gpu, precision="32", seed=4, _backend_lib=backend_lib)
+        scene = gs.Scene(sim_options=gs.options.SimOptions(dt=0.02, substeps=2))
+        scene.add_entity(gs.morphs.URDF(file="urdf/plane/plane.urdf", fixed=True))
+        robot = scene.add_entity(gs.morphs.URDF(file="urdf/go2/urdf/go2.urdf", pos=env_cfg["base_init_pos"], quat=env_cfg["base_init_quat"]))
+        scene.build(n_envs=9)
+        motors = [robot.get_joint(n).dof_start for n in env_cfg["joint_names"]]
+        robot.set_dofs_kp([60.0] * 12, motors); robot.set_dofs_kv([2.0] * 12, motors)
+        default = torch.tensor([env_cfg["default_joint_angles"][n] for n in env_cfg["joint_names"]], device=gs.device)
+        robot.set_dofs_position(default.repeat(9, 1), motors, zero_velocity=True)
+        for _ in range(20):
+            robot.control_dofs_position(default.repeat(9, 1), motors)
+            scene.step()
+        assert robot.get_pos().device.type == ("cuda" if backend_lib is None else "cpu")
+        res.append([t.cpu().numpy() for t in (robot.get_pos(), robot.get_quat(), robot.get_dofs_position(motors), robot.get_links_net_contact_force())])
+    for a, b in zip(*res):
+        assert bits_equal(a, b)
