@@ -902,6 +902,7 @@ struct DynData {
   float f_ang[ND * 3], f_vel[ND * 3];
   float vel[ND], qf_applied[ND], qf_passive[ND], force[ND], out[ND], Dinv[ND];
   float M[ND * ND], L[ND * ND];
+  int ctrl_mode[ND];
 };
 
 // kernel_step_1 without the (already fresh) FK, rigid_solver.py:3008-3069: func_compute_mass_matrix (forward_dynamics.py:291-541),
@@ -930,6 +931,7 @@ __global__ __launch_bounds__(64) void k_dynamics_team(Pool P, const ModelS* __re
   for (int k = tl; k < NL * 9; k += T) { float v = aload(e, AO(cinr_inertial), k); s->cinr_I[k] = v; s->crb_I[k] = v; }
   for (int k = tl; k < NL * 3; k += T) { float v = aload(e, AO(cinr_pos), k); s->cinr_pos[k] = v; s->crb_pos[k] = v; }
   for (int k = tl; k < NL; k += T) { float v = aload(e, AO(cinr_mass), k); s->cinr_mass[k] = v; s->crb_mass[k] = v; }
+  for (int d = tl; d < ND; d += T) s->ctrl_mode[d] = e.ctrl_mode()[d];
   for (int k = tl; k < ND * 3; k += T) {
     s->cdof_ang[k] = aload(e, AO(cdof_ang), k); s->cdof_vel[k] = aload(e, AO(cdof_vel), k);
     s->cdofd_ang[k] = aload(e, AO(cdofd_ang), k); s->cdofd_vel[k] = aload(e, AO(cdofd_vel), k);
@@ -967,7 +969,7 @@ __global__ __launch_bounds__(64) void k_dynamics_team(Pool P, const ModelS* __re
     if (i_d == j_d) {
       v = v + m.dofs[i_d].armature;
       v = v + m.dofs[i_d].damping * m.substep_dt;                      // implicit damping (approximate_implicitfast)
-      int cm = e.ctrl_mode()[i_d];
+      int cm = s->ctrl_mode[i_d];
       if (cm == CTRL_POSITION || cm == CTRL_VELOCITY) v = v + m.dofs[i_d].kv * m.substep_dt;
     }
     s->M[i_d * ND + j_d] = v; s->M[j_d * ND + i_d] = v;
@@ -997,7 +999,7 @@ __global__ __launch_bounds__(64) void k_dynamics_team(Pool P, const ModelS* __re
     const auto& L = m.links[m.dof_link[i_d]];
     int joint_type = m.joints[L.joint_start].type;
     float force = 0.0f;
-    int cm = e.ctrl_mode()[i_d];
+    int cm = s->ctrl_mode[i_d];
     if (cm == CTRL_FORCE) force = gload(e, FO(ctrl_force), i_d);
     else if (cm == CTRL_VELOCITY) force = D.kv * (gload(e, FO(ctrl_vel), i_d) - s->vel[i_d]);
     else if (cm == CTRL_POSITION && !(joint_type == JOINT_FREE && i_d >= L.dof_start + 3))
