@@ -1132,27 +1132,29 @@ DEV V3 support_prism(const V3* prism, V3 d) {
   for (int i = istart + 1; i < istart + 3; ++i) { float dt_ = dot(prism[i], d); if (dt_ > best) { ibest = i; best = dt_; } }
   return prism[ibest];
 }
-DEV V3 support_driver(const Model& m, V3 direction, int i_g, V3 pos, Q4 quat, const V3* prism = nullptr) {
-  const Geom& G = m.geoms[i_g];
-  if (G.type == GEOM_TERRAIN) return support_prism(prism, direction);
-  if (G.type == GEOM_SPHERE) {
-    return pos + direction * G.data[0];
-  } else if (G.type == GEOM_BOX) {
+// type and size of a geom, read once per pair so that the MPR iterations do not go back to the model in global memory
+struct GeomLite { int type; float d0, d1, d2; };
+DEV GeomLite geom_lite(const Model& m, int i_g) { const Geom& G = m.geoms[i_g]; GeomLite r = {G.type, G.data[0], G.data[1], G.data[2]}; return r; }
+DEV V3 support_driver(const Model& m, V3 direction, int i_g, const GeomLite& gl, V3 pos, Q4 quat, const V3* prism = nullptr) {
+  if (gl.type == GEOM_TERRAIN) return support_prism(prism, direction);
+  if (gl.type == GEOM_SPHERE) {
+    return pos + direction * gl.d0;
+  } else if (gl.type == GEOM_BOX) {
     V3 d_box = inv_transform_by_quat(direction, quat);
-    V3 v_ = v3((d_box.x < 0.0f ? -1.0f : 1.0f) * G.data[0] * 0.5f, (d_box.y < 0.0f ? -1.0f : 1.0f) * G.data[1] * 0.5f,
-               (d_box.z < 0.0f ? -1.0f : 1.0f) * G.data[2] * 0.5f);
+    V3 v_ = v3((d_box.x < 0.0f ? -1.0f : 1.0f) * gl.d0 * 0.5f, (d_box.y < 0.0f ? -1.0f : 1.0f) * gl.d1 * 0.5f,
+               (d_box.z < 0.0f ? -1.0f : 1.0f) * gl.d2 * 0.5f);
     return transform_by_trans_quat(v_, pos, quat);
   } else {
     V3 d_mesh = transform_by_quat(direction, inv_quat(quat));
-    V3 v_ = support_cylinder_local(m, G, d_mesh);
+    V3 v_ = support_cylinder_local(m, m.geoms[i_g], d_mesh);
     return transform_by_trans_quat(v_, pos, quat);
   }
 }
-struct Pair { int i_ga, i_gb; V3 pos_a; Q4 quat_a; V3 pos_b; Q4 quat_b; const V3* prism; };
+struct Pair { int i_ga, i_gb; V3 pos_a; Q4 quat_a; V3 pos_b; Q4 quat_b; const V3* prism; GeomLite ga, gb; };
 // compute_support, collider/mpr.py:179-202
 DEVN void compute_support(const Model& m, V3 direction, const Pair& pr, V3& v, V3& v1, V3& v2) {
-  v1 = support_driver(m, direction, pr.i_ga, pr.pos_a, pr.quat_a);
-  v2 = support_driver(m, -direction, pr.i_gb, pr.pos_b, pr.quat_b, pr.prism);
+  v1 = support_driver(m, direction, pr.i_ga, pr.ga, pr.pos_a, pr.quat_a);
+  v2 = support_driver(m, -direction, pr.i_gb, pr.gb, pr.pos_b, pr.quat_b, pr.prism);
   v = v1 - v2;
 }
 
@@ -1464,7 +1466,7 @@ DEV void convex_convex_contact_staged(const Model& m, const E& e, int i_ga, int 
   bool multi_contact = (type_a != GEOM_SPHERE) && (type_b != GEOM_SPHERE);
   float tolerance = compute_tolerance(m, i_ga, i_gb, m.mc_tolerance);
   V3 ga_pos_o = e.g_pos()[i_ga], gb_pos_o = e.g_pos()[i_gb]; Q4 ga_quat_o = e.g_quat()[i_ga], gb_quat_o = e.g_quat()[i_gb];
-  Pair pr; pr.i_ga = i_ga; pr.i_gb = i_gb; pr.pos_a = ga_pos_o; pr.quat_a = ga_quat_o; pr.pos_b = gb_pos_o; pr.quat_b = gb_quat_o; pr.prism = nullptr;
+  Pair pr; pr.i_ga = i_ga; pr.i_gb = i_gb; pr.pos_a = ga_pos_o; pr.quat_a = ga_quat_o; pr.pos_b = gb_pos_o; pr.quat_b = gb_quat_o; pr.prism = nullptr; pr.ga = geom_lite(m, i_ga); pr.gb = geom_lite(m, i_gb);
   bool is_col_0 = false; V3 normal_0 = v3(0, 0, 0), contact_pos_0 = v3(0, 0, 0);
   bool is_col = false; float penetration = 0.0f; V3 normal = v3(0, 0, 0), contact_pos = v3(0, 0, 0);
   V3 axis_0 = v3(0, 0, 0), axis_1 = v3(0, 0, 0); Q4 qrot = q4(0, 0, 0, 0);
@@ -1541,7 +1543,7 @@ DEV void contact_mpr_terrain_staged(const Model& m, const E& e, int i_ga, int i_
   V3 prism[6]; float xyz_max_min[6];
 #pragma unroll
   for (int i = 0; i < 6; ++i) prism[i] = v3(0, 0, 0);
-  Pair pr; pr.i_ga = i_ga; pr.i_gb = i_gb; pr.prism = prism;
+  Pair pr; pr.i_ga = i_ga; pr.i_gb = i_gb; pr.prism = prism; pr.ga = geom_lite(m, i_ga); pr.gb = geom_lite(m, i_gb);
   transform_pos_quat_by_trans_quat(ga_pos - gb_pos, ga_quat, v3(0, 0, 0), inv_quat(gb_quat), pr.pos_a, pr.quat_a);
   pr.pos_b = v3(0, 0, 0); pr.quat_b = qident();
   V3 center_a = transform_by_trans_quat(m.geoms[i_ga].center, pr.pos_a, pr.quat_a);
@@ -1549,7 +1551,7 @@ DEV void contact_mpr_terrain_staged(const Model& m, const E& e, int i_ga, int i_
     for (int i_m = 0; i_m < 2; ++i_m) {
       V3 direction = v3(0, 0, 0);
       vset(direction, i_axis, (i_m == 0) ? 1.0f : -1.0f);
-      V3 v1 = support_driver(m, direction, i_ga, pr.pos_a, pr.quat_a);
+      V3 v1 = support_driver(m, direction, i_ga, pr.ga, pr.pos_a, pr.quat_a);
       xyz_max_min[3 * i_m + i_axis] = vget(v1, i_axis);
     }
   const float* tmm = m.terrain_xyz_maxmin;
