@@ -7,14 +7,15 @@
 // observations, 19 reward terms, command resampling, termination, reset with domain randomisation and
 // metric-gated curriculum) with NO host synchronisation inside a step.
 //
-// Data layout: every per-env quantity lives in one HBM pool laid out SoA  [feature][n_envs]
-// (env index innermost => lane b of a wave reads word b of a 256-byte line: fully coalesced).
-// Execution model: one environment per lane, 64 environments per wavefront / workgroup.
+// Data layout: two pools.  SoA rows [feature][n_envs] hold what the lane-per-env Go2Env kernels touch; AoS records [n_envs][record]
+// hold the physics-internal arrays of the team kernels (see GO2SIM_FLOAT_FIELDS / GO2SIM_AOS_FLOAT_FIELDS below and DESIGN.md).
+// Execution model: the physics kernels (k_*_team) give T lanes to each environment (64/T environments per single-wavefront
+// workgroup) and keep an environment's working set in LDS; the Go2Env bookkeeping kernels run one environment per lane.
 //
-// Reference citations use `R/` = genesis/engine/solvers/rigid/ and `E/` =
-// examples/locomotion/final/ of the reference tree.  Arithmetic follows the reference's serial
-// (`backend == gs.cpu`) evaluation order so that results are bit-identical to the CPU oracle
-// (oracle/go2sim_cpu.cpp) when both are built with -ffp-contract=off.
+// Reference citations use `R/` = genesis/engine/solvers/rigid/ and `E/` = examples/locomotion/final/ of the reference tree.
+// Arithmetic follows the reference's serial (`backend == gs.cpu`) evaluation order -- independent outputs are spread over lanes, chained
+// sums stay first-to-last -- so that results are bit-identical to the CPU oracle (oracle/go2sim_cpu.cpp) when both are built with
+// -ffp-contract=off.
 
 #include <hip/hip_runtime.h>
 
@@ -595,15 +596,6 @@ DEV void wg_load(const Pool& P, int b0, int off, int count, F put) {
     for (int k = k0; k < count; k += 64 / EPW) put(ev, k, P.f[(size_t)(off + k) * P.B + b]);
   }
 }
-template <int EPW, class F>
-DEV void wg_store(const Pool& P, int b0, int off, int count, F get) {
-  const int ev = threadIdx.x % EPW, k0 = threadIdx.x / EPW;
-  const int b = b0 + ev;
-  if (b < P.B) {
-#pragma unroll 4
-    for (int k = k0; k < count; k += 64 / EPW) P.f[(size_t)(off + k) * P.B + b] = get(ev, k);
-  }
-}
 
 // ---- optional per-phase cycle accounting (build with -DGO2SIM_PHASE_PROFILE; development aid, see tools/phase_profile.py) ----
 #ifdef GO2SIM_PHASE_PROFILE
@@ -635,13 +627,6 @@ DEV M3 ld9(const float* p, int i) { M3 r;
 DEV void st9(float* p, int i, const M3& r) {
 #pragma unroll
   for (int k = 0; k < 9; ++k) p[9 * i + k] = r.m[k / 3][k % 3]; }
-// (row, col) of the idx-th entry of a lower triangle stored row by row
-DEV void tri_index(int idx, int& i, int& j) {
-  i = (int)((sqrtf(8.0f * (float)idx + 1.0f) - 1.0f) * 0.5f);
-  while (i * (i + 1) / 2 > idx) --i;
-  while ((i + 1) * (i + 2) / 2 <= idx) ++i;
-  j = idx - i * (i + 1) / 2;
-}
 
 struct KinData {
   float qpos[NQ], vel[ND], qpos_next[NQ], vel_next[ND];
