@@ -213,7 +213,7 @@ def main():
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        n_cpu_envs, n_cpu_steps = 4096, 200   # ~13 s on the 256 host threads of the GPU box
+        n_cpu_envs, n_cpu_steps = 4096, 1500   # ~15-20 s on the 256 host threads of the GPU box
         v, dt = cpu_baseline(n_cpu_envs, n_cpu_steps, 3)
         cpu = {"value": round(v, 1), "unit": "env-steps/s", "cores": os.cpu_count(), "kind": "port",
                "sample": f"CPU oracle (OpenMP over envs, all host cores), same walk cfg/action set, {n_cpu_envs} envs x {n_cpu_steps} steps after 3 warm-up steps ({dt:.1f} s)"}
