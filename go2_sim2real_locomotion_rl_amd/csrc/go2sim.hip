@@ -1435,6 +1435,9 @@ struct CollideData {
   int cand_key[MAXB], cand_pair[MAXB], pair_sorted[MAXB];
   float stage[T][5][7];
   int cnt[T];
+  // terrain pass: one slot per (geom, terrain) pair of the broad-phase list
+  struct TPair { int i_ga, r_min, r_max, c_min, c_max, n_items, item_off; float zmin; V3 pos_a; Q4 quat_a; V3 center_a; } tp[NG];
+  float acc_pos[5][3];   // contacts already accepted for the current terrain pair (dedupe)
 };
 struct ContactStage { float* st; int n; };   // per-lane staging of the (<= 5) contacts of one pair
 
@@ -1519,69 +1522,74 @@ DEV void convex_convex_contact_staged(const Model& m, const E& e, int i_ga, int 
   }
 }
 
-// func_contact_mpr_terrain, narrowphase.py:345-490: geom i_ga against the heightfield cells under its bounding box; contacts are staged
-DEV void contact_mpr_terrain_staged(const Model& m, const E& e, int i_ga, int i_gb, ContactStage& cs) {
+// func_contact_mpr_terrain, narrowphase.py:345-490, split for one-lane-per-prism execution.
+// (1) per pair: geom pose in the terrain frame, its bounding box from six support points, the cell range under it.
+template <class TP>
+DEV bool terrain_pair_setup(const Model& m, const E& e, int i_ga, int i_gb, TP& t) {
   V3 ga_pos = e.g_pos()[i_ga], gb_pos = e.g_pos()[i_gb]; Q4 ga_quat = e.g_quat()[i_ga], gb_quat = e.g_quat()[i_gb];
   const float margin = 0.0f;
-  bool is_return = false;
-  float tolerance = compute_tolerance(m, i_ga, i_gb, m.mc_tolerance);
-  V3 prism[6]; float xyz_max_min[6];
-#pragma unroll
-  for (int i = 0; i < 6; ++i) prism[i] = v3(0, 0, 0);
-  Pair pr; pr.i_ga = i_ga; pr.i_gb = i_gb; pr.prism = prism; pr.ga = geom_lite(m, i_ga); pr.gb = geom_lite(m, i_gb);
-  transform_pos_quat_by_trans_quat(ga_pos - gb_pos, ga_quat, v3(0, 0, 0), inv_quat(gb_quat), pr.pos_a, pr.quat_a);
-  pr.pos_b = v3(0, 0, 0); pr.quat_b = qident();
-  V3 center_a = transform_by_trans_quat(m.geoms[i_ga].center, pr.pos_a, pr.quat_a);
+  transform_pos_quat_by_trans_quat(ga_pos - gb_pos, ga_quat, v3(0, 0, 0), inv_quat(gb_quat), t.pos_a, t.quat_a);
+  t.center_a = transform_by_trans_quat(m.geoms[i_ga].center, t.pos_a, t.quat_a);
+  t.i_ga = i_ga;
+  GeomLite gl = geom_lite(m, i_ga);
+  float xyz_max_min[6];
   for (int i_axis = 0; i_axis < 3; ++i_axis)
     for (int i_m = 0; i_m < 2; ++i_m) {
       V3 direction = v3(0, 0, 0);
       vset(direction, i_axis, (i_m == 0) ? 1.0f : -1.0f);
-      V3 v1 = support_driver(m, direction, i_ga, pr.ga, pr.pos_a, pr.quat_a);
+      V3 v1 = support_driver(m, direction, i_ga, gl, t.pos_a, t.quat_a);
       xyz_max_min[3 * i_m + i_axis] = vget(v1, i_axis);
     }
   const float* tmm = m.terrain_xyz_maxmin;
+  bool is_return = false;
 #pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    prism[i].z = tmm[5];
+  for (int i = 0; i < 3; ++i)
     if (tmm[i] < xyz_max_min[i + 3] - margin || tmm[i + 3] > xyz_max_min[i] + margin) is_return = true;
-  }
-  if (is_return) return;
   const float sh = m.terrain_hs;
   int r_min = (int)dm_floor((xyz_max_min[3] - tmm[3]) / sh);
   int r_max = (int)dm_ceil((xyz_max_min[0] - tmm[3]) / sh);
   int c_min = (int)dm_floor((xyz_max_min[4] - tmm[4]) / sh);
   int c_max = (int)dm_ceil((xyz_max_min[1] - tmm[4]) / sh);
-  r_min = imx(0, r_min); c_min = imx(0, c_min);
-  r_max = imn(m.terrain_rows - 1, r_max); c_max = imn(m.terrain_cols - 1, c_max);
-  for (int r = r_min; r < r_max; ++r) {
-    int nvert = 0;
-    for (int c = c_min; c < c_max + 1; ++c)
-      for (int i = 0; i < 2; ++i)
-        if (cs.n < m.n_contacts_per_pair) {
-          nvert = nvert + 1;
-          float x = sh * (float)(r + i) + tmm[3], y = sh * (float)c + tmm[4], z = m.terrain_hf[(size_t)(r + i) * m.terrain_cols + c] + margin;
-          prism[0] = prism[1]; prism[1] = prism[2]; prism[3] = prism[4]; prism[4] = prism[5];            // func_add_prism_vert :493-512
-          prism[2].x = x; prism[5].x = x; prism[2].y = y; prism[5].y = y; prism[5].z = z;
-          if (nvert > 2 && (prism[3].z >= xyz_max_min[5] || prism[4].z >= xyz_max_min[5] || prism[5].z >= xyz_max_min[5])) {
-            V3 center_b = v3(0, 0, 0);
-            for (int i_p = 0; i_p < 6; ++i_p) center_b = center_b + prism[i_p];
-            center_b = center_b / 6.0f;
-            bool is_col; V3 normal, contact_pos; float penetration;
-            mpr_contact_from_centers(m, pr, center_a, center_b, is_col, normal, penetration, contact_pos);
-            if (is_col) {
-              normal = transform_by_quat(normal, gb_quat);
-              contact_pos = transform_by_quat(contact_pos, gb_quat);
-              contact_pos = contact_pos + gb_pos;
-              bool valid = true;
-              for (int j = 0; j < cs.n; ++j) {
-                const float* prev = cs.st + 7 * (cs.n - j - 1);
-                if (norm(contact_pos - v3(prev[3], prev[4], prev[5])) < tolerance) { valid = false; break; }
-              }
-              if (valid) stage_contact(cs, normal, contact_pos, penetration);
-            }
-          }
-        }
+  t.r_min = imx(0, r_min); t.c_min = imx(0, c_min);
+  t.r_max = imn(m.terrain_rows - 1, r_max); t.c_max = imn(m.terrain_cols - 1, c_max);
+  t.zmin = xyz_max_min[5];
+  if (is_return) { t.r_max = t.r_min; }   // empty cell range
+  return !is_return;
+}
+// height of the k-th vertex of the strip of row r (vertex order of func_add_prism_vert: (c, i) with i fastest)
+DEV float terrain_strip_z(const Model& m, int r, int c_min, int k) { return m.terrain_hf[(size_t)(r + (k & 1)) * m.terrain_cols + c_min + (k >> 1)]; }
+// (2) the prism that exists after the k-th vertex of row r was pushed (k >= 2) is tested iff one of its top vertices reaches the geom
+template <class TP>
+DEV bool terrain_prism_eligible(const Model& m, const TP& t, int r, int k) {
+  return terrain_strip_z(m, r, t.c_min, k - 2) >= t.zmin || terrain_strip_z(m, r, t.c_min, k - 1) >= t.zmin || terrain_strip_z(m, r, t.c_min, k) >= t.zmin;
+}
+// (3) MPR of the geom against that prism; the contact is returned in world coordinates
+template <class TP>
+DEV bool terrain_prism_contact(const Model& m, const E& e, const TP& t, int i_gb, int r, int k, V3& normal, V3& contact_pos, float& penetration) {
+  const float* tmm = m.terrain_xyz_maxmin;
+  const float sh = m.terrain_hs;
+  V3 prism[6];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    int kk = k - 2 + j;
+    float x = sh * (float)(r + (kk & 1)) + tmm[3], y = sh * (float)(t.c_min + (kk >> 1)) + tmm[4];
+    prism[j] = v3(x, y, tmm[5]);
+    prism[3 + j] = v3(x, y, terrain_strip_z(m, r, t.c_min, kk) + 0.0f);
   }
+  Pair pr; pr.i_ga = t.i_ga; pr.i_gb = i_gb; pr.prism = prism; pr.pos_a = t.pos_a; pr.quat_a = t.quat_a; pr.pos_b = v3(0, 0, 0); pr.quat_b = qident();
+  pr.ga = geom_lite(m, t.i_ga); pr.gb = geom_lite(m, i_gb);
+  V3 center_b = v3(0, 0, 0);
+  for (int i_p = 0; i_p < 6; ++i_p) center_b = center_b + prism[i_p];
+  center_b = center_b / 6.0f;
+  bool is_col;
+  mpr_contact_from_centers(m, pr, t.center_a, center_b, is_col, normal, penetration, contact_pos);
+  if (is_col) {
+    V3 gb_pos = e.g_pos()[i_gb]; Q4 gb_quat = e.g_quat()[i_gb];
+    normal = transform_by_quat(normal, gb_quat);
+    contact_pos = transform_by_quat(contact_pos, gb_quat);
+    contact_pos = contact_pos + gb_pos;
+  }
+  return is_col;
 }
 
 template <int T>
@@ -1687,7 +1695,6 @@ __global__ __launch_bounds__(64) void k_collide_team(Pool P, const Model* __rest
   //      pair, ordered compaction; the terrain pass appends after all convex-convex contacts, as the two reference kernels do ----
   int nc_run = 0;
   const int n_np_iter = (n_broad + T - 1) / T;
-  for (int pass = 0; pass < (m.terrain_enabled ? 2 : 1); ++pass)
   for (int it = 0; it < n_np_iter; ++it) {
     int ip = it * T + tl;
     ContactStage cs; cs.st = &s->stage[tl][0][0]; cs.n = 0;
@@ -1697,8 +1704,7 @@ __global__ __launch_bounds__(64) void k_collide_team(Pool P, const Model* __rest
       i_ga = pk & 0xff; i_gb = pk >> 8;
       if (m.geoms[i_ga].type > m.geoms[i_gb].type) { int t = i_ga; i_ga = i_gb; i_gb = t; }
       const bool with_terrain = m.geoms[i_gb].type == GEOM_TERRAIN;
-      if (pass == 0 && !with_terrain) convex_convex_contact_staged(m, e, i_ga, i_gb, cs, &gjk_scratch[(size_t)b * T + tl]);
-      if (pass == 1 && with_terrain) contact_mpr_terrain_staged(m, e, i_ga, i_gb, cs);
+      if (!with_terrain) convex_convex_contact_staged(m, e, i_ga, i_gb, cs, &gjk_scratch[(size_t)b * T + tl]);
     }
     s->cnt[tl] = cs.n;
     team_sync();
@@ -1722,6 +1728,99 @@ __global__ __launch_bounds__(64) void k_collide_team(Pool P, const Model* __rest
     }
     nc_run += tot;
     team_sync();
+  }
+  // ---- func_narrow_phase_any_vs_terrain (narrowphase.py:1197-1244): appended after all convex-convex contacts.  One lane per heightfield
+  //      prism: the pairs enumerate the prisms their geom can reach, the MPR queries run T at a time, and the accept / dedupe / cap logic of
+  //      the serial loop is replayed in prism order, which reproduces the contact list of the reference exactly. ----
+  if (m.terrain_enabled) {
+    int n_tp = 0;                                                       // terrain pairs, in broad-phase order
+    for (int ip = 0; ip < n_broad; ++ip) {
+      int pk = s->pair_sorted[ip];
+      int i_ga = pk & 0xff, i_gb = pk >> 8;
+      if (m.geoms[i_ga].type == GEOM_TERRAIN) { int t = i_ga; i_ga = i_gb; i_gb = t; }
+      if (m.geoms[i_gb].type != GEOM_TERRAIN) continue;
+      if (n_tp < NG) { if (tl == 0) { s->tp[n_tp].i_ga = i_ga; s->tp[n_tp].n_items = i_gb; } n_tp++; }
+    }
+    team_sync();
+    for (int p = tl; p < n_tp; p += T) {                                // pair setup + count of reachable prisms
+      auto& t = s->tp[p];
+      int i_gb = t.n_items;
+      terrain_pair_setup(m, e, t.i_ga, i_gb, t);
+      int cnt = 0;
+      const int nk = 2 * (t.c_max - t.c_min + 1);
+      for (int r = t.r_min; r < t.r_max; ++r)
+        for (int k = 2; k < nk; ++k) cnt += terrain_prism_eligible(m, t, r, k);
+      t.n_items = cnt; t.item_off = i_gb;                                // item_off temporarily carries the terrain geom index
+    }
+    team_sync();
+    int* items = (int*)&gjk_scratch[(size_t)b * T];                     // prism descriptors p | r << 5 | k << 18 (the GJK scratch is idle in this pass)
+    const int items_cap = (int)(sizeof(GjkScratch) * T / sizeof(int));
+    int i_terrain = 0, n_items = 0;
+    for (int p = 0; p < n_tp; ++p) { int c = s->tp[p].n_items; if (p == 0) i_terrain = s->tp[p].item_off; n_items += c; }
+    team_sync();
+    { int off = 0; for (int p = 0; p < n_tp; ++p) { int c = s->tp[p].n_items; if (tl == 0) s->tp[p].item_off = off; off += c; } }
+    team_sync();
+    for (int p = tl; p < n_tp; p += T) {                                // descriptors in (pair, row, vertex) order
+      const auto& t = s->tp[p];
+      int q = t.item_off;
+      const int nk = 2 * (t.c_max - t.c_min + 1);
+      for (int r = t.r_min; r < t.r_max; ++r)
+        for (int k = 2; k < nk; ++k)
+          if (terrain_prism_eligible(m, t, r, k)) { if (q < items_cap) items[q] = p | (r << 5) | (k << 18); q++; }
+    }
+    if (n_items > items_cap) n_items = items_cap;
+    team_sync();
+    int cur_p = -1, n_con = 0;                                          // replay state (identical on every lane)
+    float tolerance = 0.0f;
+    for (int base = 0; base < n_items; base += T) {
+      const int q = base + tl;
+      float* st = &s->stage[tl][0][0];
+      int has = 0;
+      if (q < n_items) {
+        int d = items[q];
+        const auto& t = s->tp[d & 31];
+        V3 normal, cpos; float pen;
+        if (terrain_prism_contact(m, e, t, i_terrain, (d >> 5) & 0x1fff, d >> 18, normal, cpos, pen)) {
+          has = 1;
+          st[0] = normal.x; st[1] = normal.y; st[2] = normal.z; st[3] = cpos.x; st[4] = cpos.y; st[5] = cpos.z; st[6] = pen;
+        }
+      }
+      s->cnt[tl] = has;
+      team_sync();
+      const int n_chunk = imn(T, n_items - base);
+      for (int l = 0; l < n_chunk; ++l) {
+        const int p = items[base + l] & 31;
+        if (p != cur_p) { cur_p = p; n_con = 0; tolerance = compute_tolerance(m, s->tp[p].i_ga, i_terrain, m.mc_tolerance); }
+        if (!s->cnt[l] || n_con >= m.n_contacts_per_pair) continue;
+        const float* pc = &s->stage[l][0][0];
+        V3 cpos = v3(pc[3], pc[4], pc[5]);
+        bool valid = true;
+        for (int j = 0; j < n_con; ++j) {
+          if (nc_run - j - 1 < m.max_contact_pairs && norm(cpos - v3(s->acc_pos[n_con - j - 1][0], s->acc_pos[n_con - j - 1][1], s->acc_pos[n_con - j - 1][2])) < tolerance) { valid = false; break; }
+        }
+        if (!valid) continue;
+        const int i_ga = s->tp[p].i_ga, i_c = nc_run;
+        team_sync();
+        if (tl == 0 && n_con < 5) { s->acc_pos[n_con][0] = cpos.x; s->acc_pos[n_con][1] = cpos.y; s->acc_pos[n_con][2] = cpos.z; }
+        if (i_c < m.max_contact_pairs) {
+          if (tl == 0) {                                                 // func_add_contact, contact.py:165-199
+            float friction_a = e.geom_friction()[i_ga] * e.friction_ratio()[i_ga];
+            float friction_b = e.geom_friction()[i_terrain] * e.friction_ratio()[i_terrain];
+            e.c_geom()[i_c] = i_ga; e.c_geom()[MAXC + i_c] = i_terrain;
+            e.c_normal()[i_c] = v3(pc[0], pc[1], pc[2]); e.c_pos()[i_c] = cpos; e.c_pen()[i_c] = pc[6];
+            e.c_friction()[i_c] = fmx(fmx(friction_a, friction_b), 1e-2f);
+            auto sol = e.c_sol()[i_c];
+            for (int qq = 0; qq < 7; ++qq) sol[qq] = 0.5f * (m.geoms[i_ga].sol_params[qq] + m.geoms[i_terrain].sol_params[qq]);
+            e.c_link()[i_c] = m.geoms[i_ga].link; e.c_link()[MAXC + i_c] = m.geoms[i_terrain].link;
+          }
+        } else if (tl == 0) {
+          atomicOr(&e.err()[0], GO2SIM_ERR_OVERFLOW_COLLISION_PAIRS);
+        }
+        nc_run++; n_con++;
+        team_sync();                                                     // the dedupe of later prisms reads this contact back
+      }
+      team_sync();
+    }
   }
   if (tl == 0) { e.n_broad()[0] = n_broad; e.n_contacts()[0] = imn(nc_run, m.max_contact_pairs); }
   PH(33)
