@@ -2145,6 +2145,9 @@ DEV float ts_linesearch(const MT& m, S* s, int tl, int n_con, float gauss) {
 template <int T, class S, class MT>
 DEV int ts_solve(const MT& m, const E& e, S* s, int tl, int nc, int n_con) {
   PH_BEGIN
+#ifdef GO2SIM_REPEAT_PHASE      // profiling builds: run one idempotent phase twice, the time difference is that phase's cost
+  for (int rep_stage = 0; rep_stage < (GO2SIM_REPEAT_PHASE == 0 ? 2 : 1); ++rep_stage) {
+#endif
   // ---- stage inputs ----
   bool ws = (n_con > 0) && e.is_warmstart()[0];
 #pragma unroll
@@ -2165,8 +2168,15 @@ DEV int ts_solve(const MT& m, const E& e, S* s, int tl, int nc, int n_con) {
     }
   }
   team_sync();
+#ifdef GO2SIM_REPEAT_PHASE
+  }
+  for (int rep_rows = 0; rep_rows < (GO2SIM_REPEAT_PHASE == 1 ? 2 : (GO2SIM_REPEAT_PHASE == 12 ? 0 : 1)); ++rep_rows) {
+#endif
   PH(0)
   // ---- contact rows: one lane per row ----
+#if defined(GO2SIM_REPEAT_PHASE) && GO2SIM_REPEAT_PHASE == 13
+  for (int rep_c = 0; rep_c < 2; ++rep_c)
+#endif
   for (int r = tl; r < 4 * nc; r += T) {
     int i_col = r >> 2, i = r & 3;
     int link_a = e.c_link()[i_col], link_b = e.c_link()[MAXC + i_col];
@@ -2213,6 +2223,9 @@ DEV int ts_solve(const MT& m, const E& e, S* s, int tl, int nc, int n_con) {
     s->aref[r] = aref; s->efc_D[r] = 1.0f / diag;
   }
   // ---- joint-limit rows: one lane per joint, ordered compaction ----
+#if defined(GO2SIM_REPEAT_PHASE) && GO2SIM_REPEAT_PHASE == 14
+  for (int rep_c = 0; rep_c < 2; ++rep_c)
+#endif
   for (int i_j = tl; i_j < NJ; i_j += T) {
     const Joint& Jt = m.joints[i_j];
     if (Jt.type != JOINT_REVOLUTE) continue;
@@ -2242,6 +2255,9 @@ DEV int ts_solve(const MT& m, const E& e, S* s, int tl, int nc, int n_con) {
     }
   }
   team_sync();
+#ifdef GO2SIM_REPEAT_PHASE
+  }
+#endif
   PH(1)
   // ---- func_solve_init ----
   {
@@ -2266,16 +2282,30 @@ DEV int ts_solve(const MT& m, const E& e, S* s, int tl, int nc, int n_con) {
   ts_update_constraint<T>(m, s, tl, n_con, cost, prev_cost, gauss);
   PH(2)
   int iters = 0;
+#if defined(GO2SIM_REPEAT_PHASE) && GO2SIM_REPEAT_PHASE == 20
+  if (n_con > 100000) {
+#else
   if (n_con > 0) {
+#endif
     const float tol_scaled = (m.meaninertia * (float)imx(1, ND)) * m.tolerance;
     bool need_full = true;
     for (int it = 0;; ++it) {
       if (need_full) {                       // single call site of the direct Hessian + factorisation (init and degenerate rebuild)
+#if defined(GO2SIM_REPEAT_PHASE) && GO2SIM_REPEAT_PHASE == 3
+        ts_hessian_direct<T>(m, s, tl, n_con);
+        ts_cholesky_factor<T>(m, s, tl);
+#endif
+#if defined(GO2SIM_REPEAT_PHASE) && GO2SIM_REPEAT_PHASE == 4
+        ts_hessian_direct<T>(m, s, tl, n_con);
+#endif
         ts_hessian_direct<T>(m, s, tl, n_con);
         PH(3)
         ts_cholesky_factor<T>(m, s, tl);
         PH(4)
       }
+#if defined(GO2SIM_REPEAT_PHASE) && GO2SIM_REPEAT_PHASE == 5
+      ts_update_gradient<T>(s, tl);
+#endif
       ts_update_gradient<T>(s, tl);
       PH(5)
       if (it > 0) {
@@ -2290,6 +2320,9 @@ DEV int ts_solve(const MT& m, const E& e, S* s, int tl, int nc, int n_con) {
       if (it == m.iterations) break;
       for (int d = tl; d < ND; d += T) s->search[d] = -s->Mgrad[d];
       team_sync();
+#if defined(GO2SIM_REPEAT_PHASE) && GO2SIM_REPEAT_PHASE == 6
+      { float alpha0 = ts_linesearch<T>(m, s, tl, n_con, gauss); if (alpha0 == 12345.0f) s->search[0] = 0.0f; team_sync(); }
+#endif
       float alpha = ts_linesearch<T>(m, s, tl, n_con, gauss);
       PH(6)
       iters++;
@@ -2303,7 +2336,11 @@ DEV int ts_solve(const MT& m, const E& e, S* s, int tl, int nc, int n_con) {
       team_sync();
       ts_update_constraint<T>(m, s, tl, n_con, cost, prev_cost, gauss);
       PH(7)
+#if defined(GO2SIM_REPEAT_PHASE) && GO2SIM_REPEAT_PHASE == 8
+      need_full = true;                      // profiling: always rebuild instead of the incremental update (same H up to rounding; timing only)
+#else
       need_full = ts_cholesky_incremental<T>(m, s, tl, n_con);
+#endif
       team_sync();
       PH(8)
     }
@@ -2390,10 +2427,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     if (fmn(q - m.dofs[Jt.dof_start].limit[0], m.dofs[Jt.dof_start].limit[1] - q) < 0) n_lim++;
   }
   const int n_con = 4 * nc + n_lim;
+#if defined(GO2SIM_REPEAT_PHASE) && GO2SIM_REPEAT_PHASE == 21
+  if (n_con < 100000) return;
+#endif
   if (n_con <= RLN) {
     SolverData<RLN>* s = &lds[slot];
     int iters = ts_solve<T>(m, e, s, tl, nc, n_con);
     PH_BEGIN
+#if defined(GO2SIM_REPEAT_PHASE) && GO2SIM_REPEAT_PHASE == 11
+    ts_commit<T>(m, e, s, tl, nc, n_con, iters);
+    team_sync();
+#endif
     ts_commit<T>(m, e, s, tl, nc, n_con, iters);
     PH(11)
   } else {
@@ -2543,25 +2587,47 @@ DEV bool curriculum_update(const DCfg& c, Glob& g, double timeout_rate, double t
 }
 
 // Go2Env.step pre-physics part: go2_env_walk.py:985-1023 (+ _apply_push :872-906)
-__global__ __launch_bounds__(WG) void k_env_pre(Pool P, const Model* __restrict__ mp, const DCfg* __restrict__ cp, const Glob* __restrict__ gp,
+__global__ __launch_bounds__(WG) void k_env_pre(Pool P, const Model* __restrict__ mp, const DCfg cv, const Glob* __restrict__ gp,
                                                 const float* __restrict__ actions_in, uint64_t seed, uint32_t step_count, int write_idx) {
   int b = blockIdx.x * WG + threadIdx.x;
   if (b >= P.B) return;
-  const DCfg& c = *cp; const Glob& g = *gp;
+  const DCfg& c = cv;  const Glob& g = *gp;
   E e(P, b);
   const int na = c.i[GO2SIM_IC_NUM_ACTIONS];
   float clip = c.f[GO2SIM_FC_CLIP_ACTIONS];
   auto actions = e.actions(); auto hist = e.action_history(); auto applied = e.applied_actions();
+  auto target_dof_pos = e.target_dof_pos(); auto kp_factors = e.kp_factors(); auto kd_factors = e.kd_factors(); auto motor_strength = e.motor_strength();
+  auto dof_pos = e.e_dof_pos(); auto dof_vel = e.e_dof_vel(); auto torque_ = e.torque(); auto ctrl_mode = e.ctrl_mode(); auto ctrl_force = e.ctrl_force();
+  auto cpf = e.current_push_force(); auto psf = e.push_stored_force(); auto prem = e.push_remaining(); auto ext = e.ext();
+  const bool manual_pd = c.i[GO2SIM_IC_MANUAL_PD] != 0, pls = c.i[GO2SIM_IC_PLS_ENABLE] != 0;
+  const bool push_on = c.i[GO2SIM_IC_HAS_PUSH] && g.push_enable;
+  const int pl = c.i[GO2SIM_IC_PUSH_LINK];
+  // ---- loads first (one wave per 64 envs: the kernel's duration is its chain of memory round trips) ----
   int delay = e.delay_steps()[0];
+  float a_in[NA], h0_[NA], h1_[NA];
+#pragma unroll
+  for (int i = 0; i < NA; ++i) {
+    a_in[i] = (i < na) ? actions_in[(size_t)b * na + i] : 0.0f;
+    h0_[i] = hist[0][i]; h1_[i] = hist[1][i];
+  }
+  float kpf[NM], kdf[NM], mst[NM], dp[NM], dv[NM];
+#pragma unroll
+  for (int i = 0; i < NM; ++i) { kpf[i] = kp_factors[i]; kdf[i] = kd_factors[i]; mst[i] = motor_strength[i]; dp[i] = dof_pos[i]; dv[i] = dof_vel[i]; }
+  float psf_[3] = {psf[0], psf[1], psf[2]}; int rem0 = prem[0];
+  V3 pl_pos = e.l_pos()[pl], pl_com = e.root_com()[pl];
+  float ext_[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) ext_[k] = ext[6 * pl + k];
+  // ---- compute + stores ----
   int w_after = (write_idx + 1) % 2;
   int read_idx = (((w_after - 1 - delay) % 2) + 2) % 2;
   float delayed[NA];
 #pragma unroll
   for (int i = 0; i < NA; ++i) {
     if (i < na) {
-      float a = fmn(fmx(actions_in[(size_t)b * na + i], -clip), clip);
+      float a = fmn(fmx(a_in[i], -clip), clip);
       actions[i] = a;
-      float h0 = (write_idx == 0) ? a : hist[0][i], h1 = (write_idx == 1) ? a : hist[1][i];
+      float h0 = (write_idx == 0) ? a : h0_[i], h1 = (write_idx == 1) ? a : h1_[i];
       hist[write_idx][i] = a;
       float d = (read_idx == 0) ? h0 : h1;
       delayed[i] = d; applied[i] = d;
@@ -2584,10 +2650,9 @@ __global__ __launch_bounds__(WG) void k_env_pre(Pool P, const Model* __restrict_
       target[4 * blk + 3] = target[4 * blk + 3] + n3 * g.action_noise_std_cur;
     }
   }
-  auto target_dof_pos = e.target_dof_pos(); auto kp_factors = e.kp_factors(); auto kd_factors = e.kd_factors(); auto motor_strength = e.motor_strength();
-  auto dof_pos = e.e_dof_pos(); auto dof_vel = e.e_dof_vel(); auto torque_ = e.torque(); auto ctrl_mode = e.ctrl_mode(); auto ctrl_force = e.ctrl_force();
-  if (!c.i[GO2SIM_IC_MANUAL_PD]) {                                   // go2_env_base.py:127: control_dofs_position (engine PD)
+  if (!manual_pd) {                                                  // go2_env_base.py:127: control_dofs_position (engine PD)
     auto ctrl_pos = e.ctrl_pos(); auto ctrl_vel = e.ctrl_vel();
+#pragma unroll
     for (int i = 0; i < NM; ++i) {
       target_dof_pos[i] = target[i];
       int d = c.i[GO2SIM_IC_MOTOR_DOF0 + i];
@@ -2599,54 +2664,83 @@ __global__ __launch_bounds__(WG) void k_env_pre(Pool P, const Model* __restrict_
   for (int i = 0; i < NM; ++i) {
     target_dof_pos[i] = target[i];
     float eff_kp, eff_kd;
-    if (c.i[GO2SIM_IC_PLS_ENABLE]) {                                 // _compute_pls_kp_kd :969-979
+    if (pls) {                                                       // _compute_pls_kp_kd :969-979
       int leg = i / 3;
       float kp_leg = c.f[GO2SIM_FC_PLS_KP_DEFAULT] + delayed[NM + leg] * c.f[GO2SIM_FC_PLS_KP_ACTION_SCALE];
       kp_leg = fmn(fmx(kp_leg, c.f[GO2SIM_FC_PLS_KP_MIN]), c.f[GO2SIM_FC_PLS_KP_MAX]);
       float kd_j = 0.2f * dm_sqrt(kp_leg);
-      eff_kp = kp_leg * kp_factors[i] * motor_strength[i];
-      eff_kd = kd_j * kd_factors[i];
+      eff_kp = kp_leg * kpf[i] * mst[i];
+      eff_kd = kd_j * kdf[i];
     } else {
-      eff_kp = c.f[GO2SIM_FC_KP] * kp_factors[i]; eff_kd = c.f[GO2SIM_FC_KD] * kd_factors[i];
+      eff_kp = c.f[GO2SIM_FC_KP] * kpf[i]; eff_kd = c.f[GO2SIM_FC_KD] * kdf[i];
     }
-    float pos_error = target[i] - dof_pos[i];
-    float torque = eff_kp * pos_error - eff_kd * dof_vel[i];
+    float pos_error = target[i] - dp[i];
+    float torque = eff_kp * pos_error - eff_kd * dv[i];
     float lim = c.f[GO2SIM_FC_TORQUE_LIMIT0 + i];
     torque = fmn(fmx(torque, -lim), lim);
     torque_[i] = torque;
     int d = c.i[GO2SIM_IC_MOTOR_DOF0 + i];
     ctrl_mode[d] = CTRL_FORCE; ctrl_force[d] = torque;
   }
-  auto cpf = e.current_push_force();
-  if (!c.i[GO2SIM_IC_HAS_PUSH] || !g.push_enable) {
+  if (!push_on) {
     cpf[0] = 0.0f; cpf[1] = 0.0f; cpf[2] = 0.0f;
   } else {
-    auto psf = e.push_stored_force(); auto prem = e.push_remaining();
     if (g.push_counter % g.push_interval == 0) {
       dm_u4 r = rng4(seed, RNG_PUSH, b, step_count, 0);
-      psf[0] = rand_float(g.push_force_lo, g.push_force_hi, r.v[0]);
-      psf[1] = rand_float(g.push_force_lo, g.push_force_hi, r.v[1]);
-      psf[2] = 0.0f;
-      prem[0] = rand_int(c.i[GO2SIM_IC_PUSH_DUR_LO], c.i[GO2SIM_IC_PUSH_DUR_HI], r.v[2]);
+      psf_[0] = rand_float(g.push_force_lo, g.push_force_hi, r.v[0]);
+      psf_[1] = rand_float(g.push_force_lo, g.push_force_hi, r.v[1]);
+      psf_[2] = 0.0f;
+      psf[0] = psf_[0]; psf[1] = psf_[1]; psf[2] = psf_[2];
+      rem0 = rand_int(c.i[GO2SIM_IC_PUSH_DUR_LO], c.i[GO2SIM_IC_PUSH_DUR_HI], r.v[2]);
     }
-    int rem = prem[0];
+    int rem = rem0;
     float active = (rem > 0) ? 1.0f : 0.0f;
-    V3 force = v3(psf[0] * active, psf[1] * active, psf[2] * active);
+    V3 force = v3(psf_[0] * active, psf_[1] * active, psf_[2] * active);
     cpf[0] = force.x; cpf[1] = force.y; cpf[2] = force.z;
     prem[0] = imx(rem - 1, 0);
-    int l = c.i[GO2SIM_IC_PUSH_LINK];                                  // func_apply_link_external_force ref=link_origin, abd/misc.py:695-715
-    V3 tq = cross((V3)e.l_pos()[l] - (V3)e.root_com()[l], force);
-    auto ext = e.ext();
-    ext[6 * l + 0] = ext[6 * l + 0] - tq.x; ext[6 * l + 1] = ext[6 * l + 1] - tq.y; ext[6 * l + 2] = ext[6 * l + 2] - tq.z;
-    ext[6 * l + 3] = ext[6 * l + 3] - force.x; ext[6 * l + 4] = ext[6 * l + 4] - force.y; ext[6 * l + 5] = ext[6 * l + 5] - force.z;
+    V3 tq = cross(pl_pos - pl_com, force);                             // func_apply_link_external_force ref=link_origin, abd/misc.py:695-715
+    ext[6 * pl + 0] = ext_[0] - tq.x; ext[6 * pl + 1] = ext_[1] - tq.y; ext[6 * pl + 2] = ext_[2] - tq.z;
+    ext[6 * pl + 3] = ext_[3] - force.x; ext[6 * pl + 4] = ext_[4] - force.y; ext[6 * pl + 5] = ext_[5] - force.z;
   }
 }
 
 struct RewCtx { float link_vel_xy[8], foot_z[4], foot_xy[8]; float vel_world[3]; int was_reset; };
+// Everything the reward terms read, held in registers: the loads are issued together ahead of the (serial) term loop, so the loop itself
+// never waits on memory.  Terms that mutate env buffers (feet_air_time, forward_progress) update the copy; the caller writes it back.
+struct RewState {
+  float cmd[3], blv[3], bav[3], pg[3], base_pos[3];
+  float dof_pos[NM], dof_vel[NM], last_dof_vel[NM], target[NM], ctrl_force[NM];
+  float actions[NA], last_actions[NA];
+  float fat[4]; int fc[4];
+  float last_x;
+  float ctrl_pos[NM], ctrl_vel[NM], s_vel[NM], s_dof_pos[NM]; int ctrl_mode[NM];   // base env only (engine PD, accessor.py:848-875)
+};
+// the part of RewState that is plain env-buffer content (the caller fills blv, bav, pg, base_pos, dof_pos, dof_vel, fc)
+DEV void load_rew_state(const DCfg& c, const E& e, RewState& rs) {
+  auto cmd = e.commands(); auto ldv = e.last_dof_vel(); auto t = e.target_dof_pos(); auto cf = e.ctrl_force(); auto a = e.actions(); auto la = e.last_actions();
+  auto fat = e.feet_air_time();
+#pragma unroll
+  for (int i = 0; i < 3; ++i) rs.cmd[i] = cmd[i];
+#pragma unroll
+  for (int i = 0; i < NM; ++i) { rs.last_dof_vel[i] = ldv[i]; rs.target[i] = t[i]; rs.ctrl_force[i] = cf[c.i[GO2SIM_IC_MOTOR_DOF0 + i]]; }
+#pragma unroll
+  for (int i = 0; i < NA; ++i) { rs.actions[i] = a[i]; rs.last_actions[i] = la[i]; }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) rs.fat[i] = fat[i];
+  rs.last_x = e.last_base_pos_x()[0];
+  if (c.i[GO2SIM_IC_ENV_KIND] == 1) {
+    auto ctrl_mode = e.ctrl_mode(); auto cp = e.ctrl_pos(); auto cv = e.ctrl_vel(); auto vel = e.vel(); auto sdp = e.dof_pos();
+#pragma unroll
+    for (int i = 0; i < NM; ++i) {
+      int d = c.i[GO2SIM_IC_MOTOR_DOF0 + i];
+      rs.ctrl_mode[i] = ctrl_mode[d]; rs.ctrl_pos[i] = cp[d]; rs.ctrl_vel[i] = cv[d]; rs.s_vel[i] = vel[d]; rs.s_dof_pos[i] = sdp[d];
+    }
+  }
+}
 // reward terms, go2_env_walk.py:1251-1366
-DEV float reward_term(const Model& m, const DCfg& c, const E& e, int id, const RewCtx& rc) {
+DEV float reward_term(const Model& m, const DCfg& c, RewState& rs, int id, const RewCtx& rc) {
   const float dt = c.f[GO2SIM_FC_DT];
-  auto cmd = e.commands(); auto blv = e.base_lin_vel(); auto bav = e.base_ang_vel(); auto dof_pos = e.e_dof_pos(); auto dof_vel = e.e_dof_vel();
+  const float* cmd = rs.cmd; const float* blv = rs.blv; const float* bav = rs.bav; const float* dof_pos = rs.dof_pos; const float* dof_vel = rs.dof_vel;
   float c0 = cmd[0], c1 = cmd[1], c2 = cmd[2];
   float cmd_norm = dm_sqrt(c0 * c0 + c1 * c1 + c2 * c2);
   float still = (cmd_norm < 0.1f) ? 1.0f : 0.0f;
@@ -2659,111 +2753,182 @@ DEV float reward_term(const Model& m, const DCfg& c, const E& e, int id, const R
       if (dz > 0.0f) { float ex = fmx(dm_abs(v) - dz, 0.0f); return ex * ex; }
       return v * v;
     }
-    case GO2SIM_R_ACTION_RATE: { float s = 0.0f; auto la = e.last_actions(); auto a = e.actions(); for (int i = 0; i < c.i[GO2SIM_IC_NUM_ACTIONS]; ++i) { float d = la[i] - a[i]; s = s + d * d; } return s; }
-    case GO2SIM_R_SIMILAR_TO_DEFAULT: { float s = 0.0f; for (int i = 0; i < NM; ++i) s = s + dm_abs(dof_pos[i] - c.f[GO2SIM_FC_DEFAULT_DOF_POS0 + i]); return s; }
+    case GO2SIM_R_ACTION_RATE: {
+      float s = 0.0f; const int na = c.i[GO2SIM_IC_NUM_ACTIONS];
+#pragma unroll
+      for (int i = 0; i < NA; ++i) if (i < na) { float d = rs.last_actions[i] - rs.actions[i]; s = s + d * d; }
+      return s;
+    }
+    case GO2SIM_R_SIMILAR_TO_DEFAULT: {
+      float s = 0.0f;
+#pragma unroll
+      for (int i = 0; i < NM; ++i) s = s + dm_abs(dof_pos[i] - c.f[GO2SIM_FC_DEFAULT_DOF_POS0 + i]);
+      return s;
+    }
     case GO2SIM_R_BASE_HEIGHT: {                                     // go2_env_stair.py:1634-1648: height above the local terrain
-      auto bp = e.base_pos();
-      float hgt = bp[2];
-      if (c.i[GO2SIM_IC_USE_TERRAIN]) hgt = bp[2] - terrain_height(m, c, bp[0], bp[1]);
+      float hgt = rs.base_pos[2];
+      if (c.i[GO2SIM_IC_USE_TERRAIN]) hgt = rs.base_pos[2] - terrain_height(m, c, rs.base_pos[0], rs.base_pos[1]);
       float d = hgt - c.f[GO2SIM_FC_BASE_HEIGHT_TARGET]; return d * d;
     }
-    case GO2SIM_R_DOF_ACC: { float s = 0.0f; auto ldv = e.last_dof_vel(); for (int i = 0; i < NM; ++i) { float a = (dof_vel[i] - ldv[i]) / dt; s = s + a * a; } return s; }
-    case GO2SIM_R_DOF_VEL: { float s = 0.0f; for (int i = 0; i < NM; ++i) { float v = dof_vel[i]; s = s + v * v; } return s; }
-    case GO2SIM_R_ORIENTATION_PENALTY: { auto pg = e.projected_gravity(); float a = pg[0], b2 = pg[1]; return a * a + b2 * b2; }
+    case GO2SIM_R_DOF_ACC: {
+      float s = 0.0f;
+#pragma unroll
+      for (int i = 0; i < NM; ++i) { float a = (dof_vel[i] - rs.last_dof_vel[i]) / dt; s = s + a * a; }
+      return s;
+    }
+    case GO2SIM_R_DOF_VEL: {
+      float s = 0.0f;
+#pragma unroll
+      for (int i = 0; i < NM; ++i) { float v = dof_vel[i]; s = s + v * v; }
+      return s;
+    }
+    case GO2SIM_R_ORIENTATION_PENALTY: { float a = rs.pg[0], b2 = rs.pg[1]; return a * a + b2 * b2; }
     case GO2SIM_R_ANG_VEL_XY: { float a = bav[0], b2 = bav[1]; return a * a + b2 * b2; }
-    case GO2SIM_R_STAND_STILL: { float s = 0.0f; for (int i = 0; i < NM; ++i) s = s + dm_abs(dof_pos[i] - c.f[GO2SIM_FC_DEFAULT_DOF_POS0 + i]); return s * still; }
+    case GO2SIM_R_STAND_STILL: {
+      float s = 0.0f;
+#pragma unroll
+      for (int i = 0; i < NM; ++i) s = s + dm_abs(dof_pos[i] - c.f[GO2SIM_FC_DEFAULT_DOF_POS0 + i]);
+      return s * still;
+    }
     case GO2SIM_R_STAND_STILL_VEL: { float a = blv[0], b2 = blv[1], w = bav[2]; float lin = a * a + b2 * b2; float ang = w * w; return (lin + 0.5f * ang) * still; }
     case GO2SIM_R_FEET_STANCE: {
-      float sa = 0.0f, sn = 0.0f; auto fat = e.feet_air_time(); auto fc = e.foot_contact();
-      for (int i = 0; i < 4; ++i) { sa = sa + fat[i]; sn = sn + (fc[i] ? 0.0f : 1.0f); }
+      float sa = 0.0f, sn = 0.0f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { sa = sa + rs.fat[i]; sn = sn + (rs.fc[i] ? 0.0f : 1.0f); }
       return (sa + sn) * still;
     }
     case GO2SIM_R_FEET_AIR_TIME: {                                     // mutates _feet_air_time (:1303-1314)
-      auto fat = e.feet_air_time(); auto fc = e.foot_contact();
       float first[4], at[4];
-      for (int i = 0; i < 4; ++i) { float a = fat[i]; int ct = fc[i]; first[i] = (a > 0.0f && ct) ? 1.0f : 0.0f; a = a + dt; a = a * (ct ? 0.0f : 1.0f); fat[i] = a; at[i] = a; }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { float a = rs.fat[i]; int ct = rs.fc[i]; first[i] = (a > 0.0f && ct) ? 1.0f : 0.0f; a = a + dt; a = a * (ct ? 0.0f : 1.0f); rs.fat[i] = a; at[i] = a; }
       float s = 0.0f;
+#pragma unroll
       for (int i = 0; i < 4; ++i) s = s + (at[i] - c.f[GO2SIM_FC_FEET_AIR_TIME_TARGET]) * first[i];
       return s * moving;
     }
     case GO2SIM_R_FOOT_SLIP: {
-      float slip = 0.0f; auto fc = e.foot_contact();
-      for (int i = 0; i < 4; ++i) { float vx = rc.link_vel_xy[2 * i], vy = rc.link_vel_xy[2 * i + 1]; slip = slip + (fc[i] ? 1.0f : 0.0f) * (vx * vx + vy * vy); }
+      float slip = 0.0f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { float vx = rc.link_vel_xy[2 * i], vy = rc.link_vel_xy[2 * i + 1]; slip = slip + (rs.fc[i] ? 1.0f : 0.0f) * (vx * vx + vy * vy); }
       return slip;
     }
     case GO2SIM_R_FOOT_CLEARANCE: {
-      float pen = 0.0f; auto fc = e.foot_contact();
+      float pen = 0.0f;
+#pragma unroll
       for (int i = 0; i < 4; ++i) {
         float vx = rc.link_vel_xy[2 * i], vy = rc.link_vel_xy[2 * i + 1];
         float vn = dm_sqrt(vx * vx + vy * vy);
         float fz = rc.foot_z[i];
         if (c.i[GO2SIM_IC_USE_TERRAIN]) fz = rc.foot_z[i] - terrain_height(m, c, rc.foot_xy[2 * i], rc.foot_xy[2 * i + 1]);   // go2_env_stair.py:1742-1747
         float he = c.f[GO2SIM_FC_FEET_HEIGHT_TARGET] - fz; he = he * he;
-        pen = pen + (fc[i] ? 0.0f : 1.0f) * he * vn;
+        pen = pen + (rs.fc[i] ? 0.0f : 1.0f) * he * vn;
       }
       return pen * moving;
     }
-    case GO2SIM_R_JOINT_TRACKING: { float s = 0.0f; auto t = e.target_dof_pos(); for (int i = 0; i < NM; ++i) { float d = t[i] - dof_pos[i]; s = s + d * d; } return s; }
+    case GO2SIM_R_JOINT_TRACKING: {
+      float s = 0.0f;
+#pragma unroll
+      for (int i = 0; i < NM; ++i) { float d = rs.target[i] - dof_pos[i]; s = s + d * d; }
+      return s;
+    }
     case GO2SIM_R_ENERGY: case GO2SIM_R_TORQUE_LOAD: {                 // get_dofs_control_force, abd/accessor.py:848-875
-      float s = 0.0f; auto cf = e.ctrl_force();
+      float s = 0.0f;
+#pragma unroll
       for (int i = 0; i < NM; ++i) {
         int d = c.i[GO2SIM_IC_MOTOR_DOF0 + i];
-        float tau = clampf(cf[d], m.dofs[d].force_range[0], m.dofs[d].force_range[1]);
+        float tau = clampf(rs.ctrl_force[i], m.dofs[d].force_range[0], m.dofs[d].force_range[1]);
         s = s + ((id == GO2SIM_R_ENERGY) ? dm_abs(tau * dof_vel[i]) : dm_abs(tau));
       }
       return s;
     }
     // ---- go2_env_base.py:246-390 (crouch / jump) ----
-    case GO2SIM_R_JUMP_IMPULSE: { float gate = (e.base_pos()[2] < 0.50f) ? 1.0f : 0.0f; return gate * fmx(blv[2], 0.0f); }
-    case GO2SIM_R_JUMP_APEX: { float q = (e.base_pos()[2] - c.f[GO2SIM_FC_JUMP_APEX_HEIGHT]) / c.f[GO2SIM_FC_JUMP_APEX_SIGMA]; return dm_exp(-(q * q)); }
+    case GO2SIM_R_JUMP_IMPULSE: { float gate = (rs.base_pos[2] < 0.50f) ? 1.0f : 0.0f; return gate * fmx(blv[2], 0.0f); }
+    case GO2SIM_R_JUMP_APEX: { float q = (rs.base_pos[2] - c.f[GO2SIM_FC_JUMP_APEX_HEIGHT]) / c.f[GO2SIM_FC_JUMP_APEX_SIGMA]; return dm_exp(-(q * q)); }
     case GO2SIM_R_XY_STABILITY: { float vx = rc.vel_world[0], vy = rc.vel_world[1]; return -(vx * vx + vy * vy); }
-    case GO2SIM_R_ORIENTATION: return -e.projected_gravity()[2];
+    case GO2SIM_R_ORIENTATION: return -rs.pg[2];
     case GO2SIM_R_NO_SHAKE: { float a = bav[0], b2 = bav[1], c3 = bav[2]; return -((a * a + b2 * b2) + c3 * c3) / 1.0f; }
-    case GO2SIM_R_CROUCH: return (e.base_pos()[2] < 0.25f) ? 1.0f : 0.0f;
-    case GO2SIM_R_CROUCH_2: { float z = e.base_pos()[2]; return (z <= 0.30f && z >= 0.20f) ? 1.0f : 0.0f; }
-    case GO2SIM_R_GROUND_PENALTY: { float v = (0.15f - e.base_pos()[2]) / 0.1f; v = fmn(fmx(v, 0.0f), 1.0f); return -(v * v); }
-    case GO2SIM_R_CROUCH_TARGET: { float q = (e.base_pos()[2] - 0.15f) / 0.03f; return dm_exp(-(q * q)); }
+    case GO2SIM_R_CROUCH: return (rs.base_pos[2] < 0.25f) ? 1.0f : 0.0f;
+    case GO2SIM_R_CROUCH_2: { float z = rs.base_pos[2]; return (z <= 0.30f && z >= 0.20f) ? 1.0f : 0.0f; }
+    case GO2SIM_R_GROUND_PENALTY: { float v = (0.15f - rs.base_pos[2]) / 0.1f; v = fmn(fmx(v, 0.0f), 1.0f); return -(v * v); }
+    case GO2SIM_R_CROUCH_TARGET: { float q = (rs.base_pos[2] - 0.15f) / 0.03f; return dm_exp(-(q * q)); }
     case GO2SIM_R_NO_FALL: { float dn = fmx(-blv[2] - 0.5f, 0.0f); return -(dn * dn); }
     case GO2SIM_R_Y_STABILITY: { float vy = rc.vel_world[1]; return -(vy * vy); }
     case GO2SIM_R_TORQUE_LOAD_BASE: {                                  // get_dofs_control_force of the current state, accessor.py:848-875
-      float s = 0.0f; auto ctrl_mode = e.ctrl_mode(); auto cf = e.ctrl_force(); auto cp = e.ctrl_pos(); auto cv = e.ctrl_vel(); auto vel = e.vel(); auto sdp = e.dof_pos();
+      float s = 0.0f;
+#pragma unroll
       for (int i = 0; i < NM; ++i) {
         int d = c.i[GO2SIM_IC_MOTOR_DOF0 + i];
         const Dof& D = m.dofs[d];
         // a freshly reset env has (qpos0 + default) - qpos0 and zero velocity once its FK refresh has run (it follows this kernel)
-        float pos_d = rc.was_reset ? ((m.qpos0[d + 1] + dof_pos[i]) - m.qpos0[d + 1]) : sdp[d];
-        float vel_d = rc.was_reset ? 0.0f : vel[d];
+        float pos_d = rc.was_reset ? ((m.qpos0[d + 1] + dof_pos[i]) - m.qpos0[d + 1]) : rs.s_dof_pos[i];
+        float vel_d = rc.was_reset ? 0.0f : rs.s_vel[i];
         float force = 0.0f;
-        int cm = ctrl_mode[d];
-        if (cm == CTRL_FORCE) force = cf[d];
-        else if (cm == CTRL_VELOCITY) force = D.kv * (cv[d] - vel_d);
-        else if (cm == CTRL_POSITION) force = D.kp * (cp[d] - pos_d) + D.kv * (cv[d] - vel_d);
+        int cm = rs.ctrl_mode[i];
+        if (cm == CTRL_FORCE) force = rs.ctrl_force[i];
+        else if (cm == CTRL_VELOCITY) force = D.kv * (rs.ctrl_vel[i] - vel_d);
+        else if (cm == CTRL_POSITION) force = D.kp * (rs.ctrl_pos[i] - pos_d) + D.kv * (rs.ctrl_vel[i] - vel_d);
         s = s + dm_abs(clampf(force, D.force_range[0], D.force_range[1]));
       }
       return -0.001f * s;
     }
-    case GO2SIM_R_CROUCH_PROGRESS: return fmx(0.35f - e.base_pos()[2], 0.0f);
+    case GO2SIM_R_CROUCH_PROGRESS: return fmx(0.35f - rs.base_pos[2], 0.0f);
     case GO2SIM_R_CROUCH_SPEED: return -(blv[2] * blv[2]);
     // ---- go2_env_stair.py:1659-1771 ----
-    case GO2SIM_R_ORIENTATION_ROLL_ONLY: { float gy = e.projected_gravity()[1]; return gy * gy; }
-    case GO2SIM_R_FORWARD_PROGRESS: { auto lx = e.last_base_pos_x(); float bx = e.base_pos()[0]; float dx = bx - lx[0]; lx[0] = bx; return dx; }   // mutates _last_base_pos_x
+    case GO2SIM_R_ORIENTATION_ROLL_ONLY: { float gy = rs.pg[1]; return gy * gy; }
+    case GO2SIM_R_FORWARD_PROGRESS: { float bx = rs.base_pos[0]; float dx = bx - rs.last_x; rs.last_x = bx; return dx; }   // mutates _last_base_pos_x
   }
   return 0.0f;
 }
 
 // Go2Env.step post-physics part A: clear_external_force, state read-back, commands, termination, rewards
-// (simulator.py:283-284, go2_env_walk.py:1026-1077) + reset-call statistics (:688-715,1228-1235)
-__global__ __launch_bounds__(WG) void k_env_post_a(Pool P, const Model* __restrict__ mp, const DCfg* __restrict__ cp, const Glob* __restrict__ gp,
+// (simulator.py:283-284, go2_env_walk.py:1026-1077) + reset-call statistics (:688-715,1228-1235).
+// One lane per env; the kernel is a single wave per 64 envs, so its duration is its dependency chain: every input is loaded before the
+// first store (one memory round trip instead of one per reward term) and the per-term episode sums sit in LDS for the dynamic term loop.
+__global__ __launch_bounds__(WG) void k_env_post_a(Pool P, const Model* __restrict__ mp, const DCfg cv, const Glob* __restrict__ gp,
                                                    Acc* acc, uint64_t seed, uint32_t step_count) {
+  __shared__ float s_es[NREW][WG], s_r[NREW][WG];
   int b = blockIdx.x * WG + threadIdx.x;
   if (b >= P.B) return;
-  const Model& m = *mp; const DCfg& c = *cp; const Glob& g = *gp;
+  const int ln = threadIdx.x;
+  const Model& m = *mp; const DCfg& c = cv;  const Glob& g = *gp;
   E e(P, b);
-  { auto ext = e.ext(); for (int i = 0; i < NL * 6; ++i) ext[i] = 0.0f; }
+  const int nrew = c.i[GO2SIM_IC_N_REWARDS];
+  const bool base_env = c.i[GO2SIM_IC_ENV_KIND] == 1;               // base env: rewards follow the reset (k_env_post_b_team)
+  // ---- loads ----
   int ep_len = e.episode_length()[0] + 1;
-  e.episode_length()[0] = ep_len;
   int bl = c.i[GO2SIM_IC_BASE_LINK];
   V3 bp = e.l_pos()[bl]; Q4 bq = e.l_quat()[bl];
+  V3 rcom = e.root_com()[bl];
+  V3 cda = e.cd_ang()[bl], cdv = e.cd_vel()[bl];
+  V3 f_cf[4], f_lp[4], f_cdv[4], f_cda[4]; int fc_old[4];
+  {
+    auto fc = e.foot_contact();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int l = c.i[GO2SIM_IC_FOOT_LINK0 + i];
+      fc_old[i] = fc[i];
+      f_cf[i] = e.contact_force()[l]; f_lp[i] = e.l_pos()[l]; f_cdv[i] = e.cd_vel()[l]; f_cda[i] = e.cd_ang()[l];
+    }
+  }
+  RewState rs;
+  {
+    auto sdof_pos = e.dof_pos(); auto vel = e.vel();
+#pragma unroll
+    for (int i = 0; i < NM; ++i) { int d = c.i[GO2SIM_IC_MOTOR_DOF0 + i]; rs.dof_pos[i] = sdof_pos[d]; rs.dof_vel[i] = vel[d]; }
+  }
+  if (!base_env) load_rew_state(c, e, rs);
+  else { auto cmd = e.commands(); for (int i = 0; i < 3; ++i) rs.cmd[i] = cmd[i]; }
+  {
+    auto episode_sums = e.episode_sums();
+    float es_[NREW];
+#pragma unroll
+    for (int k = 0; k < NREW; ++k) es_[k] = episode_sums[k];           // all NREW rows exist; unconditional loads stay in flight together
+#pragma unroll
+    for (int k = 0; k < NREW; ++k) s_es[k][ln] = es_[k];
+  }
+  // ---- stores start here ----
+  { auto ext = e.ext(); for (int i = 0; i < NL * 6; ++i) ext[i] = 0.0f; }
+  e.episode_length()[0] = ep_len;
   auto base_pos = e.base_pos(); auto base_quat = e.base_quat();
   base_pos[0] = bp.x; base_pos[1] = bp.y; base_pos[2] = bp.z;
   base_quat[0] = bq.w; base_quat[1] = bq.x; base_quat[2] = bq.y; base_quat[3] = bq.z;
@@ -2772,9 +2937,7 @@ __global__ __launch_bounds__(WG) void k_env_post_a(Pool P, const Model* __restri
   auto base_euler = e.base_euler();
   base_euler[0] = eul.x; base_euler[1] = eul.y; base_euler[2] = eul.z;
   Q4 inv_bq = inv_quat(bq);
-  V3 rcom = e.root_com()[bl];
-  V3 cda = e.cd_ang()[bl];
-  V3 velw = (V3)e.cd_vel()[bl] + cross(cda, bp - rcom);
+  V3 velw = cdv + cross(cda, bp - rcom);
   { auto bvw = e.base_vel_world(); bvw[0] = velw.x; bvw[1] = velw.y; bvw[2] = velw.z; }
   V3 blv = tc_transform_by_quat(velw, inv_bq), bav = tc_transform_by_quat(cda, inv_bq);
   V3 pg = tc_transform_by_quat(v3(0.0f, 0.0f, -1.0f), inv_bq);
@@ -2782,25 +2945,29 @@ __global__ __launch_bounds__(WG) void k_env_post_a(Pool P, const Model* __restri
   o_blv[0] = blv.x; o_blv[1] = blv.y; o_blv[2] = blv.z;
   o_bav[0] = bav.x; o_bav[1] = bav.y; o_bav[2] = bav.z;
   o_pg[0] = pg.x; o_pg[1] = pg.y; o_pg[2] = pg.z;
-  auto dof_pos = e.e_dof_pos(); auto dof_vel = e.e_dof_vel(); auto sdof_pos = e.dof_pos(); auto vel = e.vel();
-  for (int i = 0; i < NM; ++i) { int d = c.i[GO2SIM_IC_MOTOR_DOF0 + i]; dof_pos[i] = sdof_pos[d]; dof_vel[i] = vel[d]; }
+  rs.blv[0] = blv.x; rs.blv[1] = blv.y; rs.blv[2] = blv.z; rs.bav[0] = bav.x; rs.bav[1] = bav.y; rs.bav[2] = bav.z;
+  rs.pg[0] = pg.x; rs.pg[1] = pg.y; rs.pg[2] = pg.z; rs.base_pos[0] = bp.x; rs.base_pos[1] = bp.y; rs.base_pos[2] = bp.z;
+  auto dof_pos = e.e_dof_pos(); auto dof_vel = e.e_dof_vel();
+#pragma unroll
+  for (int i = 0; i < NM; ++i) { dof_pos[i] = rs.dof_pos[i]; dof_vel[i] = rs.dof_vel[i]; }
   RewCtx rc; rc.was_reset = 0; rc.vel_world[0] = velw.x; rc.vel_world[1] = velw.y; rc.vel_world[2] = velw.z;
   auto fc = e.foot_contact(); auto lfc = e.last_foot_contact();
+#pragma unroll
   for (int i = 0; i < 4; ++i) {
-    int l = c.i[GO2SIM_IC_FOOT_LINK0 + i];
-    lfc[i] = fc[i];
-    V3 cf = e.contact_force()[l];
-    fc[i] = dm_abs(cf.z) > c.f[GO2SIM_FC_FOOT_CONTACT_THRESHOLD];
-    V3 lp = e.l_pos()[l];
-    V3 lv = (V3)e.cd_vel()[l] + cross((V3)e.cd_ang()[l], lp - rcom);
+    lfc[i] = fc_old[i];
+    int ct = dm_abs(f_cf[i].z) > c.f[GO2SIM_FC_FOOT_CONTACT_THRESHOLD];
+    fc[i] = ct; rs.fc[i] = ct;
+    V3 lp = f_lp[i];
+    V3 lv = f_cdv[i] + cross(f_cda[i], lp - rcom);
     rc.link_vel_xy[2 * i] = lv.x; rc.link_vel_xy[2 * i + 1] = lv.y; rc.foot_z[i] = lp.z; rc.foot_xy[2 * i] = lp.x; rc.foot_xy[2 * i + 1] = lp.y;
   }
-  auto cmd = e.commands();
   if (ep_len % c.i[GO2SIM_IC_RESAMPLE_STEPS] == 0) {
+    auto cmd = e.commands();
     dm_u4 r = rng4(seed, RNG_CMD, b, step_count, 0);
     float cx = rand_float(g.cmd_x_lo, g.cmd_x_hi, r.v[0]), cy = rand_float(g.cmd_y_lo, g.cmd_y_hi, r.v[1]), cz = rand_float(g.cmd_yaw_lo, g.cmd_yaw_hi, r.v[2]);
     if (b < c.i[GO2SIM_IC_N_STANDING]) { cx = 0.0f; cy = 0.0f; cz = 0.0f; }
     cmd[0] = cx; cmd[1] = cy; cmd[2] = cz;
+    rs.cmd[0] = cx; rs.cmd[1] = cy; rs.cmd[2] = cz;
   }
   int maxlen = c.i[GO2SIM_IC_MAX_EPISODE_LENGTH];
   int rst = ep_len > maxlen;
@@ -2812,27 +2979,34 @@ __global__ __launch_bounds__(WG) void k_env_post_a(Pool P, const Model* __restri
   float time_out = (ep_len > maxlen) ? 1.0f : 0.0f;
   e.time_out()[0] = time_out;
   float rew = 0.0f;
-  auto rew_terms = e.rew_terms(); auto episode_sums = e.episode_sums();
-  int nrew = c.i[GO2SIM_IC_N_REWARDS];
   float tracking_int = 0.0f;
-  const bool base_env = c.i[GO2SIM_IC_ENV_KIND] == 1;               // base env: rewards follow the reset (k_env_post_b_team)
+  const float fat0[4] = {rs.fat[0], rs.fat[1], rs.fat[2], rs.fat[3]};
+  const float last_x0 = rs.last_x;
   for (int k = 0; k < nrew; ++k) {
     int id = c.i[GO2SIM_IC_REWARD_ID0 + k];
-    float es = episode_sums[k];
+    float es = s_es[k][ln];
     if (!base_env) {
-      float r = reward_term(m, c, e, id, rc) * c.f[GO2SIM_FC_REWARD_SCALE0 + k];
-      rew_terms[k] = r;
+      float r = reward_term(m, c, rs, id, rc) * c.f[GO2SIM_FC_REWARD_SCALE0 + k];
+      s_r[k][ln] = r;
       rew = rew + r;
       es = es + r;
-      episode_sums[k] = es;
+      s_es[k][ln] = es;
     }
     if (id == GO2SIM_R_TRACKING_LIN_VEL || id == GO2SIM_R_TRACKING_ANG_VEL) tracking_int = tracking_int + es;
   }
-  if (!base_env) e.rew()[0] = rew;
+  if (!base_env) {
+    e.rew()[0] = rew;
+    auto rew_terms = e.rew_terms(); auto episode_sums = e.episode_sums();
+    for (int k = 0; k < nrew; ++k) { rew_terms[k] = s_r[k][ln]; episode_sums[k] = s_es[k][ln]; }
+    auto fat = e.feet_air_time();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) if (rs.fat[i] != fat0[i]) fat[i] = rs.fat[i];
+    if (rs.last_x != last_x0) e.last_base_pos_x()[0] = rs.last_x;
+  }
   if (rst) {
     float ep_steps = fmx((float)ep_len, 1.0f);
     float ep_seconds = ep_steps * c.f[GO2SIM_FC_DT];
-    for (int k = 0; k < nrew; ++k) atomicAdd(&acc->ep[k], base_env ? (double)episode_sums[k] : (double)(episode_sums[k] / ep_seconds));
+    for (int k = 0; k < nrew; ++k) atomicAdd(&acc->ep[k], base_env ? (double)s_es[k][ln] : (double)(s_es[k][ln] / ep_seconds));
     atomicAdd(&acc->tracking, (double)(tracking_int / ep_seconds));
     atomicAdd(&acc->timeouts, (double)time_out);
     atomicAdd(&acc->n_reset_now, 1);
@@ -3080,15 +3254,24 @@ __global__ __launch_bounds__(64) void k_env_post_b_team(Pool P, const Model* __r
       RewCtx rc; rc.was_reset = was_reset;
       auto bvw = e.base_vel_world();
       for (int k = 0; k < 3; ++k) rc.vel_world[k] = was_reset ? 0.0f : bvw[k];    // get_vel() after zero_all_dofs_velocity
+      RewState rs;
+      load_rew_state(c, e, rs);
+      {
+        auto blv = e.base_lin_vel(); auto bav = e.base_ang_vel(); auto pg = e.projected_gravity(); auto bp = e.base_pos(); auto dp = e.e_dof_pos(); auto dv = e.e_dof_vel(); auto fc = e.foot_contact();
+        for (int k = 0; k < 3; ++k) { rs.blv[k] = blv[k]; rs.bav[k] = bav[k]; rs.pg[k] = pg[k]; rs.base_pos[k] = bp[k]; }
+        for (int k = 0; k < NM; ++k) { rs.dof_pos[k] = dp[k]; rs.dof_vel[k] = dv[k]; }
+        for (int k = 0; k < 4; ++k) rs.fc[k] = fc[k];
+      }
       float rew = 0.0f;
       auto rew_terms = e.rew_terms(); auto episode_sums = e.episode_sums();
       for (int k = 0; k < c.i[GO2SIM_IC_N_REWARDS]; ++k) {
-        float r = reward_term(m, c, e, c.i[GO2SIM_IC_REWARD_ID0 + k], rc) * c.f[GO2SIM_FC_REWARD_SCALE0 + k];
+        float r = reward_term(m, c, rs, c.i[GO2SIM_IC_REWARD_ID0 + k], rc) * c.f[GO2SIM_FC_REWARD_SCALE0 + k];
         rew_terms[k] = r;
         rew = rew + r;
         episode_sums[k] = episode_sums[k] + r;
       }
       e.rew()[0] = rew;
+      { auto fat = e.feet_air_time(); for (int k = 0; k < 4; ++k) fat[k] = rs.fat[k]; e.last_base_pos_x()[0] = rs.last_x; }
     }
     team_sync();
     for (int i = tl; i < nobs; i += T) {
@@ -3666,12 +3849,12 @@ int go2sim_env_step(go2sim_t* h, const float* actions, float* obs, float* priv, 
   dim3 g = grid_for(h->B), b(WG);
   if (h->timing && h->ev_n + 64 > TIMING_RING) timing_flush(h);   // all pending events belong to completed launches
   ScopedTimer total(h, s, T_TOTAL);
-  { ScopedTimer t(h, s, T_ENV_PRE); hipLaunchKernelGGL(k_env_pre, g, b, 0, s, h->P, h->dm, h->dcfg, h->dglob, actions, h->seed, h->step_count, h->action_write_idx); }
+  { ScopedTimer t(h, s, T_ENV_PRE); hipLaunchKernelGGL(k_env_pre, g, b, 0, s, h->P, h->dm, h->hcfg, h->dglob, actions, h->seed, h->step_count, h->action_write_idx); }
   int substeps = h->hcfg.i[GO2SIM_IC_SUBSTEPS];
   for (int i = 0; i < substeps; ++i) launch_substep(h, s);
   {
     ScopedTimer t(h, s, T_ENV_POST);
-    hipLaunchKernelGGL(k_env_post_a, g, b, 0, s, h->P, h->dm, h->dcfg, h->dglob, h->dacc, h->seed, h->step_count);
+    hipLaunchKernelGGL(k_env_post_a, g, b, 0, s, h->P, h->dm, h->hcfg, h->dglob, h->dacc, h->seed, h->step_count);
     hipLaunchKernelGGL(k_env_globals, dim3(1), dim3(1), 0, s, h->dcfg, h->dglob, h->dacc, h->seed, 1);
     if (h->hcfg.i[GO2SIM_IC_USE_TERRAIN]) hipLaunchKernelGGL(k_env_terrain_rows, dim3((h->B + 255) / 256), dim3(256), 0, s, h->P, h->dcfg, h->dglob, h->seed);
     hipLaunchKernelGGL(k_env_post_b_team<16>, dim3((h->B + 3) / 4), dim3(64), 0, s, h->P, h->dm, h->dcfg, h->dglob, h->seed, h->step_count, obs, priv, rew, reset, timeout);

@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""Kernel time of the walk workload with a given build of the library (profiling builds: -DGO2SIM_REPEAT_PHASE=k).
+usage: repeat_probe.py lib1.so [lib2.so ...]   -> per-kernel ms/step for each"""
+import os, sys
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from bench import make_actions
+from go2_sim2real_locomotion_rl_amd import capi
+from go2_sim2real_locomotion_rl_amd.configs import flatten_walk_cfg, get_walk_cfgs
+from go2_sim2real_locomotion_rl_amd.model_blob import pack_model
+
+B, W, N = 4096, 50, 150
+dev = torch.device("cuda", 0)
+act = make_actions(W + N, B, dev)
+for so in sys.argv[1:]:
+    lib = capi.Go2SimLib(os.path.abspath(so), "go2sim_")
+    sim = capi.Go2Sim(lib, pack_model(), B, 0, 1)
+    f, i, _ = flatten_walk_cfg(B, *get_walk_cfgs(), freeze_curriculum=True)
+    sim.env_configure(f, i); sim.env_reset()
+    obs = torch.zeros(B, 49, device=dev); priv = torch.zeros(B, 104, device=dev); rew = torch.zeros(B, device=dev)
+    rst = torch.zeros(B, dtype=torch.uint8, device=dev); to = torch.zeros(B, device=dev)
+    for s in range(W):
+        sim.env_step(act[s], obs, priv, rew, rst, to)
+    sim.enable_timing(True); sim.read_timing(reset=True)
+    for s in range(W, W + N):
+        sim.env_step(act[s], obs, priv, rew, rst, to)
+    torch.cuda.synchronize()
+    ms, cnt = sim.read_timing(reset=True)
+    print(os.path.basename(so), " ".join(f"{m / N:.4f}" for m in ms), "checksum", float(obs.double().sum()), flush=True)
+    del sim
