@@ -363,7 +363,7 @@ struct LinkS {
 };
 struct GeomS { int type, link; V3 pos; Q4 quat; };
 constexpr int NTRI = ND * (ND + 1) / 2;
-struct ModelS {
+struct alignas(16) ModelS {
   int n_levels, iterations, ls_iterations, pad0;
   float substep_dt; V3 gravity; float eps, tolerance, ls_tolerance, meaninertia;
   LinkS links[NL]; Joint joints[NJ]; Dof dofs[ND]; GeomS geoms[NG]; Entity entities[2];
@@ -371,7 +371,7 @@ struct ModelS {
   int level_start[NL + 1], level_links[NL], child_start[NL + 1], child_list[NL], dof_link[ND];
   unsigned char tri_i[NTRI + 1], tri_j[NTRI + 1];
 };
-static_assert(sizeof(ModelS) % 4 == 0, "ModelS is copied word by word");
+static_assert(sizeof(ModelS) % 16 == 0 && (sizeof(LinkS) * NL) % 16 == 0 && offsetof(ModelS, links) % 16 == 0, "ModelS is copied in 16-byte granules");
 
 bool build_model_s(const Model& m, ModelS& o) {
   memset(&o, 0, sizeof(o));
@@ -427,12 +427,27 @@ struct ModelView {
 DEV float mass_mask(const ModelView& m, int i, int j) { return (float)((m.mass_mask_bits[i] >> j) & 1u); }
 DEV void tri_index(const ModelView& m, int idx, int& i, int& j) { i = m.tri_i[idx]; j = m.tri_j[idx]; }
 // workgroup-cooperative copy of the compact model into LDS (64 threads)
-DEV void load_model_s(ModelS* dst, const ModelS* __restrict__ src) {
-  const int* sp = (const int*)src; int* dp = (int*)dst;
-#pragma unroll 4
-  for (int i = threadIdx.x; i < (int)(sizeof(ModelS) / 4); i += 64) dp[i] = sp[i];
-  __syncthreads();
-}
+// (all 128-bit loads are issued before the first LDS write: one memory round trip for the whole table)
+template <int NBYTES>
+struct WgCopy {                       // issue() early, commit() after the kernel's other staging loads have been issued, then one barrier
+  static_assert(NBYTES % 16 == 0, "16-byte granules");
+  static constexpr int N4 = NBYTES / 16, NIT = (N4 + 63) / 64;
+  static_assert(NIT <= 8, "at most 8 KiB per copy");
+  int4 t0, t1, t2, t3, t4, t5, t6, t7;  // named registers: an indexed private array is moved to scratch / LDS by the compiler
+#define GO2SIM_WGC_LD(k) if constexpr (NIT > k) { int i = threadIdx.x + 64 * k; t##k = sp[i < N4 ? i : 0]; } else { t##k = make_int4(0, 0, 0, 0); }
+#define GO2SIM_WGC_ST(k) if constexpr (NIT > k) { int i = threadIdx.x + 64 * k; if (i < N4) dp[i] = t##k; }
+  DEV void issue(const void* __restrict__ src) {
+    const int4* sp = (const int4*)src;
+    GO2SIM_WGC_LD(0) GO2SIM_WGC_LD(1) GO2SIM_WGC_LD(2) GO2SIM_WGC_LD(3) GO2SIM_WGC_LD(4) GO2SIM_WGC_LD(5) GO2SIM_WGC_LD(6) GO2SIM_WGC_LD(7)
+  }
+  DEV void commit(void* dst) const {
+    int4* dp = (int4*)dst;
+    GO2SIM_WGC_ST(0) GO2SIM_WGC_ST(1) GO2SIM_WGC_ST(2) GO2SIM_WGC_ST(3) GO2SIM_WGC_ST(4) GO2SIM_WGC_ST(5) GO2SIM_WGC_ST(6) GO2SIM_WGC_ST(7)
+  }
+#undef GO2SIM_WGC_LD
+#undef GO2SIM_WGC_ST
+};
+typedef WgCopy<(int)sizeof(ModelS)> ModelCopy;
 
 // ---------------------------------------------------------------------------------------------
 // SoA state pool.  X(name, floats_per_env).  Order of the first group matches enum go2sim_field so
@@ -638,13 +653,15 @@ struct KinData {
   int valid;
 };
 
+DEV void tk_stage_links(const E& e, KinData* s, int tl, int T) {
+  for (int i_l = tl; i_l < NL; i_l += T) { st3(s->l_pos, i_l, e.l_pos()[i_l]); st4(s->l_quat, i_l, e.l_quat()[i_l]); }
+}
 // update_cartesian_space + forward_velocity of the state held in s->qpos / s->vel
 // (func_forward_kinematics_entity :463-618, func_COM_links_entity :224-459, func_update_geoms_entity :709-744,
 //  func_forward_velocity_entity :871-994 of forward_kinematics.py)
 template <int T, class MT>
 DEV void tk_kinematics(const MT& m, const E& e, KinData* s, int tl, bool force_update_fixed) {
-  for (int i_l = tl; i_l < NL; i_l += T) { st3(s->l_pos, i_l, e.l_pos()[i_l]); st4(s->l_quat, i_l, e.l_quat()[i_l]); }
-  team_sync();
+  // s->l_pos / s->l_quat hold the current link poses (tk_stage_links, issued with the kernel's other staging loads)
   for (int lev = 0; lev < m.n_levels; ++lev) {
     for (int k = m.level_start[lev] + tl; k < m.level_start[lev + 1]; k += T) {
       int i_l = m.level_links[k];
@@ -810,18 +827,20 @@ __global__ __launch_bounds__(64) void k_integrate_fk_team(Pool P, const ModelS* 
   constexpr int EPW = 64 / T;
   __shared__ KinData lds[EPW];
   __shared__ ModelS ms;
-  load_model_s(&ms, mp);
+  ModelCopy mc; mc.issue(mp);
   const int tl = threadIdx.x % T, slot = threadIdx.x / T;
   const int b = blockIdx.x * EPW + slot;
-  if (b >= P.B) return;
   const ModelView m(&ms, mp);
-  E e(P, b);
+  E e(P, b < P.B ? b : P.B - 1);
   KinData* s = &lds[slot];
   PH_BEGIN
   for (int d = tl; d < ND; d += T) { float v = gload(e, FO(vel), d); s->vel[d] = v; s->vel_next[d] = v + aload(e, AO(acc), d) * m.substep_dt; }
   for (int q = tl; q < NQ; q += T) s->qpos[q] = gload(e, FO(qpos), q);
   if (tl == 0) s->valid = 1;
+  tk_stage_links(e, s, tl, T);
+  mc.commit(&ms);
   team_sync();
+  if (b >= P.B) return;
   for (int i_l = tl; i_l < NL; i_l += T) {
     const auto& L = m.links[i_l];
     if (L.n_dofs == 0) continue;
@@ -866,16 +885,18 @@ __global__ __launch_bounds__(64) void k_fk_team(Pool P, const ModelS* __restrict
   __shared__ KinData lds[EPW];
   __shared__ ModelS ms;
   if (cond && *cond <= 0) return;
-  load_model_s(&ms, mp);
+  ModelCopy mc; mc.issue(mp);
   const int tl = threadIdx.x % T, slot = threadIdx.x / T;
   const int b = blockIdx.x * EPW + slot;
-  if (b >= P.B) return;
   const ModelView m(&ms, mp);
-  E e(P, b);
+  E e(P, b < P.B ? b : P.B - 1);
   KinData* s = &lds[slot];
   for (int d = tl; d < ND; d += T) s->vel[d] = gload(e, FO(vel), d);
   for (int q = tl; q < NQ; q += T) s->qpos[q] = gload(e, FO(qpos), q);
+  tk_stage_links(e, s, tl, T);
+  mc.commit(&ms);
   team_sync();
+  if (b >= P.B) return;
   tk_kinematics<T>(m, e, s, tl, force_update_fixed != 0);
 }
 
@@ -898,7 +919,7 @@ __global__ __launch_bounds__(64) void k_dynamics_team(Pool P, const ModelS* __re
   constexpr int EPW = 64 / T;
   __shared__ DynData lds[EPW];
   __shared__ ModelS ms;
-  load_model_s(&ms, mp);
+  ModelCopy mc; mc.issue(mp);
   {  // ---- stage the SoA inputs cooperatively (adjacent lanes = adjacent envs), before any lane retires ----
     const int b0 = blockIdx.x * EPW;
     wg_load<EPW>(P, b0, FO(cd_vel), NL * 3, [&](int ev, int k, float v) { lds[ev].cd_vel[k] = v; });
@@ -921,6 +942,7 @@ __global__ __launch_bounds__(64) void k_dynamics_team(Pool P, const ModelS* __re
     s->cdof_ang[k] = aload(e, AO(cdof_ang), k); s->cdof_vel[k] = aload(e, AO(cdof_vel), k);
     s->cdofd_ang[k] = aload(e, AO(cdofd_ang), k); s->cdofd_vel[k] = aload(e, AO(cdofd_vel), k);
   }
+  mc.commit(&ms);
   team_sync();
   PH(20)
   // ---- composite rigid bodies, leaf -> root ----
@@ -1428,10 +1450,10 @@ DEV void rotate_frame(V3 pos, Q4 quat, V3 contact_pos, Q4 qrot, V3& new_pos, Q4&
 // ---------------------------------------------------------------------------------------------
 template <int T>
 struct CollideData {
-  float amin[NG * 3], amax[NG * 3];
+  alignas(16) float amin[NG * 4], amax[NG * 4];   // xyz + pad: one 128-bit LDS read per corner
   float sval[2 * NG], sval_sorted[2 * NG];
   int sig[2 * NG], sig_sorted[2 * NG];
-  int rank_min[NG], rank_max[NG];
+  alignas(8) int rank_mm[NG * 2];                  // (rank of the min endpoint, rank of the max endpoint) per geom
   int cand_key[MAXB], cand_pair[MAXB], pair_sorted[MAXB];
   float stage[T][5][7];
   int cnt[T];
@@ -1611,6 +1633,9 @@ __global__ __launch_bounds__(64) void k_collide_team(Pool P, const Model* __rest
     e.c_pen()[i_c] = 0.0f; e.c_pos()[i_c] = v3(0, 0, 0); e.c_normal()[i_c] = v3(0, 0, 0); e.c_force()[i_c] = v3(0, 0, 0);
   }
   // ---- kernel_update_geom_aabbs, forward_kinematics.py:1171-1193 ----
+#if defined(GO2SIM_REPEAT_PHASE) && GO2SIM_REPEAT_PHASE == 30
+  for (int rep = 0; rep < 2; ++rep)
+#endif
   for (int i_g = tl; i_g < NG; i_g += T) {
     V3 lower = v3(inf, inf, inf), upper = v3(-inf, -inf, -inf);
     V3 gp = e.g_pos()[i_g]; Q4 gq = e.g_quat()[i_g];
@@ -1619,14 +1644,18 @@ __global__ __launch_bounds__(64) void k_collide_team(Pool P, const Model* __rest
       V3 corner = transform_by_trans_quat(m.geoms[i_g].aabb[c], gp, gq);
       lower = vmin(lower, corner); upper = vmax(upper, corner);
     }
-    s->amin[3 * i_g] = lower.x; s->amin[3 * i_g + 1] = lower.y; s->amin[3 * i_g + 2] = lower.z;
-    s->amax[3 * i_g] = upper.x; s->amax[3 * i_g + 1] = upper.y; s->amax[3 * i_g + 2] = upper.z;
+    *(float4*)&s->amin[4 * i_g] = make_float4(lower.x, lower.y, lower.z, 0.0f);
+    *(float4*)&s->amax[4 * i_g] = make_float4(upper.x, upper.y, upper.z, 0.0f);
   }
   team_sync();
   PH(30)
   // ---- func_broad_phase, broadphase.py:141-396: endpoint refresh + stable sort ----
   const int n2 = 2 * NG;
   const bool first = e.first_time()[0] != 0;
+#if defined(GO2SIM_REPEAT_PHASE) && GO2SIM_REPEAT_PHASE == 31
+  for (int rep = 0; rep < 2; ++rep) {
+  team_sync();
+#endif
   for (int i = tl; i < n2; i += T) {
     int sg;
     if (first) {
@@ -1637,7 +1666,7 @@ __global__ __launch_bounds__(64) void k_collide_team(Pool P, const Model* __rest
     }
     int g = sg & 0xff;
     s->sig[i] = sg;
-    s->sval[i] = (sg & 0x100) ? s->amax[3 * g] : s->amin[3 * g];
+    s->sval[i] = (sg & 0x100) ? s->amax[4 * g] : s->amin[4 * g];
   }
   team_sync();
   for (int i = tl; i < n2; i += T) {
@@ -1647,39 +1676,64 @@ __global__ __launch_bounds__(64) void k_collide_team(Pool P, const Model* __rest
     for (int j = 0; j < 2 * NG; ++j) { float w = s->sval[j]; r += (w < v) || (w == v && j < i); }
     int sg = s->sig[i];
     s->sval_sorted[r] = v; s->sig_sorted[r] = sg;
-    if (sg & 0x100) s->rank_max[sg & 0xff] = r; else s->rank_min[sg] = r;
+    s->rank_mm[2 * (sg & 0xff) + ((sg & 0x100) ? 1 : 0)] = r;
     e.sort_value()[r] = v; e.sort_ig()[r] = sg;
   }
+#if defined(GO2SIM_REPEAT_PHASE) && GO2SIM_REPEAT_PHASE == 31
+  }
+#endif
   if (tl == 0 && first) e.first_time()[0] = 0;
   team_sync();
   PH(31)
   // ---- candidate pairs: every valid geom pair is tested by one lane ----
   int n_cand = 0;
-  const unsigned long long team_mask = (T == 64) ? ~0ull : ((1ull << T) - 1ull);
-  const int n_pair_iter = (m.n_pairs + T - 1) / T;
-  for (int it = 0; it < n_pair_iter; ++it) {
-    int pidx = it * T + tl;
-    bool is_cand = false; int key = 0, packed = 0;
-    if (pidx < m.n_pairs) {
-      packed = m.pair_list[pidx];
-      int a = packed & 0xff, bg = packed >> 8;
-      int ra = s->rank_min[a], rb = s->rank_min[bg];
-      int firstg = (ra < rb) ? a : bg, secondg = (ra < rb) ? bg : a;
-      int rs = (ra < rb) ? rb : ra, rf = (ra < rb) ? ra : rb;
-      if (rs < s->rank_max[firstg]) {
-        (void)secondg;
-        bool any1 = (s->amax[3 * a] <= s->amin[3 * bg]) || (s->amax[3 * a + 1] <= s->amin[3 * bg + 1]) || (s->amax[3 * a + 2] <= s->amin[3 * bg + 2]);
-        bool any2 = (s->amin[3 * a] >= s->amax[3 * bg]) || (s->amin[3 * a + 1] >= s->amax[3 * bg + 1]) || (s->amin[3 * a + 2] >= s->amax[3 * bg + 2]);
-        if (any1 || any2) e.normal_cache()[pidx] = v3(0, 0, 0);
-        else { is_cand = true; key = rs * 64 + rf; }
-      }
+#if defined(GO2SIM_REPEAT_PHASE) && GO2SIM_REPEAT_PHASE == 32
+  for (int rep = 0; rep < 2; ++rep) { n_cand = 0; team_sync();
+#endif
+  // the pair table is fetched for all rounds up front and every LDS operand of a test is read unconditionally, so that the reads of a
+  // round are in flight together; only the ballot compaction is sequential
+  constexpr int NPI = (NPAIR + T - 1) / T;
+  int packed_[NPI];
+#pragma unroll
+  for (int it = 0; it < NPI; ++it) { int pidx = it * T + tl; packed_[it] = (pidx < m.n_pairs) ? m.pair_list[pidx] : -1; }
+  unsigned cmask = 0; int key_[NPI];
+#pragma unroll
+  for (int it = 0; it < NPI; ++it) {                                   // the rounds are independent: candidates are only marked here
+    const int pidx = it * T + tl;
+    const int packed = packed_[it];
+    const int a = (packed < 0) ? 0 : (packed & 0xff), bg = (packed < 0) ? 0 : (packed >> 8);
+    const int2 rka = *(const int2*)&s->rank_mm[2 * a], rkb = *(const int2*)&s->rank_mm[2 * bg];
+    const float4 amn = *(const float4*)&s->amin[4 * a], amx = *(const float4*)&s->amax[4 * a], bmn = *(const float4*)&s->amin[4 * bg], bmx = *(const float4*)&s->amax[4 * bg];
+    const int ra = rka.x, rb = rkb.x;
+    const int rs = (ra < rb) ? rb : ra, rf = (ra < rb) ? ra : rb;
+    const int rmax_first = (ra < rb) ? rka.y : rkb.y;
+    key_[it] = rs * 64 + rf;
+    if (packed >= 0 && rs < rmax_first) {
+      bool any1 = (amx.x <= bmn.x) || (amx.y <= bmn.y) || (amx.z <= bmn.z);
+      bool any2 = (amn.x >= bmx.x) || (amn.y >= bmx.y) || (amn.z >= bmx.z);
+#if defined(GO2SIM_REPEAT_PHASE) && GO2SIM_REPEAT_PHASE == 34
+      if (any1 || any2) { } else cmask |= 1u << it;
+#else
+      if (any1 || any2) e.normal_cache()[pidx] = v3(0, 0, 0);
+      else cmask |= 1u << it;
+#endif
     }
-    unsigned long long bal = __ballot(is_cand);
-    unsigned long long tm = (bal >> (slot * T)) & team_mask;
-    int pos = n_cand + __popcll(tm & ((1ull << tl) - 1ull));
-    if (is_cand && pos < MAXB) { s->cand_key[pos] = key; s->cand_pair[pos] = packed; }
-    n_cand += __popcll(tm);
   }
+  {                                                                    // compaction; the list is sorted by key below, so its order is free
+    const int mine = __popc(cmask);
+    s->cnt[tl] = mine;
+    team_sync();
+    int pos = 0, tot = 0;
+    for (int l = 0; l < T; ++l) { int c = s->cnt[l]; pos += (l < tl) ? c : 0; tot += c; }
+    team_sync();
+#pragma unroll
+    for (int it = 0; it < NPI; ++it)
+      if (cmask & (1u << it)) { if (pos < MAXB) { s->cand_key[pos] = key_[it]; s->cand_pair[pos] = packed_[it]; } pos++; }
+    n_cand = tot;
+  }
+#if defined(GO2SIM_REPEAT_PHASE) && GO2SIM_REPEAT_PHASE == 32
+  }
+#endif
   if (n_cand > m.max_broad_pairs) { if (tl == 0) atomicOr(&e.err()[0], GO2SIM_ERR_OVERFLOW_CANDIDATE_CONTACTS); n_cand = m.max_broad_pairs; }
   team_sync();
   for (int c = tl; c < n_cand; c += T) {
@@ -2143,7 +2197,7 @@ DEV float ts_linesearch(const MT& m, S* s, int tl, int n_con, float gauss) {
 // rows + resolve for one environment (add_collision_constraints solver.py:498-595, add_joint_limit_constraints :1088-1143,
 // func_solve_init :2739-2859, func_solve_body :2941-2966, func_solve_iter :2862-2938)
 template <int T, class S, class MT>
-DEV int ts_solve(const MT& m, const E& e, S* s, int tl, int nc, int n_con) {
+DEV int ts_solve(const MT& m, const E& e, S* s, int tl, int nc, int n_con, unsigned lim_mask) {
   PH_BEGIN
 #ifdef GO2SIM_REPEAT_PHASE      // profiling builds: run one idempotent phase twice, the time difference is that phase's cost
   for (int rep_stage = 0; rep_stage < (GO2SIM_REPEAT_PHASE == 0 ? 2 : 1); ++rep_stage) {
@@ -2227,21 +2281,15 @@ DEV int ts_solve(const MT& m, const E& e, S* s, int tl, int nc, int n_con) {
   for (int rep_c = 0; rep_c < 2; ++rep_c)
 #endif
   for (int i_j = tl; i_j < NJ; i_j += T) {
+    if (!((lim_mask >> i_j) & 1u)) continue;                           // joints past a limit, found by the kernel prologue
     const Joint& Jt = m.joints[i_j];
-    if (Jt.type != JOINT_REVOLUTE) continue;
     int i_d = Jt.dof_start;
     float q = gload(e, FO(qpos), Jt.q_start);
     float pos_delta_min = q - m.dofs[i_d].limit[0];
     float pos_delta_max = m.dofs[i_d].limit[1] - q;
     float pos_delta = fmn(pos_delta_min, pos_delta_max);
-    if (pos_delta < 0) {
-      int r = 4 * nc;
-      for (int k = 0; k < i_j; ++k) {
-        const Joint& Jk = m.joints[k];
-        if (Jk.type != JOINT_REVOLUTE) continue;
-        float qk = gload(e, FO(qpos), Jk.q_start);
-        if (fmn(qk - m.dofs[Jk.dof_start].limit[0], m.dofs[Jk.dof_start].limit[1] - qk) < 0) r++;
-      }
+    {
+      int r = 4 * nc + __popc(lim_mask & ((1u << i_j) - 1u));           // ordered compaction: rows follow the joint order
       float j = (float)((pos_delta_min < pos_delta_max) * 2 - 1);
       float jac_qvel = j * s->vel[i_d];
       float imp, aref;
@@ -2396,8 +2444,8 @@ DEV void ts_commit(const MT& m, const E& e, S* s, int tl, int nc, int n_con, int
 
 // cold path: more rows than fit in LDS; same code on a per-env global scratch block
 template <int T, class MT>
-DEVN void ts_solve_overflow(const MT& m, const E& e, SolverData<MAXR>* s, int tl, int nc, int n_con) {
-  int iters = ts_solve<T>(m, e, s, tl, nc, n_con);
+DEVN void ts_solve_overflow(const MT& m, const E& e, SolverData<MAXR>* s, int tl, int nc, int n_con, unsigned lim_mask) {
+  int iters = ts_solve<T>(m, e, s, tl, nc, n_con, lim_mask);
   ts_commit<T>(m, e, s, tl, nc, n_con, iters);
 }
 
@@ -2405,34 +2453,48 @@ template <int T, int RLN>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_constraint_solve_team(Pool P, const Model* __restrict__ gm, const ModelS* __restrict__ mp, SolverData<MAXR>* __restrict__ overflow) {
   constexpr int EPW = 64 / T;
   __shared__ SolverData<RLN> lds[EPW];
-  __shared__ LinkS lnk[NL];
+  __shared__ alignas(16) LinkS lnk[NL];
   __shared__ unsigned char tri_i[NTRI + 1], tri_j[NTRI + 1];
-  {
-    const int* sp = (const int*)mp->links; int* dp = (int*)lnk;
-    for (int i = threadIdx.x; i < (int)(sizeof(LinkS) * NL / 4); i += 64) dp[i] = sp[i];
-    for (int i = threadIdx.x; i < NTRI; i += 64) { tri_i[i] = mp->tri_i[i]; tri_j[i] = mp->tri_j[i]; }
-    __syncthreads();
-  }
-  const ModelView m(lnk, tri_i, tri_j, gm);
+#if defined(GO2SIM_REPEAT_PHASE) && GO2SIM_REPEAT_PHASE == 22
+  if (P.B > 0) return;
+#endif
+  // all loads of the prologue (link table, triangle LUT, contact count, joint-limit test) are issued before the first wait
+  static_assert(T >= NJ, "one lane per joint in the limit test");
+  WgCopy<(int)(sizeof(LinkS) * NL)> lc; lc.issue(mp->links);
+  unsigned char ti[(NTRI + 63) / 64], tj[(NTRI + 63) / 64];
+#pragma unroll
+  for (int k = 0; k < (NTRI + 63) / 64; ++k) { int i = threadIdx.x + 64 * k; if (i < NTRI) { ti[k] = mp->tri_i[i]; tj[k] = mp->tri_j[i]; } }
   const int tl = threadIdx.x % T, slot = threadIdx.x / T;
   const int b = blockIdx.x * EPW + slot;
-  if (b >= P.B) return;
-  E e(P, b);
+  const bool env_valid = b < P.B;
+  E e(P, env_valid ? b : P.B - 1);
   const int nc = e.n_contacts()[0];
-  int n_lim = 0;
-  for (int i_j = 0; i_j < NJ; ++i_j) {
-    const Joint& Jt = m.joints[i_j];
-    if (Jt.type != JOINT_REVOLUTE) continue;
-    float q = gload(e, FO(qpos), Jt.q_start);
-    if (fmn(q - m.dofs[Jt.dof_start].limit[0], m.dofs[Jt.dof_start].limit[1] - q) < 0) n_lim++;
+  bool lim = false;                                                    // add_joint_limit_constraints, solver.py:1088-1143: which joints are past a limit
+  if (tl < NJ) {
+    const Joint& Jt = gm->joints[tl];
+    if (Jt.type == JOINT_REVOLUTE) {
+      float q = gload(e, FO(qpos), Jt.q_start);
+      lim = fmn(q - gm->dofs[Jt.dof_start].limit[0], gm->dofs[Jt.dof_start].limit[1] - q) < 0;
+    }
   }
+  const unsigned lim_mask = (unsigned)((__ballot(lim) >> (slot * T)) & ((T == 64) ? ~0ull : ((1ull << T) - 1ull)));
+  const int n_lim = __popc(lim_mask);
+  lc.commit(lnk);
+#pragma unroll
+  for (int k = 0; k < (NTRI + 63) / 64; ++k) { int i = threadIdx.x + 64 * k; if (i < NTRI) { tri_i[i] = ti[k]; tri_j[i] = tj[k]; } }
+  __syncthreads();
+  const ModelView m(lnk, tri_i, tri_j, gm);
+  if (!env_valid) return;
+#if defined(GO2SIM_REPEAT_PHASE) && GO2SIM_REPEAT_PHASE == 23
+  if (nc < 100000) return;
+#endif
   const int n_con = 4 * nc + n_lim;
 #if defined(GO2SIM_REPEAT_PHASE) && GO2SIM_REPEAT_PHASE == 21
   if (n_con < 100000) return;
 #endif
   if (n_con <= RLN) {
     SolverData<RLN>* s = &lds[slot];
-    int iters = ts_solve<T>(m, e, s, tl, nc, n_con);
+    int iters = ts_solve<T>(m, e, s, tl, nc, n_con, lim_mask);
     PH_BEGIN
 #if defined(GO2SIM_REPEAT_PHASE) && GO2SIM_REPEAT_PHASE == 11
     ts_commit<T>(m, e, s, tl, nc, n_con, iters);
@@ -2441,7 +2503,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     ts_commit<T>(m, e, s, tl, nc, n_con, iters);
     PH(11)
   } else {
-    ts_solve_overflow<T>(m, e, &overflow[b], tl, nc, n_con);
+    ts_solve_overflow<T>(m, e, &overflow[b], tl, nc, n_con, lim_mask);
   }
 }
 
