@@ -427,27 +427,18 @@ struct ModelView {
 DEV float mass_mask(const ModelView& m, int i, int j) { return (float)((m.mass_mask_bits[i] >> j) & 1u); }
 DEV void tri_index(const ModelView& m, int idx, int& i, int& j) { i = m.tri_i[idx]; j = m.tri_j[idx]; }
 // workgroup-cooperative copy of the compact model into LDS (64 threads)
-// (all 128-bit loads are issued before the first LDS write: one memory round trip for the whole table)
+// Global -> LDS copy of a read-only table by the memory pipeline itself (global_load_lds_dwordx4: 64 lanes x 16 B = 1 KiB per instruction,
+// no staging registers).  Asynchronous: it is issued first, the kernel's other staging loads follow, and the barrier that ends the staging
+// (team_sync = s_waitcnt vmcnt(0) + s_barrier) makes the table visible.  Source and destination are padded to whole KiB.
+constexpr int lds_dma_bytes(int nbytes) { return (nbytes + 1023) / 1024 * 1024; }
 template <int NBYTES>
-struct WgCopy {                       // issue() early, commit() after the kernel's other staging loads have been issued, then one barrier
-  static_assert(NBYTES % 16 == 0, "16-byte granules");
-  static constexpr int N4 = NBYTES / 16, NIT = (N4 + 63) / 64;
-  static_assert(NIT <= 8, "at most 8 KiB per copy");
-  int4 t0, t1, t2, t3, t4, t5, t6, t7;  // named registers: an indexed private array is moved to scratch / LDS by the compiler
-#define GO2SIM_WGC_LD(k) if constexpr (NIT > k) { int i = threadIdx.x + 64 * k; t##k = sp[i < N4 ? i : 0]; } else { t##k = make_int4(0, 0, 0, 0); }
-#define GO2SIM_WGC_ST(k) if constexpr (NIT > k) { int i = threadIdx.x + 64 * k; if (i < N4) dp[i] = t##k; }
-  DEV void issue(const void* __restrict__ src) {
-    const int4* sp = (const int4*)src;
-    GO2SIM_WGC_LD(0) GO2SIM_WGC_LD(1) GO2SIM_WGC_LD(2) GO2SIM_WGC_LD(3) GO2SIM_WGC_LD(4) GO2SIM_WGC_LD(5) GO2SIM_WGC_LD(6) GO2SIM_WGC_LD(7)
-  }
-  DEV void commit(void* dst) const {
-    int4* dp = (int4*)dst;
-    GO2SIM_WGC_ST(0) GO2SIM_WGC_ST(1) GO2SIM_WGC_ST(2) GO2SIM_WGC_ST(3) GO2SIM_WGC_ST(4) GO2SIM_WGC_ST(5) GO2SIM_WGC_ST(6) GO2SIM_WGC_ST(7)
-  }
-#undef GO2SIM_WGC_LD
-#undef GO2SIM_WGC_ST
-};
-typedef WgCopy<(int)sizeof(ModelS)> ModelCopy;
+DEV void wg_dma_to_lds(void* lds_dst, const void* __restrict__ src) {
+#pragma unroll
+  for (int k = 0; k < lds_dma_bytes(NBYTES) / 1024; ++k)
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((const char*)src + (k * 64 + (int)threadIdx.x) * 16),
+                                     (__attribute__((address_space(3))) void*)((char*)lds_dst + k * 1024), 16, 0, 0);
+}
+constexpr int MODELS_LDS_BYTES = lds_dma_bytes((int)sizeof(ModelS));
 
 // ---------------------------------------------------------------------------------------------
 // SoA state pool.  X(name, floats_per_env).  Order of the first group matches enum go2sim_field so
@@ -602,14 +593,35 @@ DEV void astore(const E& e, int off, int k, float v) { e.fa[off + k] = v; }
 
 // Workgroup-cooperative staging between the SoA pool and per-env LDS blocks: adjacent lanes address adjacent environments of the same
 // pool row, so one wave instruction touches 64/EPW rows with EPW contiguous floats each instead of 64 separate sectors.
-template <int EPW, class F>
-DEV void wg_load(const Pool& P, int b0, int off, int count, F put) {
-  const int ev = threadIdx.x % EPW, k0 = threadIdx.x / EPW;
-  const int b = b0 + ev;
-  if (b < P.B) {
-#pragma unroll 4
-    for (int k = k0; k < count; k += 64 / EPW) put(ev, k, P.f[(size_t)(off + k) * P.B + b]);
+// statically unrolled team loop: k = tl, tl + T, ... < N.  With compile-time bounds the loads of all rounds are issued before the first
+// wait; a dynamic `for (k = tl; k < N; k += T)` loop pays one memory round trip per round instead.
+template <int N, int T, class F>
+DEV void team_for(int tl, F f) {
+#pragma unroll
+  for (int k0 = 0; k0 < N; k0 += T) { int k = k0 + tl; if (k < N) f(k); }
+}
+// branch-free staging: out-of-range lanes redo the last element (same value to the same address), so neither the loads nor the stores
+// sit behind a branch and the loads of consecutive team_stage calls are all in flight together.
+// (written as a recursion: round r loads, the deeper rounds run, then round r stores -- no private array for the compiler to spill)
+template <int N, int STRIDE, int R, class FL, class FS>
+DEV void team_stage_r(int k0, FL& ld, FS& st) {
+  if constexpr (R * STRIDE < N) {
+    int k = R * STRIDE + k0;
+    k = k < N ? k : N - 1;
+    const float v = ld(k);
+    team_stage_r<N, STRIDE, R + 1>(k0, ld, st);
+    st(k, v);
   }
+}
+template <int N, int T, class FL, class FS>
+DEV void team_stage(int tl, FL ld, FS st) { team_stage_r<N, T, 0>(tl, ld, st); }
+template <int EPW, int COUNT, class F>
+DEV void wg_load(const Pool& P, int b0, int off, F put) {
+  const int ev = threadIdx.x % EPW, k0 = threadIdx.x / EPW;
+  const int b = (b0 + ev < P.B) ? b0 + ev : P.B - 1;
+  auto ld = [&](int k) { return P.f[(size_t)(off + k) * P.B + b]; };
+  auto st = [&](int k, float v) { put(ev, k, v); };
+  team_stage_r<COUNT, 64 / EPW, 0>(k0, ld, st);
 }
 
 // ---- optional per-phase cycle accounting (build with -DGO2SIM_PHASE_PROFILE; development aid, see tools/phase_profile.py) ----
@@ -653,8 +665,9 @@ struct KinData {
   int valid;
 };
 
-DEV void tk_stage_links(const E& e, KinData* s, int tl, int T) {
-  for (int i_l = tl; i_l < NL; i_l += T) { st3(s->l_pos, i_l, e.l_pos()[i_l]); st4(s->l_quat, i_l, e.l_quat()[i_l]); }
+template <int T>
+DEV void tk_stage_links(const E& e, KinData* s, int tl) {
+  team_for<NL, T>(tl, [&](int i_l) { st3(s->l_pos, i_l, e.l_pos()[i_l]); st4(s->l_quat, i_l, e.l_quat()[i_l]); });
 }
 // update_cartesian_space + forward_velocity of the state held in s->qpos / s->vel
 // (func_forward_kinematics_entity :463-618, func_COM_links_entity :224-459, func_update_geoms_entity :709-744,
@@ -826,19 +839,21 @@ template <int T>
 __global__ __launch_bounds__(64) void k_integrate_fk_team(Pool P, const ModelS* __restrict__ mp) {
   constexpr int EPW = 64 / T;
   __shared__ KinData lds[EPW];
-  __shared__ ModelS ms;
-  ModelCopy mc; mc.issue(mp);
+  __shared__ alignas(16) char ms_raw[MODELS_LDS_BYTES];
+  const ModelS& ms = *(const ModelS*)ms_raw;
+  wg_dma_to_lds<(int)sizeof(ModelS)>(ms_raw, mp);
   const int tl = threadIdx.x % T, slot = threadIdx.x / T;
   const int b = blockIdx.x * EPW + slot;
   const ModelView m(&ms, mp);
   E e(P, b < P.B ? b : P.B - 1);
   KinData* s = &lds[slot];
   PH_BEGIN
-  for (int d = tl; d < ND; d += T) { float v = gload(e, FO(vel), d); s->vel[d] = v; s->vel_next[d] = v + aload(e, AO(acc), d) * m.substep_dt; }
-  for (int q = tl; q < NQ; q += T) s->qpos[q] = gload(e, FO(qpos), q);
+  team_stage<ND, T>(tl, [&](int d) { return gload(e, FO(vel), d); }, [&](int d, float v) { s->vel[d] = v; });
+  team_stage<ND, T>(tl, [&](int d) { return aload(e, AO(acc), d); }, [&](int d, float a) { s->vel_next[d] = a; });
+  team_stage<NQ, T>(tl, [&](int q) { return gload(e, FO(qpos), q); }, [&](int q, float v) { s->qpos[q] = v; });
+  team_for<ND, T>(tl, [&](int d) { s->vel_next[d] = s->vel[d] + s->vel_next[d] * m.substep_dt; });
   if (tl == 0) s->valid = 1;
-  tk_stage_links(e, s, tl, T);
-  mc.commit(&ms);
+  tk_stage_links<T>(e, s, tl);
   team_sync();
   if (b >= P.B) return;
   for (int i_l = tl; i_l < NL; i_l += T) {
@@ -883,18 +898,18 @@ template <int T>
 __global__ __launch_bounds__(64) void k_fk_team(Pool P, const ModelS* __restrict__ mp, int force_update_fixed, const int* __restrict__ cond) {
   constexpr int EPW = 64 / T;
   __shared__ KinData lds[EPW];
-  __shared__ ModelS ms;
+  __shared__ alignas(16) char ms_raw[MODELS_LDS_BYTES];
+  const ModelS& ms = *(const ModelS*)ms_raw;
   if (cond && *cond <= 0) return;
-  ModelCopy mc; mc.issue(mp);
+  wg_dma_to_lds<(int)sizeof(ModelS)>(ms_raw, mp);
   const int tl = threadIdx.x % T, slot = threadIdx.x / T;
   const int b = blockIdx.x * EPW + slot;
   const ModelView m(&ms, mp);
   E e(P, b < P.B ? b : P.B - 1);
   KinData* s = &lds[slot];
-  for (int d = tl; d < ND; d += T) s->vel[d] = gload(e, FO(vel), d);
-  for (int q = tl; q < NQ; q += T) s->qpos[q] = gload(e, FO(qpos), q);
-  tk_stage_links(e, s, tl, T);
-  mc.commit(&ms);
+  team_stage<ND, T>(tl, [&](int d) { return gload(e, FO(vel), d); }, [&](int d, float v) { s->vel[d] = v; });
+  team_stage<NQ, T>(tl, [&](int q) { return gload(e, FO(qpos), q); }, [&](int q, float v) { s->qpos[q] = v; });
+  tk_stage_links<T>(e, s, tl);
   team_sync();
   if (b >= P.B) return;
   tk_kinematics<T>(m, e, s, tl, force_update_fixed != 0);
@@ -918,13 +933,14 @@ template <int T>
 __global__ __launch_bounds__(64) void k_dynamics_team(Pool P, const ModelS* __restrict__ mp) {
   constexpr int EPW = 64 / T;
   __shared__ DynData lds[EPW];
-  __shared__ ModelS ms;
-  ModelCopy mc; mc.issue(mp);
+  __shared__ alignas(16) char ms_raw[MODELS_LDS_BYTES];
+  const ModelS& ms = *(const ModelS*)ms_raw;
+  wg_dma_to_lds<(int)sizeof(ModelS)>(ms_raw, mp);
   {  // ---- stage the SoA inputs cooperatively (adjacent lanes = adjacent envs), before any lane retires ----
     const int b0 = blockIdx.x * EPW;
-    wg_load<EPW>(P, b0, FO(cd_vel), NL * 3, [&](int ev, int k, float v) { lds[ev].cd_vel[k] = v; });
-    wg_load<EPW>(P, b0, FO(cd_ang), NL * 3, [&](int ev, int k, float v) { lds[ev].cd_ang[k] = v; });
-    wg_load<EPW>(P, b0, FO(vel), ND, [&](int ev, int k, float v) { lds[ev].vel[k] = v; });
+    wg_load<EPW, NL * 3>(P, b0, FO(cd_vel), [&](int ev, int k, float v) { lds[ev].cd_vel[k] = v; });
+    wg_load<EPW, NL * 3>(P, b0, FO(cd_ang), [&](int ev, int k, float v) { lds[ev].cd_ang[k] = v; });
+    wg_load<EPW, ND>(P, b0, FO(vel), [&](int ev, int k, float v) { lds[ev].vel[k] = v; });
   }
   const int tl = threadIdx.x % T, slot = threadIdx.x / T;
   const int b = blockIdx.x * EPW + slot;
@@ -934,15 +950,14 @@ __global__ __launch_bounds__(64) void k_dynamics_team(Pool P, const ModelS* __re
   DynData* s = &lds[slot];
   PH_BEGIN
   // AoS record: the team reads consecutive words
-  for (int k = tl; k < NL * 9; k += T) { float v = aload(e, AO(cinr_inertial), k); s->cinr_I[k] = v; s->crb_I[k] = v; }
-  for (int k = tl; k < NL * 3; k += T) { float v = aload(e, AO(cinr_pos), k); s->cinr_pos[k] = v; s->crb_pos[k] = v; }
-  for (int k = tl; k < NL; k += T) { float v = aload(e, AO(cinr_mass), k); s->cinr_mass[k] = v; s->crb_mass[k] = v; }
-  for (int d = tl; d < ND; d += T) s->ctrl_mode[d] = e.ctrl_mode()[d];
-  for (int k = tl; k < ND * 3; k += T) {
-    s->cdof_ang[k] = aload(e, AO(cdof_ang), k); s->cdof_vel[k] = aload(e, AO(cdof_vel), k);
-    s->cdofd_ang[k] = aload(e, AO(cdofd_ang), k); s->cdofd_vel[k] = aload(e, AO(cdofd_vel), k);
-  }
-  mc.commit(&ms);
+  team_stage<NL * 9, T>(tl, [&](int k) { return aload(e, AO(cinr_inertial), k); }, [&](int k, float v) { s->cinr_I[k] = v; s->crb_I[k] = v; });
+  team_stage<NL * 3, T>(tl, [&](int k) { return aload(e, AO(cinr_pos), k); }, [&](int k, float v) { s->cinr_pos[k] = v; s->crb_pos[k] = v; });
+  team_stage<NL, T>(tl, [&](int k) { return aload(e, AO(cinr_mass), k); }, [&](int k, float v) { s->cinr_mass[k] = v; s->crb_mass[k] = v; });
+  team_stage<ND, T>(tl, [&](int d) { return __int_as_float((int)e.ctrl_mode()[d]); }, [&](int d, float v) { s->ctrl_mode[d] = __float_as_int(v); });
+  team_stage<ND * 3, T>(tl, [&](int k) { return aload(e, AO(cdof_ang), k); }, [&](int k, float v) { s->cdof_ang[k] = v; });
+  team_stage<ND * 3, T>(tl, [&](int k) { return aload(e, AO(cdof_vel), k); }, [&](int k, float v) { s->cdof_vel[k] = v; });
+  team_stage<ND * 3, T>(tl, [&](int k) { return aload(e, AO(cdofd_ang), k); }, [&](int k, float v) { s->cdofd_ang[k] = v; });
+  team_stage<ND * 3, T>(tl, [&](int k) { return aload(e, AO(cdofd_vel), k); }, [&](int k, float v) { s->cdofd_vel[k] = v; });
   team_sync();
   PH(20)
   // ---- composite rigid bodies, leaf -> root ----
@@ -985,6 +1000,7 @@ __global__ __launch_bounds__(64) void k_dynamics_team(Pool P, const ModelS* __re
   team_sync();
   PH(22)
   // ---- reverse-order LDL^T ----
+#pragma unroll
   for (int i_d_ = 0; i_d_ < ND; ++i_d_) {
     const int i_d = ND - i_d_ - 1;
     float D_inv = 1.0f / s->L[i_d * ND + i_d];
@@ -1072,17 +1088,29 @@ __global__ __launch_bounds__(64) void k_dynamics_team(Pool P, const ModelS* __re
   team_sync();
   PH(24)
   // ---- acc_smooth = L^-T D^-1 L^-1 force: serial chains, evaluated redundantly by every lane on the LDS copy ----
-  for (int i_d_ = 0; i_d_ < ND; ++i_d_) {
-    int i_d = ND - i_d_ - 1;
-    float cur = s->force[i_d];
-    for (int j_d = i_d + 1; j_d < ND; ++j_d) cur = cur - s->L[j_d * ND + i_d] * s->out[j_d];
-    s->out[i_d] = cur;
-  }
-  for (int i_d = 0; i_d < ND; ++i_d) s->out[i_d] = s->out[i_d] * s->Dinv[i_d];
-  for (int i_d = 0; i_d < ND; ++i_d) {
-    float cur = s->out[i_d];
-    for (int j_d = 0; j_d < i_d; ++j_d) cur = cur - s->L[i_d * ND + j_d] * s->out[j_d];
-    s->out[i_d] = cur;
+  {
+    float y[ND];                                                       // statically unrolled: the running vector stays in registers
+#pragma unroll
+    for (int i_d_ = 0; i_d_ < ND; ++i_d_) {
+      const int i_d = ND - i_d_ - 1;
+      float cur = s->force[i_d];
+#pragma unroll
+      for (int j_d = i_d + 1; j_d < ND; ++j_d) cur = cur - s->L[j_d * ND + i_d] * y[j_d];
+      y[i_d] = cur;
+    }
+#pragma unroll
+    for (int i_d = 0; i_d < ND; ++i_d) y[i_d] = y[i_d] * s->Dinv[i_d];
+#pragma unroll
+    for (int i_d = 0; i_d < ND; ++i_d) {
+      float cur = y[i_d];
+#pragma unroll
+      for (int j_d = 0; j_d < i_d; ++j_d) cur = cur - s->L[i_d * ND + j_d] * y[j_d];
+      y[i_d] = cur;
+    }
+    if (tl == 0) {
+#pragma unroll
+      for (int i_d = 0; i_d < ND; ++i_d) s->out[i_d] = y[i_d];
+    }
   }
   team_sync();
   if (env_valid) for (int i_d = tl; i_d < ND; i_d += T) { float a = s->out[i_d]; astore(e, AO(acc_smooth), i_d, a); astore(e, AO(acc), i_d, a); }
@@ -2453,14 +2481,15 @@ template <int T, int RLN>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_constraint_solve_team(Pool P, const Model* __restrict__ gm, const ModelS* __restrict__ mp, SolverData<MAXR>* __restrict__ overflow) {
   constexpr int EPW = 64 / T;
   __shared__ SolverData<RLN> lds[EPW];
-  __shared__ alignas(16) LinkS lnk[NL];
+  __shared__ alignas(16) char lnk_raw[lds_dma_bytes((int)(sizeof(LinkS) * NL))];
+  const LinkS* lnk = (const LinkS*)lnk_raw;
   __shared__ unsigned char tri_i[NTRI + 1], tri_j[NTRI + 1];
 #if defined(GO2SIM_REPEAT_PHASE) && GO2SIM_REPEAT_PHASE == 22
   if (P.B > 0) return;
 #endif
   // all loads of the prologue (link table, triangle LUT, contact count, joint-limit test) are issued before the first wait
   static_assert(T >= NJ, "one lane per joint in the limit test");
-  WgCopy<(int)(sizeof(LinkS) * NL)> lc; lc.issue(mp->links);
+  wg_dma_to_lds<(int)(sizeof(LinkS) * NL)>(lnk_raw, mp->links);
   unsigned char ti[(NTRI + 63) / 64], tj[(NTRI + 63) / 64];
 #pragma unroll
   for (int k = 0; k < (NTRI + 63) / 64; ++k) { int i = threadIdx.x + 64 * k; if (i < NTRI) { ti[k] = mp->tri_i[i]; tj[k] = mp->tri_j[i]; } }
@@ -2479,7 +2508,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   }
   const unsigned lim_mask = (unsigned)((__ballot(lim) >> (slot * T)) & ((T == 64) ? ~0ull : ((1ull << T) - 1ull)));
   const int n_lim = __popc(lim_mask);
-  lc.commit(lnk);
 #pragma unroll
   for (int k = 0; k < (NTRI + 63) / 64; ++k) { int i = threadIdx.x + 64 * k; if (i < NTRI) { tri_i[i] = ti[k]; tri_j[i] = tj[k]; } }
   __syncthreads();
@@ -3646,7 +3674,8 @@ int go2sim_create(const void* blob, size_t nbytes, int n_envs, int device, uint6
   {
     ModelS hs;
     if (!build_model_s(h->hm, hs)) return GO2SIM_E_BADMODEL;
-    HIPCHK(hipMalloc((void**)&h->dms, sizeof(ModelS)));
+    HIPCHK(hipMalloc((void**)&h->dms, MODELS_LDS_BYTES));   // padded: the LDS DMA of the team kernels reads whole KiB
+    HIPCHK(hipMemset(h->dms, 0, MODELS_LDS_BYTES));
     HIPCHK(hipMemcpy(h->dms, &hs, sizeof(ModelS), hipMemcpyHostToDevice));
   }
   HIPCHK(hipMalloc((void**)&h->dcfg, sizeof(DCfg)));
