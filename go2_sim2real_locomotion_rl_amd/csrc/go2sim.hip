@@ -1187,7 +1187,7 @@ DEV V3 support_driver(const Model& m, V3 direction, int i_g, const GeomLite& gl,
 }
 struct Pair { int i_ga, i_gb; V3 pos_a; Q4 quat_a; V3 pos_b; Q4 quat_b; const V3* prism; GeomLite ga, gb; };
 // compute_support, collider/mpr.py:179-202
-DEVN void compute_support(const Model& m, V3 direction, const Pair& pr, V3& v, V3& v1, V3& v2) {
+DEV void compute_support(const Model& m, V3 direction, const Pair& pr, V3& v, V3& v1, V3& v2) {
   v1 = support_driver(m, direction, pr.i_ga, pr.ga, pr.pos_a, pr.quat_a);
   v2 = support_driver(m, -direction, pr.i_gb, pr.gb, pr.pos_b, pr.quat_b, pr.prism);
   v = v1 - v2;
