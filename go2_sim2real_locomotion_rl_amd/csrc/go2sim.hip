@@ -362,16 +362,22 @@ struct LinkS {
   V3 pos; Q4 quat; V3 inertial_pos; Q4 inertial_quat; M3 inertial_i; float mass; float invweight[2];
 };
 struct GeomS { int type, link; V3 pos; Q4 quat; };
+struct JLim { int q_start, dof_start; float lo, hi; };   // revolute joints; q_start = -1 for the others (add_joint_limit_constraints, solver.py:1088-1143)
 constexpr int NTRI = ND * (ND + 1) / 2;
 struct alignas(16) ModelS {
   int n_levels, iterations, ls_iterations, pad0;
   float substep_dt; V3 gravity; float eps, tolerance, ls_tolerance, meaninertia;
-  LinkS links[NL]; Joint joints[NJ]; Dof dofs[ND]; GeomS geoms[NG]; Entity entities[2];
+  // ---- block staged by the constraint solver (contiguous: links, triangle LUT, joint-limit table) ----
+  LinkS links[NL];
+  unsigned char tri_i[NTRI + 1], tri_j[NTRI + 1];
+  JLim jlim[NJ];
+  // ---- the rest is only needed by the kinematics / dynamics kernels ----
+  Joint joints[NJ]; Dof dofs[ND]; GeomS geoms[NG]; Entity entities[2];
   float qpos0[NQ]; unsigned mass_mask_bits[ND];
   int level_start[NL + 1], level_links[NL], child_start[NL + 1], child_list[NL], dof_link[ND];
-  unsigned char tri_i[NTRI + 1], tri_j[NTRI + 1];
 };
-static_assert(sizeof(ModelS) % 16 == 0 && (sizeof(LinkS) * NL) % 16 == 0 && offsetof(ModelS, links) % 16 == 0, "ModelS is copied in 16-byte granules");
+constexpr int SOLVER_BLOCK_BYTES = (int)(sizeof(LinkS) * NL + 2 * (NTRI + 1) + sizeof(JLim) * NJ);
+static_assert(sizeof(ModelS) % 16 == 0 && (2 * (NTRI + 1)) % 4 == 0 && offsetof(ModelS, links) % 16 == 0 && offsetof(ModelS, jlim) == offsetof(ModelS, links) + sizeof(LinkS) * NL + 2 * (NTRI + 1), "ModelS is copied in 16-byte granules");
 
 bool build_model_s(const Model& m, ModelS& o) {
   memset(&o, 0, sizeof(o));
@@ -401,6 +407,12 @@ bool build_model_s(const Model& m, ModelS& o) {
   for (int i = 0; i < ND; ++i) o.dof_link[i] = m.dof_link[i];
   int k = 0;
   for (int i = 0; i < ND; ++i) for (int j = 0; j <= i; ++j) { o.tri_i[k] = (unsigned char)i; o.tri_j[k] = (unsigned char)j; k++; }
+  for (int i = 0; i < NJ; ++i) {
+    const Joint& J = m.joints[i];
+    bool rev = J.type == JOINT_REVOLUTE;
+    o.jlim[i].q_start = rev ? J.q_start : -1; o.jlim[i].dof_start = J.dof_start;
+    o.jlim[i].lo = rev ? m.dofs[J.dof_start].limit[0] : 0.0f; o.jlim[i].hi = rev ? m.dofs[J.dof_start].limit[1] : 0.0f;
+  }
   return true;
 }
 DEV float mass_mask(const ModelS& m, int i, int j) { return (float)((m.mass_mask_bits[i] >> j) & 1u); }
@@ -2225,30 +2237,23 @@ DEV float ts_linesearch(const MT& m, S* s, int tl, int n_con, float gauss) {
 // rows + resolve for one environment (add_collision_constraints solver.py:498-595, add_joint_limit_constraints :1088-1143,
 // func_solve_init :2739-2859, func_solve_body :2941-2966, func_solve_iter :2862-2938)
 template <int T, class S, class MT>
-DEV int ts_solve(const MT& m, const E& e, S* s, int tl, int nc, int n_con, unsigned lim_mask) {
+DEV int ts_solve(const MT& m, const E& e, S* s, int tl, int nc, int n_con, unsigned lim_mask, int ws_flag) {
   PH_BEGIN
 #ifdef GO2SIM_REPEAT_PHASE      // profiling builds: run one idempotent phase twice, the time difference is that phase's cost
   for (int rep_stage = 0; rep_stage < (GO2SIM_REPEAT_PHASE == 0 ? 2 : 1); ++rep_stage) {
 #endif
-  // ---- stage inputs ----
-  bool ws = (n_con > 0) && e.is_warmstart()[0];
-#pragma unroll
-  for (int k0 = 0; k0 < ND * ND; k0 += T) { int k = k0 + tl; if (k < ND * ND) s->M[(k / ND) * DS + (k % ND)] = aload(e, AO(mass_mat), k); }
-#pragma unroll
-  for (int k0 = 0; k0 < ND * 3; k0 += T) { int k = k0 + tl; if (k < ND * 3) { s->cdof_ang[k] = aload(e, AO(cdof_ang), k); s->cdof_vel[k] = aload(e, AO(cdof_vel), k); } }
-#pragma unroll
-  for (int k0 = 0; k0 < NL * 3; k0 += T) { int k = k0 + tl; if (k < NL * 3) s->root_com[k] = gload(e, FO(root_com), k); }
-#pragma unroll
-  for (int d0 = 0; d0 < ND; d0 += T) {
-    int d = d0 + tl;
-    if (d < ND) {
-      s->vel[d] = gload(e, FO(vel), d);
-      s->force[d] = aload(e, AO(force), d);
-      float as = aload(e, AO(acc_smooth), d);
-      s->acc_smooth[d] = as;
-      s->qacc[d] = ws ? aload(e, AO(qacc_ws), d) : as;
-    }
-  }
+  // ---- stage inputs (branch-free: all loads of the stage are in flight together) ----
+  const bool ws = (n_con > 0) && ws_flag;
+  team_stage<ND * ND, T>(tl, [&](int k) { return aload(e, AO(mass_mat), k); }, [&](int k, float v) { s->M[(k / ND) * DS + (k % ND)] = v; });
+  team_stage<ND * 3, T>(tl, [&](int k) { return aload(e, AO(cdof_ang), k); }, [&](int k, float v) { s->cdof_ang[k] = v; });
+  team_stage<ND * 3, T>(tl, [&](int k) { return aload(e, AO(cdof_vel), k); }, [&](int k, float v) { s->cdof_vel[k] = v; });
+  team_stage<NL * 3, T>(tl, [&](int k) { return gload(e, FO(root_com), k); }, [&](int k, float v) { s->root_com[k] = v; });
+  team_stage<ND, T>(tl, [&](int d) { return gload(e, FO(vel), d); }, [&](int d, float v) { s->vel[d] = v; });
+  team_stage<ND, T>(tl, [&](int d) { return aload(e, AO(force), d); }, [&](int d, float v) { s->force[d] = v; });
+  team_stage<ND, T>(tl, [&](int d) { return aload(e, AO(acc_smooth), d); }, [&](int d, float v) { s->acc_smooth[d] = v; });
+  team_stage<ND, T>(tl, [&](int d) { return aload(e, AO(qacc_ws), d); }, [&](int d, float v) { s->qacc[d] = v; });
+  team_sync();
+  if (!ws) team_for<ND, T>(tl, [&](int d) { s->qacc[d] = s->acc_smooth[d]; });
   team_sync();
 #ifdef GO2SIM_REPEAT_PHASE
   }
@@ -2472,8 +2477,8 @@ DEV void ts_commit(const MT& m, const E& e, S* s, int tl, int nc, int n_con, int
 
 // cold path: more rows than fit in LDS; same code on a per-env global scratch block
 template <int T, class MT>
-DEVN void ts_solve_overflow(const MT& m, const E& e, SolverData<MAXR>* s, int tl, int nc, int n_con, unsigned lim_mask) {
-  int iters = ts_solve<T>(m, e, s, tl, nc, n_con, lim_mask);
+DEVN void ts_solve_overflow(const MT& m, const E& e, SolverData<MAXR>* s, int tl, int nc, int n_con, unsigned lim_mask, int ws_flag) {
+  int iters = ts_solve<T>(m, e, s, tl, nc, n_con, lim_mask, ws_flag);
   ts_commit<T>(m, e, s, tl, nc, n_con, iters);
 }
 
@@ -2481,35 +2486,28 @@ template <int T, int RLN>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_constraint_solve_team(Pool P, const Model* __restrict__ gm, const ModelS* __restrict__ mp, SolverData<MAXR>* __restrict__ overflow) {
   constexpr int EPW = 64 / T;
   __shared__ SolverData<RLN> lds[EPW];
-  __shared__ alignas(16) char lnk_raw[lds_dma_bytes((int)(sizeof(LinkS) * NL))];
-  const LinkS* lnk = (const LinkS*)lnk_raw;
-  __shared__ unsigned char tri_i[NTRI + 1], tri_j[NTRI + 1];
+  __shared__ alignas(16) char blk_raw[lds_dma_bytes(SOLVER_BLOCK_BYTES)];
+  const LinkS* lnk = (const LinkS*)blk_raw;
+  const unsigned char* tri_i = (const unsigned char*)(blk_raw + sizeof(LinkS) * NL);
+  const unsigned char* tri_j = tri_i + (NTRI + 1);
 #if defined(GO2SIM_REPEAT_PHASE) && GO2SIM_REPEAT_PHASE == 22
   if (P.B > 0) return;
 #endif
-  // all loads of the prologue (link table, triangle LUT, contact count, joint-limit test) are issued before the first wait
+  // every load of the prologue (solver block by LDS DMA, contact count, warm-start flag, the joint coordinates of the limit test) is issued
+  // before the first wait
   static_assert(T >= NJ, "one lane per joint in the limit test");
-  wg_dma_to_lds<(int)(sizeof(LinkS) * NL)>(lnk_raw, mp->links);
-  unsigned char ti[(NTRI + 63) / 64], tj[(NTRI + 63) / 64];
-#pragma unroll
-  for (int k = 0; k < (NTRI + 63) / 64; ++k) { int i = threadIdx.x + 64 * k; if (i < NTRI) { ti[k] = mp->tri_i[i]; tj[k] = mp->tri_j[i]; } }
+  wg_dma_to_lds<SOLVER_BLOCK_BYTES>(blk_raw, mp->links);
   const int tl = threadIdx.x % T, slot = threadIdx.x / T;
   const int b = blockIdx.x * EPW + slot;
   const bool env_valid = b < P.B;
   E e(P, env_valid ? b : P.B - 1);
   const int nc = e.n_contacts()[0];
-  bool lim = false;                                                    // add_joint_limit_constraints, solver.py:1088-1143: which joints are past a limit
-  if (tl < NJ) {
-    const Joint& Jt = gm->joints[tl];
-    if (Jt.type == JOINT_REVOLUTE) {
-      float q = gload(e, FO(qpos), Jt.q_start);
-      lim = fmn(q - gm->dofs[Jt.dof_start].limit[0], gm->dofs[Jt.dof_start].limit[1] - q) < 0;
-    }
-  }
+  const int ws_flag = e.is_warmstart()[0];
+  const JLim jl = mp->jlim[tl < NJ ? tl : NJ - 1];
+  const float q_lim = gload(e, FO(qpos), jl.q_start < 0 ? 0 : jl.q_start);
+  const bool lim = tl < NJ && jl.q_start >= 0 && fmn(q_lim - jl.lo, jl.hi - q_lim) < 0;   // add_joint_limit_constraints, solver.py:1088-1143
   const unsigned lim_mask = (unsigned)((__ballot(lim) >> (slot * T)) & ((T == 64) ? ~0ull : ((1ull << T) - 1ull)));
   const int n_lim = __popc(lim_mask);
-#pragma unroll
-  for (int k = 0; k < (NTRI + 63) / 64; ++k) { int i = threadIdx.x + 64 * k; if (i < NTRI) { tri_i[i] = ti[k]; tri_j[i] = tj[k]; } }
   __syncthreads();
   const ModelView m(lnk, tri_i, tri_j, gm);
   if (!env_valid) return;
@@ -2522,7 +2520,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 #endif
   if (n_con <= RLN) {
     SolverData<RLN>* s = &lds[slot];
-    int iters = ts_solve<T>(m, e, s, tl, nc, n_con, lim_mask);
+    int iters = ts_solve<T>(m, e, s, tl, nc, n_con, lim_mask, ws_flag);
     PH_BEGIN
 #if defined(GO2SIM_REPEAT_PHASE) && GO2SIM_REPEAT_PHASE == 11
     ts_commit<T>(m, e, s, tl, nc, n_con, iters);
@@ -2531,7 +2529,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     ts_commit<T>(m, e, s, tl, nc, n_con, iters);
     PH(11)
   } else {
-    ts_solve_overflow<T>(m, e, &overflow[b], tl, nc, n_con, lim_mask);
+    ts_solve_overflow<T>(m, e, &overflow[b], tl, nc, n_con, lim_mask, ws_flag);
   }
 }
 
