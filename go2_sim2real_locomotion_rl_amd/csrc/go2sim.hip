@@ -1666,17 +1666,25 @@ __global__ __launch_bounds__(64) void k_collide_team(Pool P, const Model* __rest
   CollideData<T>* s = &lds[slot];
   const float inf = dm_bits2f(0x7f800000u);
   PH_BEGIN
-  // ---- func_collision_clear, broadphase.py:73-138 ----
+  // ---- loads of the prologue first: previous contact count, first-step flag, the persistent sort order, geom poses ----
   const int nc_old = e.n_contacts()[0];
-  for (int i_c = tl; i_c < nc_old; i_c += T) {
-    e.c_link()[i_c] = -1; e.c_link()[MAXC + i_c] = -1; e.c_geom()[i_c] = -1; e.c_geom()[MAXC + i_c] = -1;
-    e.c_pen()[i_c] = 0.0f; e.c_pos()[i_c] = v3(0, 0, 0); e.c_normal()[i_c] = v3(0, 0, 0); e.c_force()[i_c] = v3(0, 0, 0);
+  const bool first = e.first_time()[0] != 0;
+  const int n2 = 2 * NG;
+  team_stage<2 * NG, T>(tl, [&](int i) { return __int_as_float(e.sort_ig()[i]); }, [&](int i, float v) { s->sig[i] = __float_as_int(v); });
+  constexpr int NPI = (NPAIR + T - 1) / T;                            // the pair table of the candidate test, fetched for all rounds up front
+  int packed_[NPI];
+  {
+    const int n_pairs = m.n_pairs;
+#pragma unroll
+    for (int it = 0; it < NPI; ++it) { int pidx = it * T + tl; int v = m.pair_list[pidx < NPAIR ? pidx : NPAIR - 1]; packed_[it] = (pidx < n_pairs) ? v : -1; }
   }
-  // ---- kernel_update_geom_aabbs, forward_kinematics.py:1171-1193 ----
+  // ---- kernel_update_geom_aabbs, forward_kinematics.py:1171-1193 (out-of-range lanes redo the last geom: no branch between the loads) ----
 #if defined(GO2SIM_REPEAT_PHASE) && GO2SIM_REPEAT_PHASE == 30
   for (int rep = 0; rep < 2; ++rep)
 #endif
-  for (int i_g = tl; i_g < NG; i_g += T) {
+#pragma unroll
+  for (int g0 = 0; g0 < NG; g0 += T) {
+    const int i_g = (g0 + tl < NG) ? g0 + tl : NG - 1;
     V3 lower = v3(inf, inf, inf), upper = v3(-inf, -inf, -inf);
     V3 gp = e.g_pos()[i_g]; Q4 gq = e.g_quat()[i_g];
 #pragma unroll
@@ -1687,23 +1695,21 @@ __global__ __launch_bounds__(64) void k_collide_team(Pool P, const Model* __rest
     *(float4*)&s->amin[4 * i_g] = make_float4(lower.x, lower.y, lower.z, 0.0f);
     *(float4*)&s->amax[4 * i_g] = make_float4(upper.x, upper.y, upper.z, 0.0f);
   }
+  // ---- func_collision_clear, broadphase.py:73-138 ----
+  for (int i_c = tl; i_c < nc_old; i_c += T) {
+    e.c_link()[i_c] = -1; e.c_link()[MAXC + i_c] = -1; e.c_geom()[i_c] = -1; e.c_geom()[MAXC + i_c] = -1;
+    e.c_pen()[i_c] = 0.0f; e.c_pos()[i_c] = v3(0, 0, 0); e.c_normal()[i_c] = v3(0, 0, 0); e.c_force()[i_c] = v3(0, 0, 0);
+  }
   team_sync();
   PH(30)
   // ---- func_broad_phase, broadphase.py:141-396: endpoint refresh + stable sort ----
-  const int n2 = 2 * NG;
-  const bool first = e.first_time()[0] != 0;
 #if defined(GO2SIM_REPEAT_PHASE) && GO2SIM_REPEAT_PHASE == 31
   for (int rep = 0; rep < 2; ++rep) {
   team_sync();
 #endif
   for (int i = tl; i < n2; i += T) {
-    int sg;
-    if (first) {
-      // endpoints in (link, geom) order: geoms are stored link-major, so buffer slot i/2 holds geom i/2
-      sg = (i >> 1) | ((i & 1) ? 0x100 : 0);
-    } else {
-      sg = e.sort_ig()[i];
-    }
+    // first step: endpoints in (link, geom) order: geoms are stored link-major, so buffer slot i/2 holds geom i/2
+    int sg = first ? ((i >> 1) | ((i & 1) ? 0x100 : 0)) : s->sig[i];
     int g = sg & 0xff;
     s->sig[i] = sg;
     s->sval[i] = (sg & 0x100) ? s->amax[4 * g] : s->amin[4 * g];
@@ -1732,10 +1738,6 @@ __global__ __launch_bounds__(64) void k_collide_team(Pool P, const Model* __rest
 #endif
   // the pair table is fetched for all rounds up front and every LDS operand of a test is read unconditionally, so that the reads of a
   // round are in flight together; only the ballot compaction is sequential
-  constexpr int NPI = (NPAIR + T - 1) / T;
-  int packed_[NPI];
-#pragma unroll
-  for (int it = 0; it < NPI; ++it) { int pidx = it * T + tl; packed_[it] = (pidx < m.n_pairs) ? m.pair_list[pidx] : -1; }
   unsigned cmask = 0; int key_[NPI];
 #pragma unroll
   for (int it = 0; it < NPI; ++it) {                                   // the rounds are independent: candidates are only marked here
