@@ -3565,7 +3565,8 @@ struct go2sim {
   float* terrain_hf = nullptr;              // device copy of the heightfield in metres (go2sim_set_terrain)
   GjkScratch* gjk_scratch = nullptr;        // working memory of the GJK/EPA fallback: one block per (env, narrow-phase lane)
   SolverData<MAXR>* solver_ovf = nullptr;   // per-env global scratch for solves that do not fit in LDS (> RL rows)
-  int dyn_team = 16;                        // lanes per environment in k_dynamics_team / k_integrate_fk_team / k_fk_team
+  int dyn_team = 32;                        // lanes per environment in k_dynamics_team
+  int fk_team = 16;                         // lanes per environment in k_integrate_fk_team / k_fk_team
   int collide_team = 16;                    // lanes per environment in k_collide_team
   int solver_team = 32;                     // lanes per environment in k_constraint_solve_team
   uint32_t step_count = 0; int action_write_idx = 0;
@@ -3598,7 +3599,7 @@ struct ScopedTimer {
 };
 
 static void launch_fk_team(go2sim* h, hipStream_t s, int force_update_fixed, const int* cond) {
-  const int T = h->dyn_team;
+  const int T = h->fk_team;
   dim3 gd((h->B + 64 / T - 1) / (64 / T)), b(64);
   if (T == 16) hipLaunchKernelGGL(k_fk_team<16>, gd, b, 0, s, h->P, h->dms, force_update_fixed, cond);
   else if (T == 32) hipLaunchKernelGGL(k_fk_team<32>, gd, b, 0, s, h->P, h->dms, force_update_fixed, cond);
@@ -3638,7 +3639,7 @@ static int launch_substep(go2sim* h, hipStream_t s) {
   }
   {
     ScopedTimer t(h, s, T_INTEGRATE);
-    const int T = h->dyn_team;
+    const int T = h->fk_team;
     dim3 gd((h->B + 64 / T - 1) / (64 / T));
     if (T == 16) hipLaunchKernelGGL(k_integrate_fk_team<16>, gd, b, 0, s, h->P, h->dms);
     else if (T == 32) hipLaunchKernelGGL(k_integrate_fk_team<32>, gd, b, 0, s, h->P, h->dms);
@@ -3684,6 +3685,7 @@ int go2sim_create(const void* blob, size_t nbytes, int n_envs, int device, uint6
   HIPCHK(hipMalloc((void**)&h->derr, sizeof(int)));
   HIPCHK(hipMalloc((void**)&h->solver_ovf, (size_t)n_envs * sizeof(SolverData<MAXR>)));
   if (const char* t = getenv("GO2SIM_DYN_TEAM")) { int v = atoi(t); if (v == 16 || v == 32 || v == 64) h->dyn_team = v; }
+  if (const char* t = getenv("GO2SIM_FK_TEAM")) { int v = atoi(t); if (v == 16 || v == 32 || v == 64) h->fk_team = v; }
   if (const char* t = getenv("GO2SIM_COLLIDE_TEAM")) { int v = atoi(t); if (v == 16 || v == 32 || v == 64) h->collide_team = v; }
   HIPCHK(hipMalloc((void**)&h->gjk_scratch, (size_t)n_envs * h->collide_team * sizeof(GjkScratch)));   // ~31 KB per narrow-phase lane
   if (const char* t = getenv("GO2SIM_SOLVER_TEAM")) { int v = atoi(t); if (v == 16 || v == 32 || v == 64) h->solver_team = v; }
