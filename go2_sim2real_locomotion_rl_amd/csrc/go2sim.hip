@@ -970,6 +970,14 @@ __global__ __launch_bounds__(64) void k_dynamics_team(Pool P, const ModelS* __re
   team_stage<ND * 3, T>(tl, [&](int k) { return aload(e, AO(cdof_vel), k); }, [&](int k, float v) { s->cdof_vel[k] = v; });
   team_stage<ND * 3, T>(tl, [&](int k) { return aload(e, AO(cdofd_ang), k); }, [&](int k, float v) { s->cdofd_ang[k] = v; });
   team_stage<ND * 3, T>(tl, [&](int k) { return aload(e, AO(cdofd_vel), k); }, [&](int k, float v) { s->cdofd_vel[k] = v; });
+  // inputs of the later phases, parked in LDS slots that are only written afterwards (by the same lane that reads the parked value):
+  // control targets -> qf_applied / qf_passive / force / out, external link forces -> cfrc_ang / cfrc_vel
+  team_stage<ND, T>(tl, [&](int d) { return gload(e, FO(ctrl_force), d); }, [&](int d, float v) { s->qf_applied[d] = v; });
+  team_stage<ND, T>(tl, [&](int d) { return gload(e, FO(ctrl_pos), d); }, [&](int d, float v) { s->qf_passive[d] = v; });
+  team_stage<ND, T>(tl, [&](int d) { return gload(e, FO(ctrl_vel), d); }, [&](int d, float v) { s->force[d] = v; });
+  team_stage<ND, T>(tl, [&](int d) { return gload(e, FO(dof_pos), d); }, [&](int d, float v) { s->out[d] = v; });
+  team_stage<NL * 6, T>(tl, [&](int k) { return gload(e, FO(ext), k); },
+                        [&](int k, float v) { int i_l = k / 6, c = k % 6; if (c < 3) s->cfrc_ang[3 * i_l + c] = v; else s->cfrc_vel[3 * i_l + c - 3] = v; });
   team_sync();
   PH(20)
   // ---- composite rigid bodies, leaf -> root ----
@@ -1035,13 +1043,14 @@ __global__ __launch_bounds__(64) void k_dynamics_team(Pool P, const ModelS* __re
     int joint_type = m.joints[L.joint_start].type;
     float force = 0.0f;
     int cm = s->ctrl_mode[i_d];
-    if (cm == CTRL_FORCE) force = gload(e, FO(ctrl_force), i_d);
-    else if (cm == CTRL_VELOCITY) force = D.kv * (gload(e, FO(ctrl_vel), i_d) - s->vel[i_d]);
+    const float in_ctrl_force = s->qf_applied[i_d], in_ctrl_pos = s->qf_passive[i_d], in_ctrl_vel = s->force[i_d], in_dof_pos = s->out[i_d];   // parked by the staging
+    if (cm == CTRL_FORCE) force = in_ctrl_force;
+    else if (cm == CTRL_VELOCITY) force = D.kv * (in_ctrl_vel - s->vel[i_d]);
     else if (cm == CTRL_POSITION && !(joint_type == JOINT_FREE && i_d >= L.dof_start + 3))
-      force = D.kp * (gload(e, FO(ctrl_pos), i_d) - gload(e, FO(dof_pos), i_d)) + D.kv * (gload(e, FO(ctrl_vel), i_d) - s->vel[i_d]);
+      force = D.kp * (in_ctrl_pos - in_dof_pos) + D.kv * (in_ctrl_vel - s->vel[i_d]);
     s->qf_applied[i_d] = clampf(force, D.force_range[0], D.force_range[1]);
     float qp = -D.damping * s->vel[i_d];
-    if (joint_type != JOINT_FREE && joint_type != JOINT_FIXED) qp = qp + (-gload(e, FO(dof_pos), i_d) * D.stiffness);
+    if (joint_type != JOINT_FREE && joint_type != JOINT_FIXED) qp = qp + (-in_dof_pos * D.stiffness);
     s->qf_passive[i_d] = qp;
   }
   // ---- bias forces: accelerations root -> leaf ----
@@ -1070,8 +1079,7 @@ __global__ __launch_bounds__(64) void k_dynamics_team(Pool P, const ModelS* __re
     inertial_mul(cp, I, cm, ld3(s->cdd_vel, i_l), ld3(s->cdd_ang, i_l), f1_ang, f1_vel);
     inertial_mul(cp, I, cm, cdv, cda, f2_ang, f2_vel);
     motion_cross_force(cda, cdv, f2_ang, f2_vel, f3_ang, f3_vel);
-    V3 ext_ang = v3(gload(e, FO(ext), 6 * i_l + 0), gload(e, FO(ext), 6 * i_l + 1), gload(e, FO(ext), 6 * i_l + 2));
-    V3 ext_vel = v3(gload(e, FO(ext), 6 * i_l + 3), gload(e, FO(ext), 6 * i_l + 4), gload(e, FO(ext), 6 * i_l + 5));
+    V3 ext_ang = ld3(s->cfrc_ang, i_l), ext_vel = ld3(s->cfrc_vel, i_l);   // parked by the staging
     st3(s->cfrc_vel, i_l, f1_vel + f3_vel + ext_vel + v3(0, 0, 0));
     st3(s->cfrc_ang, i_l, f1_ang + f3_ang + ext_ang + v3(0, 0, 0));
   }
@@ -3316,6 +3324,23 @@ __global__ __launch_bounds__(WG) void k_env_reset_tail(Pool P, const Model* __re
 // Go2Env.step tail (go2_env_walk.py:1078-1109): reset_idx of the flagged envs, observation + privileged observation assembly, output
 // copies.  Team kernel: T lanes per env.  The reset (rare, serial) runs on lane 0; the 49 observations are produced four per lane (one
 // Philox block of noise each), the privileged tail one entry per lane, and the [n_envs, k] outputs are written with coalesced rows.
+// sources of the walk-layout observation vectors, staged into LDS in one batch (k_env_post_b_team)
+enum { PB_BAV = 0, PB_PG = 3, PB_GOFF = 6, PB_CMD = 9, PB_DP = 12, PB_DV = 24, PB_ACT = 36, PB_BLV = 52, PB_KP = 55, PB_KD = 67, PB_MS = 79, PB_PUSH = 91, PB_N = 94 };
+DEV int post_b_src_off(int k) {
+  int off = FO(base_ang_vel) + k;
+  off = (k >= PB_PG) ? FO(projected_gravity) + k - PB_PG : off;
+  off = (k >= PB_GOFF) ? FO(gravity_offset) + k - PB_GOFF : off;
+  off = (k >= PB_CMD) ? FO(commands) + k - PB_CMD : off;
+  off = (k >= PB_DP) ? FO(e_dof_pos) + k - PB_DP : off;
+  off = (k >= PB_DV) ? FO(e_dof_vel) + k - PB_DV : off;
+  off = (k >= PB_ACT) ? FO(applied_actions) + k - PB_ACT : off;
+  off = (k >= PB_BLV) ? FO(base_lin_vel) + k - PB_BLV : off;
+  off = (k >= PB_KP) ? FO(kp_factors) + k - PB_KP : off;
+  off = (k >= PB_KD) ? FO(kd_factors) + k - PB_KD : off;
+  off = (k >= PB_MS) ? FO(motor_strength) + k - PB_MS : off;
+  off = (k >= PB_PUSH) ? FO(current_push_force) + k - PB_PUSH : off;
+  return off;
+}
 template <int T>
 __global__ __launch_bounds__(64) void k_env_post_b_team(Pool P, const Model* __restrict__ mp, const DCfg* __restrict__ cp, const Glob* __restrict__ gp,
                                                         uint64_t seed, uint32_t step_count, float* __restrict__ obs_out, float* __restrict__ priv_out,
@@ -3385,6 +3410,11 @@ __global__ __launch_bounds__(64) void k_env_post_b_team(Pool P, const Model* __r
     }
     return;
   }
+  // every source of the two observation vectors is fetched in one batch (the assembly below would otherwise pay a memory round trip per entry)
+  __shared__ float pb_src[EPW][PB_N + 2];
+  float* src = pb_src[slot];
+  team_stage<PB_N, T>(tl, [&](int k) { return gload(e, post_b_src_off(k), 0); }, [&](int k, float v) { src[k] = v; });
+  team_sync();
   const bool noisy = c.i[GO2SIM_IC_HAS_OBS_NOISE] && c.f[GO2SIM_FC_OBS_NOISE_LEVEL_MAX] > 0.0f;
   const float lvl = g.obs_noise_level_cur;
   for (int blk = tl; blk * 4 < nobs; blk += T) {
@@ -3398,12 +3428,12 @@ __global__ __launch_bounds__(64) void k_env_post_b_team(Pool P, const Model* __r
       int i = 4 * blk + k;
       if (i < nobs) {
         float v, nv = 0.0f;
-        if (i < 3) { v = gload(e, FO(base_ang_vel), i) * c.f[GO2SIM_FC_OBS_SCALE_ANG_VEL]; nv = c.f[GO2SIM_FC_OBS_NOISE_ANG_VEL] * c.f[GO2SIM_FC_OBS_SCALE_ANG_VEL] * lvl; }
-        else if (i < 6) { v = gload(e, FO(projected_gravity), i - 3) + gload(e, FO(gravity_offset), i - 3); nv = c.f[GO2SIM_FC_OBS_NOISE_GRAVITY] * lvl; }
-        else if (i < 9) { v = gload(e, FO(commands), i - 6) * ((i - 6 < 2) ? c.f[GO2SIM_FC_OBS_SCALE_LIN_VEL] : c.f[GO2SIM_FC_OBS_SCALE_ANG_VEL]); nv = 0.0f; }
-        else if (i < 21) { v = (gload(e, FO(e_dof_pos), i - 9) - c.f[GO2SIM_FC_DEFAULT_DOF_POS0 + i - 9]) * c.f[GO2SIM_FC_OBS_SCALE_DOF_POS]; nv = c.f[GO2SIM_FC_OBS_NOISE_DOF_POS] * c.f[GO2SIM_FC_OBS_SCALE_DOF_POS] * lvl; }
-        else if (i < 33) { v = gload(e, FO(e_dof_vel), i - 21) * c.f[GO2SIM_FC_OBS_SCALE_DOF_VEL]; nv = c.f[GO2SIM_FC_OBS_NOISE_DOF_VEL] * c.f[GO2SIM_FC_OBS_SCALE_DOF_VEL] * lvl; }
-        else { v = (i - 33 < na) ? gload(e, FO(applied_actions), i - 33) : gload(e, FO(obs), i); }
+        if (i < 3) { v = src[PB_BAV + i] * c.f[GO2SIM_FC_OBS_SCALE_ANG_VEL]; nv = c.f[GO2SIM_FC_OBS_NOISE_ANG_VEL] * c.f[GO2SIM_FC_OBS_SCALE_ANG_VEL] * lvl; }
+        else if (i < 6) { v = src[PB_PG + i - 3] + src[PB_GOFF + i - 3]; nv = c.f[GO2SIM_FC_OBS_NOISE_GRAVITY] * lvl; }
+        else if (i < 9) { v = src[PB_CMD + i - 6] * ((i - 6 < 2) ? c.f[GO2SIM_FC_OBS_SCALE_LIN_VEL] : c.f[GO2SIM_FC_OBS_SCALE_ANG_VEL]); nv = 0.0f; }
+        else if (i < 21) { v = (src[PB_DP + i - 9] - c.f[GO2SIM_FC_DEFAULT_DOF_POS0 + i - 9]) * c.f[GO2SIM_FC_OBS_SCALE_DOF_POS]; nv = c.f[GO2SIM_FC_OBS_NOISE_DOF_POS] * c.f[GO2SIM_FC_OBS_SCALE_DOF_POS] * lvl; }
+        else if (i < 33) { v = src[PB_DV + i - 21] * c.f[GO2SIM_FC_OBS_SCALE_DOF_VEL]; nv = c.f[GO2SIM_FC_OBS_NOISE_DOF_VEL] * c.f[GO2SIM_FC_OBS_SCALE_DOF_VEL] * lvl; }
+        else { v = (i - 33 < na) ? src[PB_ACT + i - 33] : gload(e, FO(obs), i); }
         if (noisy) v = v + n[k] * nv;
         gstore(e, FO(obs), i, v); gstore(e, FO(priv), i, v);
         if (obs_out) obs_out[(size_t)b * nobs + i] = v;
@@ -3415,16 +3445,16 @@ __global__ __launch_bounds__(64) void k_env_post_b_team(Pool P, const Model* __r
   for (int i = nobs + tl; i < npriv; i += T) {
     int j = i - nobs;
     float v; bool write = true;
-    if (j < 3) v = gload(e, FO(base_lin_vel), j) * c.f[GO2SIM_FC_OBS_SCALE_LIN_VEL];
+    if (j < 3) v = src[PB_BLV + j] * c.f[GO2SIM_FC_OBS_SCALE_LIN_VEL];
     else if (j < 4) v = g.friction;
-    else if (j < 16) v = gload(e, FO(kp_factors), j - 4);
-    else if (j < 28) v = gload(e, FO(kd_factors), j - 16);
-    else if (j < 40) v = gload(e, FO(motor_strength), j - 28);
+    else if (j < 16) v = src[PB_KP + j - 4];
+    else if (j < 28) v = src[PB_KD + j - 16];
+    else if (j < 40) v = src[PB_MS + j - 28];
     else if (j < 41) v = g.mass_shift;
     else if (j < 44) v = g.com_shift[j - 41];
     else if (j < 48) v = g.leg_mass_shift[j - 44];
-    else if (j < 51) v = gload(e, FO(gravity_offset), j - 48);
-    else if (j < 54) v = gload(e, FO(current_push_force), j - 51);
+    else if (j < 51) v = src[PB_GOFF + j - 48];
+    else if (j < 54) v = src[PB_PUSH + j - 51];
     else if (j < 55) { write = c.i[GO2SIM_IC_MAX_DELAY] > 0; v = write ? (float)e.delay_steps()[0] / (float)c.i[GO2SIM_IC_MAX_DELAY] : gload(e, FO(priv), i); }
     else if (c.i[GO2SIM_IC_USE_TERRAIN] && j == 55) v = (float)e.terrain_row()[0] / (float)imx(1, c.i[GO2SIM_IC_N_TERRAIN_ROWS] - 1);   // go2_env_stair.py:1466-1472
     else if (c.i[GO2SIM_IC_USE_TERRAIN] && j - 56 < c.i[GO2SIM_IC_SCAN_N] && 56 + c.i[GO2SIM_IC_SCAN_N] <= npriv - nobs) {        // _compute_height_scan :772-803
@@ -3443,7 +3473,7 @@ __global__ __launch_bounds__(64) void k_env_post_b_team(Pool P, const Model* __r
     if (priv_out) priv_out[(size_t)b * npriv + i] = v;
   }
   for (int i = tl; i < na; i += T) gstore(e, FO(last_actions), i, gload(e, FO(actions), i));
-  for (int i = tl; i < NM; i += T) gstore(e, FO(last_dof_vel), i, gload(e, FO(e_dof_vel), i));
+  for (int i = tl; i < NM; i += T) gstore(e, FO(last_dof_vel), i, src[PB_DV + i]);
   if (tl == 0) {
     if (rew_out) rew_out[b] = e.rew()[0];
     if (reset_out) reset_out[b] = (uint8_t)was_reset;
