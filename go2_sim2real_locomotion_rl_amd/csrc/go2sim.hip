@@ -2486,8 +2486,14 @@ DEV void ts_commit(const MT& m, const E& e, S* s, int tl, int nc, int n_con, int
 }
 
 // cold path: more rows than fit in LDS; same code on a per-env global scratch block
-template <int T, class MT>
-DEVN void ts_solve_overflow(const MT& m, const E& e, SolverData<MAXR>* s, int tl, int nc, int n_con, unsigned lim_mask, int ws_flag) {
+// (arguments are plain scalars / pointers and the views are rebuilt inside: by-reference or by-value aggregates would make the caller keep
+//  stack copies, i.e. scratch stores on the hot path of every wave)
+template <int T>
+DEVN void ts_solve_overflow(float* Pf, int* Pi, int PB, float* Pfa, int* Pia, int b, const LinkS* lnk, const unsigned char* tri_i, const unsigned char* tri_j,
+                            const Model* __restrict__ gm, SolverData<MAXR>* s, int tl, int nc, int n_con, unsigned lim_mask, int ws_flag) {
+  Pool P; P.f = Pf; P.i = Pi; P.B = PB; P.fa = Pfa; P.ia = Pia;
+  const E e(P, b);
+  const ModelView m(lnk, tri_i, tri_j, gm);
   int iters = ts_solve<T>(m, e, s, tl, nc, n_con, lim_mask, ws_flag);
   ts_commit<T>(m, e, s, tl, nc, n_con, iters);
 }
@@ -2539,7 +2545,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     ts_commit<T>(m, e, s, tl, nc, n_con, iters);
     PH(11)
   } else {
-    ts_solve_overflow<T>(m, e, &overflow[b], tl, nc, n_con, lim_mask, ws_flag);
+    ts_solve_overflow<T>(P.f, P.i, P.B, P.fa, P.ia, b, lnk, tri_i, tri_j, gm, &overflow[b], tl, nc, n_con, lim_mask, ws_flag);
   }
 }
 
