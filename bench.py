@@ -32,14 +32,17 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from go2_sim2real_locomotion_rl_amd.capi import C, Go2Sim, load_hip_lib  # noqa: E402
-from go2_sim2real_locomotion_rl_amd.configs import build_stair_terrain, flatten_walk_cfg, get_stair_cfgs, get_walk_cfgs  # noqa: E402
+from go2_sim2real_locomotion_rl_amd.configs import (build_stair_terrain, flatten_base_cfg, flatten_walk_cfg, get_jump_cfgs, get_stair_cfgs,  # noqa: E402
+                                                    get_walk_cfgs, with_per_env_dr)
 from go2_sim2real_locomotion_rl_amd.model_blob import pack_model  # noqa: E402
 
 ENVS_PER_GPU = 4096
 ALGO_BYTES_WALK = 5701  # algorithmic HBM bytes per env-step, SURVEY.md section 8(d)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 ROLLOUT_LEN = 24  # num_steps_per_env, go2_train_walk.py:60
-NPRIV = {"walk": 104, "stairs": 182}
+NPRIV = {"walk": 104, "stairs": 182, "jump_dr": 45}
+NOBS = {"walk": 49, "stairs": 49, "jump_dr": 45}
+NACT = {"walk": 16, "stairs": 16, "jump_dr": 12}
 WORKLOAD = "walk"
 KERNEL_CLASSES = ["k_dynamics", "k_collide", "k_constraint_solve", "k_integrate_fk", "k_env_pre", "k_env_post(a+globals+b)", "misc", "env_step_total"]
 
@@ -53,7 +56,7 @@ def make_actions(n_steps, n_envs, device, dt=0.02):
     gain = joint_gain[None, :].expand(4, 3).reshape(12)
     env_phase = torch.linspace(0.0, 2 * math.pi, n_envs, device=device)[None, :, None]
     pos = 0.3 * gain * torch.sin(2 * math.pi * 1.5 * t + phase + env_phase)
-    act = torch.zeros(n_steps, n_envs, 16, device=device)
+    act = torch.zeros(n_steps, n_envs, NACT[WORKLOAD], device=device)
     act[:, :, :12] = pos
     return act.contiguous()
 
@@ -71,6 +74,11 @@ def pmc_traffic_bytes(kernel, n_envs):
 def make_sim(lib, n_envs, device_index, seed, workload):
     """Configured handle: walk (flat plane) or stairs (go2_train_stair.py terrain + cfg), curriculum frozen at its initial level."""
     sim = Go2Sim(lib, pack_model(), n_envs, device_index, seed)
+    if workload == "jump_dr":       # BASELINE configs[4]: base env (go2_train_jump.py) + per-env friction / base-mass randomisation
+        f, i, _ = flatten_base_cfg(n_envs, *with_per_env_dr(get_jump_cfgs()))
+        sim.env_configure(f, i)
+        sim.env_reset()
+        return sim
     cfgs = get_stair_cfgs() if workload == "stairs" else get_walk_cfgs()
     if workload == "stairs":
         hf, info = build_stair_terrain(cfgs[0]["terrain"])
@@ -87,7 +95,7 @@ def cpu_baseline(n_envs, steps, warmup):
     lib = load_cpu_oracle_lib()
     sim = make_sim(lib, n_envs, 0, 1, WORKLOAD)
     act = make_actions(steps + warmup, n_envs, torch.device("cpu")).numpy()
-    obs = np.zeros((n_envs, 49), np.float32); priv = np.zeros((n_envs, NPRIV[WORKLOAD]), np.float32)
+    obs = np.zeros((n_envs, NOBS[WORKLOAD]), np.float32); priv = np.zeros((n_envs, NPRIV[WORKLOAD]), np.float32)
     rew = np.zeros(n_envs, np.float32); rst = np.zeros(n_envs, np.uint8); to = np.zeros(n_envs, np.float32)
     for s in range(warmup):
         sim.env_step(act[s], obs, priv, rew, rst, to)
@@ -104,8 +112,9 @@ def main():
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
-    ap.add_argument("--workload", choices=["walk", "stairs"], default="walk",
-                    help="walk = BASELINE configs[1] (the headline metric); stairs = configs[2] (heightfield terrain, reported for information)")
+    ap.add_argument("--workload", choices=["walk", "stairs", "jump_dr"], default="walk",
+                    help="walk = BASELINE configs[1] (the headline metric); stairs = configs[2] (heightfield terrain), jump_dr = configs[4] "
+                         "(jump env + per-env mass / friction randomisation) -- both reported for information")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile-pass", action="store_true")
     args = ap.parse_args()
@@ -142,7 +151,7 @@ def main():
     sim = make_sim(load_hip_lib(), B, local_rank, 1 + rank, WORKLOAD)
     K, W = args.steps, args.warmup
     actions = make_actions(K + W, B, device)
-    obs = torch.zeros(B, 49, device=device); priv = torch.zeros(B, NPRIV[WORKLOAD], device=device)
+    obs = torch.zeros(B, NOBS[WORKLOAD], device=device); priv = torch.zeros(B, NPRIV[WORKLOAD], device=device)
     rew = torch.zeros(B, device=device); rst = torch.zeros(B, dtype=torch.uint8, device=device); to = torch.zeros(B, device=device)
     stats = torch.zeros(3, device=device)
     gathered = torch.zeros(3 * world, device=coll_device) if world > 1 else None
@@ -225,7 +234,9 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": ("Go2 walk flat-plane, num_envs=4096 per GPU, 2 substeps x dt 0.01, action set C (open-loop sine gait), curriculum frozen at level 0.10"
                                     if WORKLOAD == "walk" else
-                                    "Go2 stairs heightfield terrain (BASELINE configs[2], NOT the headline metric), num_envs per GPU as given, action set C, curriculum frozen at level 0.65"),
+                                    "Go2 stairs heightfield terrain (BASELINE configs[2], NOT the headline metric), num_envs per GPU as given, action set C, curriculum frozen at level 0.65"
+                                    if WORKLOAD == "stairs" else
+                                    "Go2 jump env + per-env mass / friction randomisation (BASELINE configs[4], NOT the headline metric), num_envs per GPU as given, action set C on 12 position actions"),
                        "envs_per_gpu": B, "total_envs": total_envs, "parallelism": f"env-shard x{world}", "errno": errno},
             "roofline": roofline, "cpu_baseline": cpu,
         }

@@ -301,6 +301,14 @@ def get_crouch_cfgs():
     return env_cfg, copy.deepcopy(_BASE_OBS), reward_cfg, copy.deepcopy(_ZERO_CMD)
 
 
+def with_per_env_dr(cfgs, friction_range=(0.4, 0.9), mass_shift_range=(-1.0, 3.0)):
+    """BASELINE.json configs[4]: a base-env configuration plus per-env friction / base-mass randomisation at reset
+    (ranges: go2_train_jump.py:58 `friction_range`, go2_train_walk.py:135 `mass_shift_range`)."""
+    env_cfg, obs_cfg, reward_cfg, command_cfg = cfgs
+    env_cfg = dict(env_cfg, per_env_dr={"friction_range": tuple(friction_range), "mass_shift_range": tuple(mass_shift_range)})
+    return env_cfg, obs_cfg, reward_cfg, command_cfg
+
+
 def get_jump_cfgs():
     """go2_train_jump.py:10-101 (values transcribed; the DR / push keys of that file are not read by go2_env_base.py)."""
     env_cfg = dict(_BASE_JOINTS, num_actions=12, kp=60.0, kd=2.0, termination_if_roll_greater_than=25, termination_if_pitch_greater_than=25,
@@ -375,6 +383,20 @@ def flatten_base_cfg(num_envs, env_cfg, obs_cfg, reward_cfg, command_cfg, *, mod
     i[I("CURR_UPDATE_EVERY")] = 1 << 30
     i[I("GLOBAL_DR_INTERVAL")] = 1 << 30
     i[I("FREEZE_CURRICULUM")] = 1
+    # Extension for BASELINE.json configs[4] ("crouch+jump with per-env mass/friction domain randomisation"); go2_env_base.py itself
+    # reads none of the DR keys of its train scripts.  env_cfg["per_env_dr"] = {"friction_range": (lo, hi), "mass_shift_range": (lo, hi)}
+    # draws, at every reset of an env, one friction coefficient for all its geoms and one mass shift of its base link.
+    dr = env_cfg.get("per_env_dr")
+    if dr:
+        i[I("PER_ENV_GLOBAL_DR")] = 1
+        if dr.get("friction_range") is not None:
+            lo, hi = dr["friction_range"]
+            i[I("HAS_FRICTION_DR")] = 1
+            f[F("FRICTION_EASY_LO"):F("FRICTION_EASY_LO") + 4] = [lo, hi, lo, hi]
+        if dr.get("mass_shift_range") is not None:
+            lo, hi = dr["mass_shift_range"]
+            i[I("HAS_MASS_DR")] = 1
+            f[F("MASS_EASY_LO"):F("MASS_EASY_LO") + 4] = [lo, hi, lo, hi]
     return f, i, names
 
 

@@ -3211,6 +3211,16 @@ DEV void env_reset_one(const Model& m, const DCfg& c, const Glob& g, const E& e,
   }
   if (c.i[GO2SIM_IC_HAS_MSTR_DR])
     for (int blk = 0; blk < 3; ++blk) { dm_u4 r = rng4(seed, RNG_RESET_DR, b, rc, 7 + blk); for (int k = 0; k < 4; ++k) motor_strength[4 * blk + k] = rand_float(lerp_lo(c, GO2SIM_FC_MSTR_EASY_LO, ts), lerp_hi(c, GO2SIM_FC_MSTR_EASY_LO, ts), r.v[k]); }
+  if (c.i[GO2SIM_IC_PER_ENV_GLOBAL_DR]) {   // extension (BASELINE configs[4], not in the reference): the friction / base-mass scalars are drawn per env
+    dm_u4 r = rng4(seed, RNG_RESET_DR, b, rc, 10);
+    if (c.i[GO2SIM_IC_HAS_FRICTION_DR]) {
+      float mu = rand_float(lerp_lo(c, GO2SIM_FC_FRICTION_EASY_LO, ts), lerp_hi(c, GO2SIM_FC_FRICTION_EASY_LO, ts), r.v[0]);
+      auto gf = e.geom_friction();
+      for (int i = 0; i < NG; ++i) gf[i] = mu;
+    }
+    if (c.i[GO2SIM_IC_HAS_MASS_DR])
+      e.mass_shift()[c.i[GO2SIM_IC_BASE_LINK]] = rand_float(lerp_lo(c, GO2SIM_FC_MASS_EASY_LO, ts), lerp_hi(c, GO2SIM_FC_MASS_EASY_LO, ts), r.v[1]);
+  }
   dm_u4 rp = rng4(seed, RNG_RESET_POSE, b, rc, 0);
   {
     int max_d = imx(c.i[GO2SIM_IC_MIN_DELAY], imn(g.delay_max_cur, c.i[GO2SIM_IC_MAX_DELAY]));
@@ -3275,9 +3285,10 @@ DEV void env_reset_one(const Model& m, const DCfg& c, const Glob& g, const E& e,
 DEV void reset_tail(const Model& m, const DCfg& c, const Glob& g, const E& e, int b, uint64_t seed) {
   if (g.n_reset_now <= 0) return;
   if (e.reset_buf()[0]) env_reset_one(m, c, g, e, b, seed);
-  if (c.i[GO2SIM_IC_HAS_FRICTION_DR]) { auto gf = e.geom_friction(); for (int i = 0; i < NG; ++i) gf[i] = g.friction; }
+  const bool per_env = c.i[GO2SIM_IC_PER_ENV_GLOBAL_DR] != 0;      // per-env draws were applied by env_reset_one
+  if (c.i[GO2SIM_IC_HAS_FRICTION_DR] && !per_env) { auto gf = e.geom_friction(); for (int i = 0; i < NG; ++i) gf[i] = g.friction; }
   int bl = c.i[GO2SIM_IC_BASE_LINK];
-  if (c.i[GO2SIM_IC_HAS_MASS_DR]) e.mass_shift()[bl] = g.mass_shift;
+  if (c.i[GO2SIM_IC_HAS_MASS_DR] && !per_env) e.mass_shift()[bl] = g.mass_shift;
   if (c.i[GO2SIM_IC_HAS_COM_DR]) e.com_shift()[bl] = v3(g.com_shift[0], g.com_shift[1], g.com_shift[2]);
   if (c.i[GO2SIM_IC_HAS_LEGM_DR]) for (int k = 0; k < 4; ++k) e.mass_shift()[c.i[GO2SIM_IC_HIP_LINK0 + k]] = g.leg_mass_shift[k];
   // the full-batch FK refresh follows as k_fk_team gated on g.n_reset_now (launch_fk_team)
@@ -3360,10 +3371,11 @@ __global__ __launch_bounds__(64) void k_env_post_b_team(Pool P, const Model* __r
   const int was_reset = e.reset_buf()[0];
   if (g.n_reset_now > 0) {                                             // reset_tail, spread over the team
     if (tl == 0 && was_reset) env_reset_one(m, c, g, e, b, seed);
-    if (c.i[GO2SIM_IC_HAS_FRICTION_DR]) for (int i = tl; i < NG; i += T) e.geom_friction()[i] = g.friction;
+    const bool per_env = c.i[GO2SIM_IC_PER_ENV_GLOBAL_DR] != 0;      // per-env draws were applied by env_reset_one
+    if (c.i[GO2SIM_IC_HAS_FRICTION_DR] && !per_env) for (int i = tl; i < NG; i += T) e.geom_friction()[i] = g.friction;
     if (tl == 0) {
       int bl = c.i[GO2SIM_IC_BASE_LINK];
-      if (c.i[GO2SIM_IC_HAS_MASS_DR]) e.mass_shift()[bl] = g.mass_shift;
+      if (c.i[GO2SIM_IC_HAS_MASS_DR] && !per_env) e.mass_shift()[bl] = g.mass_shift;
       if (c.i[GO2SIM_IC_HAS_COM_DR]) e.com_shift()[bl] = v3(g.com_shift[0], g.com_shift[1], g.com_shift[2]);
       if (c.i[GO2SIM_IC_HAS_LEGM_DR]) for (int k = 0; k < 4; ++k) e.mass_shift()[c.i[GO2SIM_IC_HIP_LINK0 + k]] = g.leg_mass_shift[k];
     }
@@ -3452,11 +3464,11 @@ __global__ __launch_bounds__(64) void k_env_post_b_team(Pool P, const Model* __r
     int j = i - nobs;
     float v; bool write = true;
     if (j < 3) v = src[PB_BLV + j] * c.f[GO2SIM_FC_OBS_SCALE_LIN_VEL];
-    else if (j < 4) v = g.friction;
+    else if (j < 4) v = c.i[GO2SIM_IC_PER_ENV_GLOBAL_DR] ? gload(e, FO(geom_friction), NG - 1) : g.friction;
     else if (j < 16) v = src[PB_KP + j - 4];
     else if (j < 28) v = src[PB_KD + j - 16];
     else if (j < 40) v = src[PB_MS + j - 28];
-    else if (j < 41) v = g.mass_shift;
+    else if (j < 41) v = c.i[GO2SIM_IC_PER_ENV_GLOBAL_DR] ? gload(e, FO(mass_shift), c.i[GO2SIM_IC_BASE_LINK]) : g.mass_shift;
     else if (j < 44) v = g.com_shift[j - 41];
     else if (j < 48) v = g.leg_mass_shift[j - 44];
     else if (j < 51) v = src[PB_GOFF + j - 48];

@@ -2234,6 +2234,15 @@ void env_reset_one(go2sim* h, int b) {
   }
   if (c.i[GO2SIM_IC_HAS_MSTR_DR])                                                          // _randomize_motor_strength :850-858
     for (int blk = 0; blk < 3; ++blk) { dm_u4 r = rng4(h, RNG_RESET_DR, b, rc, 7 + blk); for (int k = 0; k < 4; ++k) x.motor_strength[4 * blk + k] = rand_float(lerp_lo(c, GO2SIM_FC_MSTR_EASY_LO, ts), lerp_hi(c, GO2SIM_FC_MSTR_EASY_LO, ts), r.v[k]); }
+  if (c.i[GO2SIM_IC_PER_ENV_GLOBAL_DR]) {   // extension (BASELINE configs[4], not in the reference): the friction / base-mass scalars are drawn per env
+    dm_u4 r = rng4(h, RNG_RESET_DR, b, rc, 10);
+    if (c.i[GO2SIM_IC_HAS_FRICTION_DR]) {
+      real mu = rand_float(lerp_lo(c, GO2SIM_FC_FRICTION_EASY_LO, ts), lerp_hi(c, GO2SIM_FC_FRICTION_EASY_LO, ts), r.v[0]);
+      for (int i = 0; i < NG; ++i) e.geom_friction[i] = mu;
+    }
+    if (c.i[GO2SIM_IC_HAS_MASS_DR])
+      e.mass_shift[c.i[GO2SIM_IC_BASE_LINK]] = rand_float(lerp_lo(c, GO2SIM_FC_MASS_EASY_LO, ts), lerp_hi(c, GO2SIM_FC_MASS_EASY_LO, ts), r.v[1]);
+  }
   dm_u4 rp = rng4(h, RNG_RESET_POSE, b, rc, 0);
   {                                                                                        // _randomize_delay :860-866
     int max_d = std::max(c.i[GO2SIM_IC_MIN_DELAY], std::min(g.delay_max_cur, c.i[GO2SIM_IC_MAX_DELAY]));
@@ -2292,9 +2301,10 @@ void env_reset_one(go2sim* h, int b) {
 void env_apply_globals_and_fk(go2sim* h, int b) {
   const Model& m = h->m; const Cfg& c = h->cfg; const go2sim_env_globals_t& g = h->g;
   Env& e = h->envs[b];
-  if (c.i[GO2SIM_IC_HAS_FRICTION_DR]) for (int i = 0; i < NG; ++i) e.geom_friction[i] = g.friction;
+  const bool per_env = c.i[GO2SIM_IC_PER_ENV_GLOBAL_DR] != 0;   // per-env draws were applied by env_reset_one
+  if (c.i[GO2SIM_IC_HAS_FRICTION_DR] && !per_env) for (int i = 0; i < NG; ++i) e.geom_friction[i] = g.friction;
   int bl = c.i[GO2SIM_IC_BASE_LINK];
-  if (c.i[GO2SIM_IC_HAS_MASS_DR]) e.mass_shift[bl] = g.mass_shift;
+  if (c.i[GO2SIM_IC_HAS_MASS_DR] && !per_env) e.mass_shift[bl] = g.mass_shift;
   if (c.i[GO2SIM_IC_HAS_COM_DR]) e.com_shift[bl] = v3(g.com_shift[0], g.com_shift[1], g.com_shift[2]);
   if (c.i[GO2SIM_IC_HAS_LEGM_DR]) for (int k = 0; k < 4; ++k) e.mass_shift[c.i[GO2SIM_IC_HIP_LINK0 + k]] = g.leg_mass_shift[k];
   update_cartesian_space(m, e, true);
@@ -2360,14 +2370,14 @@ void env_post_b(go2sim* h, int b, real* obs, real* priv) {
   int idx = nobs;
   for (int k = 0; k < 3; ++k) p[idx + k] = x.base_lin_vel[k] * c.f[GO2SIM_FC_OBS_SCALE_LIN_VEL];
   idx += 3;
-  p[idx] = g.friction; idx += 1;
+  p[idx] = c.i[GO2SIM_IC_PER_ENV_GLOBAL_DR] ? h->envs[b].geom_friction[NG - 1] : g.friction; idx += 1;
   for (int i = 0; i < NM; ++i) p[idx + i] = x.kp_factors[i];
   idx += 12;
   for (int i = 0; i < NM; ++i) p[idx + i] = x.kd_factors[i];
   idx += 12;
   for (int i = 0; i < NM; ++i) p[idx + i] = x.motor_strength[i];
   idx += 12;
-  p[idx] = g.mass_shift; idx += 1;
+  p[idx] = c.i[GO2SIM_IC_PER_ENV_GLOBAL_DR] ? h->envs[b].mass_shift[c.i[GO2SIM_IC_BASE_LINK]] : g.mass_shift; idx += 1;
   for (int k = 0; k < 3; ++k) p[idx + k] = g.com_shift[k];
   idx += 3;
   for (int k = 0; k < 4; ++k) p[idx + k] = g.leg_mass_shift[k];

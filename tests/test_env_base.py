@@ -83,3 +83,32 @@ def test_base_env_engine_pd_holds_the_default_pose(oracle_lib, blob):
     assert np.abs(obs[:, 9:21]).max() < 0.15 and (st["base_pos"][:, 2] > 0.25).all()
     mode = env.field("I_CTRL_MODE")
     assert (mode[6:] == 2).all()   # CTRL_MODE.POSITION on the 12 motors
+
+
+def test_per_env_dr_extension(oracle_lib, blob):
+    """BASELINE.json configs[4] (extension, not in go2_env_base.py): every reset draws one friction coefficient for all geoms of the env
+    and one base-link mass shift, from the per-env Philox stream; nothing else about the base env changes."""
+    B, steps = 48, 90
+    env = CpuEnv(oracle_lib, blob, B, seed=11, task="jump_dr")
+    ref = CpuEnv(oracle_lib, blob, B, seed=11, task="jump")
+    env.reset(); ref.reset()
+    mu = env.field("F_GEOM_FRICTION").reshape(28, B)
+    ms = env.field("F_MASS_SHIFT").reshape(14, B)
+    assert (mu == mu[0:1]).all() and (mu[0] >= 0.4).all() and (mu[0] <= 0.9).all() and len(np.unique(mu[0])) > B // 2
+    assert (ms[1] >= -1.0).all() and (ms[1] <= 3.0).all() and len(np.unique(ms[1])) > B // 2 and (ms[2:] == 0).all() and (ms[0] == 0).all()
+    assert (ref.field("F_GEOM_FRICTION") == 1.0).all() and (ref.field("F_MASS_SHIFT") == 0.0).all()
+    acts = make_actions(steps, B, seed=12, kind="0.5", n_act=12)
+    redrawn = np.zeros(B, bool)
+    diverged = False
+    for a in acts:
+        mu0, ms0 = mu[0].copy(), ms[1].copy()
+        o1, _, r1, d1, _ = env.step(a)
+        o2, _, r2, d2, _ = ref.step(a)
+        diverged |= not np.array_equal(o1, o2)
+        mu = env.field("F_GEOM_FRICTION").reshape(28, B); ms = env.field("F_MASS_SHIFT").reshape(14, B)
+        was = d1.astype(bool)
+        assert (mu[0][~was] == mu0[~was]).all() and (ms[1][~was] == ms0[~was]).all()       # only reset envs redraw
+        assert (mu == mu[0:1]).all() and (mu[0] >= 0.4).all() and (mu[0] <= 0.9).all() and (ms[1] >= -1.0).all() and (ms[1] <= 3.0).all()
+        redrawn |= was & (mu[0] != mu0)
+        assert np.isfinite(o1).all() and np.isfinite(r1).all()
+    assert redrawn.any() and diverged            # the physics sees the randomised mass / friction

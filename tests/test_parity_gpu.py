@@ -184,7 +184,7 @@ def test_go2env_class_matches_c_abi(hip_lib, blob):
         env.step(torch.zeros(B, 12, device=env.device))
 
 
-@pytest.mark.parametrize("task,n_envs,steps,kind,seed", [("crouch", 70, 120, "0.5", 3), ("jump", 33, 160, "mixed", 8)])
+@pytest.mark.parametrize("task,n_envs,steps,kind,seed", [("crouch", 70, 120, "0.5", 3), ("jump", 33, 160, "mixed", 8), ("jump_dr", 40, 140, "0.5", 9)])
 def test_base_env_bit_exact(oracle_lib, hip_lib, blob, task, n_envs, steps, kind, seed):
     """go2_env_base.py (crouch / jump): engine PD, reset before reward, 45 observations -- GPU vs oracle, tolerance 0."""
     cpu, gpu = CpuEnv(oracle_lib, blob, n_envs, seed=seed, task=task), GpuEnv(hip_lib, blob, n_envs, seed=seed, task=task)

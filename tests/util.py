@@ -3,7 +3,7 @@ import numpy as np
 
 from go2_sim2real_locomotion_rl_amd.capi import C, Go2Sim
 from go2_sim2real_locomotion_rl_amd.configs import (build_stair_terrain, flatten_base_cfg, flatten_walk_cfg, get_crouch_cfgs, get_jump_cfgs,
-                                                    get_stair_cfgs, get_walk_cfgs)
+                                                    get_stair_cfgs, get_walk_cfgs, with_per_env_dr)
 
 NOBS, NPRIV, NACT = 49, 104, 16
 
@@ -29,6 +29,8 @@ def task_cfg(task, n_envs, mutate=None, **kw):
             mutate(*cfgs)
         return flatten_walk_cfg(n_envs, *cfgs, **kw) + (NOBS, 182, NACT)
     cfgs = get_crouch_cfgs() if task == "crouch" else get_jump_cfgs()
+    if task.endswith("_dr"):                       # BASELINE.json configs[4]: base env + per-env friction / base-mass randomisation
+        cfgs = with_per_env_dr(get_crouch_cfgs() if task.startswith("crouch") else get_jump_cfgs())
     if mutate is not None:
         mutate(*cfgs)
     return flatten_base_cfg(n_envs, *cfgs) + (45, 45, 12)
