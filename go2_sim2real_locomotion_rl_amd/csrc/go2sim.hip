@@ -2563,7 +2563,7 @@ __global__ __launch_bounds__(WG) void k_clear_ext(Pool P) {             // kerne
 // scalars (curriculum state machine, "global" domain-randomisation draws).
 // ---------------------------------------------------------------------------------------------
 struct DCfg { float f[GO2SIM_FC_COUNT]; int i[GO2SIM_IC_COUNT]; };
-struct Acc { double timeouts, tracking, ep[NREW]; int n_reset_now; int pad; };
+struct Acc { double timeouts, tracking, ep[NREW]; int n_reset_now; int done; };   // done: workgroups of k_env_post_a that have finished
 typedef go2sim_env_globals_t Glob;
 
 enum { RNG_ACTION_NOISE = 1, RNG_PUSH = 2, RNG_CMD = 3, RNG_OBS_NOISE = 4, RNG_RESET_DR = 5, RNG_GLOBAL_DR = 6, RNG_RESET_CMD = 7, RNG_RESET_POSE = 8, RNG_TERRAIN_ROW = 9, RNG_TERRAIN_PERM = 10 };
@@ -2988,7 +2988,8 @@ DEV float reward_term(const Model& m, const DCfg& c, RewState& rs, int id, const
 // (simulator.py:283-284, go2_env_walk.py:1026-1077) + reset-call statistics (:688-715,1228-1235).
 // One lane per env; the kernel is a single wave per 64 envs, so its duration is its dependency chain: every input is loaded before the
 // first store (one memory round trip instead of one per reward term) and the per-term episode sums sit in LDS for the dynamic term loop.
-__global__ __launch_bounds__(WG) void k_env_post_a(Pool P, const Model* __restrict__ mp, const DCfg cv, const Glob* __restrict__ gp,
+DEV void env_globals_body(const DCfg& c, Glob& g, Acc* acc, uint64_t seed, int count_push);
+__global__ __launch_bounds__(WG) void k_env_post_a(Pool P, const Model* __restrict__ mp, const DCfg cv, Glob* gp,
                                                    Acc* acc, uint64_t seed, uint32_t step_count) {
   __shared__ float s_es[NREW][WG], s_r[NREW][WG];
   int b = blockIdx.x * WG + threadIdx.x;
@@ -3115,6 +3116,18 @@ __global__ __launch_bounds__(WG) void k_env_post_a(Pool P, const Model* __restri
     atomicAdd(&acc->timeouts, (double)time_out);
     atomicAdd(&acc->n_reset_now, 1);
   }
+  // The single-thread part of the step (curriculum state machine, "global" DR draws: the quantities the reference keeps in Python scalars)
+  // runs in whichever workgroup finishes last, instead of in a kernel of its own.
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int ticket = atomicAdd(&acc->done, 1);
+    if (ticket == (int)gridDim.x - 1) {
+      __threadfence();
+      acc->done = 0;
+      env_globals_body(c, *gp, acc, seed, 1);
+    }
+  }
 }
 
 // Go2Env.reset: mark every env for reset + statistics (go2_env_walk.py:1242-1245)
@@ -3142,9 +3155,7 @@ __global__ __launch_bounds__(WG) void k_env_mark_all(Pool P, const DCfg* __restr
 }
 
 // single-instance part of reset_idx: curriculum, t_sample, "global" DR (go2_env_walk.py:688-756,803-848,1160-1171)
-__global__ void k_env_globals(const DCfg* __restrict__ cp, Glob* gp, Acc* acc, uint64_t seed, int count_push) {
-  if (blockIdx.x != 0 || threadIdx.x != 0) return;
-  const DCfg& c = *cp; Glob& g = *gp;
+DEV void env_globals_body(const DCfg& c, Glob& g, Acc* acc, uint64_t seed, int count_push) {
   if (count_push && c.i[GO2SIM_IC_HAS_PUSH] && g.push_enable) g.push_counter += 1;
   int n = acc->n_reset_now;
   g.n_reset_now = n;
@@ -3194,6 +3205,11 @@ __global__ void k_env_globals(const DCfg* __restrict__ cp, Glob* gp, Acc* acc, u
     acc->timeouts = 0.0; acc->tracking = 0.0; acc->n_reset_now = 0;
     for (int k = 0; k < NREW; ++k) acc->ep[k] = 0.0;
   }
+}
+// single-thread launch (Go2Env.reset path; the step path runs the body in the last workgroup of k_env_post_a)
+__global__ void k_env_globals(const DCfg* __restrict__ cp, Glob* gp, Acc* acc, uint64_t seed, int count_push) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  env_globals_body(*cp, *gp, acc, seed, count_push);
 }
 
 // per-env part of reset_idx (go2_env_walk.py:1156-1240)
@@ -3359,15 +3375,34 @@ DEV int post_b_src_off(int k) {
   return off;
 }
 template <int T>
-__global__ __launch_bounds__(64) void k_env_post_b_team(Pool P, const Model* __restrict__ mp, const DCfg* __restrict__ cp, const Glob* __restrict__ gp,
-                                                        uint64_t seed, uint32_t step_count, float* __restrict__ obs_out, float* __restrict__ priv_out,
-                                                        float* __restrict__ rew_out, uint8_t* __restrict__ reset_out, float* __restrict__ timeout_out) {
+__global__ __launch_bounds__(64) void k_env_post_b_team(Pool P, const Model* __restrict__ mp, const ModelS* __restrict__ msp, const DCfg* __restrict__ cp,
+                                                        const Glob* __restrict__ gp, uint64_t seed, uint32_t step_count, float* __restrict__ obs_out,
+                                                        float* __restrict__ priv_out, float* __restrict__ rew_out, uint8_t* __restrict__ reset_out,
+                                                        float* __restrict__ timeout_out) {
   constexpr int EPW = 64 / T;
+  // FK refresh after a reset call (the reference's set_dofs_position / set_pos / set_quat re-run the full-batch FK, and the "global" mass /
+  // COM randomisation touches every env): done here, at the end of the kernel, instead of in a launch of its own.  The model tables are
+  // requested first (LDS DMA by all 64 lanes, before any lane retires) and are complete at the barrier that precedes their use.
+  __shared__ KinData fk_lds[EPW];
+  __shared__ alignas(16) char ms_raw[MODELS_LDS_BYTES];
+  const bool fk_needed = gp->n_reset_now > 0;
+  if (fk_needed) wg_dma_to_lds<(int)sizeof(ModelS)>(ms_raw, msp);
   const int tl = threadIdx.x % T, slot = threadIdx.x / T;
   const int b = blockIdx.x * EPW + slot;
   if (b >= P.B) return;
   const Model& m = *mp; const DCfg& c = *cp; const Glob& g = *gp;
   E e(P, b);
+  auto fk_refresh = [&]() {
+    if (!fk_needed) return;
+    KinData* ks = &fk_lds[slot];
+    team_sync();                                                       // the reset's qpos / vel / DR stores of this team are visible
+    team_stage<ND, T>(tl, [&](int d) { return gload(e, FO(vel), d); }, [&](int d, float v) { ks->vel[d] = v; });
+    team_stage<NQ, T>(tl, [&](int q) { return gload(e, FO(qpos), q); }, [&](int q, float v) { ks->qpos[q] = v; });
+    tk_stage_links<T>(e, ks, tl);
+    team_sync();
+    const ModelView mv((const ModelS*)ms_raw, msp);
+    tk_kinematics<T>(mv, e, ks, tl, true);
+  };
   const int was_reset = e.reset_buf()[0];
   if (g.n_reset_now > 0) {                                             // reset_tail, spread over the team
     if (tl == 0 && was_reset) env_reset_one(m, c, g, e, b, seed);
@@ -3426,6 +3461,7 @@ __global__ __launch_bounds__(64) void k_env_post_b_team(Pool P, const Model* __r
       if (reset_out) reset_out[b] = (uint8_t)was_reset;
       if (timeout_out) timeout_out[b] = e.time_out()[0];
     }
+    fk_refresh();
     return;
   }
   // every source of the two observation vectors is fetched in one batch (the assembly below would otherwise pay a memory round trip per entry)
@@ -3497,6 +3533,7 @@ __global__ __launch_bounds__(64) void k_env_post_b_team(Pool P, const Model* __r
     if (reset_out) reset_out[b] = (uint8_t)was_reset;
     if (timeout_out) timeout_out[b] = e.time_out()[0];
   }
+  fk_refresh();
 }
 
 __global__ __launch_bounds__(WG) void k_init_state(Pool P, const Model* __restrict__ mp, int keep_dr) {
@@ -3996,10 +4033,8 @@ int go2sim_env_step(go2sim_t* h, const float* actions, float* obs, float* priv, 
   {
     ScopedTimer t(h, s, T_ENV_POST);
     hipLaunchKernelGGL(k_env_post_a, g, b, 0, s, h->P, h->dm, h->hcfg, h->dglob, h->dacc, h->seed, h->step_count);
-    hipLaunchKernelGGL(k_env_globals, dim3(1), dim3(1), 0, s, h->dcfg, h->dglob, h->dacc, h->seed, 1);
     if (h->hcfg.i[GO2SIM_IC_USE_TERRAIN]) hipLaunchKernelGGL(k_env_terrain_rows, dim3((h->B + 255) / 256), dim3(256), 0, s, h->P, h->dcfg, h->dglob, h->seed);
-    hipLaunchKernelGGL(k_env_post_b_team<16>, dim3((h->B + 3) / 4), dim3(64), 0, s, h->P, h->dm, h->dcfg, h->dglob, h->seed, h->step_count, obs, priv, rew, reset, timeout);
-    launch_fk_team(h, s, 1, &h->dglob->n_reset_now);
+    hipLaunchKernelGGL(k_env_post_b_team<16>, dim3((h->B + 3) / 4), dim3(64), 0, s, h->P, h->dm, h->dms, h->dcfg, h->dglob, h->seed, h->step_count, obs, priv, rew, reset, timeout);
   }
   HIPCHK(hipGetLastError());
   h->action_write_idx = (h->action_write_idx + 1) % 2;
