@@ -8,8 +8,10 @@ import sys
 _HERE = os.path.dirname(os.path.abspath(__file__))
 REPO_ROOT = os.path.dirname(_HERE)
 HIP_SRC = os.path.join(_HERE, "csrc", "go2sim.hip")
+HIP_SRC_POLICY = os.path.join(_HERE, "csrc", "go2sim_policy.hip")
 HIP_LIB = os.path.join(_HERE, "csrc", "libgo2sim.so")
 ORACLE_SRC = os.path.join(REPO_ROOT, "oracle", "go2sim_cpu.cpp")
+ORACLE_SRC_POLICY = os.path.join(REPO_ROOT, "oracle", "policy_cpu.cpp")
 ORACLE_LIB = os.path.join(REPO_ROOT, "oracle", "libgo2sim_cpu.so")
 
 # -ffp-contract=off on BOTH sides is part of the numeric contract (include/go2sim_detmath.h):
@@ -32,10 +34,10 @@ def _headers():
 
 
 def build_hip(force=False, verbose=True):
-    if not force and _newer(HIP_LIB, HIP_SRC, *_headers()):
+    if not force and _newer(HIP_LIB, HIP_SRC, HIP_SRC_POLICY, *_headers()):
         return HIP_LIB
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    cmd = [hipcc, *HIP_FLAGS, HIP_SRC, "-o", HIP_LIB]
+    cmd = [hipcc, *HIP_FLAGS, HIP_SRC, HIP_SRC_POLICY, "-o", HIP_LIB]
     if verbose:
         print("[build]", " ".join(cmd), file=sys.stderr)
     subprocess.run(cmd, check=True)
@@ -43,9 +45,9 @@ def build_hip(force=False, verbose=True):
 
 
 def build_oracle(force=False, verbose=True):
-    if not force and _newer(ORACLE_LIB, ORACLE_SRC, *_headers()):
+    if not force and _newer(ORACLE_LIB, ORACLE_SRC, ORACLE_SRC_POLICY, *_headers()):
         return ORACLE_LIB
-    cmd = ["g++", *CPU_FLAGS, ORACLE_SRC, "-o", ORACLE_LIB]
+    cmd = ["g++", *CPU_FLAGS, ORACLE_SRC, ORACLE_SRC_POLICY, "-o", ORACLE_LIB]
     if verbose:
         print("[build]", " ".join(cmd), file=sys.stderr)
     subprocess.run(cmd, check=True)

@@ -43,6 +43,10 @@ def _parse_header(path=HEADER):
 
 
 C, DECLARED_FUNCS = _parse_header()
+# the policy-inference entry points (include/go2sim_policy.h) live in the same two libraries
+_C_POLICY, _DECL_POLICY = _parse_header(os.path.join(REPO_ROOT, "include", "go2sim_policy.h"))
+C.update(_C_POLICY)
+DECLARED_FUNCS = DECLARED_FUNCS + _DECL_POLICY
 
 
 class EnvGlobals(ctypes.Structure):

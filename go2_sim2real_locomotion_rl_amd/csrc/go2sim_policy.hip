@@ -1,0 +1,232 @@
+// go2sim_policy.hip -- policy inference next to the env step (include/go2sim_policy.h).  gfx950 only.
+//
+// One kernel evaluates a whole MLP: a workgroup (4 wavefronts) owns 16 rows of the batch and keeps their activations in LDS across all
+// layers; a layer is a [16 x K] x [K x N] product on the fp32 matrix cores (v_mfma_f32_16x16x4_f32, exact fp32: a k-ordered fma chain), the
+// four wavefronts take the 16-column output tiles round-robin, bias and ELU are applied on the accumulator and the result goes to the other
+// LDS buffer.  Weights stream from L2 (0.8 MB actor / 0.9 MB critic, shared by all 256 workgroups of a 4096-row batch).
+// At 4096 rows this is 256 workgroups = one per CU, 3.3 GFLOP for actor + critic.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../../include/go2sim.h"
+#include "../../include/go2sim_detmath.h"
+#include "../../include/go2sim_policy.h"
+
+namespace {
+
+constexpr int MAXL = GO2SIM_MLP_MAX_LAYERS, MAXW = GO2SIM_MLP_MAX_WIDTH, TM = 16, NWAVE = 4, LDW = MAXW + 4;
+constexpr uint32_t RNG_POLICY_NOISE = 11;   // purposes 1..10 belong to the environment (csrc/go2sim.hip)
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct MlpDev {
+  int n_layers;
+  int din[MAXL], dout[MAXL], kpad[MAXL], npad[MAXL];
+  const float* W[MAXL];   // [npad][kpad], zero padded
+  const float* b[MAXL];   // [npad], zero padded
+};
+
+#define HIPCHK(x)                                                                                   \
+  do {                                                                                              \
+    hipError_t e_ = (x);                                                                            \
+    if (e_ != hipSuccess) { fprintf(stderr, "go2sim_policy: %s failed: %s\n", #x, hipGetErrorString(e_)); return GO2SIM_E_HIP; } \
+  } while (0)
+
+__device__ __forceinline__ float elu1(float v) { return v > 0.0f ? v : dm_exp(v) - 1.0f; }   // nn.ELU(alpha=1)
+
+__global__ __launch_bounds__(64 * NWAVE) void k_mlp_forward(MlpDev M, const float* __restrict__ x, float* __restrict__ y, int B) {
+  __shared__ alignas(16) float act[2][TM][LDW];
+  const int row0 = blockIdx.x * TM;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  {
+    const int K0 = M.kpad[0], d0 = M.din[0];
+    for (int idx = tid; idx < TM * K0; idx += 64 * NWAVE) {
+      int r = idx / K0, k = idx - r * K0, gr = row0 + r;
+      act[0][r][k] = (gr < B && k < d0) ? x[(size_t)gr * d0 + k] : 0.0f;
+    }
+  }
+  __syncthreads();
+  int cur = 0;
+  const int arow = lane & 15, kq = lane >> 4;
+  for (int l = 0; l < M.n_layers; ++l) {
+    const int K = M.kpad[l], N = M.npad[l], dout = M.dout[l];
+    const float* __restrict__ W = M.W[l];
+    const float* __restrict__ bias = M.b[l];
+    const bool last = l == M.n_layers - 1;
+    for (int nt = wave; nt * 16 < N; nt += NWAVE) {
+      const int n = nt * 16 + arow;                       // this lane's output column (B operand) / accumulator column
+      const float* __restrict__ wrow = W + (size_t)n * K + 4 * kq;
+      const float* ap = &act[cur][arow][4 * kq];
+      f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll 4
+      for (int j = 0; j < K; j += 16) {
+        const float4 wv = *(const float4*)(wrow + j);
+        const float4 av = *(const float4*)(ap + j);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, wv.x, acc, 0, 0, 0);   // k = j + 4 q + 0, q = 0..3
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, wv.y, acc, 0, 0, 0);   // k = j + 4 q + 1
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, wv.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, wv.w, acc, 0, 0, 0);
+      }
+      const float bv = bias[n];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {                       // accumulator element i of this lane: row 4 * (lane >> 4) + i, column lane & 15
+        const int r = 4 * kq + i;
+        float v = acc[i] + bv;
+        if (last) {
+          const int gr = row0 + r;
+          if (gr < B && n < dout) y[(size_t)gr * dout + n] = v;
+        } else {
+          act[cur ^ 1][r][n] = elu1(v);
+        }
+      }
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+}
+
+// Normal(mean, std).sample() + log_prob, one lane per row (A <= 16 actions)
+__global__ __launch_bounds__(64) void k_policy_sample(const float* __restrict__ mean, const float* __restrict__ std_, int B, int A, uint64_t seed, uint32_t step,
+                                                      int deterministic, float* __restrict__ actions, float* __restrict__ log_prob) {
+  const int b = blockIdx.x * 64 + threadIdx.x;
+  if (b >= B) return;
+  float lp = 0.0f;
+  for (int blk = 0; 4 * blk < A; ++blk) {
+    float n[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (!deterministic) {
+      dm_u4 r = dm_philox((uint32_t)b, step, RNG_POLICY_NOISE, (uint32_t)blk, (uint32_t)seed, (uint32_t)(seed >> 32));
+      dm_normal2(r.v[0], r.v[1], &n[0], &n[1]); dm_normal2(r.v[2], r.v[3], &n[2], &n[3]);
+    }
+    for (int k = 0; k < 4; ++k) {
+      const int a = 4 * blk + k;
+      if (a >= A) break;
+      const float mu = mean[(size_t)b * A + a], sd = std_[a];
+      const float act = mu + sd * n[k];
+      actions[(size_t)b * A + a] = act;
+      const float d = act - mu;
+      lp = lp + ((-(d * d) / (2.0f * (sd * sd)) - dm_log(sd)) - 0.91893853320467274178f);
+    }
+  }
+  if (log_prob) log_prob[b] = lp;
+}
+
+int round16(int v) { return (v + 15) / 16 * 16; }
+
+}  // namespace
+
+struct go2sim_mlp {
+  int device = 0;
+  int n_layers = 0;
+  int dims[MAXL + 1] = {0};
+  size_t n_params = 0;
+  float* dparams = nullptr;   // padded weights + biases, one allocation
+  size_t padded = 0;
+  MlpDev dev{};
+  float* scratch_mean = nullptr; int scratch_rows = 0;   // mean buffer of go2sim_policy_act when the caller passes mean == NULL
+};
+
+namespace {
+size_t expected_params(const int* dims, int n_layers) {
+  size_t n = 0;
+  for (int l = 0; l < n_layers; ++l) n += (size_t)dims[l] * dims[l + 1] + dims[l + 1];
+  return n;
+}
+// pack [out][in] + [out] into the zero-padded device layout
+void pack_padded(const go2sim_mlp* h, const float* params, std::vector<float>& out) {
+  out.assign(h->padded, 0.0f);
+  size_t src = 0, dst = 0;
+  for (int l = 0; l < h->n_layers; ++l) {
+    const int din = h->dims[l], dout = h->dims[l + 1], kp = round16(din), np = round16(dout);
+    for (int n = 0; n < dout; ++n) memcpy(&out[dst + (size_t)n * kp], &params[src + (size_t)n * din], sizeof(float) * din);
+    src += (size_t)din * dout; dst += (size_t)kp * np;
+    memcpy(&out[dst], &params[src], sizeof(float) * dout);
+    src += dout; dst += np;
+  }
+}
+}  // namespace
+
+extern "C" {
+
+int go2sim_mlp_create(int device, const int* dims, int n_layers, const float* params, size_t n_params, go2sim_mlp_t** out) {
+  if (!dims || !params || !out || n_layers < 1 || n_layers > MAXL) return GO2SIM_E_BADARG;
+  for (int l = 0; l <= n_layers; ++l) if (dims[l] < 1 || dims[l] > MAXW) return GO2SIM_E_BADARG;
+  if (n_params != expected_params(dims, n_layers)) return GO2SIM_E_BADARG;
+  HIPCHK(hipSetDevice(device));
+  go2sim_mlp* h = new (std::nothrow) go2sim_mlp();
+  if (!h) return GO2SIM_E_NOMEM;
+  h->device = device; h->n_layers = n_layers; h->n_params = n_params;
+  memcpy(h->dims, dims, sizeof(int) * (n_layers + 1));
+  size_t padded = 0;
+  for (int l = 0; l < n_layers; ++l) padded += (size_t)round16(dims[l]) * round16(dims[l + 1]) + round16(dims[l + 1]);
+  h->padded = padded;
+  if (hipMalloc((void**)&h->dparams, padded * sizeof(float)) != hipSuccess) { delete h; return GO2SIM_E_NOMEM; }
+  h->dev.n_layers = n_layers;
+  size_t off = 0;
+  for (int l = 0; l < n_layers; ++l) {
+    const int kp = round16(dims[l]), np = round16(dims[l + 1]);
+    h->dev.din[l] = dims[l]; h->dev.dout[l] = dims[l + 1]; h->dev.kpad[l] = kp; h->dev.npad[l] = np;
+    h->dev.W[l] = h->dparams + off; off += (size_t)kp * np;
+    h->dev.b[l] = h->dparams + off; off += np;
+  }
+  int rc = go2sim_mlp_set_params(h, params, n_params, nullptr);
+  if (rc != GO2SIM_E_OK) { (void)hipFree(h->dparams); delete h; return rc; }
+  HIPCHK(hipDeviceSynchronize());
+  *out = h;
+  return GO2SIM_E_OK;
+}
+
+int go2sim_mlp_destroy(go2sim_mlp_t* h) {
+  if (!h) return GO2SIM_E_BADARG;
+  (void)hipFree(h->dparams);
+  if (h->scratch_mean) (void)hipFree(h->scratch_mean);
+  delete h;
+  return GO2SIM_E_OK;
+}
+
+int go2sim_mlp_set_params(go2sim_mlp_t* h, const float* params, size_t n_params, void* stream) {
+  if (!h || !params || n_params != h->n_params) return GO2SIM_E_BADARG;
+  std::vector<float> packed;
+  pack_padded(h, params, packed);
+  HIPCHK(hipMemcpyAsync(h->dparams, packed.data(), h->padded * sizeof(float), hipMemcpyHostToDevice, (hipStream_t)stream));
+  HIPCHK(hipStreamSynchronize((hipStream_t)stream));   // `packed` is a temporary
+  return GO2SIM_E_OK;
+}
+
+int go2sim_mlp_forward(go2sim_mlp_t* h, const float* x, float* y, int n_rows, void* stream) {
+  if (!h || !x || !y || n_rows < 0) return GO2SIM_E_BADARG;
+  if (n_rows == 0) return GO2SIM_E_OK;
+  hipLaunchKernelGGL(k_mlp_forward, dim3((n_rows + TM - 1) / TM), dim3(64 * NWAVE), 0, (hipStream_t)stream, h->dev, x, y, n_rows);
+  HIPCHK(hipGetLastError());
+  return GO2SIM_E_OK;
+}
+
+int go2sim_policy_act(go2sim_mlp_t* actor, go2sim_mlp_t* critic, const float* obs, const float* critic_obs, const float* std_, int n_rows,
+                      uint64_t seed, uint32_t step, int deterministic, float* actions, float* mean, float* values, float* log_prob, void* stream) {
+  if (!actor || !obs || !std_ || !actions || n_rows < 0) return GO2SIM_E_BADARG;
+  if ((values != nullptr) != (critic != nullptr && critic_obs != nullptr)) return GO2SIM_E_BADARG;
+  if (critic && critic->dims[critic->n_layers] != 1) return GO2SIM_E_BADARG;
+  if (n_rows == 0) return GO2SIM_E_OK;
+  const int A = actor->dims[actor->n_layers];
+  float* mu = mean;
+  if (!mu) {
+    if (actor->scratch_rows < n_rows) {
+      if (actor->scratch_mean) (void)hipFree(actor->scratch_mean);
+      actor->scratch_mean = nullptr; actor->scratch_rows = 0;
+      if (hipMalloc((void**)&actor->scratch_mean, (size_t)n_rows * A * sizeof(float)) != hipSuccess) return GO2SIM_E_NOMEM;
+      actor->scratch_rows = n_rows;
+    }
+    mu = actor->scratch_mean;
+  }
+  int rc = go2sim_mlp_forward(actor, obs, mu, n_rows, stream);
+  if (rc != GO2SIM_E_OK) return rc;
+  if (critic) { rc = go2sim_mlp_forward(critic, critic_obs, values, n_rows, stream); if (rc != GO2SIM_E_OK) return rc; }
+  hipLaunchKernelGGL(k_policy_sample, dim3((n_rows + 63) / 64), dim3(64), 0, (hipStream_t)stream, mu, std_, n_rows, A, seed, step, deterministic, actions, log_prob);
+  HIPCHK(hipGetLastError());
+  return GO2SIM_E_OK;
+}
+
+}  // extern "C"
