@@ -38,8 +38,66 @@ struct MlpDev {
 
 __device__ __forceinline__ float elu1(float v) { return v > 0.0f ? v : dm_exp(v) - 1.0f; }   // nn.ELU(alpha=1)
 
-__global__ __launch_bounds__(64 * NWAVE) void k_mlp_forward(MlpDev M, const float* __restrict__ x, float* __restrict__ y, int B) {
+// One layer for the 16 rows of the workgroup.  A wavefront works on TG output tiles (16 columns each) at a time: TG independent accumulators
+// share one A fragment per K step and keep TG weight loads in flight (the loop is bound by the latency of the weight stream from L2).
+template <int TG>
+__device__ __forceinline__ void mlp_layer(const MlpDev& M, int l, const float (*in)[LDW], float (*out)[LDW], float* __restrict__ y, int row0, int B, int wave, int lane) {
+  const int K = M.kpad[l], N = M.npad[l], dout = M.dout[l], ntiles = N / 16;
+  const float* __restrict__ W = M.W[l];
+  const float* __restrict__ bias = M.b[l];
+  const bool last = l == M.n_layers - 1;
+  const int arow = lane & 15, kq = lane >> 4;
+  const float* ap = &in[arow][4 * kq];
+  for (int g0 = wave * TG; g0 < ntiles; g0 += NWAVE * TG) {
+    f32x4 acc[TG];
+    const float* wrow[TG];
+#pragma unroll
+    for (int t = 0; t < TG; ++t) {
+      acc[t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+      const int nt = (g0 + t < ntiles) ? g0 + t : ntiles - 1;          // a short last group recomputes the last tile (not stored)
+      wrow[t] = W + (size_t)(nt * 16 + arow) * K + 4 * kq;
+    }
+#pragma unroll 2
+    for (int j = 0; j < K; j += 16) {
+      const float4 av = *(const float4*)(ap + j);
+      float4 wv[TG];
+#pragma unroll
+      for (int t = 0; t < TG; ++t) wv[t] = *(const float4*)(wrow[t] + j);
+#pragma unroll
+      for (int t = 0; t < TG; ++t) {
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, wv[t].x, acc[t], 0, 0, 0);   // k = j + 4 q + 0, q = 0..3
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, wv[t].y, acc[t], 0, 0, 0);   // k = j + 4 q + 1
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, wv[t].z, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, wv[t].w, acc[t], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < TG; ++t) {
+      if (g0 + t >= ntiles) break;
+      const int n = (g0 + t) * 16 + arow;                              // accumulator element i of this lane: row 4 * (lane >> 4) + i, column lane & 15
+      const float bv = bias[n];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int r = 4 * kq + i;
+        const float v = acc[t][i] + bv;
+        if (last) {
+          const int gr = row0 + r;
+          if (gr < B && n < dout) y[(size_t)gr * dout + n] = v;
+        } else {
+          out[r][n] = elu1(v);
+        }
+      }
+    }
+  }
+}
+
+// blockIdx.y selects the network: actor and critic of one policy step share a launch (2 x 256 workgroups at 4096 rows, two per CU)
+__global__ __launch_bounds__(64 * NWAVE) void k_mlp_forward(MlpDev M0, const float* __restrict__ x0, float* __restrict__ y0,
+                                                            MlpDev M1, const float* __restrict__ x1, float* __restrict__ y1, int B) {
   __shared__ alignas(16) float act[2][TM][LDW];
+  const MlpDev& M = blockIdx.y == 0 ? M0 : M1;
+  const float* __restrict__ x = blockIdx.y == 0 ? x0 : x1;
+  float* __restrict__ y = blockIdx.y == 0 ? y0 : y1;
   const int row0 = blockIdx.x * TM;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   {
@@ -51,39 +109,11 @@ __global__ __launch_bounds__(64 * NWAVE) void k_mlp_forward(MlpDev M, const floa
   }
   __syncthreads();
   int cur = 0;
-  const int arow = lane & 15, kq = lane >> 4;
   for (int l = 0; l < M.n_layers; ++l) {
-    const int K = M.kpad[l], N = M.npad[l], dout = M.dout[l];
-    const float* __restrict__ W = M.W[l];
-    const float* __restrict__ bias = M.b[l];
-    const bool last = l == M.n_layers - 1;
-    for (int nt = wave; nt * 16 < N; nt += NWAVE) {
-      const int n = nt * 16 + arow;                       // this lane's output column (B operand) / accumulator column
-      const float* __restrict__ wrow = W + (size_t)n * K + 4 * kq;
-      const float* ap = &act[cur][arow][4 * kq];
-      f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll 4
-      for (int j = 0; j < K; j += 16) {
-        const float4 wv = *(const float4*)(wrow + j);
-        const float4 av = *(const float4*)(ap + j);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, wv.x, acc, 0, 0, 0);   // k = j + 4 q + 0, q = 0..3
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, wv.y, acc, 0, 0, 0);   // k = j + 4 q + 1
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, wv.z, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, wv.w, acc, 0, 0, 0);
-      }
-      const float bv = bias[n];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {                       // accumulator element i of this lane: row 4 * (lane >> 4) + i, column lane & 15
-        const int r = 4 * kq + i;
-        float v = acc[i] + bv;
-        if (last) {
-          const int gr = row0 + r;
-          if (gr < B && n < dout) y[(size_t)gr * dout + n] = v;
-        } else {
-          act[cur ^ 1][r][n] = elu1(v);
-        }
-      }
-    }
+    const int tiles_per_wave = (M.npad[l] / 16 + NWAVE - 1) / NWAVE;
+    if (tiles_per_wave >= 4) mlp_layer<4>(M, l, act[cur], act[cur ^ 1], y, row0, B, wave, lane);
+    else if (tiles_per_wave >= 2) mlp_layer<2>(M, l, act[cur], act[cur ^ 1], y, row0, B, wave, lane);
+    else mlp_layer<1>(M, l, act[cur], act[cur ^ 1], y, row0, B, wave, lane);
     __syncthreads();
     cur ^= 1;
   }
@@ -199,7 +229,7 @@ int go2sim_mlp_set_params(go2sim_mlp_t* h, const float* params, size_t n_params,
 int go2sim_mlp_forward(go2sim_mlp_t* h, const float* x, float* y, int n_rows, void* stream) {
   if (!h || !x || !y || n_rows < 0) return GO2SIM_E_BADARG;
   if (n_rows == 0) return GO2SIM_E_OK;
-  hipLaunchKernelGGL(k_mlp_forward, dim3((n_rows + TM - 1) / TM), dim3(64 * NWAVE), 0, (hipStream_t)stream, h->dev, x, y, n_rows);
+  hipLaunchKernelGGL(k_mlp_forward, dim3((n_rows + TM - 1) / TM, 1), dim3(64 * NWAVE), 0, (hipStream_t)stream, h->dev, x, y, h->dev, x, y, n_rows);
   HIPCHK(hipGetLastError());
   return GO2SIM_E_OK;
 }
@@ -221,9 +251,13 @@ int go2sim_policy_act(go2sim_mlp_t* actor, go2sim_mlp_t* critic, const float* ob
     }
     mu = actor->scratch_mean;
   }
-  int rc = go2sim_mlp_forward(actor, obs, mu, n_rows, stream);
-  if (rc != GO2SIM_E_OK) return rc;
-  if (critic) { rc = go2sim_mlp_forward(critic, critic_obs, values, n_rows, stream); if (rc != GO2SIM_E_OK) return rc; }
+  if (critic) {
+    hipLaunchKernelGGL(k_mlp_forward, dim3((n_rows + TM - 1) / TM, 2), dim3(64 * NWAVE), 0, (hipStream_t)stream, actor->dev, obs, mu, critic->dev, critic_obs, values, n_rows);
+    HIPCHK(hipGetLastError());
+  } else {
+    int rc = go2sim_mlp_forward(actor, obs, mu, n_rows, stream);
+    if (rc != GO2SIM_E_OK) return rc;
+  }
   hipLaunchKernelGGL(k_policy_sample, dim3((n_rows + 63) / 64), dim3(64), 0, (hipStream_t)stream, mu, std_, n_rows, A, seed, step, deterministic, actions, log_prob);
   HIPCHK(hipGetLastError());
   return GO2SIM_E_OK;
