@@ -144,6 +144,63 @@ __global__ __launch_bounds__(64) void k_policy_sample(const float* __restrict__ 
   if (log_prob) log_prob[b] = lp;
 }
 
+// ---- rollout storage (rsl_rl RolloutStorage.compute_returns) ----
+__global__ __launch_bounds__(64) void k_rollout_add(float* __restrict__ rew, float* __restrict__ val, uint8_t* __restrict__ don, int B, const float* __restrict__ r,
+                                                    const uint8_t* __restrict__ d, const float* __restrict__ v, const float* __restrict__ to, float gamma) {
+  const int b = blockIdx.x * 64 + threadIdx.x;
+  if (b >= B) return;
+  float rr = r[b];
+  const float vv = v[b];
+  if (to) rr = rr + gamma * (vv * to[b]);                               // PPO.process_env_step: bootstrap on time-outs
+  rew[b] = rr; val[b] = vv; don[b] = d[b];
+}
+constexpr int GAE_WG = 256;
+// one lane per env walks the rollout backwards; per-workgroup moments of the advantages in a fixed order
+__global__ __launch_bounds__(GAE_WG) void k_gae(const float* __restrict__ rew, const float* __restrict__ val, const uint8_t* __restrict__ don, const float* __restrict__ last_values,
+                                                int T, int B, float gamma, float lam, float* __restrict__ ret, float* __restrict__ adv, double* __restrict__ partial) {
+  __shared__ double s_sum[GAE_WG], s_sq[GAE_WG];
+  const int b = blockIdx.x * GAE_WG + threadIdx.x;
+  double sum = 0.0, sq = 0.0;
+  if (b < B) {
+    float advantage = 0.0f, next_v = last_values[b];
+    for (int t = T - 1; t >= 0; --t) {
+      const size_t i = (size_t)t * B + b;
+      const float not_terminal = 1.0f - (float)don[i];
+      const float v = val[i];
+      const float delta = (rew[i] + (not_terminal * gamma) * next_v) - v;
+      advantage = delta + ((not_terminal * gamma) * lam) * advantage;
+      const float r = advantage + v;
+      ret[i] = r;
+      const float a = r - v;
+      adv[i] = a;
+      sum += (double)a; sq += (double)a * (double)a;
+      next_v = v;
+    }
+  }
+  s_sum[threadIdx.x] = sum; s_sq[threadIdx.x] = sq;
+  __syncthreads();
+  for (int s = GAE_WG / 2; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) { s_sum[threadIdx.x] += s_sum[threadIdx.x + s]; s_sq[threadIdx.x] += s_sq[threadIdx.x + s]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { partial[2 * blockIdx.x] = s_sum[0]; partial[2 * blockIdx.x + 1] = s_sq[0]; }
+}
+__global__ void k_gae_moments(const double* __restrict__ partial, int n_wg, double count, double* __restrict__ moments3) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  double s = 0.0, q = 0.0;
+  for (int i = 0; i < n_wg; ++i) { s += partial[2 * i]; q += partial[2 * i + 1]; }
+  moments3[0] = s; moments3[1] = q; moments3[2] = count;
+}
+__global__ __launch_bounds__(256) void k_adv_normalize(float* __restrict__ adv, size_t n, const double* __restrict__ moments3) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const double N = moments3[2], mean = moments3[0] / N;
+  double var = (moments3[1] - N * mean * mean) / (N > 1.0 ? N - 1.0 : 1.0);   // torch.std: unbiased
+  if (var < 0.0) var = 0.0;
+  const float meanf = (float)mean, stdf = (float)sqrt(var);
+  adv[i] = (adv[i] - meanf) / (stdf + 1e-8f);
+}
+
 int round16(int v) { return (v + 15) / 16 * 16; }
 
 }  // namespace
@@ -157,6 +214,13 @@ struct go2sim_mlp {
   size_t padded = 0;
   MlpDev dev{};
   float* scratch_mean = nullptr; int scratch_rows = 0;   // mean buffer of go2sim_policy_act when the caller passes mean == NULL
+};
+
+struct go2sim_rollout {
+  int T = 0, B = 0, n_wg = 0;
+  float* f = nullptr;        // rewards | values | returns | advantages, each [T][B]
+  uint8_t* dones = nullptr;  // [T][B]
+  double* partial = nullptr; // per-workgroup (sum, sum of squares)
 };
 
 namespace {
@@ -260,6 +324,65 @@ int go2sim_policy_act(go2sim_mlp_t* actor, go2sim_mlp_t* critic, const float* ob
   }
   hipLaunchKernelGGL(k_policy_sample, dim3((n_rows + 63) / 64), dim3(64), 0, (hipStream_t)stream, mu, std_, n_rows, A, seed, step, deterministic, actions, log_prob);
   HIPCHK(hipGetLastError());
+  return GO2SIM_E_OK;
+}
+
+// ---- rollout storage ----
+int go2sim_rollout_create(int device, int n_steps, int n_envs, go2sim_rollout_t** out) {
+  if (!out || n_steps < 1 || n_envs < 1) return GO2SIM_E_BADARG;
+  HIPCHK(hipSetDevice(device));
+  go2sim_rollout* h = new (std::nothrow) go2sim_rollout();
+  if (!h) return GO2SIM_E_NOMEM;
+  h->T = n_steps; h->B = n_envs; h->n_wg = (n_envs + GAE_WG - 1) / GAE_WG;
+  const size_t n = (size_t)n_steps * n_envs;
+  if (hipMalloc((void**)&h->f, 4 * n * sizeof(float)) != hipSuccess || hipMalloc((void**)&h->dones, n) != hipSuccess ||
+      hipMalloc((void**)&h->partial, 2 * (size_t)h->n_wg * sizeof(double)) != hipSuccess) { go2sim_rollout_destroy(h); return GO2SIM_E_NOMEM; }
+  HIPCHK(hipMemset(h->f, 0, 4 * n * sizeof(float)));
+  HIPCHK(hipMemset(h->dones, 0, n));
+  *out = h;
+  return GO2SIM_E_OK;
+}
+int go2sim_rollout_destroy(go2sim_rollout_t* h) {
+  if (!h) return GO2SIM_E_BADARG;
+  if (h->f) (void)hipFree(h->f);
+  if (h->dones) (void)hipFree(h->dones);
+  if (h->partial) (void)hipFree(h->partial);
+  delete h;
+  return GO2SIM_E_OK;
+}
+int go2sim_rollout_add(go2sim_rollout_t* h, int t, const float* rewards, const uint8_t* dones, const float* values, const float* time_outs, float gamma, void* stream) {
+  if (!h || t < 0 || t >= h->T || !rewards || !dones || !values) return GO2SIM_E_BADARG;
+  const size_t n = (size_t)h->T * h->B, o = (size_t)t * h->B;
+  hipLaunchKernelGGL(k_rollout_add, dim3((h->B + 63) / 64), dim3(64), 0, (hipStream_t)stream, h->f + o, h->f + n + o, h->dones + o, h->B, rewards, dones, values, time_outs, gamma);
+  HIPCHK(hipGetLastError());
+  return GO2SIM_E_OK;
+}
+int go2sim_rollout_compute_returns(go2sim_rollout_t* h, const float* last_values, float gamma, float lam, double* moments3, void* stream) {
+  if (!h || !last_values || !moments3) return GO2SIM_E_BADARG;
+  const size_t n = (size_t)h->T * h->B;
+  hipLaunchKernelGGL(k_gae, dim3(h->n_wg), dim3(GAE_WG), 0, (hipStream_t)stream, h->f, h->f + n, h->dones, last_values, h->T, h->B, gamma, lam, h->f + 2 * n, h->f + 3 * n, h->partial);
+  hipLaunchKernelGGL(k_gae_moments, dim3(1), dim3(1), 0, (hipStream_t)stream, h->partial, h->n_wg, (double)n, moments3);
+  HIPCHK(hipGetLastError());
+  return GO2SIM_E_OK;
+}
+int go2sim_rollout_normalize(go2sim_rollout_t* h, const double* moments3, void* stream) {
+  if (!h || !moments3) return GO2SIM_E_BADARG;
+  const size_t n = (size_t)h->T * h->B;
+  hipLaunchKernelGGL(k_adv_normalize, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, h->f + 3 * n, n, moments3);
+  HIPCHK(hipGetLastError());
+  return GO2SIM_E_OK;
+}
+int go2sim_rollout_ptr(go2sim_rollout_t* h, int buf, void** out) {
+  if (!h || !out) return GO2SIM_E_BADARG;
+  const size_t n = (size_t)h->T * h->B;
+  switch (buf) {
+    case GO2SIM_RB_REWARDS: *out = h->f; break;
+    case GO2SIM_RB_VALUES: *out = h->f + n; break;
+    case GO2SIM_RB_DONES: *out = h->dones; break;
+    case GO2SIM_RB_RETURNS: *out = h->f + 2 * n; break;
+    case GO2SIM_RB_ADVANTAGES: *out = h->f + 3 * n; break;
+    default: return GO2SIM_E_BADARG;
+  }
   return GO2SIM_E_OK;
 }
 

@@ -43,3 +43,18 @@ def global_mean_std(x: torch.Tensor, group=None, eps: float = 1e-8):
 def normalize_advantages(adv: torch.Tensor, group=None, eps: float = 1e-8) -> torch.Tensor:
     mean, std = global_mean_std(adv, group, eps)
     return (adv - mean) / std
+
+
+def allgather_moments(moments3: torch.Tensor, group=None) -> torch.Tensor:
+    """Global [sum, sum of squares, count] from the per-rank moments of go2sim_rollout_compute_returns (float64[3]): one all-gather of
+    3 values per rank (RCCL over xGMI with backend "nccl", gloo in the CPU tests), summed in rank order so that every rank gets the same bits."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        world = dist.get_world_size(group)
+        out = torch.empty(3 * world, device=moments3.device, dtype=moments3.dtype)
+        dist.all_gather_into_tensor(out, moments3.contiguous(), group=group)
+        out = out.view(world, 3)
+        g = out[0].clone()
+        for r in range(1, world):
+            g = g + out[r]
+        return g
+    return moments3

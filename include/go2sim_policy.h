@@ -58,6 +58,30 @@ int go2sim_mlp_forward(go2sim_mlp_t* h, const float* x, float* y, int n_rows, vo
 int go2sim_policy_act(go2sim_mlp_t* actor, go2sim_mlp_t* critic, const float* obs, const float* critic_obs, const float* std, int n_rows,
                       uint64_t seed, uint32_t step, int deterministic, float* actions, float* mean, float* values, float* log_prob, void* stream);
 
+/* ---- rollout storage: returns / advantages of one rollout on the device ----------------------------------------
+ * Replaces rsl_rl.storage.RolloutStorage.add_transitions / compute_returns as PPO uses them (rsl-rl-lib==2.2.4, third party):
+ *   PPO.process_env_step : rewards += gamma * values * time_outs            (bootstrap on time-outs)
+ *   compute_returns      : advantage = 0; for t = T-1 .. 0:
+ *                            not_terminal = 1 - dones[t];  next_v = (t == T-1) ? last_values : values[t+1]
+ *                            delta = rewards[t] + not_terminal * gamma * next_v - values[t]
+ *                            advantage = delta + not_terminal * gamma * lam * advantage;  returns[t] = advantage + values[t]
+ *                          advantages = returns - values;  advantages = (advantages - mean) / (std + 1e-8)   (torch.std: unbiased)
+ * All arrays are [T][B] row-major on the device, owned by the handle.  The mean / std are taken over ALL ranks of a multi-GPU job: the
+ * library produces the local moments [sum, sum of squares, count] (float64, fixed summation order => bit-reproducible), the caller
+ * all-gathers them over RCCL (distributed.py) and hands the global moments to go2sim_rollout_normalize. */
+typedef struct go2sim_rollout go2sim_rollout_t;
+enum go2sim_rollout_buf { GO2SIM_RB_REWARDS = 0, GO2SIM_RB_VALUES, GO2SIM_RB_DONES /* u8 */, GO2SIM_RB_RETURNS, GO2SIM_RB_ADVANTAGES };
+int go2sim_rollout_create(int device, int n_steps, int n_envs, go2sim_rollout_t** out);
+int go2sim_rollout_destroy(go2sim_rollout_t* h);
+/* transition t of the rollout (device pointers [n_envs]); time_outs may be NULL */
+int go2sim_rollout_add(go2sim_rollout_t* h, int t, const float* rewards, const uint8_t* dones, const float* values, const float* time_outs, float gamma, void* stream);
+/* returns, un-normalised advantages and the local moments (moments3: device pointer to 3 float64) */
+int go2sim_rollout_compute_returns(go2sim_rollout_t* h, const float* last_values, float gamma, float lam, double* moments3, void* stream);
+/* advantages <- (advantages - mean) / (std + 1e-8) with the (global) moments */
+int go2sim_rollout_normalize(go2sim_rollout_t* h, const double* moments3, void* stream);
+/* zero-copy device pointer of one buffer (no ownership transfer) */
+int go2sim_rollout_ptr(go2sim_rollout_t* h, int buf, void** out);
+
 #ifdef __cplusplus
 }
 #endif

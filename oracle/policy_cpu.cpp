@@ -24,6 +24,8 @@ struct go2sim_mlp {
   std::vector<float> params;
 };
 
+struct go2sim_rollout { int T = 0, B = 0; std::vector<float> f; std::vector<uint8_t> dones; };
+
 namespace {
 size_t expected_params(const int* dims, int n_layers) {
   size_t n = 0;
@@ -116,6 +118,90 @@ int go2sim_cpu_policy_act(go2sim_mlp_t* actor, go2sim_mlp_t* critic, const float
       }
     }
     if (log_prob) log_prob[b] = lp;
+  }
+  return GO2SIM_E_OK;
+}
+
+// ---- rollout storage (rsl_rl.storage.RolloutStorage.add_transitions / compute_returns + PPO.process_env_step; rsl-rl-lib==2.2.4) ----
+int go2sim_cpu_rollout_create(int, int n_steps, int n_envs, go2sim_rollout_t** out) {
+  if (!out || n_steps < 1 || n_envs < 1) return GO2SIM_E_BADARG;
+  go2sim_rollout* h = new (std::nothrow) go2sim_rollout();
+  if (!h) return GO2SIM_E_NOMEM;
+  h->T = n_steps; h->B = n_envs;
+  const size_t n = (size_t)n_steps * n_envs;
+  h->f.assign(4 * n, 0.0f); h->dones.assign(n, 0);
+  *out = h;
+  return GO2SIM_E_OK;
+}
+int go2sim_cpu_rollout_destroy(go2sim_rollout_t* h) { if (!h) return GO2SIM_E_BADARG; delete h; return GO2SIM_E_OK; }
+int go2sim_cpu_rollout_add(go2sim_rollout_t* h, int t, const float* rewards, const uint8_t* dones, const float* values, const float* time_outs, float gamma, void*) {
+  if (!h || t < 0 || t >= h->T || !rewards || !dones || !values) return GO2SIM_E_BADARG;
+  const size_t n = (size_t)h->T * h->B, o = (size_t)t * h->B;
+  for (int b = 0; b < h->B; ++b) {
+    float rr = rewards[b];
+    if (time_outs) rr = rr + gamma * (values[b] * time_outs[b]);
+    h->f[o + b] = rr; h->f[n + o + b] = values[b]; h->dones[o + b] = dones[b];
+  }
+  return GO2SIM_E_OK;
+}
+int go2sim_cpu_rollout_compute_returns(go2sim_rollout_t* h, const float* last_values, float gamma, float lam, double* moments3, void*) {
+  if (!h || !last_values || !moments3) return GO2SIM_E_BADARG;
+  const int T = h->T, B = h->B;
+  const size_t n = (size_t)T * B;
+  const float* rew = h->f.data(); const float* val = rew + n; float* ret = h->f.data() + 2 * n; float* adv = h->f.data() + 3 * n;
+  // same summation tree as the device kernel: 256-env workgroups, pairwise tree inside, workgroups in order
+  const int WG = 256, n_wg = (B + WG - 1) / WG;
+  double S = 0.0, Q = 0.0;
+  for (int w = 0; w < n_wg; ++w) {
+    double s_sum[256], s_sq[256];
+    for (int l = 0; l < WG; ++l) {
+      const int b = w * WG + l;
+      double sum = 0.0, sq = 0.0;
+      if (b < B) {
+        float advantage = 0.0f, next_v = last_values[b];
+        for (int t = T - 1; t >= 0; --t) {
+          const size_t i = (size_t)t * B + b;
+          const float not_terminal = 1.0f - (float)h->dones[i];
+          const float v = val[i];
+          const float delta = (rew[i] + (not_terminal * gamma) * next_v) - v;
+          advantage = delta + ((not_terminal * gamma) * lam) * advantage;
+          const float r = advantage + v;
+          ret[i] = r;
+          const float a = r - v;
+          adv[i] = a;
+          sum += (double)a; sq += (double)a * (double)a;
+          next_v = v;
+        }
+      }
+      s_sum[l] = sum; s_sq[l] = sq;
+    }
+    for (int s = WG / 2; s > 0; s >>= 1) for (int l = 0; l < s; ++l) { s_sum[l] += s_sum[l + s]; s_sq[l] += s_sq[l + s]; }
+    S += s_sum[0]; Q += s_sq[0];
+  }
+  moments3[0] = S; moments3[1] = Q; moments3[2] = (double)n;
+  return GO2SIM_E_OK;
+}
+int go2sim_cpu_rollout_normalize(go2sim_rollout_t* h, const double* moments3, void*) {
+  if (!h || !moments3) return GO2SIM_E_BADARG;
+  const size_t n = (size_t)h->T * h->B;
+  float* adv = h->f.data() + 3 * n;
+  const double N = moments3[2], mean = moments3[0] / N;
+  double var = (moments3[1] - N * mean * mean) / (N > 1.0 ? N - 1.0 : 1.0);
+  if (var < 0.0) var = 0.0;
+  const float meanf = (float)mean, stdf = (float)sqrt(var);
+  for (size_t i = 0; i < n; ++i) adv[i] = (adv[i] - meanf) / (stdf + 1e-8f);
+  return GO2SIM_E_OK;
+}
+int go2sim_cpu_rollout_ptr(go2sim_rollout_t* h, int buf, void** out) {
+  if (!h || !out) return GO2SIM_E_BADARG;
+  const size_t n = (size_t)h->T * h->B;
+  switch (buf) {
+    case GO2SIM_RB_REWARDS: *out = h->f.data(); break;
+    case GO2SIM_RB_VALUES: *out = h->f.data() + n; break;
+    case GO2SIM_RB_DONES: *out = h->dones.data(); break;
+    case GO2SIM_RB_RETURNS: *out = h->f.data() + 2 * n; break;
+    case GO2SIM_RB_ADVANTAGES: *out = h->f.data() + 3 * n; break;
+    default: return GO2SIM_E_BADARG;
   }
   return GO2SIM_E_OK;
 }
