@@ -115,6 +115,9 @@ def main():
     ap.add_argument("--workload", choices=["walk", "stairs", "jump_dr"], default="walk",
                     help="walk = BASELINE configs[1] (the headline metric); stairs = configs[2] (heightfield terrain), jump_dr = configs[4] "
                          "(jump env + per-env mass / friction randomisation) -- both reported for information")
+    ap.add_argument("--rollout", action="store_true",
+                    help="closed rollout loop for information (NOT the headline metric): actions from ActorCritic.act (random-init weights), "
+                         "RolloutStorage.add_transitions every step, compute_returns + global advantage statistics every 24 steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile-pass", action="store_true")
     args = ap.parse_args()
@@ -147,6 +150,8 @@ def main():
 
     global WORKLOAD
     WORKLOAD = args.workload
+    if args.rollout:                      # information-only mode: no per-kernel replay, no CPU baseline
+        args.no_profile_pass = args.no_cpu_baseline = True
     B = args.envs_per_gpu
     sim = make_sim(load_hip_lib(), B, local_rank, 1 + rank, WORKLOAD)
     K, W = args.steps, args.warmup
@@ -157,7 +162,22 @@ def main():
     gathered = torch.zeros(3 * world, device=coll_device) if world > 1 else None
     stream = torch.cuda.current_stream().cuda_stream
 
+    policy = storage = None
+    if args.rollout:
+        from go2_sim2real_locomotion_rl_amd import ActorCritic, RolloutStorage
+
+        policy = ActorCritic(NOBS[WORKLOAD], NPRIV[WORKLOAD], NACT[WORKLOAD], [512, 256, 128], [512, 256, 128], activation="elu", init_noise_std=0.3,
+                             device=device, seed=1 + rank)
+        storage = RolloutStorage(ROLLOUT_LEN, B, device=device)
+
     def step(s):
+        if policy is not None:                                           # closed loop: policy -> env -> storage (-> returns every 24 steps)
+            a = policy.act(obs, priv)
+            sim.env_step(a, obs, priv, rew, rst, to, stream)
+            storage.add_transitions(s % ROLLOUT_LEN, rew, rst, policy.values, to, gamma=0.99)
+            if (s + 1) % ROLLOUT_LEN == 0:
+                storage.compute_returns(policy.evaluate(priv), 0.99, 0.95)      # all-gathers the advantage moments when world > 1
+            return
         sim.env_step(actions[s], obs, priv, rew, rst, to, stream)
         if world > 1 and (s + 1) % ROLLOUT_LEN == 0:
             # rollout advantage-normalisation statistics: [sum, sum of squares, count] per rank, all-gathered over xGMI
@@ -237,7 +257,8 @@ def main():
                                     "Go2 stairs heightfield terrain (BASELINE configs[2], NOT the headline metric), num_envs per GPU as given, action set C, curriculum frozen at level 0.65"
                                     if WORKLOAD == "stairs" else
                                     "Go2 jump env + per-env mass / friction randomisation (BASELINE configs[4], NOT the headline metric), num_envs per GPU as given, action set C on 12 position actions"),
-                       "envs_per_gpu": B, "total_envs": total_envs, "parallelism": f"env-shard x{world}", "errno": errno},
+                       "envs_per_gpu": B, "total_envs": total_envs, "parallelism": f"env-shard x{world}", "errno": errno,
+                       "loop": "closed rollout loop: ActorCritic.act + env step + RolloutStorage (information only)" if args.rollout else "env step, open-loop actions"},
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)
