@@ -2049,9 +2049,56 @@ DEV void ts_cholesky_factor(const MT& m, S* s, int tl) {
   }
 }
 
-// func_hessian_and_cholesky_factor_incremental_dense_batch, solver.py:1632-1675; returns true when the factor degenerated
+// func_hessian_and_cholesky_factor_incremental_dense_batch, solver.py:1632-1675; returns true when the factor degenerated.
+// Register-resident form (T >= ND): lane i owns row i of the factor and element i of the update vector for the whole call; step k of a rank-1
+// update needs only (v_k, L_kk) from lane k, which travel by a lane shuffle -- no LDS round trip and no barrier inside the k loop.  The
+// arithmetic per element is the serial algorithm's (same operands, same order), so the result is unchanged.
+template <int T, class S, class MT>
+DEV bool ts_cholesky_incremental_reg(const MT& m, S* s, int tl, int n_con) {
+  static_assert(T >= ND, "one lane per row of the factor");
+  bool degenerated = false, touched = false;
+  const int row = tl < ND ? tl : ND - 1;                               // lanes beyond the matrix shadow the last row (never written back)
+  float Lr[ND];
+#pragma unroll
+  for (int k = 0; k < ND; ++k) Lr[k] = s->H[row * DS + k];
+  for (int c = 0; c < n_con && !degenerated; ++c) {
+    const bool is_active = s->active[c] != 0, was_active = s->prev_active[c] != 0;
+    if (is_active ^ was_active) {
+      touched = true;
+      const float sign = is_active ? 1.0f : -1.0f;
+      const float efc_D_sqrt = dm_sqrt(s->efc_D[c]);
+      float v = s->J[c * DS + row] * efc_D_sqrt;
+#pragma unroll
+      for (int k = 0; k < ND; ++k) {
+        const float vk = __shfl(v, k, T), Lkk = __shfl(Lr[k], k, T);
+        if (dm_abs(vk) > m.eps) {
+          const float tmp = Lkk * Lkk + sign * (vk * vk);
+          if (tmp < m.eps) { degenerated = true; break; }
+          const float r = dm_sqrt(tmp);
+          const float cc = r / Lkk;
+          const float cinv = 1.0f / cc;
+          const float sk = vk / Lkk;
+          if (row == k) Lr[k] = r;
+          else if (row > k) {
+            const float hik = (Lr[k] + sk * v * sign) * cinv;
+            Lr[k] = hik;
+            v = v * cc - sk * hik;
+          }
+        }
+      }
+    }
+  }
+  if (touched && !degenerated && tl < ND) {                            // a degenerated factor is rebuilt from scratch by the caller
+#pragma unroll
+    for (int k = 0; k < ND; ++k)
+      if (k <= row) { s->H[row * DS + k] = Lr[k]; if (k < row) s->H[k * DS + row] = Lr[k]; }
+  }
+  team_sync();
+  return degenerated;
+}
 template <int T, class S, class MT>
 DEV bool ts_cholesky_incremental(const MT& m, S* s, int tl, int n_con) {
+  if constexpr (T >= ND) return ts_cholesky_incremental_reg<T>(m, s, tl, n_con);
   bool degenerated = false;
   for (int c = 0; c < n_con && !degenerated; ++c) {
     bool is_active = s->active[c] != 0, was_active = s->prev_active[c] != 0;
