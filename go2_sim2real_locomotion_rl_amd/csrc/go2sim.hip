@@ -646,6 +646,9 @@ __device__ unsigned long long g_phase_cycles[64];
 #define PH(i)
 #endif
 
+// -DGO2SIM_REPEAT_PHASE=k (profiling builds, tools/repeat_probe.py): phase k runs twice; every such phase is idempotent, so the results
+// are unchanged and the time difference prices the phase.  Solver: 0 stage, 1 rows (13 contact rows, 14 joint-limit rows), 3 Hessian +
+// factorisation, 4 Hessian, 5 gradient, 6 line search, 11 commit.  Collision: 30 AABBs, 31 endpoint sort, 32 candidate pairs.
 // scalar slots
 enum { SV_COST = 0, SV_PREV_COST, SV_GAUSS, SV_QG0, SV_QG1, SV_QG2, SV_GTOL };
 enum { SI_LS_IT = 0, SI_LS_RESULT, SI_IMPROVED };
@@ -1761,12 +1764,8 @@ __global__ __launch_bounds__(64) void k_collide_team(Pool P, const Model* __rest
     if (packed >= 0 && rs < rmax_first) {
       bool any1 = (amx.x <= bmn.x) || (amx.y <= bmn.y) || (amx.z <= bmn.z);
       bool any2 = (amn.x >= bmx.x) || (amn.y >= bmx.y) || (amn.z >= bmx.z);
-#if defined(GO2SIM_REPEAT_PHASE) && GO2SIM_REPEAT_PHASE == 34
-      if (any1 || any2) { } else cmask |= 1u << it;
-#else
       if (any1 || any2) e.normal_cache()[pidx] = v3(0, 0, 0);
       else cmask |= 1u << it;
-#endif
     }
   }
   {                                                                    // compaction; the list is sorted by key below, so its order is free
@@ -2314,7 +2313,7 @@ DEV int ts_solve(const MT& m, const E& e, S* s, int tl, int nc, int n_con, unsig
   team_sync();
 #ifdef GO2SIM_REPEAT_PHASE
   }
-  for (int rep_rows = 0; rep_rows < (GO2SIM_REPEAT_PHASE == 1 ? 2 : (GO2SIM_REPEAT_PHASE == 12 ? 0 : 1)); ++rep_rows) {
+  for (int rep_rows = 0; rep_rows < (GO2SIM_REPEAT_PHASE == 1 ? 2 : 1); ++rep_rows) {
 #endif
   PH(0)
   // ---- contact rows: one lane per row ----
@@ -2420,11 +2419,7 @@ DEV int ts_solve(const MT& m, const E& e, S* s, int tl, int nc, int n_con, unsig
   ts_update_constraint<T>(m, s, tl, n_con, cost, prev_cost, gauss);
   PH(2)
   int iters = 0;
-#if defined(GO2SIM_REPEAT_PHASE) && GO2SIM_REPEAT_PHASE == 20
-  if (n_con > 100000) {
-#else
   if (n_con > 0) {
-#endif
     const float tol_scaled = (m.meaninertia * (float)imx(1, ND)) * m.tolerance;
     bool need_full = true;
     for (int it = 0;; ++it) {
@@ -2474,11 +2469,7 @@ DEV int ts_solve(const MT& m, const E& e, S* s, int tl, int nc, int n_con, unsig
       team_sync();
       ts_update_constraint<T>(m, s, tl, n_con, cost, prev_cost, gauss);
       PH(7)
-#if defined(GO2SIM_REPEAT_PHASE) && GO2SIM_REPEAT_PHASE == 8
-      need_full = true;                      // profiling: always rebuild instead of the incremental update (same H up to rounding; timing only)
-#else
       need_full = ts_cholesky_incremental<T>(m, s, tl, n_con);
-#endif
       team_sync();
       PH(8)
     }
@@ -2553,9 +2544,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   const LinkS* lnk = (const LinkS*)blk_raw;
   const unsigned char* tri_i = (const unsigned char*)(blk_raw + sizeof(LinkS) * NL);
   const unsigned char* tri_j = tri_i + (NTRI + 1);
-#if defined(GO2SIM_REPEAT_PHASE) && GO2SIM_REPEAT_PHASE == 22
-  if (P.B > 0) return;
-#endif
   // every load of the prologue (solver block by LDS DMA, contact count, warm-start flag, the joint coordinates of the limit test) is issued
   // before the first wait
   static_assert(T >= NJ, "one lane per joint in the limit test");
@@ -2574,13 +2562,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   __syncthreads();
   const ModelView m(lnk, tri_i, tri_j, gm);
   if (!env_valid) return;
-#if defined(GO2SIM_REPEAT_PHASE) && GO2SIM_REPEAT_PHASE == 23
-  if (nc < 100000) return;
-#endif
   const int n_con = 4 * nc + n_lim;
-#if defined(GO2SIM_REPEAT_PHASE) && GO2SIM_REPEAT_PHASE == 21
-  if (n_con < 100000) return;
-#endif
   if (n_con <= RLN) {
     SolverData<RLN>* s = &lds[slot];
     int iters = ts_solve<T>(m, e, s, tl, nc, n_con, lim_mask, ws_flag);
