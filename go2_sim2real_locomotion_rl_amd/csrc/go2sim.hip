@@ -2480,11 +2480,16 @@ DEV int ts_solve(const MT& m, const E& e, S* s, int tl, int nc, int n_con, unsig
 // func_update_qacc (solver.py:3016-3037) + func_update_contact_force (:2974-3013) + public row outputs
 template <int T, class S, class MT>
 DEV void ts_commit(const MT& m, const E& e, S* s, int tl, int nc, int n_con, int iters) {
+  // every global input of the commit is requested first (one round trip): the smooth force of the lane's dof, the geometry of the lane's contact
+  const int d0 = tl < ND ? tl : ND - 1, c0 = tl < nc ? tl : (nc > 0 ? nc - 1 : 0);
+  const float qfs0 = aload(e, AO(qf_smooth), d0);
+  V3 cn0 = v3(0, 0, 0); float fr0 = 0.0f; int lk0 = 0;
+  if (nc > 0) { cn0 = e.c_normal()[c0]; fr0 = e.c_friction()[c0]; lk0 = e.c_link()[c0] | (e.c_link()[MAXC + c0] << 8); }
   int err = 0;
   for (int d = tl; d < ND; d += T) {
     float q = s->qacc[d];
     astore(e, AO(acc), d, q);
-    astore(e, AO(force), d, aload(e, AO(qf_smooth), d) + s->qfrc[d]);
+    astore(e, AO(force), d, ((d == d0) ? qfs0 : aload(e, AO(qf_smooth), d)) + s->qfrc[d]);
     astore(e, AO(qacc_ws), d, q);
     astore(e, AO(qfrc_constraint), d, s->qfrc[d]);
     if (isnan_(q)) err |= GO2SIM_ERR_INVALID_FORCE_NAN;
@@ -2495,7 +2500,8 @@ DEV void ts_commit(const MT& m, const E& e, S* s, int tl, int nc, int n_con, int
   team_sync();
   float* cf = s->J;  // the Jacobian is dead from here on: reuse its storage for the per-contact forces
   for (int i_c = tl; i_c < nc; i_c += T) {
-    V3 cnormal = e.c_normal()[i_c]; float friction = e.c_friction()[i_c];
+    const bool pre = i_c == c0;
+    V3 cnormal = pre ? cn0 : (V3)e.c_normal()[i_c]; float friction = pre ? fr0 : (float)e.c_friction()[i_c];
     V3 f = v3(0, 0, 0), d1, d2;
     orthogonals(cnormal, d1, d2);
 #pragma unroll
@@ -2506,7 +2512,7 @@ DEV void ts_commit(const MT& m, const E& e, S* s, int tl, int nc, int n_con, int
     }
     e.c_force()[i_c] = f;
     cf[4 * i_c] = f.x; cf[4 * i_c + 1] = f.y; cf[4 * i_c + 2] = f.z;
-    ((int*)cf)[4 * i_c + 3] = e.c_link()[i_c] | (e.c_link()[MAXC + i_c] << 8);
+    ((int*)cf)[4 * i_c + 3] = pre ? lk0 : (e.c_link()[i_c] | (e.c_link()[MAXC + i_c] << 8));
   }
   team_sync();
   for (int i_l = tl; i_l < NL; i_l += T) {
