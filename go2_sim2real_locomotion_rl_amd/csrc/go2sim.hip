@@ -1437,7 +1437,7 @@ DEV void guess_geoms_center(const Model& m, const Pair& pr, V3 normal_ws, V3& ce
 }
 // func_mpr_contact -> func_mpr_contact_from_centers, mpr.py:686-819
 // func_mpr_contact_from_centers, mpr.py:686-760
-DEVN void mpr_contact_from_centers(const Model& m, const Pair& pr, V3 center_a, V3 center_b, bool& is_col, V3& normal, float& penetration, V3& pos) {
+DEV void mpr_contact_from_centers(const Model& m, const Pair& pr, V3 center_a, V3 center_b, bool& is_col, V3& normal, float& penetration, V3& pos) {
   Simplex s;
   int res = mpr_discover_portal(m, s, pr, center_a, center_b);
   is_col = false; pos = v3(0, 0, 0); normal = v3(0, 0, 0); penetration = 0.0f;
