@@ -1278,11 +1278,14 @@ DEV bool mpr_portal_reach_tolerance(const Model& m, const Simplex& s, V3 v, V3 d
   float dot1 = fmn(fmn(dv4 - dv1, dv4 - dv2), dv4 - dv3);
   return dot1 < m.ccd_tolerance + m.ccd_eps * fmx(1.0f, dot1);
 }
+DEV V3 vsel(bool c, V3 a, V3 b) { return v3(c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z); }
 DEV void simplex_set(Simplex& s, int i, V3 v, V3 v1, V3 v2) {
-  // static indexing keeps the simplex in VGPRs
-  if (i == 1) { s.v[1] = v; s.v1[1] = v1; s.v2[1] = v2; }
-  else if (i == 2) { s.v[2] = v; s.v1[2] = v1; s.v2[2] = v2; }
-  else { s.v[3] = v; s.v1[3] = v1; s.v2[3] = v2; }
+  // value selects on every slot (not branches around stores): the compiler otherwise turns the three stores into one store through a
+  // computed address, which moves the whole simplex to scratch memory and adds two memory round trips to every portal iteration
+  const bool c1 = i == 1, c2 = i == 2, c3 = !(c1 || c2);
+  s.v[1] = vsel(c1, v, s.v[1]); s.v1[1] = vsel(c1, v1, s.v1[1]); s.v2[1] = vsel(c1, v2, s.v2[1]);
+  s.v[2] = vsel(c2, v, s.v[2]); s.v1[2] = vsel(c2, v1, s.v1[2]); s.v2[2] = vsel(c2, v2, s.v2[2]);
+  s.v[3] = vsel(c3, v, s.v[3]); s.v1[3] = vsel(c3, v1, s.v1[3]); s.v2[3] = vsel(c3, v2, s.v2[3]);
 }
 DEV void mpr_expand_portal(Simplex& s, V3 v, V3 v1, V3 v2) {
   V3 v4v0 = cross(v, s.v[0]);
@@ -1557,7 +1560,8 @@ DEV void convex_convex_contact_staged(const Model& m, const E& e, int i_ga, int 
       if (penetration > tolerance) prefer_gjk = !guess_available || (m.mc_tolerance * penetration >= m.mpr_to_gjk_ratio * tolerance);
       if (prefer_gjk) {                                          // narrowphase.py:734-845: safe GJK + EPA replaces the MPR answer
         atomicAdd(&e.gjk_fallback()[0], 1);
-        GjkResult gr = gjk_contact_pair(m, gjk_scratch, pr);
+        const Pair pr_copy = pr;                                   // the out-of-line callee takes a reference: give it a copy that only exists on
+        GjkResult gr = gjk_contact_pair(m, gjk_scratch, pr_copy);  // this cold path, so that `pr` itself can stay in registers
         is_col = gr.is_col != 0;
         penetration = gr.penetration;
         if (is_col) { contact_pos = v3(gr.pos.x, gr.pos.y, gr.pos.z); normal = v3(gr.normal.x, gr.normal.y, gr.normal.z); }
@@ -1606,7 +1610,9 @@ DEV bool terrain_pair_setup(const Model& m, const E& e, int i_ga, int i_gb, TP& 
   t.i_ga = i_ga;
   GeomLite gl = geom_lite(m, i_ga);
   float xyz_max_min[6];
+#pragma unroll
   for (int i_axis = 0; i_axis < 3; ++i_axis)
+#pragma unroll
     for (int i_m = 0; i_m < 2; ++i_m) {
       V3 direction = v3(0, 0, 0);
       vset(direction, i_axis, (i_m == 0) ? 1.0f : -1.0f);
