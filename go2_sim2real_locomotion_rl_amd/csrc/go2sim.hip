@@ -1182,13 +1182,20 @@ DEV V3 support_cylinder_local(const Model& m, const Geom& G, V3 d_mesh, int* vid
 }
 // support_driver, collider/mpr.py:146-176
 // _func_support_prism, support_field.py:262-280: the terrain geom is represented by the current 6-vertex prism
+DEV V3 vsel(bool c, V3 a, V3 b) { return v3(c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z); }
 DEV V3 support_prism(const V3* prism, V3 d) {
-  int istart = 3;
-  if (d.z < 0) istart = 0;
-  int ibest = istart;
-  float best = dot(prism[istart], d);
-  for (int i = istart + 1; i < istart + 3; ++i) { float dt_ = dot(prism[i], d); if (dt_ > best) { ibest = i; best = dt_; } }
-  return prism[ibest];
+  // the bottom (0..2) or top (3..5) triangle, then the first vertex with the largest projection; written with value selects and constant
+  // indices so that the six vertices stay in registers (an index computed at run time would put the prism in scratch memory)
+  const bool bottom = d.z < 0;
+  const V3 p0 = vsel(bottom, prism[0], prism[3]), p1 = vsel(bottom, prism[1], prism[4]), p2 = vsel(bottom, prism[2], prism[5]);
+  float best = dot(p0, d);
+  V3 v = p0;
+  const float dt1 = dot(p1, d);
+  const bool b1 = dt1 > best;
+  v = vsel(b1, p1, v); best = b1 ? dt1 : best;
+  const float dt2 = dot(p2, d);
+  v = vsel(dt2 > best, p2, v);
+  return v;
 }
 // type and size of a geom, read once per pair so that the MPR iterations do not go back to the model in global memory
 struct GeomLite { int type; float d0, d1, d2; };
@@ -1278,7 +1285,6 @@ DEV bool mpr_portal_reach_tolerance(const Model& m, const Simplex& s, V3 v, V3 d
   float dot1 = fmn(fmn(dv4 - dv1, dv4 - dv2), dv4 - dv3);
   return dot1 < m.ccd_tolerance + m.ccd_eps * fmx(1.0f, dot1);
 }
-DEV V3 vsel(bool c, V3 a, V3 b) { return v3(c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z); }
 DEV void simplex_set(Simplex& s, int i, V3 v, V3 v1, V3 v2) {
   // value selects on every slot (not branches around stores): the compiler otherwise turns the three stores into one store through a
   // computed address, which moves the whole simplex to scratch memory and adds two memory round trips to every portal iteration
