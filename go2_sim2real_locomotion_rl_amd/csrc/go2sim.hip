@@ -1979,8 +1979,10 @@ struct alignas(16) SolverData {
   float M[ND * DS];
   float qacc[DS], Ma[DS], grad[DS], Mgrad[DS], search[DS], mv[DS], force[DS], acc_smooth[DS], qfrc[DS], ntv[DS], vel[DS];
   float cdof_ang[ND * 3], cdof_vel[ND * 3], root_com[NL * 3];
-  float aref[R], efc_D[R], Jaref[R], jv[R], efc_force[R], qf0[R], qf1[R], qf2[R], DA[R];
-  int active[R], prev_active[R];
+  alignas(16) float aref[R];   // the row-indexed arrays are 16-byte aligned: the redundant passes over the rows use 128-bit LDS reads
+  alignas(16) float efc_D[R]; alignas(16) float Jaref[R]; alignas(16) float jv[R]; alignas(16) float efc_force[R];
+  alignas(16) float qf0[R]; alignas(16) float qf1[R]; alignas(16) float qf2[R]; alignas(16) float DA[R];
+  alignas(16) int active[R]; alignas(16) int prev_active[R];
 };
 
 template <int T, class S, class MT>
@@ -1998,7 +2000,7 @@ DEV void ts_update_constraint(const MT& m, S* s, int tl, int n_con, float& cost,
   team_sync();
   for (int d = tl; d < ND; d += T) {
     float q = 0.0f;
-#pragma unroll 8
+#pragma unroll 16
     for (int c = 0; c < n_con; ++c) q = q + s->J[c * DS + d] * s->efc_force[c];
     s->qfrc[d] = q;
   }
@@ -2009,7 +2011,7 @@ DEV void ts_update_constraint(const MT& m, S* s, int tl, int n_con, float& cost,
     gauss_i = gauss_i + v;
     cost_i = cost_i + v;
   }
-#pragma unroll 8
+#pragma unroll 16
   for (int c = 0; c < n_con; ++c) { float Ja = s->Jaref[c]; cost_i = cost_i + 0.5f * (Ja * Ja * s->DA[c]); }
   gauss = gauss_i; cost = cost_i;
   team_sync();
@@ -2022,7 +2024,7 @@ DEV void ts_hessian_direct(const MT& m, S* s, int tl, int n_con) {
     int i, j;
     tri_index(m, idx, i, j);
     float h = 0.0f;
-#pragma unroll 8
+#pragma unroll 16
     for (int c = 0; c < n_con; ++c) {
       float j1 = s->J[c * DS + i];
       float t = s->J[c * DS + j] * j1 * s->DA[c];     // (row[j] * j1 * D) * active, active in {0,1}
@@ -2177,7 +2179,7 @@ DEV void ts_update_gradient(S* s, int tl) {
 template <class S, class MT>
 DEV LsPoint ts_ls_point(const MT& m, S* s, int n_con, float alpha, float qg0, float qg1, float qg2) {
   float t0 = qg0 + 0.0f, t1 = qg1 + 0.0f, t2 = qg2 + 0.0f;
-#pragma unroll 4
+#pragma unroll 16
   for (int c = 0; c < n_con; ++c) {
     float x = s->Jaref[c] + alpha * s->jv[c];
     float active = (float)(x < 0.0f);
@@ -2194,7 +2196,7 @@ template <class S, class MT>
 DEV void ts_ls_point3(const MT& m, S* s, int n_con, const float a[3], float qg0, float qg1, float qg2, float costs[3], float grads[3], float hess[3]) {
   float b0 = qg0 + 0.0f, b1 = qg1 + 0.0f, b2 = qg2 + 0.0f;
   float t00 = b0, t01 = b1, t02 = b2, t10 = b0, t11 = b1, t12 = b2, t20 = b0, t21 = b1, t22 = b2;
-#pragma unroll 4
+#pragma unroll 16
   for (int c = 0; c < n_con; ++c) {
     float Ja = s->Jaref[c], jv = s->jv[c];
     float qf_0 = s->qf0[c], qf_1 = s->qf1[c], qf_2 = s->qf2[c];
@@ -2253,7 +2255,7 @@ DEV float ts_linesearch(const MT& m, S* s, int tl, int n_con, float gauss) {
   LsPoint p0;
   {
     float t0 = qg0, t1 = qg1, t2 = qg2;
-#pragma unroll 4
+#pragma unroll 16
     for (int c = 0; c < n_con; ++c) {
       float active = (float)(s->Jaref[c] < 0.0f);
       t0 = t0 + s->qf0[c] * active; t1 = t1 + s->qf1[c] * active; t2 = t2 + s->qf2[c] * active;
