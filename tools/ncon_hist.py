@@ -1,21 +1,18 @@
 #!/usr/bin/env python3
-"""Distribution of contacts / constraint rows / Newton iterations over the bench workload (GPU)."""
+"""Distribution of contacts / constraint rows / Newton iterations over the bench workload (GPU).  usage: ncon_hist.py [walk|stairs|jump_dr]"""
 import os, sys
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from bench import make_actions
-from go2_sim2real_locomotion_rl_amd.capi import C, Go2Sim, load_hip_lib
-from go2_sim2real_locomotion_rl_amd.configs import flatten_walk_cfg, get_walk_cfgs
-from go2_sim2real_locomotion_rl_amd.model_blob import pack_model
+import bench
+from go2_sim2real_locomotion_rl_amd.capi import C, load_hip_lib
 
 B = 4096
 dev = torch.device("cuda", 0)
-sim = Go2Sim(load_hip_lib(), pack_model(), B, 0, 1)
-f, i, _ = flatten_walk_cfg(B, *get_walk_cfgs(), freeze_curriculum=True)
-sim.env_configure(f, i); sim.env_reset()
-act = make_actions(300, B, dev)
-obs = torch.zeros(B, 49, device=dev); priv = torch.zeros(B, 104, device=dev); rew = torch.zeros(B, device=dev)
+bench.WORKLOAD = sys.argv[1] if len(sys.argv) > 1 else "walk"
+sim = bench.make_sim(load_hip_lib(), B, 0, 1, bench.WORKLOAD)
+act = bench.make_actions(300, B, dev)
+obs = torch.zeros(B, bench.NOBS[bench.WORKLOAD], device=dev); priv = torch.zeros(B, bench.NPRIV[bench.WORKLOAD], device=dev); rew = torch.zeros(B, device=dev)
 rst = torch.zeros(B, dtype=torch.uint8, device=dev); to = torch.zeros(B, device=dev)
 buf = torch.zeros(B, dtype=torch.int32, device=dev)
 H = {"I_N_CONTACTS": [], "I_N_CONSTRAINTS": [], "I_SOLVER_ITERS": [], "I_N_BROAD": []}
