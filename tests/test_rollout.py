@@ -52,14 +52,16 @@ def run(lib, data, device_tensors=False):
     return rb, mom
 
 
-def read(rb, which, dtype=np.float32, device_tensors=False):
+def read(rb, which, device_tensors=False):
+    """[T, B] float32 copy of one buffer of the handle (host memory for the oracle, device memory for the product)."""
     import ctypes
+
     n = rb.T * rb.B
     if device_tensors:
         out = torch.empty(n, dtype=torch.float32, device="cuda")
-        import ctypes as c
-        hip = c.CDLL("libamdhip64.so")
-        hip.hipMemcpy(c.c_void_p(out.data_ptr()), c.c_void_p(rb.ptr(which)), c.c_size_t(4 * n), c.c_int(3))
+        hip = ctypes.CDLL("libamdhip64.so")
+        rc = hip.hipMemcpy(ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(rb.ptr(which)), ctypes.c_size_t(4 * n), ctypes.c_int(3))   # device to device
+        assert rc == 0
         return out.cpu().numpy().reshape(rb.T, rb.B)
     return np.ctypeslib.as_array((ctypes.c_float * n).from_address(rb.ptr(which))).reshape(rb.T, rb.B).copy()
 
