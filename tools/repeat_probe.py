@@ -10,7 +10,7 @@ from go2_sim2real_locomotion_rl_amd import capi
 from go2_sim2real_locomotion_rl_amd.configs import flatten_walk_cfg, get_walk_cfgs
 from go2_sim2real_locomotion_rl_amd.model_blob import pack_model
 
-B, W, N = 4096, 50, 150
+B, W, N = 4096, 150, 200
 dev = torch.device("cuda", 0)
 act = make_actions(W + N, B, dev)
 for so in sys.argv[1:]:
