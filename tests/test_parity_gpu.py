@@ -59,6 +59,38 @@ def test_env_step_bit_exact(oracle_lib, hip_lib, blob, n_envs, steps, kind, seed
         assert n_resets > 0, "the action set was meant to provoke falls / resets"
 
 
+def test_live_curriculum_long_run_bit_exact(oracle_lib, hip_lib, blob):
+    """600 steps with the curriculum state machine updating every few episodes (level moves in both directions, DR ranges and command
+    ranges follow it, pushes start once the level is up): the device-side CurriculumManager / global DR (run by the last workgroup of the
+    post-physics kernel) against the oracle, bit for bit, including the level trajectory."""
+    def mutate(env_cfg, *_):
+        env_cfg["episode_length_s"] = 1.0                         # 50-step episodes: calm phases end in time-outs, violent ones in falls
+        env_cfg["curriculum"].update({"update_every_episodes": 24, "ready_streak": 1, "hard_streak": 1, "cooldown_updates": 1, "step_up": 0.05,
+                                      "step_down": 0.04, "ready_timeout_rate": 0.5, "ready_tracking": -1.0, "ready_fall_rate": 0.5,
+                                      "hard_fall_rate": 0.6, "ema_alpha": 0.5, "global_dr_update_interval": 16})
+
+    n_envs, steps = 96, 600
+    cpu, gpu = CpuEnv(oracle_lib, blob, n_envs, seed=21, mutate=mutate), GpuEnv(hip_lib, blob, n_envs, seed=21, mutate=mutate)
+    for e in (cpu, gpu):
+        e.sim.env_set_level(0.3)
+        e.reset()
+    rng = np.random.default_rng(5)
+    levels = []
+    for s in range(steps):
+        scale = 3.0 if (s // 150) % 2 else 0.02                   # calm and violent phases: the level goes up, down, up, down
+        a = (scale * rng.standard_normal((n_envs, 16))).astype(np.float32)
+        oc, pc, rc, dc, tc = cpu.step(a)
+        og, pg, rg, dg, tg = gpu.step(a)
+        assert np.array_equal(dc, dg) and bits_equal(oc, og) and bits_equal(pc, pg) and bits_equal(rc, rg), f"step {s}"
+        if s % 20 == 0:
+            gc_, gg_ = cpu.sim.env_globals(), gpu.sim.env_globals()
+            assert gc_.level == gg_.level and gc_.push_enable == gg_.push_enable and gc_.friction == gg_.friction, f"globals differ at step {s}"
+            levels.append(gc_.level)
+    _compare_fields(cpu, gpu, "final")
+    _compare_globals(cpu, gpu)
+    assert max(levels) > 0.4 and min(levels) < 0.05, "the level was meant to rise and fall"
+
+
 def test_scene_step_bit_exact_with_uploaded_state(oracle_lib, hip_lib, blob):
     """gs.Scene.step parity: random (qpos, vel, ctrl) uploaded through set_field on both sides."""
     B = 96
