@@ -3699,6 +3699,19 @@ struct go2sim {
   float* terrain_hf = nullptr;              // device copy of the heightfield in metres (go2sim_set_terrain)
   GjkScratch* gjk_scratch = nullptr;        // working memory of the GJK/EPA fallback: one block per (env, narrow-phase lane)
   SolverData<MAXR>* solver_ovf = nullptr;   // per-env global scratch for solves that do not fit in LDS (> RL rows)
+  // One env step = 11 dependent kernel launches (12 with terrain).  Issued one by one they cost the host ~20 us each -- close to the GPU time of
+  // the step -- so the sequence is kept as an instantiated hipGraph: per step the three step-dependent kernel nodes get their new arguments
+  // (actions pointer, step counter, ring index) and the graph is launched with one call.  GO2SIM_NO_GRAPH=1 (or timing mode) uses plain launches.
+  struct StepGraph {
+    hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
+    hipGraphNode_t n_pre = nullptr, n_post_a = nullptr, n_post_b = nullptr;
+    hipKernelNodeParams p_pre{}, p_post_a{}, p_post_b{};
+    std::vector<void*> owned;                       // argument storage of all nodes (malloc'ed)
+    const float** a_actions = nullptr; uint32_t* a_pre_step = nullptr; int* a_pre_widx = nullptr; uint32_t* a_pa_step = nullptr; uint32_t* a_pb_step = nullptr;
+    void* key[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // output pointers the graph was built for
+    bool valid = false;
+  } sg;
+  bool use_graph = true;
   int dyn_team = 32;                        // lanes per environment in k_dynamics_team
   int fk_team = 16;                         // lanes per environment in k_integrate_fk_team / k_fk_team
   int collide_team = 16;                    // lanes per environment in k_collide_team
@@ -3782,6 +3795,93 @@ static int launch_substep(go2sim* h, hipStream_t s) {
   return GO2SIM_E_OK;
 }
 
+// ---- hipGraph of one env step -----------------------------------------------------------------------------------------------------
+static void step_graph_destroy(go2sim* h) {
+  auto& g = h->sg;
+  if (g.exec) (void)hipGraphExecDestroy(g.exec);
+  if (g.graph) (void)hipGraphDestroy(g.graph);
+  for (void* p : g.owned) free(p);
+  g = go2sim::StepGraph();
+}
+// appends one kernel node after `last`; the argument values are copied into storage owned by the graph record, laid out with the kernel's
+// own parameter types (P...), and *slots receives the addresses of the stored arguments
+template <class... P, class... A>
+static bool graph_add_kernel(go2sim* h, hipGraphNode_t& last, void (*kernel)(P...), dim3 grid, dim3 block, hipGraphNode_t* node_out, hipKernelNodeParams* params_out,
+                             void*** slots, A... a) {
+  static_assert(sizeof...(P) == sizeof...(A), "argument count");
+  auto& g = h->sg;
+  void** ptrs = (void**)malloc(sizeof(void*) * sizeof...(P));
+  g.owned.push_back(ptrs);
+  int i = 0;
+  auto store = [&](auto typed) { using T = decltype(typed); T* m = (T*)malloc(sizeof(T)); memcpy((void*)m, (const void*)&typed, sizeof(T)); g.owned.push_back((void*)m); ptrs[i++] = (void*)m; };
+  (store(static_cast<P>(a)), ...);
+  hipKernelNodeParams kp{};
+  kp.func = (void*)kernel; kp.gridDim = grid; kp.blockDim = block; kp.sharedMemBytes = 0; kp.kernelParams = ptrs; kp.extra = nullptr;
+  hipGraphNode_t node = nullptr;
+  if (hipGraphAddKernelNode(&node, g.graph, last ? &last : nullptr, last ? 1 : 0, &kp) != hipSuccess) return false;
+  last = node;
+  if (node_out) *node_out = node;
+  if (params_out) *params_out = kp;
+  if (slots) *slots = ptrs;
+  return true;
+}
+template <int T> struct TeamTag {};
+// the launch sequence of go2sim_env_step, as graph nodes (kept next to it: both must list the same kernels in the same order)
+static bool step_graph_build(go2sim* h, const float* actions, float* obs, float* priv, float* rew, uint8_t* reset, float* timeout) {
+  step_graph_destroy(h);
+  auto& g = h->sg;
+  if (hipGraphCreate(&g.graph, 0) != hipSuccess) return false;
+  hipGraphNode_t last = nullptr;
+  const dim3 ge = grid_for(h->B), be(WG), b64(64);
+  void** sl = nullptr;
+  bool ok = graph_add_kernel(h, last, k_env_pre, ge, be, &g.n_pre, &g.p_pre, &sl, h->P, h->dm, h->hcfg, h->dglob, actions, h->seed, h->step_count, h->action_write_idx);
+  if (!ok) return false;
+  g.a_actions = (const float**)sl[4]; g.a_pre_step = (uint32_t*)sl[6]; g.a_pre_widx = (int*)sl[7];
+  auto team_grid = [&](int T) { return dim3((h->B + 64 / T - 1) / (64 / T)); };
+  const int substeps = h->hcfg.i[GO2SIM_IC_SUBSTEPS];
+  for (int i = 0; i < substeps && ok; ++i) {
+    { const int T = h->dyn_team; const dim3 gd = team_grid(T);
+      ok = T == 16 ? graph_add_kernel(h, last, k_dynamics_team<16>, gd, b64, nullptr, nullptr, nullptr, h->P, h->dms)
+         : T == 32 ? graph_add_kernel(h, last, k_dynamics_team<32>, gd, b64, nullptr, nullptr, nullptr, h->P, h->dms)
+                   : graph_add_kernel(h, last, k_dynamics_team<64>, gd, b64, nullptr, nullptr, nullptr, h->P, h->dms); }
+    if (!ok) break;
+    { const int T = h->collide_team; const dim3 gc = team_grid(T);
+      ok = T == 16 ? graph_add_kernel(h, last, k_collide_team<16>, gc, b64, nullptr, nullptr, nullptr, h->P, h->dm, h->gjk_scratch)
+         : T == 32 ? graph_add_kernel(h, last, k_collide_team<32>, gc, b64, nullptr, nullptr, nullptr, h->P, h->dm, h->gjk_scratch)
+                   : graph_add_kernel(h, last, k_collide_team<64>, gc, b64, nullptr, nullptr, nullptr, h->P, h->dm, h->gjk_scratch); }
+    if (!ok) break;
+    if (h->hm.terrain_enabled) {
+      ok = graph_add_kernel(h, last, k_constraint_solve_team<64, RL_TERRAIN>, dim3(h->B), b64, nullptr, nullptr, nullptr, h->P, h->dm, h->dms, h->solver_ovf);
+    } else {
+      const int T = h->solver_team; const dim3 gs = team_grid(T);
+      ok = T == 16 ? graph_add_kernel(h, last, k_constraint_solve_team<16, RL>, gs, b64, nullptr, nullptr, nullptr, h->P, h->dm, h->dms, h->solver_ovf)
+         : T == 32 ? graph_add_kernel(h, last, k_constraint_solve_team<32, RL>, gs, b64, nullptr, nullptr, nullptr, h->P, h->dm, h->dms, h->solver_ovf)
+                   : graph_add_kernel(h, last, k_constraint_solve_team<64, RL>, gs, b64, nullptr, nullptr, nullptr, h->P, h->dm, h->dms, h->solver_ovf);
+    }
+    if (!ok) break;
+    { const int T = h->fk_team; const dim3 gd = team_grid(T);
+      ok = T == 16 ? graph_add_kernel(h, last, k_integrate_fk_team<16>, gd, b64, nullptr, nullptr, nullptr, h->P, h->dms)
+         : T == 32 ? graph_add_kernel(h, last, k_integrate_fk_team<32>, gd, b64, nullptr, nullptr, nullptr, h->P, h->dms)
+                   : graph_add_kernel(h, last, k_integrate_fk_team<64>, gd, b64, nullptr, nullptr, nullptr, h->P, h->dms); }
+  }
+  if (!ok) return false;
+  ok = graph_add_kernel(h, last, k_env_post_a, ge, be, &g.n_post_a, &g.p_post_a, &sl, h->P, h->dm, h->hcfg, h->dglob, h->dacc, h->seed, h->step_count);
+  if (!ok) return false;
+  g.a_pa_step = (uint32_t*)sl[6];
+  if (h->hcfg.i[GO2SIM_IC_USE_TERRAIN]) {
+    ok = graph_add_kernel(h, last, k_env_terrain_rows, dim3((h->B + 255) / 256), dim3(256), nullptr, nullptr, nullptr, h->P, h->dcfg, h->dglob, h->seed);
+    if (!ok) return false;
+  }
+  ok = graph_add_kernel(h, last, k_env_post_b_team<16>, dim3((h->B + 3) / 4), b64, &g.n_post_b, &g.p_post_b, &sl, h->P, h->dm, h->dms, h->dcfg, h->dglob, h->seed, h->step_count,
+                        obs, priv, rew, reset, timeout);
+  if (!ok) return false;
+  g.a_pb_step = (uint32_t*)sl[6];
+  if (hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0) != hipSuccess) return false;
+  g.key[0] = obs; g.key[1] = priv; g.key[2] = rew; g.key[3] = reset; g.key[4] = timeout;
+  g.valid = true;
+  return true;
+}
+
 extern "C" {
 
 int go2sim_create(const void* blob, size_t nbytes, int n_envs, int device, uint64_t seed, go2sim_t** out) {
@@ -3819,6 +3919,7 @@ int go2sim_create(const void* blob, size_t nbytes, int n_envs, int device, uint6
   HIPCHK(hipMalloc((void**)&h->derr, sizeof(int)));
   HIPCHK(hipMalloc((void**)&h->solver_ovf, (size_t)n_envs * sizeof(SolverData<MAXR>)));
   if (const char* t = getenv("GO2SIM_DYN_TEAM")) { int v = atoi(t); if (v == 16 || v == 32 || v == 64) h->dyn_team = v; }
+  if (const char* t = getenv("GO2SIM_NO_GRAPH")) { if (atoi(t) != 0) h->use_graph = false; }
   if (const char* t = getenv("GO2SIM_FK_TEAM")) { int v = atoi(t); if (v == 16 || v == 32 || v == 64) h->fk_team = v; }
   if (const char* t = getenv("GO2SIM_COLLIDE_TEAM")) { int v = atoi(t); if (v == 16 || v == 32 || v == 64) h->collide_team = v; }
   HIPCHK(hipMalloc((void**)&h->gjk_scratch, (size_t)n_envs * h->collide_team * sizeof(GjkScratch)));   // ~31 KB per narrow-phase lane
@@ -3839,6 +3940,7 @@ int go2sim_destroy(go2sim_t* h) {
   if (!h) return GO2SIM_E_BADARG;
   (void)hipSetDevice(h->device);
   (void)hipDeviceSynchronize();
+  step_graph_destroy(h);
   if (h->ev_created) for (int i = 0; i < TIMING_RING; ++i) { (void)hipEventDestroy(h->ev0[i]); (void)hipEventDestroy(h->ev1[i]); }
   (void)hipFree(h->P.f); (void)hipFree(h->P.i); (void)hipFree(h->P.fa); (void)hipFree(h->P.ia); (void)hipFree(h->dm); (void)hipFree(h->dcfg); (void)hipFree(h->dglob); (void)hipFree(h->dacc); (void)hipFree(h->derr); (void)hipFree(h->solver_ovf); (void)hipFree(h->gjk_scratch); if (h->terrain_hf) (void)hipFree(h->terrain_hf); (void)hipFree(h->dms);
   delete h;
@@ -3996,6 +4098,7 @@ int go2sim_set_terrain(go2sim_t* h, const int16_t* hf, int rows, int cols, float
   if (!h || !hf || rows < 2 || cols < 2 || !origin || !(horizontal_scale > 0.0f)) return GO2SIM_E_BADARG;
   hipStream_t s = (hipStream_t)stream;
   HIPCHK(hipStreamSynchronize(s));
+  step_graph_destroy(h);   // the solver kernel of the step graph depends on the terrain flag
   Model& m = h->hm;
   std::vector<float> hfm((size_t)rows * cols);
   float hmax = -1e30f, hmin = 1e30f;
@@ -4038,6 +4141,7 @@ int go2sim_check_errno(go2sim_t* h, int* out, void* stream) {
 
 int go2sim_env_configure(go2sim_t* h, const float* f, int nf, const int* i, int ni) {
   if (!h || !f || !i || nf != GO2SIM_FC_COUNT || ni != GO2SIM_IC_COUNT) return GO2SIM_E_BADARG;
+  step_graph_destroy(h);   // the configuration is baked into the kernel arguments of the step graph
   memcpy(h->hcfg.f, f, sizeof(float) * nf); memcpy(h->hcfg.i, i, sizeof(int) * ni);
   const DCfg& c = h->hcfg;
   if (c.i[GO2SIM_IC_NUM_ACTIONS] > NA || c.i[GO2SIM_IC_NUM_OBS] > NOBS_MAX || c.i[GO2SIM_IC_NUM_PRIV_OBS] > NPRIV_MAX || c.i[GO2SIM_IC_N_REWARDS] > NREW ||
@@ -4074,6 +4178,22 @@ int go2sim_env_step(go2sim_t* h, const float* actions, float* obs, float* priv, 
   if (!h || !h->cfg_set || !actions) return GO2SIM_E_BADARG;
   hipStream_t s = (hipStream_t)stream;
   dim3 g = grid_for(h->B), b(WG);
+  if (h->use_graph && !h->timing) {
+    auto& sg = h->sg;
+    if (!sg.valid || sg.key[0] != obs || sg.key[1] != priv || sg.key[2] != rew || sg.key[3] != reset || sg.key[4] != timeout) {
+      if (!step_graph_build(h, actions, obs, priv, rew, reset, timeout)) { step_graph_destroy(h); h->use_graph = false; }
+    }
+    if (h->use_graph) {
+      *sg.a_actions = actions; *sg.a_pre_step = h->step_count; *sg.a_pre_widx = h->action_write_idx; *sg.a_pa_step = h->step_count; *sg.a_pb_step = h->step_count;
+      HIPCHK(hipGraphExecKernelNodeSetParams(sg.exec, sg.n_pre, &sg.p_pre));
+      HIPCHK(hipGraphExecKernelNodeSetParams(sg.exec, sg.n_post_a, &sg.p_post_a));
+      HIPCHK(hipGraphExecKernelNodeSetParams(sg.exec, sg.n_post_b, &sg.p_post_b));
+      HIPCHK(hipGraphLaunch(sg.exec, s));
+      h->action_write_idx = (h->action_write_idx + 1) % 2;
+      h->step_count += 1;
+      return GO2SIM_E_OK;
+    }
+  }
   if (h->timing && h->ev_n + 64 > TIMING_RING) timing_flush(h);   // all pending events belong to completed launches
   ScopedTimer total(h, s, T_TOTAL);
   { ScopedTimer t(h, s, T_ENV_PRE); hipLaunchKernelGGL(k_env_pre, g, b, 0, s, h->P, h->dm, h->hcfg, h->dglob, actions, h->seed, h->step_count, h->action_write_idx); }

@@ -91,6 +91,27 @@ def test_live_curriculum_long_run_bit_exact(oracle_lib, hip_lib, blob):
     assert max(levels) > 0.4 and min(levels) < 0.05, "the level was meant to rise and fall"
 
 
+def test_graph_and_plain_launch_paths_agree(hip_lib, blob, monkeypatch):
+    """go2sim_env_step launches its kernel sequence as one hipGraph (default) or kernel by kernel (GO2SIM_NO_GRAPH=1, timing mode): same bits.
+    Also covers a change of the output buffers between steps (the graph is rebuilt) and of the action buffer (a node parameter)."""
+    import torch
+
+    n_envs, steps = 70, 60
+    g = GpuEnv(hip_lib, blob, n_envs, seed=4)
+    monkeypatch.setenv("GO2SIM_NO_GRAPH", "1")
+    p = GpuEnv(hip_lib, blob, n_envs, seed=4)
+    monkeypatch.delenv("GO2SIM_NO_GRAPH")
+    g.reset(); p.reset()
+    acts = make_actions(steps, n_envs, seed=9, kind="mixed")
+    for s_, a in enumerate(acts):
+        if s_ == 20:                                               # new output tensors -> new graph
+            g.obs = torch.zeros_like(g.obs); g.priv = torch.zeros_like(g.priv)
+        og, pg, rg, dg, tg = g.step(a)
+        op, pp, rp, dp, tp = p.step(a)
+        assert bits_equal(og, op) and bits_equal(pg, pp) and bits_equal(rg, rp) and np.array_equal(dg, dp) and bits_equal(tg, tp), f"step {s_}"
+    _compare_fields(g, p, "final")
+
+
 def test_scene_step_bit_exact_with_uploaded_state(oracle_lib, hip_lib, blob):
     """gs.Scene.step parity: random (qpos, vel, ctrl) uploaded through set_field on both sides."""
     B = 96
