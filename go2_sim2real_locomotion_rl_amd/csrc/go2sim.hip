@@ -4185,13 +4185,17 @@ int go2sim_env_step(go2sim_t* h, const float* actions, float* obs, float* priv, 
     }
     if (h->use_graph) {
       *sg.a_actions = actions; *sg.a_pre_step = h->step_count; *sg.a_pre_widx = h->action_write_idx; *sg.a_pa_step = h->step_count; *sg.a_pb_step = h->step_count;
-      HIPCHK(hipGraphExecKernelNodeSetParams(sg.exec, sg.n_pre, &sg.p_pre));
-      HIPCHK(hipGraphExecKernelNodeSetParams(sg.exec, sg.n_post_a, &sg.p_post_a));
-      HIPCHK(hipGraphExecKernelNodeSetParams(sg.exec, sg.n_post_b, &sg.p_post_b));
-      HIPCHK(hipGraphLaunch(sg.exec, s));
-      h->action_write_idx = (h->action_write_idx + 1) % 2;
-      h->step_count += 1;
-      return GO2SIM_E_OK;
+      const bool launched = hipGraphExecKernelNodeSetParams(sg.exec, sg.n_pre, &sg.p_pre) == hipSuccess &&
+                            hipGraphExecKernelNodeSetParams(sg.exec, sg.n_post_a, &sg.p_post_a) == hipSuccess &&
+                            hipGraphExecKernelNodeSetParams(sg.exec, sg.n_post_b, &sg.p_post_b) == hipSuccess && hipGraphLaunch(sg.exec, s) == hipSuccess;
+      if (launched) {
+        h->action_write_idx = (h->action_write_idx + 1) % 2;
+        h->step_count += 1;
+        return GO2SIM_E_OK;
+      }
+      (void)hipGetLastError();            // nothing of this step was enqueued: drop the graph and continue with plain launches
+      fprintf(stderr, "go2sim: hipGraph launch failed, falling back to plain kernel launches\n");
+      step_graph_destroy(h); h->use_graph = false;
     }
   }
   if (h->timing && h->ev_n + 64 > TIMING_RING) timing_flush(h);   // all pending events belong to completed launches
