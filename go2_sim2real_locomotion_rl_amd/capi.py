@@ -64,6 +64,7 @@ class EnvGlobals(ctypes.Structure):
         ("leg_mass_shift", ctypes.c_float * 4), ("action_write_idx", ctypes.c_int), ("step_count", ctypes.c_uint),
         ("reset_calls", ctypes.c_uint), ("last_reset_count", ctypes.c_int), ("last_episode_rew", ctypes.c_float * 32),
         ("n_reset_now", ctypes.c_int), ("ep_acc", ctypes.c_float * 32), ("t_sample", ctypes.c_float), ("terrain_mean_row", ctypes.c_float), ("terrain_row_sum", ctypes.c_int),
+        ("lock_terrain_rows", ctypes.c_int),
     ]
 
     def as_dict(self):
@@ -205,6 +206,32 @@ class Go2Sim:
 
     def env_reset(self, stream=None):
         self._call("env_reset", _ptr(stream))
+
+    def env_reset_idx(self, envs_idx, n=None, stream=None):
+        self._call("env_reset_idx", _ptr(envs_idx), ctypes.c_int(len(envs_idx) if n is None else n), _ptr(stream))
+
+    def env_respawn(self, envs_idx, pos, quat=None, clear_buffers=True, n=None, stream=None):
+        self._call("env_respawn", _ptr(envs_idx), ctypes.c_int(len(envs_idx) if n is None else n), _ptr(pos), _ptr(quat),
+                   ctypes.c_int(int(clear_buffers)), _ptr(stream))
+
+    def env_lock_terrain_rows(self, lock=True, stream=None):
+        self._call("env_lock_terrain_rows", ctypes.c_int(int(lock)), _ptr(stream))
+
+    def env_set_terrain_rows(self, rows, stream=None):
+        self._call("env_set_terrain_rows", _ptr(rows), _ptr(stream))
+
+    def errno_poll_begin(self, stream=None):
+        self._call("errno_poll_begin", _ptr(stream))
+
+    def errno_poll_result(self):
+        v, ready = ctypes.c_int(), ctypes.c_int()
+        self._call("errno_poll_result", ctypes.byref(v), ctypes.byref(ready))
+        return (v.value if ready.value else None)
+
+    def graph_status(self):
+        using, nfb = ctypes.c_int(), ctypes.c_int()
+        self._call("graph_status", ctypes.byref(using), ctypes.byref(nfb))
+        return bool(using.value), nfb.value
 
     def env_get(self, buf, dst, stream=None):
         self._call("env_get", ctypes.c_int(buf), _ptr(dst), _ptr(stream))

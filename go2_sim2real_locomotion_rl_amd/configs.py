@@ -468,4 +468,5 @@ def get_stair_cfgs():
         "stand_still": -0.5, "stand_still_vel": -2.0, "feet_stance": -0.3}
     command_cfg.update({"lin_vel_x_range": [0.3, 0.8], "lin_vel_y_range": [0.0, 0.0], "ang_vel_range": [0.0, 0.0], "cmd_curriculum": False,
                         "rel_standing_envs": 0.05})
+    command_cfg.pop("cmd_curriculum_start_frac", None)   # not a key of go2_train_stair.py's command_cfg (the env defaults it to 0.1, go2_env_stair.py:584)
     return env_cfg, obs_cfg, reward_cfg, command_cfg

@@ -3196,11 +3196,85 @@ __global__ __launch_bounds__(WG) void k_env_mark_all(Pool P, const DCfg* __restr
     int id = c.i[GO2SIM_IC_REWARD_ID0 + k];
     float es = episode_sums[k];
     if (id == GO2SIM_R_TRACKING_LIN_VEL || id == GO2SIM_R_TRACKING_ANG_VEL) tracking_int = tracking_int + es;
-    atomicAdd(&acc->ep[k], (double)(es / ep_seconds));
+    atomicAdd(&acc->ep[k], (c.i[GO2SIM_IC_ENV_KIND] == 1) ? (double)es : (double)(es / ep_seconds));   // go2_env_base.py:232-236 logs mean(sum) / episode_length_s
   }
   atomicAdd(&acc->tracking, (double)(tracking_int / ep_seconds));
   atomicAdd(&acc->timeouts, (double)e.time_out()[0]);
   atomicAdd(&acc->n_reset_now, 1);
+}
+
+// Go2Env.reset_idx(envs_idx) on a subset (go2_env_walk.py:1156-1240): the listed envs are flagged (all others unflagged) and their episode
+// statistics accumulated, exactly as k_env_mark_all does for the whole batch.  Two launches: clear, then mark (an index may repeat).
+__global__ __launch_bounds__(WG) void k_env_unmark_all(Pool P) {
+  int b = blockIdx.x * WG + threadIdx.x;
+  if (b >= P.B) return;
+  P.i[(size_t)IO(reset_buf) * P.B + b] = 0;
+}
+__global__ __launch_bounds__(WG) void k_env_mark_idx(Pool P, const DCfg* __restrict__ cp, Acc* acc, const int* __restrict__ envs_idx, int n_sel) {
+  int t = blockIdx.x * WG + threadIdx.x;
+  if (t >= n_sel) return;
+  int b = envs_idx[t];
+  if (b < 0 || b >= P.B) return;
+  const DCfg& c = *cp;
+  E e(P, b);
+  if (atomicExch(&e.reset_buf()[0], 1) != 0) return;                    // listed twice: counted once
+  int ep_len = e.episode_length()[0];
+  float ep_steps = fmx((float)ep_len, 1.0f);
+  float ep_seconds = ep_steps * c.f[GO2SIM_FC_DT];
+  auto episode_sums = e.episode_sums();
+  int nrew = c.i[GO2SIM_IC_N_REWARDS];
+  float tracking_int = 0.0f;
+  for (int k = 0; k < nrew; ++k) {
+    int id = c.i[GO2SIM_IC_REWARD_ID0 + k];
+    float es = episode_sums[k];
+    if (id == GO2SIM_R_TRACKING_LIN_VEL || id == GO2SIM_R_TRACKING_ANG_VEL) tracking_int = tracking_int + es;
+    atomicAdd(&acc->ep[k], (c.i[GO2SIM_IC_ENV_KIND] == 1) ? (double)es : (double)(es / ep_seconds));   // go2_env_base.py:232-236 logs mean(sum) / episode_length_s
+  }
+  atomicAdd(&acc->tracking, (double)(tracking_int / ep_seconds));
+  atomicAdd(&acc->timeouts, (double)e.time_out()[0]);
+  atomicAdd(&acc->n_reset_now, 1);
+}
+// eval-side teleport of single envs (respawn_at_start, go2_eval_stairs.py:314-361; respawn_on_tile, go2_eval_walk.py:399-480):
+// set_dofs_position(default, zero_velocity) + set_pos + set_quat + zero_all_dofs_velocity on the listed envs, optionally clearing the action /
+// velocity buffers the way respawn_at_start does.  No curriculum bookkeeping, no randomisation, episode counters untouched.
+__global__ __launch_bounds__(WG) void k_env_respawn(Pool P, const Model* __restrict__ mp, const DCfg* __restrict__ cp, const int* __restrict__ envs_idx, int n_sel,
+                                                    const float* __restrict__ pos, const float* __restrict__ quat, int clear_buffers) {
+  int t = blockIdx.x * WG + threadIdx.x;
+  if (t >= n_sel) return;
+  int b = envs_idx[t];
+  if (b < 0 || b >= P.B) return;
+  const Model& m = *mp; const DCfg& c = *cp;
+  E e(P, b);
+  auto dof_pos = e.e_dof_pos(); auto dof_vel = e.e_dof_vel(); auto qpos = e.qpos(); auto vel = e.vel();
+  for (int i = 0; i < NM; ++i) {
+    float dp = c.f[GO2SIM_FC_DEFAULT_DOF_POS0 + i];
+    dof_pos[i] = dp; dof_vel[i] = 0.0f;
+    int q = c.i[GO2SIM_IC_MOTOR_DOF0 + i] + 1;
+    qpos[q] = m.qpos0[q] + dp;
+  }
+  for (int d = 0; d < ND; ++d) vel[d] = 0.0f;
+  e.err()[0] = 0; e.is_warmstart()[0] = 0;                              // set_dofs_position: rigid_solver.py:2403-2410
+  { auto qacc_ws = e.qacc_ws(); for (int d = 0; d < ND; ++d) qacc_ws[d] = 0.0f; }
+  { auto ncache = e.normal_cache(); for (int p = 0; p < NPAIR; ++p) ncache[p] = v3(0, 0, 0); }
+  float bq[4];
+  for (int k = 0; k < 4; ++k) bq[k] = quat ? quat[4 * t + k] : c.f[GO2SIM_FC_BASE_INIT_QUAT0 + k];
+  auto base_pos = e.base_pos(); auto base_quat = e.base_quat();
+  for (int k = 0; k < 3; ++k) { base_pos[k] = pos[3 * t + k]; qpos[k] = pos[3 * t + k]; }
+  for (int k = 0; k < 4; ++k) { base_quat[k] = bq[k]; qpos[3 + k] = bq[k]; }
+  if (clear_buffers) {
+    auto blv = e.base_lin_vel(); auto bav = e.base_ang_vel();
+    for (int k = 0; k < 3; ++k) { blv[k] = 0.0f; bav[k] = 0.0f; }
+    auto la = e.last_actions(); auto aa = e.applied_actions(); auto hist = e.action_history();
+    for (int i = 0; i < NA; ++i) { la[i] = 0.0f; aa[i] = 0.0f; hist[0][i] = 0.0f; hist[1][i] = 0.0f; }
+    { auto ldv = e.last_dof_vel(); for (int i = 0; i < NM; ++i) ldv[i] = 0.0f; }
+    e.last_base_pos_x()[0] = pos[3 * t];
+  }
+}
+__global__ __launch_bounds__(WG) void k_env_set_terrain_rows(Pool P, const int* __restrict__ rows, int n_rows) {
+  int b = blockIdx.x * WG + threadIdx.x;
+  if (b >= P.B) return;
+  int r = rows[b];
+  P.i[(size_t)IO(terrain_row) * P.B + b] = r < 0 ? 0 : (r >= n_rows ? n_rows - 1 : r);
 }
 
 // single-instance part of reset_idx: curriculum, t_sample, "global" DR (go2_env_walk.py:688-756,803-848,1160-1171)
@@ -3373,7 +3447,7 @@ __global__ __launch_bounds__(256) void k_env_terrain_rows(Pool P, const DCfg* __
   const uint32_t rc = g.reset_calls - 1;
   const int n = g.n_reset_now;
   int row = e.terrain_row()[0];
-  if (n_rows > 1) {
+  if (n_rows > 1 && !g.lock_terrain_rows) {                            // `if not self._lock_terrain_rows`, go2_env_stair.py:1513
     double level = c.i[GO2SIM_IC_CURR_ENABLED] ? (double)g.level : 1.0;
     int max_row = (int)(level * (double)(n_rows - 1));
     max_row = imx(0, imn(max_row, n_rows - 1));
@@ -3695,7 +3769,9 @@ struct go2sim {
   ModelS* dms = nullptr;    // device copy of the compact tables (staged into LDS by the team kernels)
   Pool P = {nullptr, nullptr, 0, nullptr, nullptr};
   DCfg hcfg; DCfg* dcfg = nullptr; bool cfg_set = false;
-  Glob* dglob = nullptr; Acc* dacc = nullptr; int* derr = nullptr;
+  Glob* dglob = nullptr; Acc* dacc = nullptr; int* derr = nullptr;      // derr[0]: go2sim_check_errno, derr[1]: asynchronous poll
+  int* herr_pinned = nullptr; hipEvent_t ev_errno = nullptr; bool errno_poll_pending = false;   // go2sim_errno_poll_*
+  int* didx = nullptr; int didx_cap = 0;    // scratch for index lists (go2sim_env_reset_idx)
   float* terrain_hf = nullptr;              // device copy of the heightfield in metres (go2sim_set_terrain)
   GjkScratch* gjk_scratch = nullptr;        // working memory of the GJK/EPA fallback: one block per (env, narrow-phase lane)
   SolverData<MAXR>* solver_ovf = nullptr;   // per-env global scratch for solves that do not fit in LDS (> RL rows)
@@ -3708,10 +3784,13 @@ struct go2sim {
     hipKernelNodeParams p_pre{}, p_post_a{}, p_post_b{};
     std::vector<void*> owned;                       // argument storage of all nodes (malloc'ed)
     const float** a_actions = nullptr; uint32_t* a_pre_step = nullptr; int* a_pre_widx = nullptr; uint32_t* a_pa_step = nullptr; uint32_t* a_pb_step = nullptr;
-    void* key[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // output pointers the graph was built for
+    // output pointers of the step (k_env_post_b_team): rewritten every step like the step counter, so the caller may hand over fresh
+    // observation tensors per step (the reference allocates a new obs tensor each step, go2_env_walk.py:1084) without a graph rebuild
+    float** a_obs = nullptr; float** a_priv = nullptr; float** a_rew = nullptr; uint8_t** a_reset = nullptr; float** a_timeout = nullptr;
     bool valid = false;
   } sg;
   bool use_graph = true;
+  int graph_fallbacks = 0;                  // times the graph path was abandoned for plain launches (go2sim_graph_status)
   int dyn_team = 32;                        // lanes per environment in k_dynamics_team
   int fk_team = 16;                         // lanes per environment in k_integrate_fk_team / k_fk_team
   int collide_team = 16;                    // lanes per environment in k_collide_team
@@ -3876,13 +3955,25 @@ static bool step_graph_build(go2sim* h, const float* actions, float* obs, float*
                         obs, priv, rew, reset, timeout);
   if (!ok) return false;
   g.a_pb_step = (uint32_t*)sl[6];
+  g.a_obs = (float**)sl[7]; g.a_priv = (float**)sl[8]; g.a_rew = (float**)sl[9]; g.a_reset = (uint8_t**)sl[10]; g.a_timeout = (float**)sl[11];
   if (hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0) != hipSuccess) return false;
-  g.key[0] = obs; g.key[1] = priv; g.key[2] = rew; g.key[3] = reset; g.key[4] = timeout;
   g.valid = true;
   return true;
 }
 
 extern "C" {
+
+// releases everything a handle owns (hipFree(nullptr) is a no-op): shared by go2sim_destroy and the error paths of go2sim_create
+static void handle_release(go2sim* h) {
+  step_graph_destroy(h);
+  if (h->ev_created) for (int i = 0; i < TIMING_RING; ++i) { (void)hipEventDestroy(h->ev0[i]); (void)hipEventDestroy(h->ev1[i]); }
+  (void)hipFree(h->P.f); (void)hipFree(h->P.i); (void)hipFree(h->P.fa); (void)hipFree(h->P.ia); (void)hipFree(h->dm); (void)hipFree(h->dcfg);
+  (void)hipFree(h->dglob); (void)hipFree(h->dacc); (void)hipFree(h->derr); (void)hipFree(h->solver_ovf); (void)hipFree(h->gjk_scratch);
+  (void)hipFree(h->terrain_hf); (void)hipFree(h->dms); (void)hipFree(h->didx);
+  if (h->herr_pinned) (void)hipHostFree(h->herr_pinned);
+  if (h->ev_errno) (void)hipEventDestroy(h->ev_errno);
+  delete h;
+}
 
 int go2sim_create(const void* blob, size_t nbytes, int n_envs, int device, uint64_t seed, go2sim_t** out) {
   if (!blob || !out || n_envs <= 0) return GO2SIM_E_BADARG;
@@ -3893,57 +3984,67 @@ int go2sim_create(const void* blob, size_t nbytes, int n_envs, int device, uint6
   if (!h) return GO2SIM_E_NOMEM;
   if (!parse_model(blob, nbytes, h->hm)) { delete h; return GO2SIM_E_BADMODEL; }
   h->B = n_envs; h->device = device; h->seed = seed;
-  HIPCHK(hipSetDevice(device));
-  size_t nf = (size_t)FO_TOTAL * n_envs, ni = (size_t)IO_TOTAL * n_envs;
-  HIPCHK(hipMalloc((void**)&h->P.f, nf * sizeof(float)));
-  HIPCHK(hipMalloc((void**)&h->P.i, ni * sizeof(int)));
-  h->P.B = n_envs;
-  HIPCHK(hipMemset(h->P.f, 0, nf * sizeof(float)));
-  HIPCHK(hipMemset(h->P.i, 0, ni * sizeof(int)));
-  HIPCHK(hipMalloc((void**)&h->P.fa, (size_t)ASTRIDE * n_envs * sizeof(float)));      // AoS records of the physics-internal arrays
-  HIPCHK(hipMalloc((void**)&h->P.ia, (size_t)AISTRIDE * n_envs * sizeof(int)));
-  HIPCHK(hipMemset(h->P.fa, 0, (size_t)ASTRIDE * n_envs * sizeof(float)));
-  HIPCHK(hipMemset(h->P.ia, 0, (size_t)AISTRIDE * n_envs * sizeof(int)));
-  HIPCHK(hipMalloc((void**)&h->dm, sizeof(Model)));
-  HIPCHK(hipMemcpy(h->dm, &h->hm, sizeof(Model), hipMemcpyHostToDevice));
+  // every failure below releases what was allocated so far (one exit path)
+  int rc = GO2SIM_E_OK;
+#define CK(x) do { hipError_t _e = (x); if (_e != hipSuccess) { fprintf(stderr, "go2sim: HIP error %s at %s:%d\n", hipGetErrorString(_e), __FILE__, __LINE__); rc = GO2SIM_E_HIP; goto fail; } } while (0)
   {
-    ModelS hs;
-    if (!build_model_s(h->hm, hs)) return GO2SIM_E_BADMODEL;
-    HIPCHK(hipMalloc((void**)&h->dms, MODELS_LDS_BYTES));   // padded: the LDS DMA of the team kernels reads whole KiB
-    HIPCHK(hipMemset(h->dms, 0, MODELS_LDS_BYTES));
-    HIPCHK(hipMemcpy(h->dms, &hs, sizeof(ModelS), hipMemcpyHostToDevice));
+    CK(hipSetDevice(device));
+    const size_t nf = (size_t)FO_TOTAL * n_envs, ni = (size_t)IO_TOTAL * n_envs;
+    CK(hipMalloc((void**)&h->P.f, nf * sizeof(float)));
+    CK(hipMalloc((void**)&h->P.i, ni * sizeof(int)));
+    h->P.B = n_envs;
+    CK(hipMemset(h->P.f, 0, nf * sizeof(float)));
+    CK(hipMemset(h->P.i, 0, ni * sizeof(int)));
+    CK(hipMalloc((void**)&h->P.fa, (size_t)ASTRIDE * n_envs * sizeof(float)));      // AoS records of the physics-internal arrays
+    CK(hipMalloc((void**)&h->P.ia, (size_t)AISTRIDE * n_envs * sizeof(int)));
+    CK(hipMemset(h->P.fa, 0, (size_t)ASTRIDE * n_envs * sizeof(float)));
+    CK(hipMemset(h->P.ia, 0, (size_t)AISTRIDE * n_envs * sizeof(int)));
+    CK(hipMalloc((void**)&h->dm, sizeof(Model)));
+    CK(hipMemcpy(h->dm, &h->hm, sizeof(Model), hipMemcpyHostToDevice));
+    {
+      ModelS hs;
+      if (!build_model_s(h->hm, hs)) { rc = GO2SIM_E_BADMODEL; goto fail; }
+      CK(hipMalloc((void**)&h->dms, MODELS_LDS_BYTES));   // padded: the LDS DMA of the team kernels reads whole KiB
+      CK(hipMemset(h->dms, 0, MODELS_LDS_BYTES));
+      CK(hipMemcpy(h->dms, &hs, sizeof(ModelS), hipMemcpyHostToDevice));
+    }
+    CK(hipMalloc((void**)&h->dcfg, sizeof(DCfg)));
+    CK(hipMalloc((void**)&h->dglob, sizeof(Glob)));
+    CK(hipMalloc((void**)&h->dacc, sizeof(Acc)));
+    CK(hipMalloc((void**)&h->derr, 2 * sizeof(int)));
+    CK(hipMemset(h->derr, 0, 2 * sizeof(int)));
+    CK(hipHostMalloc((void**)&h->herr_pinned, 2 * sizeof(int), hipHostMallocDefault));
+    h->herr_pinned[0] = h->herr_pinned[1] = 0;
+    CK(hipEventCreateWithFlags(&h->ev_errno, hipEventDisableTiming));
+    CK(hipMalloc((void**)&h->solver_ovf, (size_t)n_envs * sizeof(SolverData<MAXR>)));
+    if (const char* t = getenv("GO2SIM_DYN_TEAM")) { int v = atoi(t); if (v == 16 || v == 32 || v == 64) h->dyn_team = v; }
+    if (const char* t = getenv("GO2SIM_NO_GRAPH")) { if (atoi(t) != 0) h->use_graph = false; }
+    if (const char* t = getenv("GO2SIM_FK_TEAM")) { int v = atoi(t); if (v == 16 || v == 32 || v == 64) h->fk_team = v; }
+    if (const char* t = getenv("GO2SIM_COLLIDE_TEAM")) { int v = atoi(t); if (v == 16 || v == 32 || v == 64) h->collide_team = v; }
+    CK(hipMalloc((void**)&h->gjk_scratch, (size_t)n_envs * h->collide_team * sizeof(GjkScratch)));   // ~31 KB per narrow-phase lane
+    if (const char* t = getenv("GO2SIM_SOLVER_TEAM")) { int v = atoi(t); if (v == 16 || v == 32 || v == 64) h->solver_team = v; }
+    Glob g0; memset(&g0, 0, sizeof(g0)); g0.friction = 1.0f;
+    CK(hipMemcpy(h->dglob, &g0, sizeof(Glob), hipMemcpyHostToDevice));
+    CK(hipMemset(h->dacc, 0, sizeof(Acc)));
+    memset(&h->hcfg, 0, sizeof(DCfg));
+    hipLaunchKernelGGL(k_init_state, grid_for(n_envs), dim3(WG), 0, 0, h->P, h->dm, 0);
+    launch_fk_team(h, 0, 1, nullptr);
+    CK(hipGetLastError());
+    CK(hipDeviceSynchronize());
   }
-  HIPCHK(hipMalloc((void**)&h->dcfg, sizeof(DCfg)));
-  HIPCHK(hipMalloc((void**)&h->dglob, sizeof(Glob)));
-  HIPCHK(hipMalloc((void**)&h->dacc, sizeof(Acc)));
-  HIPCHK(hipMalloc((void**)&h->derr, sizeof(int)));
-  HIPCHK(hipMalloc((void**)&h->solver_ovf, (size_t)n_envs * sizeof(SolverData<MAXR>)));
-  if (const char* t = getenv("GO2SIM_DYN_TEAM")) { int v = atoi(t); if (v == 16 || v == 32 || v == 64) h->dyn_team = v; }
-  if (const char* t = getenv("GO2SIM_NO_GRAPH")) { if (atoi(t) != 0) h->use_graph = false; }
-  if (const char* t = getenv("GO2SIM_FK_TEAM")) { int v = atoi(t); if (v == 16 || v == 32 || v == 64) h->fk_team = v; }
-  if (const char* t = getenv("GO2SIM_COLLIDE_TEAM")) { int v = atoi(t); if (v == 16 || v == 32 || v == 64) h->collide_team = v; }
-  HIPCHK(hipMalloc((void**)&h->gjk_scratch, (size_t)n_envs * h->collide_team * sizeof(GjkScratch)));   // ~31 KB per narrow-phase lane
-  if (const char* t = getenv("GO2SIM_SOLVER_TEAM")) { int v = atoi(t); if (v == 16 || v == 32 || v == 64) h->solver_team = v; }
-  Glob g0; memset(&g0, 0, sizeof(g0)); g0.friction = 1.0f;
-  HIPCHK(hipMemcpy(h->dglob, &g0, sizeof(Glob), hipMemcpyHostToDevice));
-  HIPCHK(hipMemset(h->dacc, 0, sizeof(Acc)));
-  memset(&h->hcfg, 0, sizeof(DCfg));
-  hipLaunchKernelGGL(k_init_state, grid_for(n_envs), dim3(WG), 0, 0, h->P, h->dm, 0);
-  launch_fk_team(h, 0, 1, nullptr);
-  HIPCHK(hipGetLastError());
-  HIPCHK(hipDeviceSynchronize());
+#undef CK
   *out = h;
   return GO2SIM_E_OK;
+fail:
+  handle_release(h);
+  return rc;
 }
 
 int go2sim_destroy(go2sim_t* h) {
   if (!h) return GO2SIM_E_BADARG;
   (void)hipSetDevice(h->device);
   (void)hipDeviceSynchronize();
-  step_graph_destroy(h);
-  if (h->ev_created) for (int i = 0; i < TIMING_RING; ++i) { (void)hipEventDestroy(h->ev0[i]); (void)hipEventDestroy(h->ev1[i]); }
-  (void)hipFree(h->P.f); (void)hipFree(h->P.i); (void)hipFree(h->P.fa); (void)hipFree(h->P.ia); (void)hipFree(h->dm); (void)hipFree(h->dcfg); (void)hipFree(h->dglob); (void)hipFree(h->dacc); (void)hipFree(h->derr); (void)hipFree(h->solver_ovf); (void)hipFree(h->gjk_scratch); if (h->terrain_hf) (void)hipFree(h->terrain_hf); (void)hipFree(h->dms);
-  delete h;
+  handle_release(h);
   return GO2SIM_E_OK;
 }
 int go2sim_n_envs(const go2sim_t* h) { return h ? h->B : GO2SIM_E_BADARG; }
@@ -4141,15 +4242,22 @@ int go2sim_check_errno(go2sim_t* h, int* out, void* stream) {
 
 int go2sim_env_configure(go2sim_t* h, const float* f, int nf, const int* i, int ni) {
   if (!h || !f || !i || nf != GO2SIM_FC_COUNT || ni != GO2SIM_IC_COUNT) return GO2SIM_E_BADARG;
-  step_graph_destroy(h);   // the configuration is baked into the kernel arguments of the step graph
-  memcpy(h->hcfg.f, f, sizeof(float) * nf); memcpy(h->hcfg.i, i, sizeof(int) * ni);
+  {                                                                       // validate a local copy: a rejected configuration leaves the handle as it was
+    DCfg c;
+    memcpy(c.f, f, sizeof(float) * nf); memcpy(c.i, i, sizeof(int) * ni);
+    if (c.i[GO2SIM_IC_NUM_ACTIONS] > NA || c.i[GO2SIM_IC_NUM_ACTIONS] < NM || c.i[GO2SIM_IC_NUM_OBS] > NOBS_MAX || c.i[GO2SIM_IC_NUM_PRIV_OBS] > NPRIV_MAX ||
+        c.i[GO2SIM_IC_N_REWARDS] > NREW || c.i[GO2SIM_IC_N_REWARDS] < 0 || c.i[GO2SIM_IC_MAX_DELAY] > 1 || c.i[GO2SIM_IC_NUM_OBS] < 33 + c.i[GO2SIM_IC_NUM_ACTIONS] ||
+        c.i[GO2SIM_IC_SUBSTEPS] < 1 || c.i[GO2SIM_IC_SUBSTEPS] > 16 || c.i[GO2SIM_IC_RESAMPLE_STEPS] < 1 || c.i[GO2SIM_IC_N_TERRAIN_ROWS] > 16 || c.i[GO2SIM_IC_SCAN_N] > 80 ||
+        c.i[GO2SIM_IC_SCAN_N] < 0)
+      return GO2SIM_E_BADARG;
+    for (int k = 0; k < NM; ++k) { int d = c.i[GO2SIM_IC_MOTOR_DOF0 + k]; if (d < 6 || d >= ND) return GO2SIM_E_BADARG; }
+    for (int k = 0; k < 4; ++k) { int l = c.i[GO2SIM_IC_FOOT_LINK0 + k], l2 = c.i[GO2SIM_IC_HIP_LINK0 + k]; if (l < 0 || l >= NL || l2 < 0 || l2 >= NL) return GO2SIM_E_BADARG; }
+    if (c.i[GO2SIM_IC_PUSH_LINK] < 0 || c.i[GO2SIM_IC_PUSH_LINK] >= NL || c.i[GO2SIM_IC_BASE_LINK] < 0 || c.i[GO2SIM_IC_BASE_LINK] >= NL) return GO2SIM_E_BADARG;
+    for (int k = 0; k < c.i[GO2SIM_IC_N_REWARDS]; ++k) { int id = c.i[GO2SIM_IC_REWARD_ID0 + k]; if (id < 0 || id >= GO2SIM_R_COUNT) return GO2SIM_E_BADARG; }
+    step_graph_destroy(h);   // the configuration is baked into the kernel arguments of the step graph
+    h->hcfg = c;
+  }
   const DCfg& c = h->hcfg;
-  if (c.i[GO2SIM_IC_NUM_ACTIONS] > NA || c.i[GO2SIM_IC_NUM_OBS] > NOBS_MAX || c.i[GO2SIM_IC_NUM_PRIV_OBS] > NPRIV_MAX || c.i[GO2SIM_IC_N_REWARDS] > NREW ||
-      c.i[GO2SIM_IC_MAX_DELAY] > 1 || c.i[GO2SIM_IC_NUM_OBS] < 33 + c.i[GO2SIM_IC_NUM_ACTIONS])
-    return GO2SIM_E_BADARG;
-  for (int k = 0; k < NM; ++k) { int d = c.i[GO2SIM_IC_MOTOR_DOF0 + k]; if (d < 6 || d >= ND) return GO2SIM_E_BADARG; }
-  for (int k = 0; k < 4; ++k) { int l = c.i[GO2SIM_IC_FOOT_LINK0 + k], l2 = c.i[GO2SIM_IC_HIP_LINK0 + k]; if (l < 0 || l >= NL || l2 < 0 || l2 >= NL) return GO2SIM_E_BADARG; }
-  if (c.i[GO2SIM_IC_PUSH_LINK] < 0 || c.i[GO2SIM_IC_PUSH_LINK] >= NL || c.i[GO2SIM_IC_BASE_LINK] < 0 || c.i[GO2SIM_IC_BASE_LINK] >= NL) return GO2SIM_E_BADARG;
   HIPCHK(hipSetDevice(h->device));
   HIPCHK(hipMemcpy(h->dcfg, &h->hcfg, sizeof(DCfg), hipMemcpyHostToDevice));
   Glob g; memset(&g, 0, sizeof(g));
@@ -4180,11 +4288,16 @@ int go2sim_env_step(go2sim_t* h, const float* actions, float* obs, float* priv, 
   dim3 g = grid_for(h->B), b(WG);
   if (h->use_graph && !h->timing) {
     auto& sg = h->sg;
-    if (!sg.valid || sg.key[0] != obs || sg.key[1] != priv || sg.key[2] != rew || sg.key[3] != reset || sg.key[4] != timeout) {
-      if (!step_graph_build(h, actions, obs, priv, rew, reset, timeout)) { step_graph_destroy(h); h->use_graph = false; }
+    if (!sg.valid) {
+      if (!step_graph_build(h, actions, obs, priv, rew, reset, timeout)) {
+        (void)hipGetLastError();
+        fprintf(stderr, "go2sim: hipGraph build failed, falling back to plain kernel launches\n");
+        step_graph_destroy(h); h->use_graph = false; h->graph_fallbacks += 1;
+      }
     }
     if (h->use_graph) {
       *sg.a_actions = actions; *sg.a_pre_step = h->step_count; *sg.a_pre_widx = h->action_write_idx; *sg.a_pa_step = h->step_count; *sg.a_pb_step = h->step_count;
+      *sg.a_obs = obs; *sg.a_priv = priv; *sg.a_rew = rew; *sg.a_reset = reset; *sg.a_timeout = timeout;
       const bool launched = hipGraphExecKernelNodeSetParams(sg.exec, sg.n_pre, &sg.p_pre) == hipSuccess &&
                             hipGraphExecKernelNodeSetParams(sg.exec, sg.n_post_a, &sg.p_post_a) == hipSuccess &&
                             hipGraphExecKernelNodeSetParams(sg.exec, sg.n_post_b, &sg.p_post_b) == hipSuccess && hipGraphLaunch(sg.exec, s) == hipSuccess;
@@ -4195,7 +4308,7 @@ int go2sim_env_step(go2sim_t* h, const float* actions, float* obs, float* priv, 
       }
       (void)hipGetLastError();            // nothing of this step was enqueued: drop the graph and continue with plain launches
       fprintf(stderr, "go2sim: hipGraph launch failed, falling back to plain kernel launches\n");
-      step_graph_destroy(h); h->use_graph = false;
+      step_graph_destroy(h); h->use_graph = false; h->graph_fallbacks += 1;
     }
   }
   if (h->timing && h->ev_n + 64 > TIMING_RING) timing_flush(h);   // all pending events belong to completed launches
@@ -4226,6 +4339,77 @@ int go2sim_env_reset(go2sim_t* h, void* stream) {
   hipLaunchKernelGGL(k_env_reset_tail, g, b, 0, s, h->P, h->dm, h->dcfg, h->dglob, h->seed);
   launch_fk_team(h, s, 1, &h->dglob->n_reset_now);
   HIPCHK(hipGetLastError());
+  return GO2SIM_E_OK;
+}
+int go2sim_env_reset_idx(go2sim_t* h, const int* envs_idx, int n_sel, void* stream) {
+  if (!h || !h->cfg_set || (n_sel > 0 && !envs_idx) || n_sel < 0) return GO2SIM_E_BADARG;
+  if (n_sel == 0) return GO2SIM_E_OK;                                  // `if len(envs_idx) == 0: return`, go2_env_walk.py:1157
+  hipStream_t s = (hipStream_t)stream;
+  dim3 g = grid_for(h->B), b(WG);
+  ScopedTimer t(h, s, T_MISC);
+  HIPCHK(hipMemsetAsync(h->dacc, 0, sizeof(Acc), s));
+  hipLaunchKernelGGL(k_env_unmark_all, g, b, 0, s, h->P);
+  hipLaunchKernelGGL(k_env_mark_idx, grid_for(n_sel), b, 0, s, h->P, h->dcfg, h->dacc, envs_idx, n_sel);
+  hipLaunchKernelGGL(k_env_globals, dim3(1), dim3(1), 0, s, h->dcfg, h->dglob, h->dacc, h->seed, 0);
+  if (h->hcfg.i[GO2SIM_IC_USE_TERRAIN]) hipLaunchKernelGGL(k_env_terrain_rows, dim3((h->B + 255) / 256), dim3(256), 0, s, h->P, h->dcfg, h->dglob, h->seed);
+  hipLaunchKernelGGL(k_env_reset_tail, g, b, 0, s, h->P, h->dm, h->dcfg, h->dglob, h->seed);
+  launch_fk_team(h, s, 1, &h->dglob->n_reset_now);
+  HIPCHK(hipGetLastError());
+  return GO2SIM_E_OK;
+}
+int go2sim_env_respawn(go2sim_t* h, const int* envs_idx, int n_sel, const float* pos, const float* quat, int clear_buffers, void* stream) {
+  if (!h || !h->cfg_set || n_sel < 0 || (n_sel > 0 && (!envs_idx || !pos))) return GO2SIM_E_BADARG;
+  if (n_sel == 0) return GO2SIM_E_OK;
+  hipStream_t s = (hipStream_t)stream;
+  ScopedTimer t(h, s, T_MISC);
+  hipLaunchKernelGGL(k_env_respawn, grid_for(n_sel), dim3(WG), 0, s, h->P, h->dm, h->dcfg, envs_idx, n_sel, pos, quat, clear_buffers);
+  launch_fk_team(h, s, 1, nullptr);                                      // set_pos / set_quat re-run the full-batch FK (rigid_solver.py:1928-1943)
+  HIPCHK(hipGetLastError());
+  return GO2SIM_E_OK;
+}
+int go2sim_env_lock_terrain_rows(go2sim_t* h, int lock, void* stream) {
+  if (!h || !h->cfg_set) return GO2SIM_E_BADARG;
+  hipStream_t s = (hipStream_t)stream;
+  int v = lock != 0;
+  HIPCHK(hipMemcpyAsync((char*)h->dglob + offsetof(Glob, lock_terrain_rows), &v, sizeof(int), hipMemcpyHostToDevice, s));
+  HIPCHK(hipStreamSynchronize(s));                                      // `v` lives on this stack frame
+  return GO2SIM_E_OK;
+}
+int go2sim_env_set_terrain_rows(go2sim_t* h, const int* rows, void* stream) {
+  if (!h || !h->cfg_set || !rows) return GO2SIM_E_BADARG;
+  int n_rows = h->hcfg.i[GO2SIM_IC_N_TERRAIN_ROWS];
+  hipLaunchKernelGGL(k_env_set_terrain_rows, grid_for(h->B), dim3(WG), 0, (hipStream_t)stream, h->P, rows, n_rows < 1 ? 1 : n_rows);
+  HIPCHK(hipGetLastError());
+  return GO2SIM_E_OK;
+}
+// Asynchronous form of RigidSolver.check_errno (rigid_solver.py:1189-1213; polled every 10 substeps by Simulator.step, simulator.py:267): _begin
+// enqueues the OR-reduction and a copy into pinned host memory and returns at once; _result reports it without blocking once the copy has landed.
+int go2sim_errno_poll_begin(go2sim_t* h, void* stream) {
+  if (!h) return GO2SIM_E_BADARG;
+  if (h->errno_poll_pending) return GO2SIM_E_OK;                        // one poll in flight at a time
+  hipStream_t s = (hipStream_t)stream;
+  HIPCHK(hipMemsetAsync(h->derr + 1, 0, sizeof(int), s));
+  hipLaunchKernelGGL(k_errno_reduce, dim3(64), dim3(256), 0, s, h->P, h->derr + 1);
+  HIPCHK(hipMemcpyAsync(h->herr_pinned, h->derr + 1, sizeof(int), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipEventRecord(h->ev_errno, s));
+  h->errno_poll_pending = true;
+  return GO2SIM_E_OK;
+}
+int go2sim_errno_poll_result(go2sim_t* h, int* errno_host, int* ready) {
+  if (!h || !errno_host || !ready) return GO2SIM_E_BADARG;
+  *ready = 0; *errno_host = 0;
+  if (!h->errno_poll_pending) return GO2SIM_E_OK;
+  hipError_t q = hipEventQuery(h->ev_errno);
+  if (q == hipErrorNotReady) return GO2SIM_E_OK;
+  HIPCHK(q);
+  h->errno_poll_pending = false;
+  *ready = 1; *errno_host = h->herr_pinned[0];
+  return GO2SIM_E_OK;
+}
+int go2sim_graph_status(go2sim_t* h, int* using_graph, int* n_fallbacks) {
+  if (!h) return GO2SIM_E_BADARG;
+  if (using_graph) *using_graph = (h->use_graph && !h->timing) ? 1 : 0;
+  if (n_fallbacks) *n_fallbacks = h->graph_fallbacks;
   return GO2SIM_E_OK;
 }
 int go2sim_env_get(go2sim_t* h, int buf, void* dst, void* stream) {

@@ -22,27 +22,27 @@ def shard_envs(total_envs: int, world_size: int, rank: int):
     return start, count
 
 
-def local_moments(x: torch.Tensor) -> torch.Tensor:
-    x = x.reshape(-1).to(torch.float32)
-    return torch.stack([x.sum(), (x * x).sum(), torch.tensor(float(x.numel()), device=x.device)])
-
-
-def global_mean_std(x: torch.Tensor, group=None, eps: float = 1e-8):
-    """Mean / std of `x` over all ranks (unbiased=False), via ONE all-gather of 3 floats per rank."""
-    m = local_moments(x)
+def global_mean_std(x: torch.Tensor, group=None):
+    """Mean / unbiased std (``torch.std``) of `x` over all ranks, via ONE all-gather of 3 values per rank.  The moments are accumulated in
+    float64, as ``k_adv_normalize`` (csrc/go2sim_policy.hip) does, so that both advantage normalisations of the package agree."""
+    xd = x.reshape(-1).to(torch.float64)
+    m = torch.stack([xd.sum(), (xd * xd).sum(), torch.tensor(float(xd.numel()), device=x.device, dtype=torch.float64)])
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         world = dist.get_world_size(group)
         out = torch.empty(3 * world, device=m.device, dtype=m.dtype)
         dist.all_gather_into_tensor(out, m, group=group)
         m = out.view(world, 3).sum(0)
-    mean = m[0] / m[2]
-    var = torch.clamp(m[1] / m[2] - mean * mean, min=0.0)
-    return mean, torch.sqrt(var + eps)
+    n = m[2]
+    mean = m[0] / n
+    var = torch.clamp((m[1] - n * mean * mean) / torch.clamp(n - 1.0, min=1.0), min=0.0)
+    return mean.to(torch.float32), torch.sqrt(var).to(torch.float32)
 
 
 def normalize_advantages(adv: torch.Tensor, group=None, eps: float = 1e-8) -> torch.Tensor:
-    mean, std = global_mean_std(adv, group, eps)
-    return (adv - mean) / std
+    """rsl_rl 2.2.4 PPO: ``(adv - adv.mean()) / (adv.std() + 1e-8)`` with the statistics taken over all ranks -- the formula of
+    ``go2sim_rollout_normalize`` (unbiased std, eps added to the std)."""
+    mean, std = global_mean_std(adv, group)
+    return (adv - mean) / (std + eps)
 
 
 def allgather_moments(moments3: torch.Tensor, group=None) -> torch.Tensor:

@@ -1,5 +1,6 @@
 """gs -- the Genesis Python surface that the reference's Go2Env files use, on top of the go2sim C ABI.
 
+    import genesis as gs                     # alias package at the repo root (genesis/__init__.py), or
     import go2_sim2real_locomotion_rl_amd.genesis_shim as gs
     gs.init(backend=gs.gpu, precision="32")
     scene = gs.Scene(sim_options=gs.options.SimOptions(dt=0.02, substeps=2), rigid_options=gs.options.RigidOptions(...))
@@ -32,17 +33,16 @@ class GenesisException(Exception):
     pass
 
 
-def init(backend=gpu, precision="32", logging_level=None, performance_mode=True, seed=None, _backend_lib=None, **_):
-    """gs.init (genesis/__init__.py:60).  `_backend_lib` lets the tests inject the CPU twin of the C ABI."""
+def init(backend=gpu, precision="32", logging_level=None, performance_mode=True, seed=None, **_):
+    """gs.init (genesis/__init__.py:60).  There is one backend: the HIP library on the current ROCm device."""
     global device, _lib, _seed
     if str(precision) != "32":
         raise GenesisException("go2sim computes in fp32 only")
-    if _backend_lib is not None:
-        _lib, device = _backend_lib, torch.device("cpu") if not _backend_lib.is_device else torch.device("cuda", 0)
-    else:
-        if not torch.cuda.is_available():
-            raise GenesisException("no ROCm GPU visible: the go2sim product path has no CPU fallback")
-        _lib, device = load_hip_lib(), torch.device("cuda", torch.cuda.current_device())
+    if backend == cpu:
+        raise GenesisException("go2sim has no CPU backend (gs.cpu is defined for source compatibility only)")
+    if not torch.cuda.is_available():
+        raise GenesisException("no ROCm GPU visible: the go2sim product path has no CPU fallback")
+    _lib, device = load_hip_lib(), torch.device("cuda", torch.cuda.current_device())
     if seed is not None:
         _seed = int(seed)
 

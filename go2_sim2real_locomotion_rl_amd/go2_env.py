@@ -12,7 +12,10 @@ train / eval scripts can use it unchanged:
 Differences that are deliberate (DESIGN.md "boundary"):
   * the whole step runs inside libgo2sim.so (HIP, gfx950); there is no per-call torch arithmetic and no
     host synchronisation: the curriculum state machine and the "global" domain randomisation live on the device;
-  * ``extras["episode"]`` values are 0-dim device tensors instead of python floats (rsl_rl accepts both);
+  * ``extras["episode"]`` / ``extras["curriculum"]`` / ``extras["domain_randomization"]`` values are 0-dim device tensors
+    (views of one per-step snapshot of the device globals) instead of python floats (rsl_rl accepts both);
+  * the errno poll of ``scene.step`` (simulator.py:267, every 10 substeps = 5 env steps) is asynchronous: the reduction is
+    enqueued after the step and examined one step later, so the loop never waits for the device;
   * random numbers come from the counter-based Philox stream of the C ABI (include/go2sim.h), not from
     torch's global generator.
 """
@@ -62,7 +65,7 @@ def _as_device_tensor(ptr, shape, dtype, device):
 
 class Go2Env:
     def __init__(self, num_envs, env_cfg, obs_cfg, reward_cfg, command_cfg, show_viewer=False, *, seed=None, device=None,
-                 freeze_curriculum=False):
+                 freeze_curriculum=False, log_extras=True, errno_poll_every=5):
         if show_viewer:
             raise Go2SimError("the viewer is outside the accelerated path (SURVEY.md section 8f)")
         self.device = device if device is not None else (_DEVICE if _DEVICE is not None else init())
@@ -113,23 +116,81 @@ class Go2Env:
         self._glob_f32 = _as_device_tensor(gptr, (ctypes.sizeof(EnvGlobals) // 4,), torch.float32, dev)
         self._ep_off = EnvGlobals.last_episode_rew.offset // 4
         self._level_off = EnvGlobals.level.offset // 4
+        self._goff = {name: getattr(EnvGlobals, name).offset // 4 for name, _ in EnvGlobals._fields_}
+        self._episode_keys = ["rew_" + n for n in self._reward_names]
+        self._use_terrain = hasattr(self, "_terrain_info")
+        self._terrain_rows_locked = False
+        self.log_extras = bool(log_extras)            # per-step snapshot of the episode / curriculum / DR logs (one small device copy)
+        self.errno_poll_every = int(errno_poll_every)  # env steps between errno polls (simulator.py:267: every 10 substeps)
+        self._steps_since_poll = 0
         self._views = {}
         self.reset()
 
     # ---- reference API -------------------------------------------------------------------------
     def step(self, actions):
-        """go2_env_walk.py:985-1109.  ``actions`` [num_envs, 16] float32 on ``self.device``."""
+        """go2_env_walk.py:985-1109.  ``actions`` [num_envs, 16] float32 on ``self.device``.
+
+        Like the reference (``self.obs_buf = torch.cat(...)``, go2_env_walk.py:1084 / go2_env_base.py:175), every step returns NEW
+        observation tensors: rsl_rl's PPO keeps ``transition.observations = obs`` by reference across ``env.step`` and copies it afterwards,
+        so an observation buffer overwritten in place would pair o_{t+1} with a_t in the rollout storage."""
         if actions.shape != (self.num_envs, self.num_actions):
             raise Go2SimError(f"actions must have shape {(self.num_envs, self.num_actions)}, got {tuple(actions.shape)}")
         a = actions
         if a.dtype != torch.float32 or not a.is_contiguous() or a.device != self.device:
             a = self._actions.copy_(actions)
+        self._raise_on_errno(self._sim.errno_poll_result())               # result of the poll enqueued after an earlier step
         stream = torch.cuda.current_stream(self.device).cuda_stream
+        self.obs_buf = torch.empty_like(self.obs_buf)                      # caching allocator: host-side only, no kernel
+        self.privileged_obs_buf = torch.empty_like(self.privileged_obs_buf)
         self._sim.env_step(a, self.obs_buf, self.privileged_obs_buf, self.rew_buf, self.reset_buf, self._time_outs, stream)
+        self._steps_since_poll += 1
+        poll = self._steps_since_poll >= self.errno_poll_every             # RATE_CHECK_ERRNO = 10 substeps, simulator.py:45,267
+        if poll:
+            self._steps_since_poll = 0
+            self._sim.errno_poll_begin(stream)
         self.extras["time_outs"] = self._time_outs
-        self.extras["episode"] = {"rew_" + n: v for n, v in zip(self._reward_names, self._glob_f32[self._ep_off:self._ep_off + len(self._reward_names)].clone())}
         self.extras["observations"]["critic"] = self.privileged_obs_buf if self.num_privileged_obs else self.obs_buf
+        if self.log_extras:
+            self._refresh_extras(full=poll)
         return self.obs_buf, self.rew_buf, self.reset_buf, self.extras
+
+    def _refresh_extras(self, full=True):
+        """extras["episode"] (go2_env_walk.py:1228-1235) every step, extras["curriculum"] (:674-686) and extras["domain_randomization"]
+        (:756,813) every ``errno_poll_every`` steps, from ONE snapshot of the device globals: a single small device copy, no synchronisation;
+        the values are 0-dim views of that snapshot (the reference stores python floats obtained with ``.item()``)."""
+        snap = self._glob_f32.clone()
+        n = len(self._reward_names)
+        self.extras["episode"] = dict(zip(self._episode_keys, snap[self._ep_off:self._ep_off + n].unbind(0)))
+        if self._use_terrain:
+            rows = snap.view(torch.int32)
+            self.extras["episode"]["terrain_mean_row"] = rows[self._goff["terrain_row_sum"]].float() / rows[self._goff["last_reset_count"]].clamp(min=1).float()
+        if self.is_base_env or not full:
+            return
+        f, i = snap, snap.view(torch.int32)
+        g = self._goff
+        self.extras["curriculum"] = {
+            "level": f[g["level"]], "timeout_rate_ema": f[g["timeout_rate_ema"]], "tracking_ema": f[g["tracking_ema"]],
+            "fall_rate_ema": f[g["fall_rate_ema"]], "ready_streak": i[g["ready_streak"]], "hard_streak": i[g["hard_streak"]],
+            "cooldown": i[g["cooldown"]], "obs_noise_level_cur": f[g["obs_noise_level_cur"]], "action_noise_std_cur": f[g["action_noise_std_cur"]],
+            "push_enable": i[g["push_enable"]], "push_force_range_cur": f[g["push_force_lo"]:g["push_force_lo"] + 2],
+            "push_interval_steps": i[g["push_interval"]], "delay_max_cur": i[g["delay_max_cur"]],
+            "cmd_ranges": {"lin_vel_x_range": f[g["cmd_x_lo"]:g["cmd_x_lo"] + 2], "lin_vel_y_range": f[g["cmd_y_lo"]:g["cmd_y_lo"] + 2],
+                           "ang_vel_range": f[g["cmd_yaw_lo"]:g["cmd_yaw_lo"] + 2]},
+        }
+        self.extras["domain_randomization"] = {"friction": f[g["friction"]], "mass_shift": f[g["mass_shift"]],
+                                               "com_shift": f[g["com_shift"]:g["com_shift"] + 3],
+                                               "leg_mass_shift": f[g["leg_mass_shift"]:g["leg_mass_shift"] + 4]}
+
+    def _raise_on_errno(self, v):
+        """rigid_solver.py:1189-1213: the exceptions scene.step raises from its errno poll."""
+        if not v:
+            return
+        if v & C["GO2SIM_ERR_INVALID_FORCE_NAN"]:
+            raise Go2SimError("Invalid constraint forces causing 'nan'. Some environments were not advanced.")
+        if v & C["GO2SIM_ERR_INVALID_ACC_NAN"]:
+            raise Go2SimError("Invalid accelerations causing 'nan'. Some environments were not advanced.")
+        if v & (C["GO2SIM_ERR_OVERFLOW_CANDIDATE_CONTACTS"] | C["GO2SIM_ERR_OVERFLOW_COLLISION_PAIRS"]):
+            raise Go2SimError("Exceeding max number of broad phase candidate contact pairs / contacts.")
 
     def get_observations(self):
         self.extras["observations"]["critic"] = self.privileged_obs_buf if self.num_privileged_obs else self.obs_buf
@@ -143,7 +204,55 @@ class Go2Env:
         stream = torch.cuda.current_stream(self.device).cuda_stream
         self._sim.env_reset(stream)
         self.reset_buf.fill_(1)
+        if self.log_extras:
+            self._refresh_extras()
         return self.obs_buf, None
+
+    def reset_idx(self, envs_idx):
+        """go2_env_walk.py:1156-1240: curriculum bookkeeping, "global" DR draws and per-env reset of ``envs_idx`` (index tensor / list)."""
+        idx = torch.as_tensor(envs_idx, device=self.device).to(torch.int32).contiguous()
+        if idx.numel() == 0:
+            return
+        self._sim.env_reset_idx(idx, idx.numel(), torch.cuda.current_stream(self.device).cuda_stream)
+        self.reset_buf[idx.long()] = 1
+        if self.log_extras:
+            self._refresh_extras()
+
+    # ---- eval / teleop surface (go2_eval_walk.py, go2_eval_stairs.py) ------------------------------
+    @property
+    def _lock_terrain_rows(self):
+        return self._terrain_rows_locked
+
+    @_lock_terrain_rows.setter
+    def _lock_terrain_rows(self, value):
+        """go2_env_stair.py:399,1513; go2_eval_stairs.py:657 sets it after the first reset."""
+        self._terrain_rows_locked = bool(value)
+        self._sim.env_lock_terrain_rows(self._terrain_rows_locked, torch.cuda.current_stream(self.device).cuda_stream)
+
+    def set_terrain_rows(self, rows):
+        """``env._env_terrain_row[:] = rows`` of the eval scripts."""
+        r = torch.as_tensor(rows, device=self.device).to(torch.int32).expand(self.num_envs).contiguous()
+        self._sim.env_set_terrain_rows(r, torch.cuda.current_stream(self.device).cuda_stream)
+
+    def respawn(self, envs_idx, pos, quat=None, clear_buffers=True):
+        """Teleport ``envs_idx`` to ``pos`` [n, 3] (``quat`` [n, 4] wxyz, default base_init_quat) in the default joint pose with zero velocity:
+        respawn_at_start (go2_eval_stairs.py:314-361, clear_buffers=True) / respawn_on_tile (go2_eval_walk.py:399-480, clear_buffers=False)."""
+        idx = torch.as_tensor(envs_idx, device=self.device).to(torch.int32).contiguous()
+        p = torch.as_tensor(pos, device=self.device, dtype=torch.float32).reshape(idx.numel(), 3).contiguous()
+        q = None if quat is None else torch.as_tensor(quat, device=self.device, dtype=torch.float32).reshape(idx.numel(), 4).contiguous()
+        self._sim.env_respawn(idx, p, q, clear_buffers, idx.numel(), torch.cuda.current_stream(self.device).cuda_stream)
+
+    def respawn_at_start(self, envs_idx=(0,)):
+        """go2_eval_stairs.py:314-361: back to the spawn point of the env's terrain row (or base_init_pos on flat ground)."""
+        idx = torch.as_tensor(envs_idx, device=self.device).long()
+        if self._use_terrain:
+            rows = self._env_view("TERRAIN_ROW", 1, torch.int32)[idx].long()
+            centers = torch.tensor(self._terrain_info["row_centers"], device=self.device, dtype=torch.float32)
+            pos = centers[rows].clone()
+            pos[:, 2] += float(self.env_cfg["base_init_pos"][2])
+        else:
+            pos = torch.tensor(self.env_cfg["base_init_pos"], device=self.device, dtype=torch.float32).expand(idx.numel(), 3)
+        self.respawn(idx, pos, None, True)
 
     # ---- state the reference exposes as attributes ----------------------------------------------
     def _env_view(self, name, k, dtype=torch.float32):
@@ -193,12 +302,11 @@ class Go2Env:
         return self._sim.env_globals(torch.cuda.current_stream(self.device).cuda_stream).as_dict()
 
     def check_errno(self):
-        """rigid_solver.py:1208-1211: raises when the solver produced NaNs."""
+        """rigid_solver.py:1208-1211: blocking form of the poll (``step`` runs the asynchronous one every ``errno_poll_every`` steps)."""
         v = self._sim.check_errno(torch.cuda.current_stream(self.device).cuda_stream)
-        if v & C["GO2SIM_ERR_INVALID_FORCE_NAN"]:
-            raise Go2SimError("Invalid constraint forces causing 'nan'. Some environments were not advanced.")
-        if v & C["GO2SIM_ERR_INVALID_ACC_NAN"]:
-            raise Go2SimError("Invalid accelerations causing 'nan'. Some environments were not advanced.")
-        if v & (C["GO2SIM_ERR_OVERFLOW_CANDIDATE_CONTACTS"] | C["GO2SIM_ERR_OVERFLOW_COLLISION_PAIRS"]):
-            raise Go2SimError("Exceeding max number of broad phase candidate contact pairs / contacts.")
+        self._raise_on_errno(v)
         return v
+
+    def graph_status(self):
+        """(step graph in use, number of times the library fell back to plain launches)."""
+        return self._sim.graph_status()

@@ -259,6 +259,7 @@ typedef struct go2sim_env_globals {
   float terrain_mean_row;      /* extras["episode"]["terrain_mean_row"] of the last reset call (go2_env_stair.py:1588-1590);
                                   filled by go2sim_env_globals() from terrain_row_sum / last_reset_count */
   int   terrain_row_sum;
+  int   lock_terrain_rows;     /* env._lock_terrain_rows (go2_env_stair.py:399,1513; set by go2_eval_stairs.py:657) */
 } go2sim_env_globals_t;
 
 typedef struct go2sim go2sim_t;
@@ -309,6 +310,13 @@ int go2sim_set_dof_gains(go2sim_t* h, int dof_idx, float kp, float kv, float for
  * host int.  This call synchronises the stream. */
 int go2sim_check_errno(go2sim_t* h, int* errno_host, void* stream);
 
+/* Non-blocking form of the same poll (Simulator.step polls every 10 substeps, simulator.py:267): _begin enqueues the reduction and a copy to
+ * pinned host memory on `stream`; _result sets *ready = 1 and *errno_host once that copy has completed (never waits). */
+int go2sim_errno_poll_begin(go2sim_t* h, void* stream);
+int go2sim_errno_poll_result(go2sim_t* h, int* errno_host, int* ready);
+/* whether go2sim_env_step currently replays its hipGraph (1) or issues plain launches (0), and how often the graph path was abandoned */
+int go2sim_graph_status(go2sim_t* h, int* using_graph, int* n_fallbacks);
+
 /* ---- fused Go2Env fast path (examples/locomotion/final/go2_env_walk.py) ------------------------ */
 /* Go2Env.__init__ buffers + cfg (go2_env_walk.py:155-525) */
 int go2sim_env_configure(go2sim_t* h, const float* fcfg_host, int n_f, const int* icfg_host, int n_i);
@@ -318,6 +326,19 @@ int go2sim_env_step(go2sim_t* h, const float* actions_dev, float* obs_dev, float
                     uint8_t* reset_dev, float* timeout_dev, void* stream);
 /* Go2Env.reset (go2_env_walk.py:1242-1245): reset_idx(all envs); obs buffers are left as they are. */
 int go2sim_env_reset(go2sim_t* h, void* stream);
+/* Go2Env.reset_idx(envs_idx) (go2_env_walk.py:1156-1240; go2_env_stair.py:1499-1600): curriculum bookkeeping + "global" DR draws + per-env
+ * reset of the listed envs (int32 device index array, n >= 0; n == 0 is a no-op as in the reference).  reset_buf is left 1 on the listed envs
+ * and 0 elsewhere (the reference leaves the other entries as they were; the next step rewrites the whole buffer). */
+int go2sim_env_reset_idx(go2sim_t* h, const int* envs_idx_dev, int n, void* stream);
+/* ---- eval / teleop surface (examples/locomotion/final/go2_eval_walk.py, go2_eval_stairs.py) ----
+ * respawn_at_start (go2_eval_stairs.py:314-361) / respawn_on_tile (go2_eval_walk.py:399-480): robot.set_dofs_position(default, zero_velocity)
+ * + set_pos + set_quat + zero_all_dofs_velocity on the listed envs; pos_dev [n][3], quat_dev [n][4] wxyz or NULL = base_init_quat;
+ * clear_buffers != 0 also clears last_actions / action history / last_dof_vel / base velocities and sets _last_base_pos_x, as respawn_at_start does. */
+int go2sim_env_respawn(go2sim_t* h, const int* envs_idx_dev, int n, const float* pos_dev, const float* quat_dev, int clear_buffers, void* stream);
+/* env._lock_terrain_rows = lock (go2_env_stair.py:399; go2_eval_stairs.py:657): reset_idx then keeps every env on its terrain row */
+int go2sim_env_lock_terrain_rows(go2sim_t* h, int lock, void* stream);
+/* env._env_terrain_row[:] = rows (int32 [n_envs] device array; clamped to the configured rows) */
+int go2sim_env_set_terrain_rows(go2sim_t* h, const int* rows_dev, void* stream);
 /* env buffers (device pointer to [n_envs][k] row-major copy) and globals snapshot (synchronises) */
 int go2sim_env_get(go2sim_t* h, int env_buf, void* dst_dev, void* stream);
 int go2sim_env_set_episode_length(go2sim_t* h, const int* ep_len_dev, void* stream); /* rsl_rl init_at_random_ep_len */

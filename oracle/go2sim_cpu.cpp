@@ -2654,7 +2654,7 @@ static void assign_terrain_rows(go2sim* h) {
   for (int b = 0; b < h->B; ++b) if (h->eb[b].reset_buf) idx.push_back(b);
   const int n = (int)idx.size();
   double mean_row = 0.0;
-  if (n_rows > 1) {
+  if (n_rows > 1 && !g.lock_terrain_rows) {                        // `if not self._lock_terrain_rows`, go2_env_stair.py:1513
     double level = c.i[GO2SIM_IC_CURR_ENABLED] ? (double)g.level : 1.0;
     int max_row = (int)(level * (double)(n_rows - 1));
     max_row = std::max(0, std::min(max_row, n_rows - 1));
@@ -2724,6 +2724,71 @@ int go2sim_cpu_env_reset(go2sim* h, void*) {
   if (!h || !h->cfg.set) return GO2SIM_E_BADARG;
   for (int b = 0; b < h->B; ++b) h->eb[b].reset_buf = 1;
   reset_call(h, false);
+  return GO2SIM_E_OK;
+}
+// Go2Env.reset_idx(envs_idx), go2_env_walk.py:1156-1240
+int go2sim_cpu_env_reset_idx(go2sim* h, const int* envs_idx, int n_sel, void*) {
+  if (!h || !h->cfg.set || n_sel < 0 || (n_sel > 0 && !envs_idx)) return GO2SIM_E_BADARG;
+  if (n_sel == 0) return GO2SIM_E_OK;
+  for (int b = 0; b < h->B; ++b) h->eb[b].reset_buf = 0;
+  for (int t = 0; t < n_sel; ++t) { int b = envs_idx[t]; if (b >= 0 && b < h->B) h->eb[b].reset_buf = 1; }
+  reset_call(h, false);
+  return GO2SIM_E_OK;
+}
+// respawn_at_start (go2_eval_stairs.py:314-361) / respawn_on_tile (go2_eval_walk.py:399-480)
+int go2sim_cpu_env_respawn(go2sim* h, const int* envs_idx, int n_sel, const float* pos, const float* quat, int clear_buffers, void*) {
+  if (!h || !h->cfg.set || n_sel < 0 || (n_sel > 0 && (!envs_idx || !pos))) return GO2SIM_E_BADARG;
+  if (n_sel == 0) return GO2SIM_E_OK;
+  const Model& m = h->m; const Cfg& c = h->cfg;
+  for (int t = 0; t < n_sel; ++t) {
+    int b = envs_idx[t];
+    if (b < 0 || b >= h->B) continue;
+    Env& e = h->envs[b]; EnvBuf& x = h->eb[b];
+    for (int i = 0; i < NM; ++i) {                                 // robot.set_dofs_position(default, zero_velocity=True)
+      real dp = c.f[GO2SIM_FC_DEFAULT_DOF_POS0 + i];
+      x.dof_pos[i] = dp; x.dof_vel[i] = 0.0f;
+      int q = c.i[GO2SIM_IC_MOTOR_DOF0 + i] + 1;
+      e.qpos[q] = m.qpos0[q] + dp;
+    }
+    for (int d = 0; d < ND; ++d) e.vel[d] = 0.0f;
+    e.err = 0; e.is_warmstart = 0;                                 // rigid_solver.py:2403-2410
+    for (int d = 0; d < ND; ++d) e.qacc_ws[d] = 0.0f;
+    for (int p = 0; p < NPAIR; ++p) e.normal_cache[p] = v3(0, 0, 0);
+    for (int k = 0; k < 3; ++k) { x.base_pos[k] = pos[3 * t + k]; e.qpos[k] = pos[3 * t + k]; }
+    for (int k = 0; k < 4; ++k) { real q = quat ? quat[4 * t + k] : c.f[GO2SIM_FC_BASE_INIT_QUAT0 + k]; x.base_quat[k] = q; e.qpos[3 + k] = q; }
+    if (clear_buffers) {
+      for (int k = 0; k < 3; ++k) { x.base_lin_vel[k] = 0.0f; x.base_ang_vel[k] = 0.0f; }
+      for (int i = 0; i < NA; ++i) { x.last_actions[i] = 0.0f; x.applied_actions[i] = 0.0f; x.action_history[0][i] = 0.0f; x.action_history[1][i] = 0.0f; }
+      for (int i = 0; i < NM; ++i) x.last_dof_vel[i] = 0.0f;
+      x.last_base_pos_x = pos[3 * t];
+    }
+  }
+#pragma omp parallel for schedule(static)
+  for (int b = 0; b < h->B; ++b) { update_cartesian_space(m, h->envs[b], true); forward_velocity(m, h->envs[b]); }   // full-batch FK, rigid_solver.py:1928-1943
+  return GO2SIM_E_OK;
+}
+int go2sim_cpu_env_lock_terrain_rows(go2sim* h, int lock, void*) {
+  if (!h || !h->cfg.set) return GO2SIM_E_BADARG;
+  h->g.lock_terrain_rows = lock != 0;
+  return GO2SIM_E_OK;
+}
+int go2sim_cpu_env_set_terrain_rows(go2sim* h, const int* rows, void*) {
+  if (!h || !h->cfg.set || !rows) return GO2SIM_E_BADARG;
+  int n_rows = std::max(1, h->cfg.i[GO2SIM_IC_N_TERRAIN_ROWS]);
+  for (int b = 0; b < h->B; ++b) h->eb[b].terrain_row = std::max(0, std::min(rows[b], n_rows - 1));
+  return GO2SIM_E_OK;
+}
+// the host-side twin has nothing asynchronous: the poll is ready at once
+int go2sim_cpu_errno_poll_begin(go2sim* h, void*) { return h ? GO2SIM_E_OK : GO2SIM_E_BADARG; }
+int go2sim_cpu_errno_poll_result(go2sim* h, int* errno_host, int* ready) {
+  if (!h || !errno_host || !ready) return GO2SIM_E_BADARG;
+  *ready = 1;
+  return go2sim_cpu_check_errno(h, errno_host, nullptr);
+}
+int go2sim_cpu_graph_status(go2sim* h, int* using_graph, int* n_fallbacks) {
+  if (!h) return GO2SIM_E_BADARG;
+  if (using_graph) *using_graph = 0;
+  if (n_fallbacks) *n_fallbacks = 0;
   return GO2SIM_E_OK;
 }
 int go2sim_cpu_env_get(go2sim* h, int buf, void* dst, void*) {

@@ -48,13 +48,14 @@ def test_global_advantage_stats_world2(tmp_path):
     outs = [torch.load(tmp_path / f"r{r}.pt") for r in range(world)]
     for o in outs:
         assert float(o["mean"]) == pytest.approx(float(full.mean()), abs=1e-6)
-        assert float(o["std"]) == pytest.approx(float(full.std()), rel=1e-5)
+        assert float(o["std"]) == pytest.approx(float(full.std(ddof=1)), rel=1e-5)          # torch.std: unbiased
     norm = torch.cat([o["norm"] for o in outs]).numpy()
-    assert np.allclose(norm, (full - full.mean()) / np.sqrt(full.var() + 1e-8), atol=1e-5)
+    ft = torch.from_numpy(full)
+    assert np.allclose(norm, ((ft - ft.mean()) / (ft.std() + 1e-8)).numpy(), atol=1e-5)   # rsl_rl 2.2.4 PPO formula
     assert [o["seed"] for o in outs] == [7, 8]
 
 
 def test_single_process_fallback():
     x = torch.arange(10, dtype=torch.float32)
     mean, std = global_mean_std(x)
-    assert float(mean) == pytest.approx(4.5) and float(std) == pytest.approx(float(x.std(unbiased=False)), rel=1e-6)
+    assert float(mean) == pytest.approx(4.5) and float(std) == pytest.approx(float(x.std()), rel=1e-6)

@@ -6,11 +6,11 @@ import torch
 
 import go2_sim2real_locomotion_rl_amd.genesis_shim as gs
 from go2_sim2real_locomotion_rl_amd.configs import get_jump_cfgs
-from util import CpuEnv, make_actions
+from util import CpuEnv, gs_on_oracle, make_actions
 
 
 def _build(oracle_lib, B, env_cfg):
-    gs.init(backend=gs.cpu, precision="32", seed=3, _backend_lib=oracle_lib)
+    gs_on_oracle(gs, oracle_lib, seed=3)
     scene = gs.Scene(sim_options=gs.options.SimOptions(dt=0.02, substeps=2),
                      rigid_options=gs.options.RigidOptions(dt=0.02, constraint_solver=gs.constraint_solver.Newton, enable_collision=True,
                                                            enable_joint_limit=True, max_collision_pairs=30), show_viewer=False)
@@ -81,3 +81,19 @@ def test_external_force_and_dr_hooks(oracle_lib):
     scene.step()
     with pytest.raises(gs.GenesisException):
         robot.get_joint("no_such_joint")
+
+
+def test_genesis_alias_package(oracle_lib):
+    """`import genesis as gs` / `from genesis.utils.geom import ...` (go2_env_walk.py:3-4) resolve to the shim; module state is forwarded."""
+    import genesis
+    from genesis.utils.geom import inv_quat, quat_to_xyz, transform_by_quat, transform_quat_by_quat
+
+    assert genesis.Scene is gs.Scene and genesis.morphs is gs.morphs and genesis.options is gs.options and genesis.constraint_solver.Newton == "Newton"
+    assert inv_quat is gs.inv_quat and quat_to_xyz is gs.quat_to_xyz and transform_by_quat is gs.transform_by_quat and transform_quat_by_quat is gs.transform_quat_by_quat
+    gs_on_oracle(gs, oracle_lib, seed=5)
+    assert genesis.device == gs.device and genesis.tc_float is torch.float32 and genesis.gpu == "gpu"
+    with pytest.raises(genesis.GenesisException):                                    # the product shim has no CPU backend and no injection hook
+        genesis.init(backend=genesis.cpu)
+    import inspect
+
+    assert "_backend_lib" not in inspect.signature(gs.init).parameters

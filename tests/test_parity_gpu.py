@@ -7,7 +7,7 @@ the only exception are the double-precision reset statistics (atomic accumulatio
 import numpy as np
 import pytest
 
-from util import CpuEnv, GpuEnv, F, bits_equal, make_actions
+from util import CpuEnv, GpuEnv, F, bits_equal, gs_on_oracle, make_actions
 
 pytestmark = pytest.mark.gpu
 
@@ -280,7 +280,10 @@ def test_gs_surface_on_hip_backend(oracle_lib):
     env_cfg = get_jump_cfgs()[0]
     res = []
     for backend_lib in (None, oracle_lib):
-        gs.init(backend=gs.gpu, precision="32", seed=4, _backend_lib=backend_lib)
+        if backend_lib is None:
+            gs.init(backend=gs.gpu, precision="32", seed=4)
+        else:
+            gs_on_oracle(gs, backend_lib, seed=4)
         scene = gs.Scene(sim_options=gs.options.SimOptions(dt=0.02, substeps=2))
         scene.add_entity(gs.morphs.URDF(file="urdf/plane/plane.urdf", fixed=True))
         robot = scene.add_entity(gs.morphs.URDF(file="urdf/go2/urdf/go2.urdf", pos=env_cfg["base_init_pos"], quat=env_cfg["base_init_quat"]))

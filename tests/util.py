@@ -136,6 +136,15 @@ class GpuEnv:
         return t.cpu().numpy()
 
 
+def gs_on_oracle(gs, oracle_lib, seed=1):
+    """TEST-ONLY: point the gs shim at the CPU twin of the C ABI (host tensors) so that scripts written against the Genesis surface can be
+    checked here without a GPU.  The product module has no such switch (gs.init always loads the HIP library); this helper rebinds the
+    module globals from outside."""
+    import torch
+
+    gs._lib, gs.device, gs._seed = oracle_lib, torch.device("cpu"), int(seed)
+
+
 def bits_equal(a, b):
     a = np.ascontiguousarray(a); b = np.ascontiguousarray(b)
     if a.dtype == np.float32:
