@@ -6,19 +6,26 @@
 One "step" = one Go2Env.step over the whole batch (2 physics substeps + env logic).  N=1 runs
 BASELINE.json configs[1]: Go2 walk, flat plane, 4096 envs, one MI355X.  N>1 (launched through
 torch.distributed.run, one rank per GPU) shards envs across GPUs as independent batches of 4096
-(weak scaling) and performs the rollout-statistics all-gather (3 floats/rank, RCCL) every 24 steps
-(SURVEY.md section 8d config 4, section 8e).
+(weak scaling); the env writes its rewards / done flags straight into the rollout storage and every 24 steps the rollout's
+GAE pass produces the advantage moments, which are all-gathered (3 float64 per rank, RCCL) and applied.
 
-Protocol: walk cfg of go2_train_walk.py:68-372, curriculum level frozen at level_init=0.10,
-action set C = open-loop sine gait 0.3*sin(2*pi*1.5Hz*t + phase_leg) (+0 stiffness actions), inputs resident
-in HBM before the timed region, synthetic data.
+Headline protocol (`value`): walk cfg of go2_train_walk.py:68-372, curriculum frozen at level_init=0.10, action set C =
+open-loop sine gait 0.3*sin(2*pi*1.5Hz*t + phase_leg) (+0 stiffness actions), inputs resident in HBM before the timed region, W warm-up
+steps from the reset, then exactly K timed steps.  With a short W the timed window is the landing / contact-onset transient.
 
-Prints ONE JSON line (rank 0).  Extra objects:
-  roofline     : dominant kernel, HIP-event timed in a separate profiling pass of the same workload
-  cpu_baseline : the CPU oracle (oracle/libgo2sim_cpu.so, kind "port") timed on the host cores on a
-                 bounded sample (rank 0, N=1 only).  The oracle is used here ONLY as the timed baseline.
+Rank 0 prints ONE JSON line.  Besides the contract keys it carries (N=1 only, all measured in this process):
+  roofline      : dominant kernel of the timed window, HIP-event timed in a replay of the same workload
+  steady_state  : the SAME handle continued: settle phase, then >= 1000 timed steps (+ per-kernel ms from 200 event-timed steps)
+  action_sets   : SURVEY 8d sets A (zeros), B (0.5*N(0,1): falls / resets) and C (sine gait), each 200 warm-up + 1000 timed steps
+  curriculum_live : set C with the metric-gated curriculum running (not frozen)
+  workloads     : BASELINE configs[2] (stairs) and configs[4] (jump + per-env mass / friction DR) at the same env count
+  ref_protocol_fps : the reference's own `go2` benchmark protocol (tests/test_rigid_benchmarks.py:316-374) through go2sim_scene_step
+  cpu_baseline  : the CPU oracle (oracle/libgo2sim_cpu.so, kind "port") on all host cores and on one thread, bounded samples.
+                  The oracle is used here ONLY as the timed baseline.
 """
 import argparse
+import ctypes
+import hashlib
 import json
 import math
 import os
@@ -37,18 +44,39 @@ from go2_sim2real_locomotion_rl_amd.configs import (build_stair_terrain, flatten
 from go2_sim2real_locomotion_rl_amd.model_blob import pack_model  # noqa: E402
 
 ENVS_PER_GPU = 4096
-ALGO_BYTES_WALK = 5701  # algorithmic HBM bytes per env-step, SURVEY.md section 8(d)
+# algorithmic HBM bytes per env-step, SURVEY.md section 8(d) table (walk flat / stairs / base env)
+ALGO_BYTES = {"walk": 5701, "stairs": 7165, "jump_dr": 4300}
+ALGO_BYTES_WALK = ALGO_BYTES["walk"]
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 ROLLOUT_LEN = 24  # num_steps_per_env, go2_train_walk.py:60
 NPRIV = {"walk": 104, "stairs": 182, "jump_dr": 45}
 NOBS = {"walk": 49, "stairs": 49, "jump_dr": 45}
 NACT = {"walk": 16, "stairs": 16, "jump_dr": 12}
-WORKLOAD = "walk"
 KERNEL_CLASSES = ["k_dynamics", "k_collide", "k_constraint_solve", "k_integrate_fk", "k_env_pre", "k_env_post(a+globals+b)", "misc", "env_step_total"]
+PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
 
 
-def make_actions(n_steps, n_envs, device, dt=0.02):
-    """Action set C of SURVEY.md 8d: trot-like open-loop sine on the 12 position actions."""
+def source_hash():
+    """sha256 over the HIP sources + headers the library is built from: stamps profiles/*_pmc_traffic.json (tools/profile_round.sh) so that a
+    counter file measured on other kernels is not reported for this build."""
+    h = hashlib.sha256()
+    files = [os.path.join(ROOT, "go2_sim2real_locomotion_rl_amd", "csrc", f) for f in ("go2sim.hip", "go2sim_policy.hip", "go2sim_gjk_dev.h")]
+    inc = os.path.join(ROOT, "include")
+    files += sorted(os.path.join(inc, f) for f in os.listdir(inc) if f.endswith(".h"))
+    for f in files:
+        if os.path.exists(f):
+            h.update(open(f, "rb").read())
+    return h.hexdigest()
+
+
+def make_actions(n_steps, n_envs, device, dt=0.02, workload="walk", kind="C", seed=0):
+    """SURVEY.md 8d action sets: A zeros; B 0.5*N(0,1) (falls, resets, worst-case contacts); C trot-like open-loop sine on the 12 position actions."""
+    na = NACT[workload]
+    if kind == "A":
+        return torch.zeros(n_steps, n_envs, na, device=device)
+    if kind == "B":
+        g = torch.Generator(device="cpu").manual_seed(1234 + seed)
+        return (0.5 * torch.randn(n_steps, n_envs, na, generator=g)).to(device).contiguous()
     t = torch.arange(n_steps, device=device, dtype=torch.float32)[:, None, None] * dt
     leg_phase = torch.tensor([0.0, math.pi, math.pi, 0.0], device=device)  # FR, FL, RR, RL
     joint_gain = torch.tensor([0.3, 1.0, 1.0], device=device)  # hip, thigh, calf
@@ -56,22 +84,29 @@ def make_actions(n_steps, n_envs, device, dt=0.02):
     gain = joint_gain[None, :].expand(4, 3).reshape(12)
     env_phase = torch.linspace(0.0, 2 * math.pi, n_envs, device=device)[None, :, None]
     pos = 0.3 * gain * torch.sin(2 * math.pi * 1.5 * t + phase + env_phase)
-    act = torch.zeros(n_steps, n_envs, NACT[WORKLOAD], device=device)
+    act = torch.zeros(n_steps, n_envs, na, device=device)
     act[:, :, :12] = pos
     return act.contiguous()
 
 
 def pmc_traffic_bytes(kernel, n_envs):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (profiles/r01_pmc_traffic.json; PMC counters cannot be
-    collected from inside the timed process).  FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, both in KB; only valid for 4096 envs."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    if n_envs != ENVS_PER_GPU or not os.path.exists(path):
-        return None
-    rec = json.load(open(path)).get(kernel)
-    return None if rec is None else int((2 * rec["fetch_size_kb"] + rec["write_size_kb"]) * 1000)
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (PMC counters cannot be collected from inside the timed
+    process).  FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, both in KB; only valid for 4096 envs AND for the sources the file was
+    measured on: a file whose source hash or kernel list does not match this build is refused (returns None, with the reason)."""
+    if n_envs != ENVS_PER_GPU:
+        return None, "traffic file is for 4096 envs"
+    if not os.path.exists(PMC_TRAFFIC_FILE):
+        return None, "no traffic file for this round"
+    doc = json.load(open(PMC_TRAFFIC_FILE))
+    if doc.get("source_sha256") != source_hash():
+        return None, "traffic file was measured on different sources (stale): refused"
+    rec = doc.get("kernels", {}).get(kernel)
+    if rec is None:
+        return None, f"kernel {kernel} not in the traffic file"
+    return int((2 * rec["fetch_size_kb"] + rec["write_size_kb"]) * 1000), None
 
 
-def make_sim(lib, n_envs, device_index, seed, workload):
+def make_sim(lib, n_envs, device_index, seed, workload, freeze_curriculum=True):
     """Configured handle: walk (flat plane) or stairs (go2_train_stair.py terrain + cfg), curriculum frozen at its initial level."""
     sim = Go2Sim(lib, pack_model(), n_envs, device_index, seed)
     if workload == "jump_dr":       # BASELINE configs[4]: base env (go2_train_jump.py) + per-env friction / base-mass randomisation
@@ -83,19 +118,106 @@ def make_sim(lib, n_envs, device_index, seed, workload):
     if workload == "stairs":
         hf, info = build_stair_terrain(cfgs[0]["terrain"])
         sim.set_terrain(hf, info["horizontal_scale"], info["vertical_scale"], info["terrain_origin"])
-    f, i, _ = flatten_walk_cfg(n_envs, *cfgs, freeze_curriculum=True)
+    f, i, _ = flatten_walk_cfg(n_envs, *cfgs, freeze_curriculum=freeze_curriculum)
     sim.env_configure(f, i)
     sim.env_reset()
     return sim
 
 
-def cpu_baseline(n_envs, steps, warmup):
+class Buffers:
+    def __init__(self, B, workload, device):
+        self.obs = torch.zeros(B, NOBS[workload], device=device); self.priv = torch.zeros(B, NPRIV[workload], device=device)
+        self.rew = torch.zeros(B, device=device); self.rst = torch.zeros(B, dtype=torch.uint8, device=device); self.to = torch.zeros(B, device=device)
+
+
+def timed_run(sim, actions, first, n, buf, stream):
+    """n un-instrumented steps (actions[first .. first+n)), bracketed by device synchronisation -> seconds."""
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for s in range(first, first + n):
+        sim.env_step(actions[s % actions.shape[0]], buf.obs, buf.priv, buf.rew, buf.rst, buf.to, stream)
+    torch.cuda.synchronize()
+    return time.perf_counter() - t0
+
+
+def kernel_ms(sim, actions, first, n, buf, stream):
+    """per-kernel-class ms of n event-timed steps on `sim` (plain launches with HIP events on the launch stream) -> (ms[8], cnt[8])"""
+    sim.enable_timing(True)
+    sim.read_timing(reset=True)
+    for s in range(first, first + n):
+        sim.env_step(actions[s % actions.shape[0]], buf.obs, buf.priv, buf.rew, buf.rst, buf.to, stream)
+    torch.cuda.synchronize()
+    ms, cnt = sim.read_timing(reset=True)
+    sim.enable_timing(False)
+    return ms, cnt
+
+
+def protocol_run(B, device, local_rank, seed, workload, kind, warm, steps, stream, freeze=True):
+    """fresh handle, `warm` warm-up steps from the reset, `steps` timed steps -> dict"""
+    sim = make_sim(load_hip_lib(), B, local_rank, seed, workload, freeze_curriculum=freeze)
+    act = make_actions(min(warm + steps, 600), B, device, workload=workload, kind=kind)   # sets A / C are periodic, B is i.i.d.: the tape is cycled
+    buf = Buffers(B, workload, device)
+    resets = 0
+    for s in range(warm):
+        sim.env_step(act[s % act.shape[0]], buf.obs, buf.priv, buf.rew, buf.rst, buf.to, stream)
+    dt = timed_run(sim, act, warm, steps, buf, stream)
+    g = sim.env_globals(stream)
+    resets = int(g.reset_calls)
+    out = {"value": round(B * steps / dt, 1), "ms_per_step": round(dt / steps * 1e3, 4), "warmup": warm, "steps": steps, "errno": sim.check_errno(),
+           "reset_calls": resets, "curriculum_level": round(float(g.level), 4)}
+    del sim
+    return out
+
+
+def ref_protocol(B, device, local_rank, stream, warm=1000, steps=1000):
+    """The reference's own `go2` benchmark (tests/test_rigid_benchmarks.py:316-374): plane + Go2, dt = 0.01 with ONE substep per scene.step,
+    engine position control (default gains kp 100 / kv 10, genesis/utils/geom.py:2042-2047) holding the standing pose, joint angles initialised
+    uniformly inside their limits, FPS = steps * n_envs / elapsed.  Differences, stated: the ground is the plane.urdf box of the Go2Env scene (the
+    benchmark uses gs.morphs.Plane), and warm-up / record are counted in steps (10 s + 10 s of simulated time) instead of 45 s + 15 s of wall clock."""
+    from go2_sim2real_locomotion_rl_amd.model_blob import load_model_json
+
+    model = load_model_json()
+    sim = Go2Sim(load_hip_lib(), pack_model(), B, local_rank, 1)
+    lim = np.array([[d["limit"][0], d["limit"][1]] for d in model["dofs"]], np.float32)[6:]
+    eff = [abs(d["force_range"][1]) for d in model["dofs"]][6:]
+    for k in range(12):
+        sim.set_dof_gains(6 + k, 100.0, 10.0, -eff[k], eff[k])
+    rng = np.random.default_rng(0)
+    qpos = np.tile(np.array([0, 0, 0.42, 1, 0, 0, 0] + [0.0] * 12, np.float32)[:, None], (1, B))
+    qpos[7:] = lim[:, :1] + (lim[:, 1:] - lim[:, :1]) * rng.random((12, B), dtype=np.float32)
+    ctrl = np.zeros((18, B), np.float32)
+    ctrl[6:] = np.array([0.0, 0.0, 0.0, 0.0, 0.8, 0.8, 1.0, 1.0, -1.5, -1.5, -1.5, -1.5], np.float32)[:, None]
+    mode = np.zeros((18, B), np.int32); mode[6:] = 2
+    put = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
+    sim.set_field(C["GO2SIM_F_QPOS"], put(qpos), stream); sim.set_field(C["GO2SIM_F_CTRL_POS"], put(ctrl), stream)
+    sim.set_field(C["GO2SIM_I_CTRL_MODE"], put(mode), stream)
+    sim.reset_caches(None, 0, stream); sim.forward_kinematics(stream)
+    for _ in range(warm):
+        sim.scene_step(1, stream)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        sim.scene_step(1, stream)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    nc = torch.zeros(1, B, dtype=torch.int32, device=device); sim.get_field(C["GO2SIM_I_N_CONSTRAINTS"], nc, stream)
+    torch.cuda.synchronize()
+    out = {"value": round(B * steps / dt, 1), "unit": "FPS = scene steps (dt 0.01, 1 substep) x n_envs / s", "realtime_factor": round(B * steps / dt * 0.01, 1),
+           "n_envs": B, "warmup_steps": warm, "steps": steps, "errno": sim.check_errno(), "constraint_rows_mean": round(float(nc.float().mean()), 2),
+           "constraint_rows_max": int(nc.max()), "protocol": "tests/test_rigid_benchmarks.py:316-374 (go2, Newton); ground = plane.urdf box; step-counted warm-up"}
+    del sim
+    return out
+
+
+def cpu_baseline(n_envs, steps, warmup, threads=None):
     from go2_sim2real_locomotion_rl_amd.capi import load_cpu_oracle_lib
 
     lib = load_cpu_oracle_lib()
-    sim = make_sim(lib, n_envs, 0, 1, WORKLOAD)
+    if threads is not None:
+        ctypes.CDLL("libgomp.so.1").omp_set_num_threads(int(threads))
+    sim = make_sim(lib, n_envs, 0, 1, "walk")
     act = make_actions(steps + warmup, n_envs, torch.device("cpu")).numpy()
-    obs = np.zeros((n_envs, NOBS[WORKLOAD]), np.float32); priv = np.zeros((n_envs, NPRIV[WORKLOAD]), np.float32)
+    obs = np.zeros((n_envs, NOBS["walk"]), np.float32); priv = np.zeros((n_envs, NPRIV["walk"]), np.float32)
     rew = np.zeros(n_envs, np.float32); rst = np.zeros(n_envs, np.uint8); to = np.zeros(n_envs, np.float32)
     for s in range(warmup):
         sim.env_step(act[s], obs, priv, rew, rst, to)
@@ -104,6 +226,25 @@ def cpu_baseline(n_envs, steps, warmup):
         sim.env_step(act[s], obs, priv, rew, rst, to)
     dt = time.perf_counter() - t0
     return n_envs * steps / dt, dt
+
+
+def roofline_of(ms, cnt, K, B, workload, value):
+    per_launch = [(ms[k] / cnt[k]) if cnt[k] else 0.0 for k in range(8)]
+    per_step = [ms[k] / K for k in range(8)]
+    dom = int(np.argmax(per_step[:6]))
+    # one launch of a substep kernel advances B envs by one substep = half an env-step (2 substeps/step); env kernels run once per env-step
+    units = B * (0.5 if dom < 4 else 1.0)
+    algo = ALGO_BYTES[workload]
+    achieved = algo * units / (per_launch[dom] * 1e-3) / 1e9 if per_launch[dom] > 0 else 0.0
+    traffic, note = pmc_traffic_bytes(KERNEL_CLASSES[dom], B) if workload == "walk" else (None, "counters are collected for the walk workload only")
+    r = {"bound": "hbm", "kernel": KERNEL_CLASSES[dom], "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "avg_launch_ms": round(per_launch[dom], 4), "launches_timed": cnt[dom],
+         "algo_bytes_per_env_step": algo, "units_per_launch_env_steps": units,
+         "ms_per_step_by_kernel": {KERNEL_CLASSES[k]: round(per_step[k], 4) for k in range(8)},
+         "whole_step_achieved_GBs": round(value * algo / 1e9, 3)}
+    if note:
+        r["traffic_note"] = note
+    return r
 
 
 def main():
@@ -120,6 +261,7 @@ def main():
                          "RolloutStorage.add_transitions every step, compute_returns + global advantage statistics every 24 steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile-pass", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip steady_state / action_sets / curriculum_live / workloads / ref_protocol_fps")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -148,27 +290,35 @@ def main():
         dist = dist_mod
     coll_device = torch.device("cpu") if rehearsal else device
 
-    global WORKLOAD
     WORKLOAD = args.workload
     if args.rollout:                      # information-only mode: no per-kernel replay, no CPU baseline
-        args.no_profile_pass = args.no_cpu_baseline = True
+        args.no_profile_pass = args.no_cpu_baseline = args.no_extras = True
     B = args.envs_per_gpu
     sim = make_sim(load_hip_lib(), B, local_rank, 1 + rank, WORKLOAD)
     K, W = args.steps, args.warmup
-    actions = make_actions(K + W, B, device)
-    obs = torch.zeros(B, NOBS[WORKLOAD], device=device); priv = torch.zeros(B, NPRIV[WORKLOAD], device=device)
-    rew = torch.zeros(B, device=device); rst = torch.zeros(B, dtype=torch.uint8, device=device); to = torch.zeros(B, device=device)
-    stats = torch.zeros(3, device=device)
-    gathered = torch.zeros(3 * world, device=coll_device) if world > 1 else None
+    SS_SETTLE, SS_STEPS, SS_KSTEPS = 150, 1000, 200
+    n_tape = K + W + (max(0, SS_SETTLE - (K + W)) + SS_STEPS + SS_KSTEPS if world == 1 else 0)
+    actions = make_actions(n_tape, B, device, workload=WORKLOAD)
+    buf = Buffers(B, WORKLOAD, device)
+    obs, priv, rew, rst, to = buf.obs, buf.priv, buf.rew, buf.rst, buf.to
     stream = torch.cuda.current_stream().cuda_stream
 
     policy = storage = None
+    zeros_B = None
+    if args.rollout or world > 1:
+        from go2_sim2real_locomotion_rl_amd import RolloutStorage
+
+        storage = RolloutStorage(ROLLOUT_LEN, B, device=device)
+        zeros_B = torch.zeros(B, device=device)
+        if rehearsal:                                                     # gloo moves host tensors
+            import go2_sim2real_locomotion_rl_amd.rollout as _ro
+            _ag = _ro.allgather_moments
+            _ro.allgather_moments = lambda m, group=None: _ag(m.cpu(), group).to(m.device)
     if args.rollout:
-        from go2_sim2real_locomotion_rl_amd import ActorCritic, RolloutStorage
+        from go2_sim2real_locomotion_rl_amd import ActorCritic
 
         policy = ActorCritic(NOBS[WORKLOAD], NPRIV[WORKLOAD], NACT[WORKLOAD], [512, 256, 128], [512, 256, 128], activation="elu", init_noise_std=0.3,
                              device=device, seed=1 + rank)
-        storage = RolloutStorage(ROLLOUT_LEN, B, device=device)
 
     def step(s):
         if policy is not None:                                           # closed loop: policy -> env -> storage (-> returns every 24 steps)
@@ -178,11 +328,16 @@ def main():
             if (s + 1) % ROLLOUT_LEN == 0:
                 storage.compute_returns(policy.evaluate(priv), 0.99, 0.95)      # all-gathers the advantage moments when world > 1
             return
+        if storage is not None:
+            # sharded job: the env writes rewards / done flags of transition t straight into the rollout storage (the step's output pointers are
+            # per-step arguments), and every 24 steps the rollout's GAE pass (zero value estimates: no critic in the open loop) yields the
+            # advantage moments [sum, sum of squares, count], which are all-gathered over RCCL / xGMI and applied -- the one exchange of the path
+            t = s % ROLLOUT_LEN
+            sim.env_step(actions[s], obs, priv, storage.rewards[t], storage.dones[t], to, stream)
+            if t == ROLLOUT_LEN - 1:
+                storage.compute_returns(zeros_B, 0.99, 0.95)
+            return
         sim.env_step(actions[s], obs, priv, rew, rst, to, stream)
-        if world > 1 and (s + 1) % ROLLOUT_LEN == 0:
-            # rollout advantage-normalisation statistics: [sum, sum of squares, count] per rank, all-gathered over xGMI
-            stats[0] = rew.sum(); stats[1] = (rew * rew).sum(); stats[2] = float(B)
-            dist.all_gather_into_tensor(gathered, stats.to(coll_device))
 
     for s in range(W):
         step(s)
@@ -203,63 +358,83 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     errno = sim.check_errno()
+    using_graph, graph_fallbacks = sim.graph_status()
     total_envs = B * world
     value = total_envs * K / elapsed
+    extras_on = rank == 0 and world == 1 and not args.no_extras
 
-    # ---- HIP-event pass: the SAME workload replayed on a fresh handle (same seed => identical trajectories), with HIP events
-    # recorded around every kernel launch on the launch stream.  Kept out of the timed region so `value` carries no event overhead.
+    # ---- steady state: the same handle continues -- settle until 150 steps after the reset, then >= 1000 un-instrumented timed steps, then
+    # 200 event-timed steps for the per-kernel split
+    steady = None
+    if extras_on:
+        pos = W + K
+        settle = max(0, SS_SETTLE - pos)
+        for s in range(pos, pos + settle):
+            sim.env_step(actions[s], obs, priv, rew, rst, to, stream)
+        pos += settle
+        dt_ss = timed_run(sim, actions, pos, SS_STEPS, buf, stream)
+        pos += SS_STEPS
+        v_ss = B * SS_STEPS / dt_ss
+        ms, cnt = kernel_ms(sim, actions, pos, SS_KSTEPS, buf, stream)
+        r = roofline_of(ms, cnt, SS_KSTEPS, B, WORKLOAD, v_ss)
+        steady = {"value": round(v_ss, 1), "unit": "env-steps/s", "ms_per_step": round(dt_ss / SS_STEPS * 1e3, 4), "settle_steps_after_reset": pos - SS_STEPS,
+                  "steps": SS_STEPS, "errno": sim.check_errno(), "ms_per_step_by_kernel": r["ms_per_step_by_kernel"],
+                  "roofline": {k: r[k] for k in ("kernel", "achieved", "frac", "avg_launch_ms", "traffic", "units_per_launch_env_steps")}}
+
+    # ---- HIP-event pass of the headline window: the SAME workload replayed on a fresh handle (same seed => identical trajectories), with HIP
+    # events recorded around every kernel launch on the launch stream.  Kept out of the timed region so `value` carries no event overhead.
     roofline = None
-    if not args.no_profile_pass:
+    if not args.no_profile_pass and world == 1:
         sim2 = make_sim(load_hip_lib(), B, local_rank, 1 + rank, WORKLOAD)
         sim2.enable_timing(True)
-        sim2.read_timing(reset=True)
         for s in range(W):
             sim2.env_step(actions[s], obs, priv, rew, rst, to, stream)
         torch.cuda.synchronize()
-        ms_w, cnt_w = sim2.read_timing(reset=True)
+        sim2.read_timing(reset=True)
         for s in range(W, W + K):
             sim2.env_step(actions[s], obs, priv, rew, rst, to, stream)
         torch.cuda.synchronize()
         ms, cnt = sim2.read_timing(reset=True)
         sim2.enable_timing(False)
-        per_launch = [(ms[k] / cnt[k]) if cnt[k] else 0.0 for k in range(8)]
-        per_launch_all = [((ms[k] + ms_w[k]) / (cnt[k] + cnt_w[k])) if cnt[k] + cnt_w[k] else 0.0 for k in range(8)]
-        per_step = [ms[k] / K for k in range(8)]
-        dom = int(np.argmax(per_step[:6]))
-        # one launch of a substep kernel advances B envs by one substep = half an env-step (2 substeps/step);
-        # env kernels run once per env-step
-        units = B * (0.5 if dom < 4 else 1.0)
-        achieved = ALGO_BYTES_WALK * units / (per_launch[dom] * 1e-3) / 1e9 if per_launch[dom] > 0 else 0.0
-        roofline = {
-            "bound": "hbm", "kernel": KERNEL_CLASSES[dom], "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic_bytes(KERNEL_CLASSES[dom], B) if WORKLOAD == "walk" else None,
-            "avg_launch_ms": round(per_launch[dom], 4), "avg_launch_ms_incl_warmup": round(per_launch_all[dom], 4),
-            "launches_timed": cnt[dom], "algo_bytes_per_env_step": ALGO_BYTES_WALK, "units_per_launch_env_steps": units,
-            "ms_per_step_by_kernel": {KERNEL_CLASSES[k]: round(per_step[k], 4) for k in range(8)},
-            "whole_step_achieved_GBs": round(value * ALGO_BYTES_WALK / 1e9, 3),
-        }
+        roofline = roofline_of(ms, cnt, K, B, WORKLOAD, value)
         del sim2
+
+    action_sets = curriculum_live = workloads = refp = None
+    if extras_on:
+        del sim
+        action_sets = {k: protocol_run(B, device, local_rank, 1, "walk", k, 200, 1000, stream) for k in ("A", "B", "C")}
+        action_sets["note"] = "SURVEY 8d: A zeros (standing), B 0.5*N(0,1) (falls / resets), C open-loop sine gait; 200 warm-up + 1000 timed steps each, curriculum frozen at 0.10"
+        curriculum_live = protocol_run(B, device, local_rank, 1, "walk", "C", 200, 1000, stream, freeze=False)
+        workloads = {"stairs": protocol_run(B, device, local_rank, 1, "stairs", "C", 100, 300, stream),
+                     "jump_dr": protocol_run(B, device, local_rank, 1, "jump_dr", "C", 100, 300, stream),
+                     "note": "BASELINE configs[2] (stair heightfield, level 0.65) and configs[4] (jump env + per-env mass / friction DR), set C, env-steps/s, 100 warm-up + 300 timed steps"}
+        refp = ref_protocol(B, device, local_rank, stream)
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        n_cpu_envs, n_cpu_steps = 4096, 1500   # ~15-20 s on the 256 host threads of the GPU box
+        n_cpu_envs, n_cpu_steps = 4096, 1000   # ~10-15 s on the 256 host threads of the GPU box
         v, dt = cpu_baseline(n_cpu_envs, n_cpu_steps, 3)
+        v1, dt1 = cpu_baseline(64, 150, 3, threads=1)   # the reference's CPU default is one thread (genesis/__init__.py:252-263)
         cpu = {"value": round(v, 1), "unit": "env-steps/s", "cores": os.cpu_count(), "kind": "port",
-               "sample": f"CPU oracle (OpenMP over envs, all host cores), same walk cfg/action set, {n_cpu_envs} envs x {n_cpu_steps} steps after 3 warm-up steps ({dt:.1f} s)"}
+               "sample": f"CPU oracle (OpenMP over envs, all host cores), same walk cfg/action set C from the reset, {n_cpu_envs} envs x {n_cpu_steps} steps after 3 warm-up steps ({dt:.1f} s)",
+               "single_thread": {"value": round(v1, 1), "cores": 1, "sample": f"same oracle on ONE thread, 64 envs x 150 steps after 3 warm-up steps ({dt1:.1f} s)"}}
 
     if rank == 0:
+        what = {"walk": f"Go2 walk flat-plane, num_envs={B} per GPU, 2 substeps x dt 0.01, action set C (open-loop sine gait), curriculum frozen at level 0.10",
+                "stairs": f"Go2 stairs heightfield terrain (BASELINE configs[2], NOT the headline metric), num_envs={B} per GPU, action set C, curriculum frozen at level 0.65",
+                "jump_dr": f"Go2 jump env + per-env mass / friction randomisation (BASELINE configs[4], NOT the headline metric), num_envs={B} per GPU, action set C on 12 position actions"}[WORKLOAD]
         out = {
             "metric": "env-steps/sec (all envs) Go2 walk 4096 envs; 1/2/4/8-GPU scaling", "value": round(value, 1), "unit": "env-steps/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(elapsed / K * 1e3, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": ("Go2 walk flat-plane, num_envs=4096 per GPU, 2 substeps x dt 0.01, action set C (open-loop sine gait), curriculum frozen at level 0.10"
-                                    if WORKLOAD == "walk" else
-                                    "Go2 stairs heightfield terrain (BASELINE configs[2], NOT the headline metric), num_envs per GPU as given, action set C, curriculum frozen at level 0.65"
-                                    if WORKLOAD == "stairs" else
-                                    "Go2 jump env + per-env mass / friction randomisation (BASELINE configs[4], NOT the headline metric), num_envs per GPU as given, action set C on 12 position actions"),
-                       "envs_per_gpu": B, "total_envs": total_envs, "parallelism": f"env-shard x{world}", "errno": errno,
-                       "loop": "closed rollout loop: ActorCritic.act + env step + RolloutStorage (information only)" if args.rollout else "env step, open-loop actions"},
-            "roofline": roofline, "cpu_baseline": cpu,
+            "config": {"workload": what, "envs_per_gpu": B, "total_envs": total_envs, "parallelism": f"env-shard x{world}", "errno": errno,
+                       "window": f"steps {W}..{W + K} after the reset" + (" (landing / contact-onset transient)" if W + K < 100 else ""),
+                       "step_graph": bool(using_graph), "graph_fallbacks": graph_fallbacks,
+                       "loop": ("closed rollout loop: ActorCritic.act + env step + RolloutStorage (information only)" if args.rollout else
+                                "env step, open-loop actions" + ("; rewards / dones land in the rollout storage, GAE + RCCL all-gather of the advantage moments every 24 steps"
+                                                                 if world > 1 else ""))},
+            "roofline": roofline, "cpu_baseline": cpu, "steady_state": steady, "action_sets": action_sets, "curriculum_live": curriculum_live,
+            "workloads": workloads, "ref_protocol_fps": refp,
         }
         print(json.dumps(out), flush=True)
     if dist is not None:

@@ -68,6 +68,11 @@ def test_fixture_layout():
 
 def test_walk_cfg_equals_reference_pickle_exactly():
     assert _full_diff("walk", configs.get_walk_cfgs()) == {}
+    # dict order is data too: reward terms are evaluated in the insertion order of reward_scales (feet_air_time mutates state that
+    # feet_stance reads, go2_env_walk.py:1303-1314), and the pickle preserves that order
+    assert list(configs.get_walk_cfgs()[2]["reward_scales"]) == list(_load("walk")["reward_cfg"]["reward_scales"])
+    assert list(configs.get_stair_cfgs()[2]["reward_scales"]) == list(_load("stairs")["reward_cfg"]["reward_scales"])
+    assert configs.get_walk_cfgs()[0]["joint_names"] == _load("walk")["env_cfg"]["joint_names"]
 
 
 def test_stairs_cfg_differs_only_in_feet_height_target():

@@ -39,7 +39,7 @@ def main():
                "env_cfg": cfgs[0], "obs_cfg": cfgs[1], "reward_cfg": cfgs[2], "command_cfg": cfgs[3], "train_cfg": cfgs[4]}
         dst = os.path.join(OUT_DIR, f"ref_cfgs_{task}.json")
         with open(dst, "w") as f:
-            json.dump(out, f, indent=1, sort_keys=True)
+            json.dump(out, f, indent=1)   # insertion order kept: the order of reward_scales is the evaluation order of the reward terms
             f.write("\n")
         print(f"{src} -> {dst} ({os.path.getsize(dst)} bytes)")
 
