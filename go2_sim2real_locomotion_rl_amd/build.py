@@ -9,6 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 REPO_ROOT = os.path.dirname(_HERE)
 HIP_SRC = os.path.join(_HERE, "csrc", "go2sim.hip")
 HIP_SRC_POLICY = os.path.join(_HERE, "csrc", "go2sim_policy.hip")
+HIP_HDR_GJK = os.path.join(_HERE, "csrc", "go2sim_gjk_dev.h")
 HIP_LIB = os.path.join(_HERE, "csrc", "libgo2sim.so")
 ORACLE_SRC = os.path.join(REPO_ROOT, "oracle", "go2sim_cpu.cpp")
 ORACLE_SRC_POLICY = os.path.join(REPO_ROOT, "oracle", "policy_cpu.cpp")
@@ -34,7 +35,7 @@ def _headers():
 
 
 def build_hip(force=False, verbose=True):
-    if not force and _newer(HIP_LIB, HIP_SRC, HIP_SRC_POLICY, *_headers()):
+    if not force and _newer(HIP_LIB, HIP_SRC, HIP_SRC_POLICY, HIP_HDR_GJK, *_headers()):
         return HIP_LIB
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     cmd = [hipcc, *HIP_FLAGS, HIP_SRC, HIP_SRC_POLICY, "-o", HIP_LIB]
@@ -45,7 +46,7 @@ def build_hip(force=False, verbose=True):
 
 
 def build_oracle(force=False, verbose=True):
-    if not force and _newer(ORACLE_LIB, ORACLE_SRC, ORACLE_SRC_POLICY, *_headers()):
+    if not force and _newer(ORACLE_LIB, ORACLE_SRC, ORACLE_SRC_POLICY, os.path.join(REPO_ROOT, "oracle", "gjk_epa_cpu.h"), *_headers()):
         return ORACLE_LIB
     cmd = ["g++", *CPU_FLAGS, ORACLE_SRC, ORACLE_SRC_POLICY, "-o", ORACLE_LIB]
     if verbose:

@@ -28,7 +28,6 @@
 
 #include "../../include/go2sim.h"
 #include "../../include/go2sim_detmath.h"
-#include "../../include/go2sim_gjk.h"
 
 #define DEV __device__ __forceinline__
 #define DEVN __device__ __noinline__
@@ -50,6 +49,7 @@ struct V3 { float x, y, z; };
 struct Q4 { float w, x, y, z; };
 struct M3 { float m[3][3]; };
 
+constexpr int GJK_SLOTS_MAX = 4;   // LDS polytope slots per environment (one per foot: the landing case asks for four queries at once)
 DEV float fmn(float a, float b) { return (b < a) ? b : a; }   // std::min semantics
 DEV float fmx(float a, float b) { return (a < b) ? b : a; }   // std::max semantics
 DEV int imn(int a, int b) { return (b < a) ? b : a; }
@@ -1224,7 +1224,7 @@ DEV void compute_support(const Model& m, V3 direction, const Pair& pr, V3& v, V3
 }
 
 
-// ---- safe GJK + EPA fallback (include/go2sim_gjk.h): geometric queries of collider/gjk_support.py:62-186, support_field.py:183-306,
+// ---- safe GJK + EPA fallback (csrc/go2sim_gjk_dev.h): geometric queries of collider/gjk_support.py:62-186, support_field.py:183-306,
 //      gjk.py:1652-1700,1854-1907.  Vertex ids only need to be unique per (geom, vertex): 64 ids are reserved per geom. ----
 DEV V3 gjk_support_driver(const Model& m, V3 direction, int i_g, V3 pos, Q4 quat, int& vid) {
   const Geom& G = m.geoms[i_g];
@@ -1245,36 +1245,26 @@ DEV V3 gjk_support_driver(const Model& m, V3 direction, int i_g, V3 pos, Q4 quat
     return transform_by_trans_quat(v_, pos, quat);
   }
 }
-struct GjkSup {
-  const Model& m; int i_ga, i_gb; V3 pos_a; Q4 quat_a; V3 pos_b; Q4 quat_b; float eps; bool discrete; int nverts_a, nverts_b;
-  DEV static G3 to_g(V3 v) { return g3(v.x, v.y, v.z); }
-  DEV void support(G3 d, G3& o1, G3& o2, int& id1, int& id2) const {
-    V3 dv = v3(d.x, d.y, d.z);
-    o1 = to_g(gjk_support_driver(m, dv, i_ga, pos_a, quat_a, id1));
-    o2 = to_g(gjk_support_driver(m, -dv, i_gb, pos_b, quat_b, id2));
-  }
-  DEV int count_one(V3 d, int i_g, Q4 quat) const {
-    if (m.geoms[i_g].type == GEOM_BOX) {
-      V3 d_box = inv_transform_by_quat(d, quat);
-      int zeros = (d_box.x == 0.0f) + (d_box.y == 0.0f) + (d_box.z == 0.0f);
-      return 1 << zeros;
+#include "go2sim_gjk_dev.h"   // device-side safe GJK + EPA (templated on the polytope store: LDS slot or full-capacity global record)
+
+// One GJK / EPA query of the narrow phase (cold path, kept out of line).  The lane takes one of its team's LDS polytope slots (bit mask, LDS
+// atomics: no waiting, a lane that finds none goes to global memory straight away); a query that outgrows the slot is repeated on the
+// full-capacity record in global memory.  Same code, same arithmetic, same answer in all three cases.
+DEVN DgResult gjk_query(const DgPair& dp, GjkStoreLds* slots, unsigned* slot_mask, GjkStoreFull* full, float eps) {
+  int slot = -1;
+  if (slots) {
+    for (int i = 0; i < GJK_SLOTS_MAX && slot < 0; ++i) {
+      const unsigned bit = 1u << i;
+      if (!(atomicOr(slot_mask, bit) & bit)) slot = i;
     }
-    return 1;
   }
-  DEV int count(G3 d) const { V3 dv = v3(d.x, d.y, d.z); return count_one(dv, i_ga, quat_a) * count_one(-dv, i_gb, quat_b); }
-  DEV void discrete_vertex(int which, int i_v, G3& obj, int& id) const {
-    int i_g = which == 0 ? i_ga : i_gb;
-    const Geom& G = m.geoms[i_g];
-    V3 v_ = v3(((i_v & 1) ? 1.0f : -1.0f) * G.data[0] * 0.5f, ((i_v & 2) ? 1.0f : -1.0f) * G.data[1] * 0.5f, ((i_v & 4) ? 1.0f : -1.0f) * G.data[2] * 0.5f);
-    obj = to_g(transform_by_trans_quat(v_, which == 0 ? pos_a : pos_b, which == 0 ? quat_a : quat_b));
-    id = 64 * i_g + i_v;
+  DgResult r; r.is_col = false; r.overflow = true; r.penetration = 0.0f; r.normal = v3(0, 0, 0); r.pos = v3(0, 0, 0);
+  if (slot >= 0) {
+    r = dg_contact(dp, slots[slot], eps);
+    atomicAnd(slot_mask, ~(1u << slot));
   }
-};
-// cold path of the narrow phase (a few percent of the substeps): kept out of line
-DEVN GjkResult gjk_contact_pair(const Model& m, GjkScratch* scratch, const Pair& pr) {
-  bool disc = m.geoms[pr.i_ga].type == GEOM_BOX && m.geoms[pr.i_gb].type == GEOM_BOX;
-  GjkSup sup{m, pr.i_ga, pr.i_gb, pr.pos_a, pr.quat_a, pr.pos_b, pr.quat_b, m.eps, disc, 8, 8};
-  return gjk_contact(sup, *scratch);
+  if (r.overflow) r = dg_contact(dp, *full, eps);
+  return r;
 }
 
 // ---- MPR, collider/mpr.py: the 4-vertex portal simplex lives in registers -----------------------
@@ -1508,18 +1498,33 @@ DEV void rotate_frame(V3 pos, Q4 quat, V3 contact_pos, Q4 qrot, V3& new_pos, Q4&
 //   * Narrow phase: one lane per broad-phase pair (MPR + multi-contact perturbations are independent per pair); the contacts of a
 //     pass of T pairs are compacted in pair order, which is the order in which the serial loop appends them.
 // ---------------------------------------------------------------------------------------------
+constexpr int GJK_SLOTS = GJK_SLOTS_MAX;
 template <int T>
 struct CollideData {
-  alignas(16) float amin[NG * 4], amax[NG * 4];   // xyz + pad: one 128-bit LDS read per corner
-  float sval[2 * NG], sval_sorted[2 * NG];
-  int sig[2 * NG], sig_sorted[2 * NG];
-  alignas(8) int rank_mm[NG * 2];                  // (rank of the min endpoint, rank of the max endpoint) per geom
-  int cand_key[MAXB], cand_pair[MAXB], pair_sorted[MAXB];
+  // the three phases of the kernel use disjoint working sets, laid over each other: broad phase -> (barrier) -> convex narrow phase (GJK / EPA
+  // polytopes of the lanes that fall back from MPR) -> (barrier) -> terrain pass
+  struct Broad {
+    alignas(16) float amin[NG * 4], amax[NG * 4];   // xyz + pad: one 128-bit LDS read per corner
+    float sval[2 * NG], sval_sorted[2 * NG];
+    int sig[2 * NG], sig_sorted[2 * NG];
+    alignas(8) int rank_mm[NG * 2];                  // (rank of the min endpoint, rank of the max endpoint) per geom
+    int cand_key[MAXB], cand_pair[MAXB];
+  };
+  // terrain pass: one slot per (geom, terrain) pair of the broad-phase list
+  struct TPair { int i_ga, r_min, r_max, c_min, c_max, n_items, item_off; float zmin; V3 pos_a; Q4 quat_a; V3 center_a; };
+  struct Terrain {
+    TPair tp[NG];
+    float acc_pos[5][3];   // contacts already accepted for the current terrain pair (dedupe)
+  };
+  union alignas(16) {
+    Broad bp;
+    GjkStoreLds gjk[GJK_SLOTS];
+    Terrain tr;
+  };
+  int pair_sorted[MAXB];
   float stage[T][5][7];
   int cnt[T];
-  // terrain pass: one slot per (geom, terrain) pair of the broad-phase list
-  struct TPair { int i_ga, r_min, r_max, c_min, c_max, n_items, item_off; float zmin; V3 pos_a; Q4 quat_a; V3 center_a; } tp[NG];
-  float acc_pos[5][3];   // contacts already accepted for the current terrain pair (dedupe)
+  unsigned gjk_slot_mask;                             // bit i set = gjk[i] is taken
 };
 struct ContactStage { float* st; int n; };   // per-lane staging of the (<= 5) contacts of one pair
 
@@ -1530,7 +1535,7 @@ DEV void stage_contact(ContactStage& cs, V3 normal, V3 pos, float pen) {
 }
 
 // func_convex_convex_contact (CCD_ALGORITHM_CODE.MPR branch), narrowphase.py:514-961; contacts go to the lane's staging buffer
-DEV void convex_convex_contact_staged(const Model& m, const E& e, int i_ga, int i_gb, ContactStage& cs, GjkScratch* gjk_scratch) {
+DEV void convex_convex_contact_staged(const Model& m, const E& e, int i_ga, int i_gb, ContactStage& cs, GjkStoreLds* gjk_slots, unsigned* gjk_slot_mask, GjkStoreFull* gjk_full) {
   const float EPS = m.eps;
   int type_a = m.geoms[i_ga].type, type_b = m.geoms[i_gb].type;
   bool multi_contact = (type_a != GEOM_SPHERE) && (type_b != GEOM_SPHERE);
@@ -1566,11 +1571,13 @@ DEV void convex_convex_contact_staged(const Model& m, const E& e, int i_ga, int 
       if (penetration > tolerance) prefer_gjk = !guess_available || (m.mc_tolerance * penetration >= m.mpr_to_gjk_ratio * tolerance);
       if (prefer_gjk) {                                          // narrowphase.py:734-845: safe GJK + EPA replaces the MPR answer
         atomicAdd(&e.gjk_fallback()[0], 1);
-        const Pair pr_copy = pr;                                   // the out-of-line callee takes a reference: give it a copy that only exists on
-        GjkResult gr = gjk_contact_pair(m, gjk_scratch, pr_copy);  // this cold path, so that `pr` itself can stay in registers
-        is_col = gr.is_col != 0;
+        DgPair dp;                                                 // the out-of-line callee takes a reference: this record only exists on the cold
+        dp.m = &m; dp.i_ga = pr.i_ga; dp.i_gb = pr.i_gb; dp.pos_a = pr.pos_a; dp.quat_a = pr.quat_a; dp.pos_b = pr.pos_b; dp.quat_b = pr.quat_b;   // path, `pr` stays in registers
+        dp.discrete = type_a == GEOM_BOX && type_b == GEOM_BOX;     // func_is_discrete_geoms, collider/utils.py:105-126
+        const DgResult gr = gjk_query(dp, gjk_slots, gjk_slot_mask, gjk_full, m.eps);
+        is_col = gr.is_col;
         penetration = gr.penetration;
-        if (is_col) { contact_pos = v3(gr.pos.x, gr.pos.y, gr.pos.z); normal = v3(gr.normal.x, gr.normal.y, gr.normal.z); }
+        if (is_col) { contact_pos = gr.pos; normal = gr.normal; }
       }
     }
     if (i_detection == 0) {
@@ -1678,7 +1685,7 @@ DEV bool terrain_prism_contact(const Model& m, const E& e, const TP& t, int i_gb
 }
 
 template <int T>
-__global__ __launch_bounds__(64) void k_collide_team(Pool P, const Model* __restrict__ mp, GjkScratch* __restrict__ gjk_scratch) {
+__global__ __launch_bounds__(64) void k_collide_team(Pool P, const Model* __restrict__ mp, GjkStoreFull* __restrict__ gjk_scratch) {
   constexpr int EPW = 64 / T;
   __shared__ CollideData<T> lds[EPW];
   const int tl = threadIdx.x % T, slot = threadIdx.x / T;
@@ -1688,12 +1695,13 @@ __global__ __launch_bounds__(64) void k_collide_team(Pool P, const Model* __rest
   E e(P, b);
   CollideData<T>* s = &lds[slot];
   const float inf = dm_bits2f(0x7f800000u);
+  if (tl == 0) s->gjk_slot_mask = 0u;                                   // made visible by the barriers of the broad phase
   PH_BEGIN
   // ---- loads of the prologue first: previous contact count, first-step flag, the persistent sort order, geom poses ----
   const int nc_old = e.n_contacts()[0];
   const bool first = e.first_time()[0] != 0;
   const int n2 = 2 * NG;
-  team_stage<2 * NG, T>(tl, [&](int i) { return __int_as_float(e.sort_ig()[i]); }, [&](int i, float v) { s->sig[i] = __float_as_int(v); });
+  team_stage<2 * NG, T>(tl, [&](int i) { return __int_as_float(e.sort_ig()[i]); }, [&](int i, float v) { s->bp.sig[i] = __float_as_int(v); });
   constexpr int NPI = (NPAIR + T - 1) / T;                            // the pair table of the candidate test, fetched for all rounds up front
   int packed_[NPI];
   {
@@ -1715,8 +1723,8 @@ __global__ __launch_bounds__(64) void k_collide_team(Pool P, const Model* __rest
       V3 corner = transform_by_trans_quat(m.geoms[i_g].aabb[c], gp, gq);
       lower = vmin(lower, corner); upper = vmax(upper, corner);
     }
-    *(float4*)&s->amin[4 * i_g] = make_float4(lower.x, lower.y, lower.z, 0.0f);
-    *(float4*)&s->amax[4 * i_g] = make_float4(upper.x, upper.y, upper.z, 0.0f);
+    *(float4*)&s->bp.amin[4 * i_g] = make_float4(lower.x, lower.y, lower.z, 0.0f);
+    *(float4*)&s->bp.amax[4 * i_g] = make_float4(upper.x, upper.y, upper.z, 0.0f);
   }
   // ---- func_collision_clear, broadphase.py:73-138 ----
   for (int i_c = tl; i_c < nc_old; i_c += T) {
@@ -1732,20 +1740,20 @@ __global__ __launch_bounds__(64) void k_collide_team(Pool P, const Model* __rest
 #endif
   for (int i = tl; i < n2; i += T) {
     // first step: endpoints in (link, geom) order: geoms are stored link-major, so buffer slot i/2 holds geom i/2
-    int sg = first ? ((i >> 1) | ((i & 1) ? 0x100 : 0)) : s->sig[i];
+    int sg = first ? ((i >> 1) | ((i & 1) ? 0x100 : 0)) : s->bp.sig[i];
     int g = sg & 0xff;
-    s->sig[i] = sg;
-    s->sval[i] = (sg & 0x100) ? s->amax[4 * g] : s->amin[4 * g];
+    s->bp.sig[i] = sg;
+    s->bp.sval[i] = (sg & 0x100) ? s->bp.amax[4 * g] : s->bp.amin[4 * g];
   }
   team_sync();
   for (int i = tl; i < n2; i += T) {
-    float v = s->sval[i];
+    float v = s->bp.sval[i];
     int r = 0;
 #pragma unroll
-    for (int j = 0; j < 2 * NG; ++j) { float w = s->sval[j]; r += (w < v) || (w == v && j < i); }
-    int sg = s->sig[i];
-    s->sval_sorted[r] = v; s->sig_sorted[r] = sg;
-    s->rank_mm[2 * (sg & 0xff) + ((sg & 0x100) ? 1 : 0)] = r;
+    for (int j = 0; j < 2 * NG; ++j) { float w = s->bp.sval[j]; r += (w < v) || (w == v && j < i); }
+    int sg = s->bp.sig[i];
+    s->bp.sval_sorted[r] = v; s->bp.sig_sorted[r] = sg;
+    s->bp.rank_mm[2 * (sg & 0xff) + ((sg & 0x100) ? 1 : 0)] = r;
     e.sort_value()[r] = v; e.sort_ig()[r] = sg;
   }
 #if defined(GO2SIM_REPEAT_PHASE) && GO2SIM_REPEAT_PHASE == 31
@@ -1767,8 +1775,8 @@ __global__ __launch_bounds__(64) void k_collide_team(Pool P, const Model* __rest
     const int pidx = it * T + tl;
     const int packed = packed_[it];
     const int a = (packed < 0) ? 0 : (packed & 0xff), bg = (packed < 0) ? 0 : (packed >> 8);
-    const int2 rka = *(const int2*)&s->rank_mm[2 * a], rkb = *(const int2*)&s->rank_mm[2 * bg];
-    const float4 amn = *(const float4*)&s->amin[4 * a], amx = *(const float4*)&s->amax[4 * a], bmn = *(const float4*)&s->amin[4 * bg], bmx = *(const float4*)&s->amax[4 * bg];
+    const int2 rka = *(const int2*)&s->bp.rank_mm[2 * a], rkb = *(const int2*)&s->bp.rank_mm[2 * bg];
+    const float4 amn = *(const float4*)&s->bp.amin[4 * a], amx = *(const float4*)&s->bp.amax[4 * a], bmn = *(const float4*)&s->bp.amin[4 * bg], bmx = *(const float4*)&s->bp.amax[4 * bg];
     const int ra = rka.x, rb = rkb.x;
     const int rs = (ra < rb) ? rb : ra, rf = (ra < rb) ? ra : rb;
     const int rmax_first = (ra < rb) ? rka.y : rkb.y;
@@ -1789,7 +1797,7 @@ __global__ __launch_bounds__(64) void k_collide_team(Pool P, const Model* __rest
     team_sync();
 #pragma unroll
     for (int it = 0; it < NPI; ++it)
-      if (cmask & (1u << it)) { if (pos < MAXB) { s->cand_key[pos] = key_[it]; s->cand_pair[pos] = packed_[it]; } pos++; }
+      if (cmask & (1u << it)) { if (pos < MAXB) { s->bp.cand_key[pos] = key_[it]; s->bp.cand_pair[pos] = packed_[it]; } pos++; }
     n_cand = tot;
   }
 #if defined(GO2SIM_REPEAT_PHASE) && GO2SIM_REPEAT_PHASE == 32
@@ -1798,9 +1806,9 @@ __global__ __launch_bounds__(64) void k_collide_team(Pool P, const Model* __rest
   if (n_cand > m.max_broad_pairs) { if (tl == 0) atomicOr(&e.err()[0], GO2SIM_ERR_OVERFLOW_CANDIDATE_CONTACTS); n_cand = m.max_broad_pairs; }
   team_sync();
   for (int c = tl; c < n_cand; c += T) {
-    int key = s->cand_key[c], r = 0;
-    for (int j = 0; j < n_cand; ++j) r += s->cand_key[j] < key;
-    s->pair_sorted[r] = s->cand_pair[c];
+    int key = s->bp.cand_key[c], r = 0;
+    for (int j = 0; j < n_cand; ++j) r += s->bp.cand_key[j] < key;
+    s->pair_sorted[r] = s->bp.cand_pair[c];
   }
   const int n_broad = n_cand;
   team_sync();
@@ -1819,7 +1827,7 @@ __global__ __launch_bounds__(64) void k_collide_team(Pool P, const Model* __rest
       i_ga = pk & 0xff; i_gb = pk >> 8;
       if (m.geoms[i_ga].type > m.geoms[i_gb].type) { int t = i_ga; i_ga = i_gb; i_gb = t; }
       const bool with_terrain = m.geoms[i_gb].type == GEOM_TERRAIN;
-      if (!with_terrain) convex_convex_contact_staged(m, e, i_ga, i_gb, cs, &gjk_scratch[(size_t)b * T + tl]);
+      if (!with_terrain) convex_convex_contact_staged(m, e, i_ga, i_gb, cs, s->gjk, &s->gjk_slot_mask, &gjk_scratch[(size_t)b * T + tl]);
     }
     s->cnt[tl] = cs.n;
     team_sync();
@@ -1854,11 +1862,11 @@ __global__ __launch_bounds__(64) void k_collide_team(Pool P, const Model* __rest
       int i_ga = pk & 0xff, i_gb = pk >> 8;
       if (m.geoms[i_ga].type == GEOM_TERRAIN) { int t = i_ga; i_ga = i_gb; i_gb = t; }
       if (m.geoms[i_gb].type != GEOM_TERRAIN) continue;
-      if (n_tp < NG) { if (tl == 0) { s->tp[n_tp].i_ga = i_ga; s->tp[n_tp].n_items = i_gb; } n_tp++; }
+      if (n_tp < NG) { if (tl == 0) { s->tr.tp[n_tp].i_ga = i_ga; s->tr.tp[n_tp].n_items = i_gb; } n_tp++; }
     }
     team_sync();
     for (int p = tl; p < n_tp; p += T) {                                // pair setup + count of reachable prisms
-      auto& t = s->tp[p];
+      auto& t = s->tr.tp[p];
       int i_gb = t.n_items;
       terrain_pair_setup(m, e, t.i_ga, i_gb, t);
       int cnt = 0;
@@ -1869,14 +1877,14 @@ __global__ __launch_bounds__(64) void k_collide_team(Pool P, const Model* __rest
     }
     team_sync();
     int* items = (int*)&gjk_scratch[(size_t)b * T];                     // prism descriptors p | r << 5 | k << 18 (the GJK scratch is idle in this pass)
-    const int items_cap = (int)(sizeof(GjkScratch) * T / sizeof(int));
+    const int items_cap = (int)(sizeof(GjkStoreFull) * T / sizeof(int));
     int i_terrain = 0, n_items = 0;
-    for (int p = 0; p < n_tp; ++p) { int c = s->tp[p].n_items; if (p == 0) i_terrain = s->tp[p].item_off; n_items += c; }
+    for (int p = 0; p < n_tp; ++p) { int c = s->tr.tp[p].n_items; if (p == 0) i_terrain = s->tr.tp[p].item_off; n_items += c; }
     team_sync();
-    { int off = 0; for (int p = 0; p < n_tp; ++p) { int c = s->tp[p].n_items; if (tl == 0) s->tp[p].item_off = off; off += c; } }
+    { int off = 0; for (int p = 0; p < n_tp; ++p) { int c = s->tr.tp[p].n_items; if (tl == 0) s->tr.tp[p].item_off = off; off += c; } }
     team_sync();
     for (int p = tl; p < n_tp; p += T) {                                // descriptors in (pair, row, vertex) order
-      const auto& t = s->tp[p];
+      const auto& t = s->tr.tp[p];
       int q = t.item_off;
       const int nk = 2 * (t.c_max - t.c_min + 1);
       for (int r = t.r_min; r < t.r_max; ++r)
@@ -1893,7 +1901,7 @@ __global__ __launch_bounds__(64) void k_collide_team(Pool P, const Model* __rest
       int has = 0;
       if (q < n_items) {
         int d = items[q];
-        const auto& t = s->tp[d & 31];
+        const auto& t = s->tr.tp[d & 31];
         V3 normal, cpos; float pen;
         if (terrain_prism_contact(m, e, t, i_terrain, (d >> 5) & 0x1fff, d >> 18, normal, cpos, pen)) {
           has = 1;
@@ -1905,18 +1913,18 @@ __global__ __launch_bounds__(64) void k_collide_team(Pool P, const Model* __rest
       const int n_chunk = imn(T, n_items - base);
       for (int l = 0; l < n_chunk; ++l) {
         const int p = items[base + l] & 31;
-        if (p != cur_p) { cur_p = p; n_con = 0; tolerance = compute_tolerance(m, s->tp[p].i_ga, i_terrain, m.mc_tolerance); }
+        if (p != cur_p) { cur_p = p; n_con = 0; tolerance = compute_tolerance(m, s->tr.tp[p].i_ga, i_terrain, m.mc_tolerance); }
         if (!s->cnt[l] || n_con >= m.n_contacts_per_pair) continue;
         const float* pc = &s->stage[l][0][0];
         V3 cpos = v3(pc[3], pc[4], pc[5]);
         bool valid = true;
         for (int j = 0; j < n_con; ++j) {
-          if (nc_run - j - 1 < m.max_contact_pairs && norm(cpos - v3(s->acc_pos[n_con - j - 1][0], s->acc_pos[n_con - j - 1][1], s->acc_pos[n_con - j - 1][2])) < tolerance) { valid = false; break; }
+          if (nc_run - j - 1 < m.max_contact_pairs && norm(cpos - v3(s->tr.acc_pos[n_con - j - 1][0], s->tr.acc_pos[n_con - j - 1][1], s->tr.acc_pos[n_con - j - 1][2])) < tolerance) { valid = false; break; }
         }
         if (!valid) continue;
-        const int i_ga = s->tp[p].i_ga, i_c = nc_run;
+        const int i_ga = s->tr.tp[p].i_ga, i_c = nc_run;
         team_sync();
-        if (tl == 0 && n_con < 5) { s->acc_pos[n_con][0] = cpos.x; s->acc_pos[n_con][1] = cpos.y; s->acc_pos[n_con][2] = cpos.z; }
+        if (tl == 0 && n_con < 5) { s->tr.acc_pos[n_con][0] = cpos.x; s->tr.acc_pos[n_con][1] = cpos.y; s->tr.acc_pos[n_con][2] = cpos.z; }
         if (i_c < m.max_contact_pairs) {
           if (tl == 0) {                                                 // func_add_contact, contact.py:165-199
             float friction_a = e.geom_friction()[i_ga] * e.friction_ratio()[i_ga];
@@ -2596,6 +2604,30 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   } else {
     ts_solve_overflow<T>(P.f, P.i, P.B, P.fa, P.ia, b, lnk, tri_i, tri_j, gm, &overflow[b], tl, nc, n_con, lim_mask, ws_flag);
   }
+}
+
+// diagnostics (go2sim_debug_narrowphase): one narrow-phase query on explicit poses, by one lane.  which = 0: MPR from a cold start
+// (func_mpr_contact, mpr.py:763-819); 1: safe GJK + EPA the way k_collide_team runs it (LDS polytope slot, global record on overflow);
+// 2: safe GJK + EPA on the full-capacity global record only.  out = {is_col, penetration, normal[3], pos[3]}
+__global__ __launch_bounds__(64) void k_debug_narrowphase(const Model* __restrict__ mp, int which, int i_ga, int i_gb, V3 pa, Q4 qa, V3 pb, Q4 qb,
+                                                          GjkStoreFull* __restrict__ full, float* __restrict__ out8) {
+  __shared__ GjkStoreLds slots[GJK_SLOTS_MAX];
+  __shared__ unsigned mask;
+  if (threadIdx.x == 0) mask = 0u;
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  const Model& m = *mp;
+  bool is_col = false; V3 normal = v3(0, 0, 0), pos = v3(0, 0, 0); float pen = 0.0f;
+  if (which == 0) {
+    Pair pr; pr.i_ga = i_ga; pr.i_gb = i_gb; pr.pos_a = pa; pr.quat_a = qa; pr.pos_b = pb; pr.quat_b = qb; pr.prism = nullptr; pr.ga = geom_lite(m, i_ga); pr.gb = geom_lite(m, i_gb);
+    mpr_contact(m, pr, v3(0, 0, 0), is_col, normal, pen, pos);
+  } else {
+    DgPair dp; dp.m = mp; dp.i_ga = i_ga; dp.i_gb = i_gb; dp.pos_a = pa; dp.quat_a = qa; dp.pos_b = pb; dp.quat_b = qb;
+    dp.discrete = m.geoms[i_ga].type == GEOM_BOX && m.geoms[i_gb].type == GEOM_BOX;
+    const DgResult r = (which == 1) ? gjk_query(dp, slots, &mask, full, m.eps) : gjk_query(dp, nullptr, &mask, full, m.eps);
+    is_col = r.is_col; pen = r.penetration; normal = r.normal; pos = r.pos;
+  }
+  out8[0] = is_col ? 1.0f : 0.0f; out8[1] = pen; out8[2] = normal.x; out8[3] = normal.y; out8[4] = normal.z; out8[5] = pos.x; out8[6] = pos.y; out8[7] = pos.z;
 }
 
 __global__ __launch_bounds__(WG) void k_clear_ext(Pool P) {             // kernel_clear_external_force, abd/misc.py:874
@@ -3773,7 +3805,8 @@ struct go2sim {
   int* herr_pinned = nullptr; hipEvent_t ev_errno = nullptr; bool errno_poll_pending = false;   // go2sim_errno_poll_*
   int* didx = nullptr; int didx_cap = 0;    // scratch for index lists (go2sim_env_reset_idx)
   float* terrain_hf = nullptr;              // device copy of the heightfield in metres (go2sim_set_terrain)
-  GjkScratch* gjk_scratch = nullptr;        // working memory of the GJK/EPA fallback: one block per (env, narrow-phase lane)
+  GjkStoreFull* gjk_scratch = nullptr;      // full-capacity polytope records of the GJK / EPA fallback (queries that outgrow their LDS slot) and
+                                            // prism descriptors of the terrain pass: one block per (env, narrow-phase lane)
   SolverData<MAXR>* solver_ovf = nullptr;   // per-env global scratch for solves that do not fit in LDS (> RL rows)
   // One env step = 11 dependent kernel launches (12 with terrain).  Issued one by one they cost the host ~20 us each -- close to the GPU time of
   // the step -- so the sequence is kept as an instantiated hipGraph: per step the three step-dependent kernel nodes get their new arguments
@@ -4021,7 +4054,7 @@ int go2sim_create(const void* blob, size_t nbytes, int n_envs, int device, uint6
     if (const char* t = getenv("GO2SIM_NO_GRAPH")) { if (atoi(t) != 0) h->use_graph = false; }
     if (const char* t = getenv("GO2SIM_FK_TEAM")) { int v = atoi(t); if (v == 16 || v == 32 || v == 64) h->fk_team = v; }
     if (const char* t = getenv("GO2SIM_COLLIDE_TEAM")) { int v = atoi(t); if (v == 16 || v == 32 || v == 64) h->collide_team = v; }
-    CK(hipMalloc((void**)&h->gjk_scratch, (size_t)n_envs * h->collide_team * sizeof(GjkScratch)));   // ~31 KB per narrow-phase lane
+    CK(hipMalloc((void**)&h->gjk_scratch, (size_t)n_envs * h->collide_team * sizeof(GjkStoreFull)));   // ~20 KB per narrow-phase lane
     if (const char* t = getenv("GO2SIM_SOLVER_TEAM")) { int v = atoi(t); if (v == 16 || v == 32 || v == 64) h->solver_team = v; }
     Glob g0; memset(&g0, 0, sizeof(g0)); g0.friction = 1.0f;
     CK(hipMemcpy(h->dglob, &g0, sizeof(Glob), hipMemcpyHostToDevice));
@@ -4493,6 +4526,20 @@ int go2sim_read_timing(go2sim_t* h, float* ms_out8, int* cnt_out8, int reset) {
   timing_flush(h);
   for (int i = 0; i < T_N; ++i) { if (ms_out8) ms_out8[i] = h->t_ms[i]; if (cnt_out8) cnt_out8[i] = h->t_cnt[i]; }
   if (reset) for (int i = 0; i < T_N; ++i) { h->t_ms[i] = 0.0f; h->t_cnt[i] = 0; }
+  return GO2SIM_E_OK;
+}
+
+int go2sim_debug_narrowphase(go2sim_t* h, int which, int i_ga, int i_gb, const float* pa, const float* qa, const float* pb, const float* qb, float* out8) {
+  if (!h || !out8 || !pa || !qa || !pb || !qb || i_ga < 0 || i_gb < 0 || i_ga >= NG || i_gb >= NG || which < 0 || which > 2) return GO2SIM_E_BADARG;
+  float* dout = nullptr;
+  HIPCHK(hipSetDevice(h->device));
+  HIPCHK(hipMalloc((void**)&dout, 8 * sizeof(float)));
+  V3 pos_a = v3h(pa[0], pa[1], pa[2]), pos_b = v3h(pb[0], pb[1], pb[2]);
+  Q4 quat_a = {qa[0], qa[1], qa[2], qa[3]}, quat_b = {qb[0], qb[1], qb[2], qb[3]};
+  hipLaunchKernelGGL(k_debug_narrowphase, dim3(1), dim3(64), 0, 0, h->dm, which, i_ga, i_gb, pos_a, quat_a, pos_b, quat_b, h->gjk_scratch, dout);
+  hipError_t e1 = hipGetLastError(), e2 = hipMemcpy(out8, dout, 8 * sizeof(float), hipMemcpyDeviceToHost);
+  (void)hipFree(dout);
+  HIPCHK(e1); HIPCHK(e2);
   return GO2SIM_E_OK;
 }
 

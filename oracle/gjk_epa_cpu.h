@@ -1,4 +1,6 @@
-/* go2sim_gjk.h -- "safe" GJK + EPA penetration query (the non-MuJoCo-compatible branch of Genesis).
+/* gjk_epa_cpu.h -- "safe" GJK + EPA penetration query (the non-MuJoCo-compatible branch of Genesis): the ORACLE's host-side restatement.
+ * Test infrastructure (oracle/): the product has its own, separately written device implementation (csrc/go2sim_gjk_dev.h), so GPU-vs-oracle
+ * parity of the GJK / EPA fallback compares two implementations, not one header with itself.
  *
  * Restates, for the convex-convex narrow phase of go2sim, the reference functions
  *   func_safe_gjk                       genesis/engine/solvers/rigid/collider/gjk.py:1200-1416
@@ -12,20 +14,15 @@
  *   func_triangle_affine_coords / func_project_origin_to_plane   collider/gjk_utils.py:49-107,185-235
  *   the tail of func_gjk_contact (witness -> contact)            gjk.py:413-437
  *
- * Header-only and compiled by BOTH hipcc (product, go2sim.hip) and gcc (CPU oracle): the geometric queries (support points,
- * vertex enumeration) are supplied by the includer through the `Sup` functor, so each side keeps its own support code while the
- * simplex / polytope bookkeeping exists once.  All arithmetic is binary32 with -ffp-contract=off on both sides.
+ * Header-only, compiled by gcc into oracle/libgo2sim_cpu.so only; the geometric queries (support points, vertex enumeration) are supplied by
+ * the includer through the `Sup` functor.  All arithmetic is binary32 with -ffp-contract=off.
  */
 #ifndef GO2SIM_GJK_H
 #define GO2SIM_GJK_H
 
-#include "go2sim_detmath.h"
+#include "../include/go2sim_detmath.h"
 
-#if defined(__HIPCC__)
-#define GJK_FN __host__ __device__ inline
-#else
 #define GJK_FN inline
-#endif
 
 #define GJK_MAX_ITERATIONS 50          /* gjk.py:53 */
 #define EPA_MAX_ITERATIONS 50          /* gjk.py:54 */

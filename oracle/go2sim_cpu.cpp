@@ -25,7 +25,7 @@
 
 #include "../include/go2sim.h"
 #include "../include/go2sim_detmath.h"
-#include "../include/go2sim_gjk.h"
+#include "gjk_epa_cpu.h"
 
 namespace {
 
@@ -840,7 +840,7 @@ V3 support_driver(const Model& m, V3 direction, int i_g, V3 pos, Q4 quat) {
     return transform_by_trans_quat(v_, pos, quat);
   }
 }
-// ---- safe GJK + EPA fallback (include/go2sim_gjk.h): geometric queries of collider/gjk_support.py:62-186, support_field.py:183-306,
+// ---- safe GJK + EPA fallback (oracle/gjk_epa_cpu.h): geometric queries of collider/gjk_support.py:62-186, support_field.py:183-306,
 //      gjk.py:1652-1700,1854-1907 ----
 // vertex ids only need to be unique per (geom, vertex): 64 ids are reserved per geom
 inline V3 gjk_support_driver(const Model& m, V3 direction, int i_g, V3 pos, Q4 quat, int& vid) {
@@ -2875,7 +2875,7 @@ int go2sim_cpu_set_terrain(go2sim* h, const int16_t* hf, int rows, int cols, flo
 }
 
 // extra oracle-only diagnostics
-// one narrow-phase query on explicit poses: which = 0 -> MPR (cold start), 1 -> safe GJK + EPA.  out = {is_col, penetration, normal[3], pos[3]}
+// one narrow-phase query on explicit poses: which = 0 -> MPR (cold start), 1 / 2 -> safe GJK + EPA (the device library distinguishes its two polytope stores).  out = {is_col, penetration, normal[3], pos[3]}
 int go2sim_cpu_debug_narrowphase(go2sim* h, int which, int i_ga, int i_gb, const float* pa, const float* qa, const float* pb, const float* qb, float* out8) {
   if (!h || !out8 || i_ga < 0 || i_gb < 0 || i_ga >= NG || i_gb >= NG) return GO2SIM_E_BADARG;
   V3 pos_a = v3(pa[0], pa[1], pa[2]), pos_b = v3(pb[0], pb[1], pb[2]);

@@ -1,7 +1,9 @@
-"""Safe GJK + EPA fallback (include/go2sim_gjk.h; reference collider/gjk.py:1200-1416, epa.py:970-1295) on analytic cases.
+"""Safe GJK + EPA fallback (reference collider/gjk.py:1200-1416, epa.py:970-1295) on analytic cases, for BOTH implementations:
+the oracle's host-side restatement (oracle/gjk_epa_cpu.h, through go2sim_cpu_debug_narrowphase) and -- under -m gpu -- the product's separately
+written device implementation (csrc/go2sim_gjk_dev.h, through go2sim_debug_narrowphase: LDS polytope slot and full-capacity global record).
 
 Parity unpinned: the reference holds no fixtures for this path; the checks are known answers (sphere / box / cylinder against the ground slab)
-and agreement with the independent MPR query of the same poses."""
+and agreement with the independent MPR query of the same poses.  A wrong depth or normal from the HIP EPA fails the closed-form cases here."""
 import ctypes
 
 import numpy as np
@@ -13,19 +15,27 @@ from go2_sim2real_locomotion_rl_amd.model_blob import load_model_json
 I = [1.0, 0.0, 0.0, 0.0]
 
 
-@pytest.fixture(scope="module")
-def query(oracle_lib, blob):
-    sim = Go2Sim(oracle_lib, blob, 1, 0, 1)
+def _make_query(lib, blob, prefix, gjk_which):
+    sim = Go2Sim(lib, blob, 1, 0, 1)
+    fn = getattr(lib.lib, prefix + "debug_narrowphase")
 
     def q(which, a, b, pa, qa, pb, qb):
         out = np.zeros(8, np.float32)
         arrs = [np.asarray(x, np.float32) for x in (pa, qa, pb, qb)]
-        rc = oracle_lib.lib.go2sim_cpu_debug_narrowphase(sim.h, which, a, b, *[x.ctypes.data_as(ctypes.c_void_p) for x in arrs], out.ctypes.data_as(ctypes.c_void_p))
+        rc = fn(sim.h, gjk_which if which else 0, a, b, *[x.ctypes.data_as(ctypes.c_void_p) for x in arrs], out.ctypes.data_as(ctypes.c_void_p))
         assert rc == 0
-        return dict(is_col=bool(out[0]), pen=float(out[1]), normal=out[2:5].copy(), pos=out[5:8].copy())
+        return dict(is_col=bool(out[0]), pen=float(out[1]), normal=out[2:5].copy(), pos=out[5:8].copy(), raw=out.copy())
 
     q.sim = sim
     return q
+
+
+# backends: the oracle (CPU), the HIP library with the LDS polytope slot (1) and with the full-capacity global record (2)
+@pytest.fixture(scope="module", params=["oracle", pytest.param("hip_lds", marks=pytest.mark.gpu), pytest.param("hip_global", marks=pytest.mark.gpu)])
+def query(request, blob):
+    if request.param == "oracle":
+        return _make_query(request.getfixturevalue("oracle_lib"), blob, "go2sim_cpu_", 1)
+    return _make_query(request.getfixturevalue("hip_lib"), blob, "go2sim_", 1 if request.param == "hip_lds" else 2)
 
 
 @pytest.fixture(scope="module")
@@ -73,3 +83,37 @@ def test_cylinder_on_ground(query, geoms):
     res = query(1, 0, geoms["cyl"], [0, 0, -geoms["ground_half"]], I, [0, 0, r - 0.01], lying)
     ref = query(0, 0, geoms["cyl"], [0, 0, -geoms["ground_half"]], I, [0, 0, r - 0.01], lying)
     assert res["is_col"] and res["pen"] == pytest.approx(ref["pen"], abs=2e-5) and res["pen"] == pytest.approx(0.01, abs=2e-4)
+
+
+@pytest.mark.gpu
+def test_hip_queries_equal_oracle_bit_for_bit(oracle_lib, hip_lib, blob, geoms):
+    """The two implementations (and both polytope stores of the device one) agree to the last bit on a sweep of poses: random orientations and depths
+    for every geom type against the ground, and box / cylinder / sphere pairs of the robot against each other."""
+    cpu = _make_query(oracle_lib, blob, "go2sim_cpu_", 1)
+    lds = _make_query(hip_lib, blob, "go2sim_", 1)
+    glb = _make_query(hip_lib, blob, "go2sim_", 2)
+    rng = np.random.default_rng(7)
+    g = geoms["all"]
+    ids = [geoms["sphere"], geoms["box"], geoms["cyl"]] + [i for i, x in enumerate(g) if x["type"] == 3][1:4]
+    n_col = 0
+    for trial in range(120):
+        a = int(rng.choice(ids))
+        quat = rng.standard_normal(4); quat /= np.linalg.norm(quat)
+        if trial % 3 == 0:                                                     # geom against the ground slab at a random depth
+            size = max(g[a]["data"][:3])
+            pa, qa, ia = [0, 0, -geoms["ground_half"]], I, 0
+            pb, qb, ib = [float(rng.uniform(-1, 1)), float(rng.uniform(-1, 1)), float(rng.uniform(-0.3, 0.6) * size)], quat, a
+            if g[a]["type"] < g[0]["type"]:
+                pa, qa, ia, pb, qb, ib = pb, qb, ib, pa, qa, ia                 # type_a <= type_b (narrowphase.py:997)
+        else:                                                                  # two robot geoms overlapping each other
+            b = int(rng.choice(ids))
+            q2 = rng.standard_normal(4); q2 /= np.linalg.norm(q2)
+            ia, ib = (a, b) if g[a]["type"] <= g[b]["type"] else (b, a)
+            pa, qa = [0.0, 0.0, 0.0], quat
+            pb, qb = list(rng.uniform(-0.03, 0.03, 3)), q2
+        for which in (0, 1):
+            rc, rl, rg = cpu(which, ia, ib, pa, qa, pb, qb), lds(which, ia, ib, pa, qa, pb, qb), glb(which, ia, ib, pa, qa, pb, qb)
+            assert np.array_equal(rc["raw"].view(np.int32), rl["raw"].view(np.int32)), (trial, which, ia, ib, rc, rl)
+            assert np.array_equal(rc["raw"].view(np.int32), rg["raw"].view(np.int32)), (trial, which, ia, ib, rc, rg)
+            n_col += int(rc["is_col"] and which == 1)
+    assert n_col > 40          # the sweep does exercise EPA
