@@ -595,8 +595,20 @@ struct E {
 #undef AA2
 #undef AIA
 };
-// single-wavefront workgroups: the barrier is a compiler/LDS ordering fence only
+// Ordering point between the phases of a team.  Workgroups are single wavefronts and a wavefront executes its LDS / memory instructions in
+// order, so what is needed is (a) that the compiler does not move accesses across the point and (b) that outstanding memory operations have
+// completed (s_waitcnt) -- a workgroup-scope release / acquire fence pair around a wave barrier.  No s_barrier: teams of one wavefront reach
+// these points under team-divergent control flow (different Newton / line-search trip counts, early exits), where a hardware barrier would be
+// undefined behaviour.
+#ifdef GO2SIM_TEAM_SYNC_SBARRIER
 DEV void team_sync() { __syncthreads(); }
+#else
+DEV void team_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+#endif
 DEV float gload(const E& e, int off, int k) { return e.f[(size_t)(off + k) * e.B]; }
 DEV void gstore(const E& e, int off, int k, float v) { e.f[(size_t)(off + k) * e.B] = v; }
 DEV float aload(const E& e, int off, int k) { return e.fa[off + k]; }              // AoS record word
@@ -638,17 +650,26 @@ DEV void wg_load(const Pool& P, int b0, int off, F put) {
 
 // ---- optional per-phase cycle accounting (build with -DGO2SIM_PHASE_PROFILE; development aid, see tools/phase_profile.py) ----
 #ifdef GO2SIM_PHASE_PROFILE
-__device__ unsigned long long g_phase_cycles[64];
+// one row of 64 counters per workgroup (no atomics, no sharing: the former single row of atomically updated counters cost more than the
+// phases it measured); phase ids are disjoint between kernels, so the kernels of a step share the rows by blockIdx
+constexpr int PH_MAX_WG = 8192;
+__device__ unsigned long long g_phase_cycles[PH_MAX_WG * 64];
 #define PH_BEGIN unsigned long long ph_t = __builtin_readcyclecounter();
-#define PH(i) { unsigned long long ph_n = __builtin_readcyclecounter(); if (threadIdx.x == 0) atomicAdd(&g_phase_cycles[i], ph_n - ph_t); ph_t = __builtin_readcyclecounter(); }
+#define PH(i) { __builtin_amdgcn_s_waitcnt(0); unsigned long long ph_n = __builtin_readcyclecounter(); if (threadIdx.x == 0 && blockIdx.x < PH_MAX_WG) g_phase_cycles[blockIdx.x * 64 + (i)] += ph_n - ph_t; ph_t = __builtin_readcyclecounter(); }
+// the same inside lane-divergent code: the first active lane of the wavefront accounts the section (all active lanes run it together)
+#define PHD_BEGIN unsigned long long phd_t = __builtin_readcyclecounter();
+#define PHD(i) { unsigned long long phd_n = __builtin_readcyclecounter(); const unsigned long long phd_a = __ballot(1); if ((int)threadIdx.x == __ffsll((long long)phd_a) - 1 && blockIdx.x < PH_MAX_WG) { atomicAdd(&g_phase_cycles[blockIdx.x * 64 + (i)], phd_n - phd_t); atomicAdd(&g_phase_cycles[blockIdx.x * 64 + (i) + 1], 1ull); } phd_t = __builtin_readcyclecounter(); }
 #else
 #define PH_BEGIN
 #define PH(i)
+#define PHD_BEGIN
+#define PHD(i)
 #endif
 
 // -DGO2SIM_REPEAT_PHASE=k (profiling builds, tools/repeat_probe.py): phase k runs twice; every such phase is idempotent, so the results
 // are unchanged and the time difference prices the phase.  Solver: 0 stage, 1 rows (13 contact rows, 14 joint-limit rows), 3 Hessian +
-// factorisation, 4 Hessian, 5 gradient, 6 line search, 11 commit.  Collision: 30 AABBs, 31 endpoint sort, 32 candidate pairs.
+// factorisation, 4 Hessian, 5 gradient, 6 line search, 11 commit.  Collision: 30 AABBs, 31 endpoint sort, 32 candidate pairs, 34 GJK / EPA
+// query, 35 MPR query.
 // scalar slots
 enum { SV_COST = 0, SV_PREV_COST, SV_GAUSS, SV_QG0, SV_QG1, SV_QG2, SV_GTOL };
 enum { SI_LS_IT = 0, SI_LS_RESULT, SI_IMPROVED };
@@ -1226,31 +1247,34 @@ DEV void compute_support(const Model& m, V3 direction, const Pair& pr, V3& v, V3
 
 // ---- safe GJK + EPA fallback (csrc/go2sim_gjk_dev.h): geometric queries of collider/gjk_support.py:62-186, support_field.py:183-306,
 //      gjk.py:1652-1700,1854-1907.  Vertex ids only need to be unique per (geom, vertex): 64 ids are reserved per geom. ----
-DEV V3 gjk_support_driver(const Model& m, V3 direction, int i_g, V3 pos, Q4 quat, int& vid) {
-  const Geom& G = m.geoms[i_g];
-  if (G.type == GEOM_SPHERE) {
+// (type and size of the geom come from the per-pair GeomLite record: a GJK / EPA query makes some sixty support calls, and fetching them from
+//  the model in global memory every time put a dependent load in front of each one)
+DEV V3 gjk_support_driver(const Model& m, V3 direction, int i_g, const GeomLite& gl, V3 pos, Q4 quat, int& vid) {
+  if (gl.type == GEOM_SPHERE) {
     vid = -1;
-    return pos + direction * G.data[0];
-  } else if (G.type == GEOM_BOX) {
+    return pos + direction * gl.d0;
+  } else if (gl.type == GEOM_BOX) {
     V3 d_box = inv_transform_by_quat(direction, quat);
-    V3 v_ = v3((d_box.x < 0.0f ? -1.0f : 1.0f) * G.data[0] * 0.5f, (d_box.y < 0.0f ? -1.0f : 1.0f) * G.data[1] * 0.5f,
-               (d_box.z < 0.0f ? -1.0f : 1.0f) * G.data[2] * 0.5f);
+    V3 v_ = v3((d_box.x < 0.0f ? -1.0f : 1.0f) * gl.d0 * 0.5f, (d_box.y < 0.0f ? -1.0f : 1.0f) * gl.d1 * 0.5f,
+               (d_box.z < 0.0f ? -1.0f : 1.0f) * gl.d2 * 0.5f);
     vid = (v_.x > 0.0f) * 1 + (v_.y > 0.0f) * 2 + (v_.z > 0.0f) * 4 + 64 * i_g;
     return transform_by_trans_quat(v_, pos, quat);
   } else {
     V3 d_mesh = transform_by_quat(direction, inv_quat(quat));
     int k = 0;
-    V3 v_ = support_cylinder_local(m, G, d_mesh, &k);
+    V3 v_ = support_cylinder_local(m, m.geoms[i_g], d_mesh, &k);
     vid = k + 64 * i_g;
     return transform_by_trans_quat(v_, pos, quat);
   }
 }
 #include "go2sim_gjk_dev.h"   // device-side safe GJK + EPA (templated on the polytope store: LDS slot or full-capacity global record)
 
-// One GJK / EPA query of the narrow phase (cold path, kept out of line).  The lane takes one of its team's LDS polytope slots (bit mask, LDS
-// atomics: no waiting, a lane that finds none goes to global memory straight away); a query that outgrows the slot is repeated on the
-// full-capacity record in global memory.  Same code, same arithmetic, same answer in all three cases.
-DEVN DgResult gjk_query(const DgPair& dp, GjkStoreLds* slots, unsigned* slot_mask, GjkStoreFull* full, float eps) {
+// One GJK / EPA query of the narrow phase.  The lane takes one of its team's LDS polytope slots (bit mask, LDS atomics: no waiting, a lane
+// that finds none goes to global memory straight away); a query that outgrows the slot is repeated on the full-capacity record in global
+// memory.  Same code, same arithmetic, same answer in all three cases.  The LDS flavour is inlined into the kernel so that the compiler sees
+// the address space of the slot (ds_read / ds_write instead of flat accesses); the global flavour is the cold path and stays out of line.
+DEVN DgResult gjk_query_global(const DgPair& dp, GjkStoreFull* full, float eps) { return dg_contact(dp, *full, eps); }
+DEV DgResult gjk_query(const DgPair& dp, GjkStoreLds* slots, unsigned* slot_mask, GjkStoreFull* full, float eps) {
   int slot = -1;
   if (slots) {
     for (int i = 0; i < GJK_SLOTS_MAX && slot < 0; ++i) {
@@ -1263,7 +1287,7 @@ DEVN DgResult gjk_query(const DgPair& dp, GjkStoreLds* slots, unsigned* slot_mas
     r = dg_contact(dp, slots[slot], eps);
     atomicAnd(slot_mask, ~(1u << slot));
   }
-  if (r.overflow) r = dg_contact(dp, *full, eps);
+  if (r.overflow) r = gjk_query_global(dp, full, eps);
   return r;
 }
 
@@ -1564,7 +1588,12 @@ DEV void convex_convex_contact_staged(const Model& m, const E& e, int i_ga, int 
           if ((i_detection == 0) && !is_col && guess_available) { normal_ws = v3(0, 0, 0); guess_available = false; is_mpr_updated = false; }
         }
         if (!is_mpr_updated) {
+          PHD_BEGIN
+#if defined(GO2SIM_REPEAT_PHASE) && GO2SIM_REPEAT_PHASE == 35
           mpr_contact(m, pr, normal_ws, is_col, normal, penetration, contact_pos);
+#endif
+          mpr_contact(m, pr, normal_ws, is_col, normal, penetration, contact_pos);
+          PHD(36)
           is_mpr_updated = true;
         }
       }
@@ -1573,8 +1602,14 @@ DEV void convex_convex_contact_staged(const Model& m, const E& e, int i_ga, int 
         atomicAdd(&e.gjk_fallback()[0], 1);
         DgPair dp;                                                 // the out-of-line callee takes a reference: this record only exists on the cold
         dp.m = &m; dp.i_ga = pr.i_ga; dp.i_gb = pr.i_gb; dp.pos_a = pr.pos_a; dp.quat_a = pr.quat_a; dp.pos_b = pr.pos_b; dp.quat_b = pr.quat_b;   // path, `pr` stays in registers
+        dp.ga = pr.ga; dp.gb = pr.gb;
         dp.discrete = type_a == GEOM_BOX && type_b == GEOM_BOX;     // func_is_discrete_geoms, collider/utils.py:105-126
+#if defined(GO2SIM_REPEAT_PHASE) && GO2SIM_REPEAT_PHASE == 34
+        { const DgResult g0 = gjk_query(dp, gjk_slots, gjk_slot_mask, gjk_full, m.eps); if (g0.penetration == 12345.0f) penetration = 0.0f; }
+#endif
+        PHD_BEGIN
         const DgResult gr = gjk_query(dp, gjk_slots, gjk_slot_mask, gjk_full, m.eps);
+        PHD(34)
         is_col = gr.is_col;
         penetration = gr.penetration;
         if (is_col) { contact_pos = gr.pos; normal = gr.normal; }
@@ -1803,14 +1838,17 @@ __global__ __launch_bounds__(64) void k_collide_team(Pool P, const Model* __rest
 #if defined(GO2SIM_REPEAT_PHASE) && GO2SIM_REPEAT_PHASE == 32
   }
 #endif
-  if (n_cand > m.max_broad_pairs) { if (tl == 0) atomicOr(&e.err()[0], GO2SIM_ERR_OVERFLOW_CANDIDATE_CONTACTS); n_cand = m.max_broad_pairs; }
+  // the serial sweep stops appending at max_broad_pairs (broadphase.py:330-338): all candidates are ranked by the sweep key first, the list is
+  // clipped afterwards, so the pairs that survive are the ones the sweep reaches first
+  if (n_cand > m.max_broad_pairs && tl == 0) atomicOr(&e.err()[0], GO2SIM_ERR_OVERFLOW_CANDIDATE_CONTACTS);
+  n_cand = imn(n_cand, MAXB);
   team_sync();
   for (int c = tl; c < n_cand; c += T) {
     int key = s->bp.cand_key[c], r = 0;
     for (int j = 0; j < n_cand; ++j) r += s->bp.cand_key[j] < key;
     s->pair_sorted[r] = s->bp.cand_pair[c];
   }
-  const int n_broad = n_cand;
+  const int n_broad = imn(n_cand, m.max_broad_pairs);
   team_sync();
   for (int c = tl; c < n_broad; c += T) { int pk = s->pair_sorted[c]; e.broad()[2 * c] = pk & 0xff; e.broad()[2 * c + 1] = pk >> 8; }
   PH(32)
@@ -1954,7 +1992,12 @@ __global__ __launch_bounds__(64) void k_collide_team(Pool P, const Model* __rest
 // ---------------------------------------------------------------------------------------------
 // ---- exact line search helpers, solver.py:1888-2417 ----
 struct LsPoint { float alpha, cost, grad, hess; };
-DEVN int update_bracket(LsPoint& p, const float alphas[3], const float costs[3], const float grads[3], const float hess[3], float& p_next_alpha) {
+#ifndef GO2SIM_BRACKET_INLINE
+#define GO2SIM_BRACKET_ATTR DEVN
+#else
+#define GO2SIM_BRACKET_ATTR DEV
+#endif
+GO2SIM_BRACKET_ATTR int update_bracket(LsPoint& p, const float alphas[3], const float costs[3], const float grads[3], const float hess[3], float& p_next_alpha) {
   int flag = 0;
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
@@ -1992,6 +2035,62 @@ struct alignas(16) SolverData {
   alignas(16) float qf0[R]; alignas(16) float qf1[R]; alignas(16) float qf2[R]; alignas(16) float DA[R];
   alignas(16) int active[R]; alignas(16) int prev_active[R];
 };
+
+// value of lane k of the caller's team (k is a compile-time constant after unrolling): v_readlane through an SGPR instead of a
+// ds_bpermute round trip through the LDS crossbar
+template <int T>
+DEV float team_bcast(float x, const int k) {
+  if constexpr (T == 64) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), k));
+  } else if constexpr (T == 32) {
+    const int lo = __builtin_amdgcn_readlane(__float_as_int(x), k), hi = __builtin_amdgcn_readlane(__float_as_int(x), 32 + k);
+    return __int_as_float((threadIdx.x & 32) ? hi : lo);
+  } else {
+    return __shfl(x, k, T);
+  }
+}
+// value of lane k of the caller's team where k is wave-uniform but only known at run time (v_readlane with the lane in an SGPR)
+template <int T>
+DEV float team_bcast_dyn(float x, int k_uniform) {
+  static_assert(T == 32 || T == 64, "teams of 32 or 64 lanes");
+  const int k = __builtin_amdgcn_readfirstlane(k_uniform);
+  if constexpr (T == 64) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), k));
+  } else {
+    const int lo = __builtin_amdgcn_readlane(__float_as_int(x), k), hi = __builtin_amdgcn_readlane(__float_as_int(x), 32 + k);
+    return __int_as_float((threadIdx.x & 32) ? hi : lo);
+  }
+}
+// ---- wavefront-level sums in the SERIAL order of the reference ----------------------------------------------------------------------------
+// The reference (and the oracle) accumulate over constraint rows / dofs first to last: t = ((base + x_0) + x_1) + ... .  A tree reduction would
+// change the rounding; instead the chain itself is moved onto the lanes: lane c holds x_c, and one DPP instruction `acc = acc[lane - 1] + x`
+// repeated n - 1 times leaves the exact serial prefix sums in the lanes (lane c becomes final in step c and recomputes the same value
+// afterwards; lanes past the last term add +0 and carry the total on).  DPP row shifts work inside rows of 16 lanes, so every 16 terms the
+// running sum is handed to the next row with a broadcast.  NQ sums are interleaved (independent chains fill each other's latency).  Cost per sum
+// ~ n instructions in total instead of ~ n per lane-visible term of a redundant scalar loop.
+DEV float dpp_row_shr1(float x) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x111, 0xf, 0xf, true)); }   // lane 0 of a row reads 0
+template <int T, int NQ>
+DEV void team_serial_sum(const float (&x)[NQ], const float (&base)[NQ], int tl, int nseg, float (&total)[NQ]) {
+  float acc[NQ], xx[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) { acc[q] = (tl == 0) ? base[q] + x[q] : x[q]; xx[q] = acc[q]; }
+  for (int seg = 0; seg < nseg; ++seg) {
+    if (seg > 0) {
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        const float carry = team_bcast_dyn<T>(acc[q], 16 * seg - 1);
+        if (tl == 16 * seg) { acc[q] = carry + x[q]; xx[q] = acc[q]; }
+      }
+    }
+#pragma unroll
+    for (int st = 1; st < 16; ++st) {
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) acc[q] = dpp_row_shr1(acc[q]) + xx[q];
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) total[q] = team_bcast_dyn<T>(acc[q], 16 * nseg - 1);
+}
 
 template <int T, class S, class MT>
 DEV void ts_update_constraint(const MT& m, S* s, int tl, int n_con, float& cost, float& prev_cost, float& gauss) {
@@ -2082,16 +2181,24 @@ DEV bool ts_cholesky_incremental_reg(const MT& m, S* s, int tl, int n_con) {
   float Lr[ND];
 #pragma unroll
   for (int k = 0; k < ND; ++k) Lr[k] = s->H[row * DS + k];
-  for (int c = 0; c < n_con && !degenerated; ++c) {
-    const bool is_active = s->active[c] != 0, was_active = s->prev_active[c] != 0;
-    if (is_active ^ was_active) {
+  // The rows whose activity flipped are found T at a time (lane c tests row c) and collected in a bit mask per team; the teams of a wavefront
+  // then walk their own lists in step: pass f updates every team's f-th flipped row at once.  (A common loop over the row index would run the
+  // rank-1 update once per flipped row of EITHER team, with the other team masked off.)
+  for (int base = 0; base < n_con && !degenerated; base += T) {
+    const int c_me = base + tl;
+    const bool flip = c_me < n_con && ((s->active[c_me] != 0) != (s->prev_active[c_me] != 0));
+    const unsigned long long bal = __ballot(flip);
+    unsigned long long mask = (T == 64) ? bal : ((bal >> ((threadIdx.x / T) * T)) & ((1ull << (T & 63)) - 1ull));
+    while (mask != 0ull && !degenerated) {
+      const int c = base + __ffsll((long long)mask) - 1;
+      mask &= mask - 1ull;
       touched = true;
-      const float sign = is_active ? 1.0f : -1.0f;
+      const float sign = (s->active[c] != 0) ? 1.0f : -1.0f;
       const float efc_D_sqrt = dm_sqrt(s->efc_D[c]);
       float v = s->J[c * DS + row] * efc_D_sqrt;
 #pragma unroll
       for (int k = 0; k < ND; ++k) {
-        const float vk = __shfl(v, k, T), Lkk = __shfl(Lr[k], k, T);
+        const float vk = team_bcast<T>(v, k), Lkk = team_bcast<T>(Lr[k], k);
         if (dm_abs(vk) > m.eps) {
           const float tmp = Lkk * Lkk + sign * (vk * vk);
           if (tmp < m.eps) { degenerated = true; break; }
@@ -2117,9 +2224,102 @@ DEV bool ts_cholesky_incremental_reg(const MT& m, S* s, int tl, int n_con) {
   team_sync();
   return degenerated;
 }
+// The same rank-1 updates, pipelined over several flipped rows (func_hessian_and_cholesky_factor_incremental_dense_batch, solver.py:1632-1675).
+// Step k of the update for flipped row f needs step k of row f-1 (the factor column it rewrites) and step k-1 of row f (its own vector), nothing
+// else -- so the pairs (f, k) with f + k = t are independent of each other and are processed together in "time step" t: 17 + n steps for n
+// flipped rows instead of 18 n.  Lane i owns row i of the factor (kept in LDS here, the column index varies at run time) and element i of every
+// update vector (W[f], registers).  In time step t lane i computes the rotation of the pair (f = t - i, k = i) -- the square root and the three
+// divisions of ALL pairs of the step are one instruction stream, lanes side by side -- then every pair's rotation is handed from its lane k to
+// the rows below it.  Each matrix / vector element sees exactly the operations of the serial algorithm in the same order, so the result is
+// bit-identical; the "degenerated" verdict is the same too (any pair degenerating makes the caller rebuild the factor from scratch).
+template <int T, int FMAX, class S, class MT>
+DEV bool ts_cholesky_incremental_pipelined(const MT& m, S* s, int tl, int n_con) {
+  static_assert(T >= ND && (T == 32 || T == 64), "one lane per row of the factor");
+  bool degenerated = false;
+  const int row = tl < ND ? tl : ND - 1;
+  const bool own = tl < ND;
+  float Ld = s->H[row * DS + row];                                     // my diagonal element
+  for (int base = 0; base < n_con && !degenerated; base += T) {
+    const int c_me = base + tl;
+    const bool flip = c_me < n_con && ((s->active[c_me] != 0) != (s->prev_active[c_me] != 0));
+    const unsigned long long bal = __ballot(flip);
+    unsigned long long mask = (T == 64) ? bal : ((bal >> ((threadIdx.x / T) * T)) & ((1ull << (T & 63)) - 1ull));
+    while (mask != 0ull && !degenerated) {                              // batches of up to FMAX flipped rows, in row order
+      float W[FMAX]; unsigned sgn = 0u; int nb = 0;
+#pragma unroll
+      for (int f = 0; f < FMAX; ++f) {
+        W[f] = 0.0f;
+        if (mask != 0ull) {
+          const int c = base + __ffsll((long long)mask) - 1;
+          mask &= mask - 1ull;
+          W[f] = s->J[c * DS + row] * dm_sqrt(s->efc_D[c]);
+          if (s->active[c] != 0) sgn |= 1u << f;
+          nb = f + 1;
+        }
+      }
+      const int nb_wave = __builtin_amdgcn_readfirstlane(imx(__shfl(nb, 0), __shfl(nb, T == 64 ? 0 : 32)));   // both teams (nb is team-uniform)
+      for (int t = 0; t < ND - 1 + nb_wave && !degenerated; ++t) {
+        // ---- my pair of this step: row f_me at my own column ----
+        const int f_me = t - row;
+        const bool valid = own && f_me >= 0 && f_me < nb;
+        float dv = 0.0f;
+#pragma unroll
+        for (int f = 0; f < FMAX; ++f) dv = (f_me == f) ? W[f] : dv;
+        const float sg_me = ((sgn >> (f_me & 31)) & 1u) ? 1.0f : -1.0f;
+        const bool rot = valid && dm_abs(dv) > m.eps;
+        const float tmp = Ld * Ld + sg_me * (dv * dv);
+        const bool deg = rot && tmp < m.eps;
+        const float r = dm_sqrt(tmp);
+        const float cc = r / Ld;
+        float cinv = 1.0f / cc;
+        const float sk = dv / Ld;
+        cinv = rot ? cinv : 0.0f;                                        // 0 marks "no rotation for this pair" (1 / cc is never 0)
+        {
+          const unsigned long long dbal = __ballot(deg);
+          const unsigned long long mine = (T == 64) ? dbal : ((dbal >> ((threadIdx.x / T) * T)) & ((1ull << (T & 63)) - 1ull));
+          if (mine != 0ull) { degenerated = true; break; }
+        }
+        if (rot) { Ld = r; s->H[row * DS + row] = r; }
+        // ---- hand every pair's rotation to the rows below its column ----
+#pragma unroll
+        for (int f = 0; f < FMAX; ++f) {
+          const int k = t - f;                                           // wave-uniform
+          if (f < nb_wave && k >= 0 && k < ND - 1) {
+            const float bcc = team_bcast_dyn<T>(cc, k), bci = team_bcast_dyn<T>(cinv, k), bsk = team_bcast_dyn<T>(sk, k);
+            if (own && f < nb && row > k && bci != 0.0f) {
+              const float sgf = ((sgn >> f) & 1u) ? 1.0f : -1.0f;
+              const float hik = (s->H[row * DS + k] + bsk * W[f] * sgf) * bci;
+              s->H[row * DS + k] = hik; s->H[k * DS + row] = hik;
+              W[f] = W[f] * bcc - bsk * hik;
+            }
+          }
+        }
+      }
+    }
+  }
+  team_sync();
+  return degenerated;
+}
 template <int T, class S, class MT>
 DEV bool ts_cholesky_incremental(const MT& m, S* s, int tl, int n_con) {
-  if constexpr (T >= ND) return ts_cholesky_incremental_reg<T>(m, s, tl, n_con);
+  if constexpr (T >= ND) {
+#ifndef GO2SIM_NO_PIPELINED_RANK1
+    // how many rows flipped (the larger count of the teams in this wavefront): one -> the register-resident serial form is the cheaper
+    // instruction stream; several -> the pipelined form is 17 + n steps long instead of 18 n
+    int n_flip = 0;
+    for (int c = tl; c < n_con; c += T) n_flip += ((s->active[c] != 0) != (s->prev_active[c] != 0)) ? 1 : 0;
+    unsigned long long any2;
+    {
+      const unsigned long long fb = __ballot(n_flip > 0);
+      // flipped rows of my team = bits of my team's lanes (each lane holds at most ceil(n_con / T) of them: count lanes, a lower bound that is
+      // exact whenever n_con <= T, which is the LDS-resident case)
+      const unsigned long long mine = (T == 64) ? fb : ((fb >> ((threadIdx.x / T) * T)) & ((1ull << (T & 63)) - 1ull));
+      any2 = __ballot(__popcll(mine) >= 2);
+    }
+    if (any2 != 0ull) return ts_cholesky_incremental_pipelined<T, 8>(m, s, tl, n_con);
+#endif
+    return ts_cholesky_incremental_reg<T>(m, s, tl, n_con);
+  }
   bool degenerated = false;
   for (int c = 0; c < n_con && !degenerated; ++c) {
     bool is_active = s->active[c] != 0, was_active = s->prev_active[c] != 0;
@@ -2184,14 +2384,32 @@ DEV void ts_update_gradient(S* s, int tl) {
   team_sync();
 }
 
-template <class S, class MT>
-DEV LsPoint ts_ls_point(const MT& m, S* s, int n_con, float alpha, float qg0, float qg1, float qg2) {
+// the lane's own constraint row during a line search (zeros on lanes without a row): Jaref, J.search and the three quadratic coefficients
+struct LsRow { float Ja, jv, q0, q1, q2; };
+// func_ls_point_fn_opt, solver.py:2009-2077.  `nseg` > 0: every row sits on its own lane and the three sums over the rows are serial-order
+// lane scans (team_serial_sum); nseg == 0: more rows than lanes (global-scratch path), the scalar loops over the LDS / scratch arrays.
+template <int T, class S, class MT>
+DEV LsPoint ts_ls_point(const MT& m, S* s, int tl, int n_con, int nseg, const LsRow& rw, float alpha, float qg0, float qg1, float qg2) {
   float t0 = qg0 + 0.0f, t1 = qg1 + 0.0f, t2 = qg2 + 0.0f;
+  bool done = false;
+  if constexpr (T >= 32) {
+    if (nseg > 0) {
+      const float x = rw.Ja + alpha * rw.jv;
+      const float active = (float)(x < 0.0f);
+      const float xs[3] = {rw.q0 * active, rw.q1 * active, rw.q2 * active}, bs[3] = {t0, t1, t2};
+      float tot[3];
+      team_serial_sum<T, 3>(xs, bs, tl, nseg, tot);
+      t0 = tot[0]; t1 = tot[1]; t2 = tot[2];
+      done = true;
+    }
+  }
+  if (!done) {
 #pragma unroll 16
-  for (int c = 0; c < n_con; ++c) {
-    float x = s->Jaref[c] + alpha * s->jv[c];
-    float active = (float)(x < 0.0f);
-    t0 = t0 + s->qf0[c] * active; t1 = t1 + s->qf1[c] * active; t2 = t2 + s->qf2[c] * active;
+    for (int c = 0; c < n_con; ++c) {
+      float x = s->Jaref[c] + alpha * s->jv[c];
+      float active = (float)(x < 0.0f);
+      t0 = t0 + s->qf0[c] * active; t1 = t1 + s->qf1[c] * active; t2 = t2 + s->qf2[c] * active;
+    }
   }
   LsPoint p; p.alpha = alpha;
   p.cost = alpha * alpha * t2 + alpha * t1 + t0;
@@ -2200,20 +2418,41 @@ DEV LsPoint ts_ls_point(const MT& m, S* s, int n_con, float alpha, float qg0, fl
   if (p.hess <= 0.0f) p.hess = m.eps;
   return p;
 }
-template <class S, class MT>
-DEV void ts_ls_point3(const MT& m, S* s, int n_con, const float a[3], float qg0, float qg1, float qg2, float costs[3], float grads[3], float hess[3]) {
+// func_ls_point_fn_3alphas_opt, solver.py:2080-2209
+template <int T, class S, class MT>
+DEV void ts_ls_point3(const MT& m, S* s, int tl, int n_con, int nseg, const LsRow& rw, const float a[3], float qg0, float qg1, float qg2, float costs[3], float grads[3],
+                      float hess[3]) {
   float b0 = qg0 + 0.0f, b1 = qg1 + 0.0f, b2 = qg2 + 0.0f;
-  float t00 = b0, t01 = b1, t02 = b2, t10 = b0, t11 = b1, t12 = b2, t20 = b0, t21 = b1, t22 = b2;
-#pragma unroll 16
-  for (int c = 0; c < n_con; ++c) {
-    float Ja = s->Jaref[c], jv = s->jv[c];
-    float qf_0 = s->qf0[c], qf_1 = s->qf1[c], qf_2 = s->qf2[c];
-    float a0 = (float)((Ja + a[0] * jv) < 0.0f), a1 = (float)((Ja + a[1] * jv) < 0.0f), a2 = (float)((Ja + a[2] * jv) < 0.0f);
-    t00 = t00 + qf_0 * a0; t01 = t01 + qf_1 * a0; t02 = t02 + qf_2 * a0;
-    t10 = t10 + qf_0 * a1; t11 = t11 + qf_1 * a1; t12 = t12 + qf_2 * a1;
-    t20 = t20 + qf_0 * a2; t21 = t21 + qf_1 * a2; t22 = t22 + qf_2 * a2;
+  float t[3][3] = {{b0, b1, b2}, {b0, b1, b2}, {b0, b1, b2}};
+  bool done = false;
+  if constexpr (T >= 32) {
+    if (nseg > 0) {
+      float xs[9], bs[9], tot[9];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const float act = (float)((rw.Ja + a[k] * rw.jv) < 0.0f);
+        xs[3 * k] = rw.q0 * act; xs[3 * k + 1] = rw.q1 * act; xs[3 * k + 2] = rw.q2 * act;
+        bs[3 * k] = b0; bs[3 * k + 1] = b1; bs[3 * k + 2] = b2;
+      }
+      team_serial_sum<T, 9>(xs, bs, tl, nseg, tot);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { t[k][0] = tot[3 * k]; t[k][1] = tot[3 * k + 1]; t[k][2] = tot[3 * k + 2]; }
+      done = true;
+    }
   }
-  float t[3][3] = {{t00, t01, t02}, {t10, t11, t12}, {t20, t21, t22}};
+  if (!done) {
+    float t00 = b0, t01 = b1, t02 = b2, t10 = b0, t11 = b1, t12 = b2, t20 = b0, t21 = b1, t22 = b2;
+#pragma unroll 16
+    for (int c = 0; c < n_con; ++c) {
+      float Ja = s->Jaref[c], jv = s->jv[c];
+      float qf_0 = s->qf0[c], qf_1 = s->qf1[c], qf_2 = s->qf2[c];
+      float a0 = (float)((Ja + a[0] * jv) < 0.0f), a1 = (float)((Ja + a[1] * jv) < 0.0f), a2 = (float)((Ja + a[2] * jv) < 0.0f);
+      t00 = t00 + qf_0 * a0; t01 = t01 + qf_1 * a0; t02 = t02 + qf_2 * a0;
+      t10 = t10 + qf_0 * a1; t11 = t11 + qf_1 * a1; t12 = t12 + qf_2 * a1;
+      t20 = t20 + qf_0 * a2; t21 = t21 + qf_1 * a2; t22 = t22 + qf_2 * a2;
+    }
+    t[0][0] = t00; t[0][1] = t01; t[0][2] = t02; t[1][0] = t10; t[1][1] = t11; t[1][2] = t12; t[2][0] = t20; t[2][1] = t21; t[2][2] = t22;
+  }
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
     costs[k] = a[k] * a[k] * t[k][2] + a[k] * t[k][1] + t[k][0];
@@ -2236,6 +2475,13 @@ DEV float ts_linesearch(const MT& m, S* s, int tl, int n_con, float gauss) {
   float scale = m.meaninertia * (float)imx(1, ND);
   float gtol = m.tolerance * m.ls_tolerance * snorm * scale;
   if (snorm < m.eps) return 0.0f;
+  // 16-lane segments holding rows (0 = rows do not fit one per lane: scalar loops).  The count must be uniform over the wavefront (DPP steps are
+  // executed by all its lanes): the teams of a wavefront may hold different row counts, the larger one decides, surplus lanes add zeros.
+  int nseg = 0;
+  if constexpr (T >= 32) {
+    const int n_wave = __builtin_amdgcn_readfirstlane(imx(__shfl(n_con, 0), __shfl(n_con, T == 64 ? 0 : 32)));
+    nseg = (n_wave <= T) ? (n_wave + 15) / 16 : 0;
+  }
   // mv = M search, jv = J search, and the alpha-independent quadratic coefficients of every row
   for (int d1 = tl; d1 < ND; d1 += T) {
     float mv = 0.0f;
@@ -2243,13 +2489,16 @@ DEV float ts_linesearch(const MT& m, S* s, int tl, int n_con, float gauss) {
     for (int d2 = 0; d2 < ND; ++d2) mv = mv + s->M[d1 * DS + d2] * sr[d2];
     s->mv[d1] = mv;
   }
+  LsRow rw = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
   for (int c = tl; c < n_con; c += T) {
     float jv = 0.0f;
 #pragma unroll
     for (int d = 0; d < ND; ++d) jv = jv + s->J[c * DS + d] * sr[d];
     s->jv[c] = jv;
     float Ja = s->Jaref[c], D = s->efc_D[c];
-    s->qf0[c] = D * (0.5f * Ja * Ja); s->qf1[c] = D * (jv * Ja); s->qf2[c] = D * (0.5f * jv * jv);
+    const float q0 = D * (0.5f * Ja * Ja), q1 = D * (jv * Ja), q2 = D * (0.5f * jv * jv);
+    s->qf0[c] = q0; s->qf1[c] = q1; s->qf2[c] = q2;
+    rw.Ja = Ja; rw.jv = jv; rw.q0 = q0; rw.q1 = q1; rw.q2 = q2;       // (the lane's row when rows sit one per lane)
   }
   team_sync();
   float qg1 = 0.0f, qg2 = 0.0f;
@@ -2263,10 +2512,23 @@ DEV float ts_linesearch(const MT& m, S* s, int tl, int n_con, float gauss) {
   LsPoint p0;
   {
     float t0 = qg0, t1 = qg1, t2 = qg2;
+    bool done = false;
+    if constexpr (T >= 32) {
+      if (nseg > 0) {
+        const float active = (float)(rw.Ja < 0.0f);
+        const float xs[3] = {rw.q0 * active, rw.q1 * active, rw.q2 * active}, bs[3] = {t0, t1, t2};
+        float tot[3];
+        team_serial_sum<T, 3>(xs, bs, tl, nseg, tot);
+        t0 = tot[0]; t1 = tot[1]; t2 = tot[2];
+        done = true;
+      }
+    }
+    if (!done) {
 #pragma unroll 16
-    for (int c = 0; c < n_con; ++c) {
-      float active = (float)(s->Jaref[c] < 0.0f);
-      t0 = t0 + s->qf0[c] * active; t1 = t1 + s->qf1[c] * active; t2 = t2 + s->qf2[c] * active;
+      for (int c = 0; c < n_con; ++c) {
+        float active = (float)(s->Jaref[c] < 0.0f);
+        t0 = t0 + s->qf0[c] * active; t1 = t1 + s->qf1[c] * active; t2 = t2 + s->qf2[c] * active;
+      }
     }
     p0.alpha = 0.0f; p0.cost = t0; p0.grad = t1; p0.hess = 2.0f * t2;
     if (p0.hess <= 0.0f) p0.hess = m.eps;
@@ -2274,7 +2536,7 @@ DEV float ts_linesearch(const MT& m, S* s, int tl, int n_con, float gauss) {
   int ls_it = 1;
   float res_alpha = 0.0f;
   bool done = false;
-  LsPoint p1 = ts_ls_point(m, s, n_con, p0.alpha - p0.grad / p0.hess, qg0, qg1, qg2);
+  LsPoint p1 = ts_ls_point<T>(m, s, tl, n_con, nseg, rw, p0.alpha - p0.grad / p0.hess, qg0, qg1, qg2);
   ls_it += 1;
   if (p0.cost < p1.cost) p1 = p0;
   if (dm_abs(p1.grad) < gtol) return p1.alpha;
@@ -2283,7 +2545,7 @@ DEV float ts_linesearch(const MT& m, S* s, int tl, int n_con, float gauss) {
   LsPoint p2 = p1;
   while (p1.grad * (float)direction <= -gtol && ls_it < m.ls_iterations) {
     p2 = p1; p2update = 1;
-    p1 = ts_ls_point(m, s, n_con, p1.alpha - p1.grad / p1.hess, qg0, qg1, qg2);
+    p1 = ts_ls_point<T>(m, s, tl, n_con, nseg, rw, p1.alpha - p1.grad / p1.hess, qg0, qg1, qg2);
     ls_it += 1;
     if (dm_abs(p1.grad) < gtol) { res_alpha = p1.alpha; done = true; break; }
   }
@@ -2294,7 +2556,7 @@ DEV float ts_linesearch(const MT& m, S* s, int tl, int n_con, float gauss) {
   al[0] = p1.alpha - p1.grad / p1.hess; al[1] = p1.alpha; al[2] = (p1.alpha + p2.alpha) * 0.5f;
   while (ls_it < m.ls_iterations) {
     float costs[3], grads[3], hess[3];
-    ts_ls_point3(m, s, n_con, al, qg0, qg1, qg2, costs, grads, hess);
+    ts_ls_point3<T>(m, s, tl, n_con, nseg, rw, al, qg0, qg1, qg2, costs, grads, hess);
     ls_it += 3;
     float p1_next_alpha = al[0], p2_next_alpha = al[1];
     float best_alpha = 0.0f, best_cost = 0.0f; bool best_found = false;
@@ -2575,6 +2837,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   // every load of the prologue (solver block by LDS DMA, contact count, warm-start flag, the joint coordinates of the limit test) is issued
   // before the first wait
   static_assert(T >= NJ, "one lane per joint in the limit test");
+  PH_BEGIN
   wg_dma_to_lds<SOLVER_BLOCK_BYTES>(blk_raw, mp->links);
   const int tl = threadIdx.x % T, slot = threadIdx.x / T;
   const int b = blockIdx.x * EPW + slot;
@@ -2588,13 +2851,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   const unsigned lim_mask = (unsigned)((__ballot(lim) >> (slot * T)) & ((T == 64) ? ~0ull : ((1ull << T) - 1ull)));
   const int n_lim = __popc(lim_mask);
   __syncthreads();
+  PH(9)
   const ModelView m(lnk, tri_i, tri_j, gm);
   if (!env_valid) return;
   const int n_con = 4 * nc + n_lim;
   if (n_con <= RLN) {
     SolverData<RLN>* s = &lds[slot];
     int iters = ts_solve<T>(m, e, s, tl, nc, n_con, lim_mask, ws_flag);
-    PH_BEGIN
+    PH(10)                                                               // (resets the timer: the phases of ts_solve are accounted inside it)
 #if defined(GO2SIM_REPEAT_PHASE) && GO2SIM_REPEAT_PHASE == 11
     ts_commit<T>(m, e, s, tl, nc, n_con, iters);
     team_sync();
@@ -2623,6 +2887,7 @@ __global__ __launch_bounds__(64) void k_debug_narrowphase(const Model* __restric
     mpr_contact(m, pr, v3(0, 0, 0), is_col, normal, pen, pos);
   } else {
     DgPair dp; dp.m = mp; dp.i_ga = i_ga; dp.i_gb = i_gb; dp.pos_a = pa; dp.quat_a = qa; dp.pos_b = pb; dp.quat_b = qb;
+    dp.ga = geom_lite(m, i_ga); dp.gb = geom_lite(m, i_gb);
     dp.discrete = m.geoms[i_ga].type == GEOM_BOX && m.geoms[i_gb].type == GEOM_BOX;
     const DgResult r = (which == 1) ? gjk_query(dp, slots, &mask, full, m.eps) : gjk_query(dp, nullptr, &mask, full, m.eps);
     is_col = r.is_col; pen = r.penetration; normal = r.normal; pos = r.pos;
@@ -4548,8 +4813,8 @@ int go2sim_debug_narrowphase(go2sim_t* h, int which, int i_ga, int i_gb, const f
 int go2sim_debug_phases(go2sim_t* h, unsigned long long* out64, int reset) {
   if (!h || !out64) return GO2SIM_E_BADARG;
   HIPCHK(hipDeviceSynchronize());
-  HIPCHK(hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_phase_cycles), sizeof(unsigned long long) * 64));
-  if (reset) { unsigned long long z[64] = {0}; HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_phase_cycles), z, sizeof(z))); }
+  HIPCHK(hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_phase_cycles), sizeof(unsigned long long) * 64 * PH_MAX_WG));   // [PH_MAX_WG][64]
+  if (reset) { void* p = nullptr; HIPCHK(hipGetSymbolAddress(&p, HIP_SYMBOL(g_phase_cycles))); HIPCHK(hipMemset(p, 0, sizeof(unsigned long long) * 64 * PH_MAX_WG)); }
   return GO2SIM_E_OK;
 }
 #endif

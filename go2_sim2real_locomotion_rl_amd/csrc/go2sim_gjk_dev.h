@@ -17,9 +17,20 @@
 // team's slots, carved out of the broad-phase arrays that are dead by then); if a query outgrows it, or no slot is free, the same code runs on
 // the full-capacity store in global memory (`GjkStoreFull`, the reference's capacities), which is deterministic and capacity-independent, so
 // the answer is the same either way.  Loop counters and sizes live in registers (`GjkCtl`), not in memory.
+
 #ifndef GO2SIM_GJK_DEV_H
 #define GO2SIM_GJK_DEV_H
 
+// Two code shapes, same arithmetic: the default inlines and unrolls (fastest measured: 107 k cycles per query at the landing peak); with
+// -DGO2SIM_GJK_COMPACT the support evaluation / face attachment are single out-of-line copies and the loops stay rolled (4 k instead of 15 k
+// instructions, but 164 k cycles per query: the call frames and rolled loops cost more than the instruction fetch they save).
+#ifdef GO2SIM_GJK_COMPACT
+#define DG_OUTLINE DEVN
+#define DG_NOUNROLL _Pragma("nounroll")
+#else
+#define DG_OUTLINE DEV
+#define DG_NOUNROLL
+#endif
 constexpr int DG_GJK_MAX_IT = 50, DG_EPA_MAX_IT = 50;                 // gjk.py:53-54
 constexpr int DG_MAX_FACES = 6 * DG_EPA_MAX_IT;                        // gjk.py:56 (polytope_max_faces)
 constexpr int DG_MAX_VERTS = 5 + DG_EPA_MAX_IT;                        // array_class.py:744
@@ -45,27 +56,30 @@ struct DgResult { bool is_col, overflow; float penetration; V3 normal, pos; };
 
 // ---- geometry of the pair: world-frame support points with vertex ids (gjk_support.py:62-186, support_field.py:183-306) ----
 struct DgPair {
-  const Model* m; int i_ga, i_gb; V3 pos_a; Q4 quat_a; V3 pos_b; Q4 quat_b; bool discrete;
-  DEV V3 support_one(V3 d, int i_g, V3 pos, Q4 quat, int& vid) const { return gjk_support_driver(*m, d, i_g, pos, quat, vid); }
-  DEV DgVert support(V3 d) const {
+  const Model* m; int i_ga, i_gb; V3 pos_a; Q4 quat_a; V3 pos_b; Q4 quat_b; bool discrete; GeomLite ga, gb;   // type / size of the two geoms, read once
+  DEV V3 support_one(V3 d, int i_g, const GeomLite& gl, V3 pos, Q4 quat, int& vid) const { return gjk_support_driver(*m, d, i_g, gl, pos, quat, vid); }
+  DG_OUTLINE void support_into(V3 d, DgVert* out) const {                   // the one copy of the support code of a query
+    PHD_BEGIN
     DgVert r;
-    r.o1 = support_one(d, i_ga, pos_a, quat_a, r.id1);
-    r.o2 = support_one(-d, i_gb, pos_b, quat_b, r.id2);
+    r.o1 = support_one(d, i_ga, ga, pos_a, quat_a, r.id1);
+    r.o2 = support_one(-d, i_gb, gb, pos_b, quat_b, r.id2);
     r.mk = r.o1 - r.o2;
-    return r;
+    *out = r;
+    PHD(48)
   }
+  DEV DgVert support(V3 d) const { DgVert r; support_into(d, &r); return r; }
   // count_support_driver, gjk.py:1854-1877: only a box can have several support points (a face / edge exactly normal to the direction)
-  DEV int count_one(V3 d, int i_g, Q4 quat) const {
-    if (m->geoms[i_g].type != GEOM_BOX) return 1;
+  DEV int count_one(V3 d, const GeomLite& gl, Q4 quat) const {
+    if (gl.type != GEOM_BOX) return 1;
     V3 db = inv_transform_by_quat(d, quat);
     return 1 << ((db.x == 0.0f) + (db.y == 0.0f) + (db.z == 0.0f));
   }
-  DEV int count(V3 d) const { return count_one(d, i_ga, quat_a) * count_one(-d, i_gb, quat_b); }
+  DG_OUTLINE int count(V3 d) const { return count_one(d, ga, quat_a) * count_one(-d, gb, quat_b); }
   // func_get_discrete_geom_vertex (BOX), gjk.py:1666-1700
   DEV void box_vertex(bool second, int i_v, V3& obj, int& id) const {
     const int i_g = second ? i_gb : i_ga;
-    const Geom& G = m->geoms[i_g];
-    V3 loc = v3(((i_v & 1) ? 1.0f : -1.0f) * G.data[0] * 0.5f, ((i_v & 2) ? 1.0f : -1.0f) * G.data[1] * 0.5f, ((i_v & 4) ? 1.0f : -1.0f) * G.data[2] * 0.5f);
+    const GeomLite& G = second ? gb : ga;
+    V3 loc = v3(((i_v & 1) ? 1.0f : -1.0f) * G.d0 * 0.5f, ((i_v & 2) ? 1.0f : -1.0f) * G.d1 * 0.5f, ((i_v & 4) ? 1.0f : -1.0f) * G.d2 * 0.5f);
     obj = transform_by_trans_quat(loc, second ? pos_b : pos_a, second ? quat_b : quat_a);
     id = 64 * i_g + i_v;
   }
@@ -105,6 +119,7 @@ DEV bool dg_valid(const S& st, int ns, const DgVert& w) { return !dg_duplicate(s
 template <class S>
 DEV DgVert dg_safe_support(const DgPair& pr, const S& st, int ns, V3 dir, float eps) {
   DgVert w; w.o1 = v3(0, 0, 0); w.o2 = v3(0, 0, 0); w.mk = v3(0, 0, 0); w.id1 = -1; w.id2 = -1;
+DG_NOUNROLL
   for (int i = 0; i < 9; ++i) {
     V3 nd = dir;
     if (i > 0) {
@@ -129,6 +144,7 @@ template <class S>
 DEV bool dg_search_vertex(const DgPair& pr, const S& st, GjkCtl& c, DgVert& w, float eps) {
   w.o1 = v3(0, 0, 0); w.o2 = v3(0, 0, 0); w.mk = v3(0, 0, 0); w.id1 = -1; w.id2 = -1;
   if (pr.discrete) {                                                    // box - box: walk the 8 x 8 vertex pairs from where the last search stopped
+DG_NOUNROLL
     for (int k = 0; k < 64; ++k) {
       const int mth = (k + c.last_searched) % 64;
       pr.box_vertex(false, mth / 8, w.o1, w.id1);
@@ -142,6 +158,7 @@ DEV bool dg_search_vertex(const DgPair& pr, const S& st, GjkCtl& c, DgVert& w, f
     V3 a = st.v[0].mk, b = st.v[1].mk, cc = st.v[2].mk;
     V3 nrm = cross(cc - a, b - a);
     V3 dir = nrm / norm(nrm);
+DG_NOUNROLL
     for (int i = 0; i < 2; ++i) {
       w = dg_safe_support(pr, st, c.ns, (i == 0) ? dir : -dir, eps);
       if (dg_valid(st, c.ns, w)) return true;
@@ -150,43 +167,53 @@ DEV bool dg_search_vertex(const DgPair& pr, const S& st, GjkCtl& c, DgVert& w, f
   return false;
 }
 
-// func_safe_gjk, gjk.py:1200-1416: true when the tetrahedron v[0..3] contains the origin
+// func_safe_gjk, gjk.py:1200-1416: true when the tetrahedron v[0..3] contains the origin.  One loop serves both stages (steps 0..3 build
+// the initial tetrahedron from the directions +-z, +-y, the later steps replace the vertex opposite to the worst face), so the safe-support
+// code has a single call site.
 template <class S>
 DEV bool dg_gjk(const DgPair& pr, S& st, GjkCtl& c, float eps) {
   c.ns = 0;
-  for (int i = 0; i < 4; ++i) {                                         // initial tetrahedron from +-z, +-y
-    V3 dir = v3(0, 0, 0);
-    const float sgn = 1.0f - 2.0f * (float)(i % 2);
-    if (i < 2) dir.z = sgn; else dir.y = sgn;
-    DgVert w = dg_safe_support(pr, st, c.ns, dir, eps);
-    if (!dg_valid(st, c.ns, w) && !dg_search_vertex(pr, st, c, w, eps)) return false;
-    st.v[i] = w;
-    c.ns += 1;
-  }
-  for (int it = 0; it < DG_GJK_MAX_IT; ++it) {
-    // outward normal and signed distance (origin inside => positive) of the four faces; face j is opposite to vertex j
-    float best_sd = 0.0f; V3 best_n = v3(0, 0, 0); int best = 0;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int a = (j == 0) ? 2 : ((j == 1) ? 0 : ((j == 2) ? 1 : 0));
-      const int b = (j == 0) ? 1 : ((j == 1) ? 2 : ((j == 2) ? 0 : 1));
-      const int cidx = (j == 3) ? 2 : 3;
-      V3 va = st.v[a].mk, vb = st.v[b].mk, vc = st.v[cidx].mk, apex = st.v[j].mk;
-      V3 nrm = cross(vc - va, vb - va);                                  // func_safe_gjk_triangle_info, gjk.py:1703-1733
-      nrm = nrm / norm(nrm);
-      if (dot(nrm, apex - va) > 0.0f) nrm = -nrm;
-      const float sd = dot(nrm, va);
-      if (j == 0 || sd < best_sd) { best_sd = sd; best_n = nrm; best = j; }
+  V3 best_n = v3(0, 0, 0);
+DG_NOUNROLL
+  for (int step = 0; step < 4 + DG_GJK_MAX_IT; ++step) {
+    const bool init = step < 4;
+    V3 dir = best_n;
+    if (init) {
+      dir = v3(0, 0, 0);
+      const float sgn = 1.0f - 2.0f * (float)(step % 2);
+      if (step < 2) dir.z = sgn; else dir.y = sgn;
+    } else {
+      // outward normal and signed distance (origin inside => positive) of the four faces; face j is opposite to vertex j
+      float best_sd = 0.0f; int best = 0;
+DG_NOUNROLL
+      for (int j = 0; j < 4; ++j) {
+        const int a = (j == 0) ? 2 : ((j == 1) ? 0 : ((j == 2) ? 1 : 0));
+        const int b = (j == 0) ? 1 : ((j == 1) ? 2 : ((j == 2) ? 0 : 1));
+        const int cidx = (j == 3) ? 2 : 3;
+        V3 va = st.v[a].mk, vb = st.v[b].mk, vc = st.v[cidx].mk, apex = st.v[j].mk;
+        V3 nrm = cross(vc - va, vb - va);                                // func_safe_gjk_triangle_info, gjk.py:1703-1733
+        nrm = nrm / norm(nrm);
+        if (dot(nrm, apex - va) > 0.0f) nrm = -nrm;
+        const float sd = dot(nrm, va);
+        if (j == 0 || sd < best_sd) { best_sd = sd; best_n = nrm; best = j; }
+      }
+      if (best_sd >= 0.0f) return true;                                  // INTERSECT
+      c.ns = 3;
+      if (best != 3) st.v[best] = st.v[3];                               // drop the vertex opposite to the worst face
+      dir = best_n;
     }
-    if (best_sd >= 0.0f) return true;                                    // INTERSECT
-    c.ns = 3;
-    if (best != 3) st.v[best] = st.v[3];                                 // drop the vertex opposite to the worst face
-    DgVert w = dg_safe_support(pr, st, c.ns, best_n, eps);
-    if (dg_duplicate(st, c.ns, w.id1, w.id2)) return false;              // SEPARATED
-    if (dg_degenerate(st, c.ns, w.mk)) return false;                     // NUM_ERROR, treated as separated
-    if (dot(w.mk, best_n) < 0.0f) return false;                          // the origin is outside the Minkowski difference
-    st.v[3] = w;
-    c.ns = 4;
+    DgVert w = dg_safe_support(pr, st, c.ns, dir, eps);
+    if (init) {
+      if (!dg_valid(st, c.ns, w) && !dg_search_vertex(pr, st, c, w, eps)) return false;
+      st.v[step] = w;
+      c.ns += 1;
+    } else {
+      if (dg_duplicate(st, c.ns, w.id1, w.id2)) return false;            // SEPARATED
+      if (dg_degenerate(st, c.ns, w.mk)) return false;                   // NUM_ERROR, treated as separated
+      if (dot(w.mk, best_n) < 0.0f) return false;                        // the origin is outside the Minkowski difference
+      st.v[3] = w;
+      c.ns = 4;
+    }
   }
   return false;
 }
@@ -207,7 +234,7 @@ DEV bool dg_plane_normal(V3 p1, V3 p2, V3 p3, V3& nrm) {
 
 // func_safe_attach_face_to_polytope, epa.py:1298-1380; the caller has checked the capacity
 template <class S>
-DEV bool dg_attach_face(S& st, GjkCtl& c, int v1, int v2, int v3_, int a1, int a2, int a3) {
+DG_OUTLINE bool dg_attach_face(S& st, GjkCtl& c, int v1, int v2, int v3_, int a1, int a2, int a3) {
   const int n = c.nf;
   DgFace& F = st.f[n];
   F.v[0] = (short)v1; F.v[1] = (short)v2; F.v[2] = (short)v3_; F.adj[0] = (short)a1; F.adj[1] = (short)a2; F.adj[2] = (short)a3;
@@ -328,10 +355,11 @@ DEV float dg_epa(const DgPair& pr, S& st, GjkCtl& c, float eps, V3& w1, V3& w2, 
   has_witness = false;
   // polytope = the GJK tetrahedron (its vertices already sit in v[0..3])
   c.nv = 4; c.nf = 0; c.nmap = 0; c.hz_n = 0;
-  dg_attach_face(st, c, 0, 1, 2, 1, 3, 2);
-  dg_attach_face(st, c, 0, 3, 1, 2, 3, 0);
-  dg_attach_face(st, c, 0, 2, 3, 0, 3, 1);
-  dg_attach_face(st, c, 3, 2, 1, 2, 0, 1);
+DG_NOUNROLL
+  for (int i = 0; i < 4; ++i) {                                          // (vertices | neighbours) of the four faces, 3 bits per index
+    const unsigned code = (i == 0) ? 0210u | (0231u << 9) : ((i == 1) ? 0130u | (0032u << 9) : ((i == 2) ? 0320u | (0130u << 9) : 0123u | (0102u << 9)));
+    dg_attach_face(st, c, (int)(code & 7u), (int)((code >> 3) & 7u), (int)((code >> 6) & 7u), (int)((code >> 9) & 7u), (int)((code >> 12) & 7u), (int)((code >> 15) & 7u));
+  }
 #pragma unroll
   for (int i = 0; i < 4; ++i) { st.map[i] = (short)i; st.f[i].map_idx = (short)i; }
   c.nmap = 4;
@@ -406,9 +434,13 @@ template <class S>
 DEV DgResult dg_contact(const DgPair& pr, S& st, float eps) {
   GjkCtl c; c.nv = c.nf = c.nmap = c.hz_n = c.ns = 0; c.last_searched = 0; c.overflow = false;
   DgResult r; r.is_col = false; r.overflow = false; r.penetration = 0.0f; r.normal = v3(0, 0, 0); r.pos = v3(0, 0, 0);
-  if (!dg_gjk(pr, st, c, eps)) return r;
+  PHD_BEGIN
+  const bool hit = dg_gjk(pr, st, c, eps);
+  PHD(38)
+  if (!hit) return r;
   V3 w1 = v3(0, 0, 0), w2 = v3(0, 0, 0); bool has_w = false;
   const float dist = dg_epa(pr, st, c, eps, w1, w2, has_w);
+  PHD(42)
   if (c.overflow) { r.overflow = true; return r; }
   if (!(dist < 0.0f) || !has_w) return r;
   const V3 nrm = w2 - w1;

@@ -40,6 +40,9 @@ def oracle_lib(libs_built):
 
 @pytest.fixture(scope="session")
 def hip_lib(libs_built):
-    from go2_sim2real_locomotion_rl_amd.capi import load_hip_lib
+    from go2_sim2real_locomotion_rl_amd.capi import Go2SimLib, load_hip_lib
 
+    alt = os.environ.get("GO2SIM_TEST_HIP_LIB")           # test infrastructure only: run the GPU parity tests against another BUILD of the HIP
+    if alt:                                                # library (e.g. tools/lib_bracket_inline.so, see DESIGN.md "update_bracket")
+        return Go2SimLib(os.path.abspath(alt), "go2sim_")
     return load_hip_lib()

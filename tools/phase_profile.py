@@ -18,20 +18,40 @@ dev = torch.device("cuda", 0)
 sim = capi.Go2Sim(lib, pack_model(), B, 0, 1)
 f, i, _ = flatten_walk_cfg(B, *get_walk_cfgs(), freeze_curriculum=True)
 sim.env_configure(f, i); sim.env_reset()
-N = 100
-act = make_actions(N + 50, B, dev)
+W = int(sys.argv[1]) if len(sys.argv) > 1 else 50      # warm-up steps from the reset (5 = the landing window of the driver's bench run)
+N = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+act = make_actions(N + W, B, dev)
 obs = torch.zeros(B, 49, device=dev); priv = torch.zeros(B, 104, device=dev); rew = torch.zeros(B, device=dev)
 rst = torch.zeros(B, dtype=torch.uint8, device=dev); to = torch.zeros(B, device=dev)
-for s in range(50):
+for s in range(W):
     sim.env_step(act[s], obs, priv, rew, rst, to)
-out = (ctypes.c_ulonglong * 64)()
+PH_MAX_WG = 8192
+out = (ctypes.c_ulonglong * (64 * PH_MAX_WG))()
 lib.lib.go2sim_debug_phases(sim.h, out, 1)
-for s in range(50, 50 + N):
+for s in range(W, W + N):
     sim.env_step(act[s], obs, priv, rew, rst, to)
 lib.lib.go2sim_debug_phases(sim.h, out, 1)
-n_wg = (B + 3) // 4 * 2 * N   # workgroups x launches
-tot = sum(out)
-for k in range(64):
-    if out[k]:
-        print(f"phase {k:2d}: {out[k] / n_wg:10.0f} cycles/WG-launch  {100.0 * out[k] / tot:5.1f}%")
-print("total cycles per WG-launch", tot / n_wg)
+a = np.frombuffer(out, dtype=np.uint64).reshape(PH_MAX_WG, 64).astype(np.float64)
+launches = 2 * N                                   # substep kernels: two launches per env step
+GROUPS = {"solver": [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 11], "dynamics": list(range(20, 26)), "collide": list(range(30, 36)), "integrate_fk": [40, 41]}   # (ids 34-39, 42-49: PHD sections, printed above)
+NAMES = {0: "stage", 1: "rows", 2: "init Ma/Jaref/update", 3: "Hessian", 4: "Cholesky factor", 5: "gradient solve", 6: "line search", 7: "qacc/constraint update",
+         8: "incremental Cholesky", 9: "prologue", 11: "commit", 30: "AABB + clear", 31: "endpoint sort", 32: "candidate pairs", 33: "narrow phase"}
+# sections inside lane-divergent code (PHD): cycles at id, number of executions at id + 1
+for name, i in (("GJK / EPA query", 34), ("  of which GJK", 38), ("  of which EPA + witness", 42), ("  support pair evaluations (GJK / EPA)", 48), ("MPR query", 36)):
+    cyc, cnt = a[:, i], a[:, i + 1]
+    if cnt.sum() > 0:
+        print(f"-- {name}: {cnt.sum() / launches:8.1f} executions per launch (wave level), {cyc.sum() / cnt.sum():9.0f} cycles each; per WG-launch mean {cyc.mean() * PH_MAX_WG / max(1, (cyc > 0).sum()) / launches:9.0f}, slowest 1% {np.sort(cyc)[-max(1, int((cyc > 0).sum()) // 100):].mean() / launches:9.0f}")
+for g, ids in GROUPS.items():
+    sub = a[:, ids]
+    tot = sub.sum(1)
+    used = tot > 0
+    if not used.any():
+        continue
+    n_wg = int(used.sum())
+    order = np.argsort(-tot)
+    top = order[:max(1, n_wg // 100)]               # the slowest 1 % of the workgroups: what a launch at full residency waits for
+    print(f"== {g}: {n_wg} workgroups, {launches} launches; cycles per WG-launch: mean {tot[used].mean() / launches:9.0f}   slowest 1% {tot[top].mean() / launches:9.0f}")
+    for k, i in enumerate(ids):
+        if sub[:, k].sum() == 0:
+            continue
+        print(f"   phase {i:2d} {NAMES.get(i, ''):24s} mean {sub[used, k].mean() / launches:9.0f} ({100 * sub[used, k].sum() / tot[used].sum():5.1f}%)   slowest 1% {sub[top, k].mean() / launches:9.0f} ({100 * sub[top, k].sum() / tot[top].sum():5.1f}%)")
