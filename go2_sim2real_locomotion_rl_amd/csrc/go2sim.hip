@@ -135,6 +135,32 @@ DEV V3 transform_by_quat(V3 v, Q4 q) {
   return r / (q_ww + q_xx + q_yy + q_zz);
 }
 DEV V3 inv_transform_by_quat(V3 v, Q4 q) { return transform_by_quat(v, inv_quat(q)); }
+// transform_by_quat with the quaternion-only part factored out: the nine coefficients and the denominator of geom.py:255-270 evaluated once per
+// pose, in the same expression order, so rot_apply(make_rot(q), v) == transform_by_quat(v, q) bit for bit.  The inverse rotation uses the
+// transposed coefficients: for q' = (w, -x, -y, -z) the products x'y', x'z', y'z' and the squares are unchanged and w x', w y', w z' only change
+// sign (exactly), which turns every coefficient of q' into the transposed coefficient of q (sums commute).  A support query of the narrow phase
+// rotates a direction into the geom frame and a vertex back some twenty times per pair with the same two poses.  When the denominator
+// |q|^2 is exactly 1 (the ground slab's identity pose) the division is the identity and is skipped.
+struct Rot { float c00, c01, c02, c10, c11, c12, c20, c21, c22, den; };
+DEV Rot make_rot(Q4 q) {
+  float q_xx = q.x * q.x, q_xy = q.x * q.y, q_xz = q.x * q.z, q_wx = q.x * q.w;
+  float q_yy = q.y * q.y, q_yz = q.y * q.z, q_wy = q.y * q.w;
+  float q_zz = q.z * q.z, q_wz = q.z * q.w;
+  float q_ww = q.w * q.w;
+  Rot R;
+  R.c00 = q_xx + q_ww - q_yy - q_zz; R.c01 = 2.0f * q_xy - 2.0f * q_wz; R.c02 = 2.0f * q_xz + 2.0f * q_wy;
+  R.c10 = 2.0f * q_wz + 2.0f * q_xy; R.c11 = q_ww - q_xx + q_yy - q_zz; R.c12 = -2.0f * q_wx + 2.0f * q_yz;
+  R.c20 = -2.0f * q_wy + 2.0f * q_xz; R.c21 = 2.0f * q_wx + 2.0f * q_yz; R.c22 = q_ww - q_xx - q_yy + q_zz;
+  R.den = q_ww + q_xx + q_yy + q_zz;
+  return R;
+}
+DEV V3 rot_finish(V3 r, float den) { return (den == 1.0f) ? r : r / den; }
+DEV V3 rot_apply(const Rot& R, V3 v) {        // == transform_by_quat(v, q)
+  return rot_finish(v3(v.x * R.c00 + v.y * R.c01 + v.z * R.c02, v.x * R.c10 + v.y * R.c11 + v.z * R.c12, v.x * R.c20 + v.y * R.c21 + v.z * R.c22), R.den);
+}
+DEV V3 rot_apply_inv(const Rot& R, V3 v) {    // == transform_by_quat(v, inv_quat(q))
+  return rot_finish(v3(v.x * R.c00 + v.y * R.c10 + v.z * R.c20, v.x * R.c01 + v.y * R.c11 + v.z * R.c21, v.x * R.c02 + v.y * R.c12 + v.z * R.c22), R.den);
+}
 DEV V3 transform_by_trans_quat(V3 p, V3 t, Q4 q) { return transform_by_quat(p, q) + t; }
 DEV void transform_pos_quat_by_trans_quat(V3 pos, Q4 quat, V3 t_trans, Q4 t_quat, V3& opos, Q4& oquat) {
   opos = t_trans + transform_by_quat(pos, t_quat);
@@ -1221,26 +1247,27 @@ DEV V3 support_prism(const V3* prism, V3 d) {
 // type and size of a geom, read once per pair so that the MPR iterations do not go back to the model in global memory
 struct GeomLite { int type; float d0, d1, d2; };
 DEV GeomLite geom_lite(const Model& m, int i_g) { const Geom& G = m.geoms[i_g]; GeomLite r = {G.type, G.data[0], G.data[1], G.data[2]}; return r; }
-DEV V3 support_driver(const Model& m, V3 direction, int i_g, const GeomLite& gl, V3 pos, Q4 quat, const V3* prism = nullptr) {
+DEV V3 support_driver(const Model& m, V3 direction, int i_g, const GeomLite& gl, V3 pos, const Rot& rot, const V3* prism = nullptr) {
   if (gl.type == GEOM_TERRAIN) return support_prism(prism, direction);
   if (gl.type == GEOM_SPHERE) {
     return pos + direction * gl.d0;
   } else if (gl.type == GEOM_BOX) {
-    V3 d_box = inv_transform_by_quat(direction, quat);
+    V3 d_box = rot_apply_inv(rot, direction);
     V3 v_ = v3((d_box.x < 0.0f ? -1.0f : 1.0f) * gl.d0 * 0.5f, (d_box.y < 0.0f ? -1.0f : 1.0f) * gl.d1 * 0.5f,
                (d_box.z < 0.0f ? -1.0f : 1.0f) * gl.d2 * 0.5f);
-    return transform_by_trans_quat(v_, pos, quat);
+    return rot_apply(rot, v_) + pos;
   } else {
-    V3 d_mesh = transform_by_quat(direction, inv_quat(quat));
+    V3 d_mesh = rot_apply_inv(rot, direction);
     V3 v_ = support_cylinder_local(m, m.geoms[i_g], d_mesh);
-    return transform_by_trans_quat(v_, pos, quat);
+    return rot_apply(rot, v_) + pos;
   }
 }
-struct Pair { int i_ga, i_gb; V3 pos_a; Q4 quat_a; V3 pos_b; Q4 quat_b; const V3* prism; GeomLite ga, gb; };
+struct Pair { int i_ga, i_gb; V3 pos_a; Q4 quat_a; V3 pos_b; Q4 quat_b; const V3* prism; GeomLite ga, gb; Rot ra, rb; };   // ra / rb = make_rot(quat_a / quat_b)
+DEV void pair_set_rots(Pair& pr) { pr.ra = make_rot(pr.quat_a); pr.rb = make_rot(pr.quat_b); }
 // compute_support, collider/mpr.py:179-202
 DEV void compute_support(const Model& m, V3 direction, const Pair& pr, V3& v, V3& v1, V3& v2) {
-  v1 = support_driver(m, direction, pr.i_ga, pr.ga, pr.pos_a, pr.quat_a);
-  v2 = support_driver(m, -direction, pr.i_gb, pr.gb, pr.pos_b, pr.quat_b, pr.prism);
+  v1 = support_driver(m, direction, pr.i_ga, pr.ga, pr.pos_a, pr.ra);
+  v2 = support_driver(m, -direction, pr.i_gb, pr.gb, pr.pos_b, pr.rb, pr.prism);
   v = v1 - v2;
 }
 
@@ -1249,22 +1276,22 @@ DEV void compute_support(const Model& m, V3 direction, const Pair& pr, V3& v, V3
 //      gjk.py:1652-1700,1854-1907.  Vertex ids only need to be unique per (geom, vertex): 64 ids are reserved per geom. ----
 // (type and size of the geom come from the per-pair GeomLite record: a GJK / EPA query makes some sixty support calls, and fetching them from
 //  the model in global memory every time put a dependent load in front of each one)
-DEV V3 gjk_support_driver(const Model& m, V3 direction, int i_g, const GeomLite& gl, V3 pos, Q4 quat, int& vid) {
+DEV V3 gjk_support_driver(const Model& m, V3 direction, int i_g, const GeomLite& gl, V3 pos, const Rot& rot, int& vid) {
   if (gl.type == GEOM_SPHERE) {
     vid = -1;
     return pos + direction * gl.d0;
   } else if (gl.type == GEOM_BOX) {
-    V3 d_box = inv_transform_by_quat(direction, quat);
+    V3 d_box = rot_apply_inv(rot, direction);
     V3 v_ = v3((d_box.x < 0.0f ? -1.0f : 1.0f) * gl.d0 * 0.5f, (d_box.y < 0.0f ? -1.0f : 1.0f) * gl.d1 * 0.5f,
                (d_box.z < 0.0f ? -1.0f : 1.0f) * gl.d2 * 0.5f);
     vid = (v_.x > 0.0f) * 1 + (v_.y > 0.0f) * 2 + (v_.z > 0.0f) * 4 + 64 * i_g;
-    return transform_by_trans_quat(v_, pos, quat);
+    return rot_apply(rot, v_) + pos;
   } else {
-    V3 d_mesh = transform_by_quat(direction, inv_quat(quat));
+    V3 d_mesh = rot_apply_inv(rot, direction);
     int k = 0;
     V3 v_ = support_cylinder_local(m, m.geoms[i_g], d_mesh, &k);
     vid = k + 64 * i_g;
-    return transform_by_trans_quat(v_, pos, quat);
+    return rot_apply(rot, v_) + pos;
   }
 }
 #include "go2sim_gjk_dev.h"   // device-side safe GJK + EPA (templated on the polytope store: LDS slot or full-capacity global record)
@@ -1566,6 +1593,7 @@ DEV void convex_convex_contact_staged(const Model& m, const E& e, int i_ga, int 
   float tolerance = compute_tolerance(m, i_ga, i_gb, m.mc_tolerance);
   V3 ga_pos_o = e.g_pos()[i_ga], gb_pos_o = e.g_pos()[i_gb]; Q4 ga_quat_o = e.g_quat()[i_ga], gb_quat_o = e.g_quat()[i_gb];
   Pair pr; pr.i_ga = i_ga; pr.i_gb = i_gb; pr.pos_a = ga_pos_o; pr.quat_a = ga_quat_o; pr.pos_b = gb_pos_o; pr.quat_b = gb_quat_o; pr.prism = nullptr; pr.ga = geom_lite(m, i_ga); pr.gb = geom_lite(m, i_gb);
+  pair_set_rots(pr);
   bool is_col_0 = false; V3 normal_0 = v3(0, 0, 0), contact_pos_0 = v3(0, 0, 0);
   bool is_col = false; float penetration = 0.0f; V3 normal = v3(0, 0, 0), contact_pos = v3(0, 0, 0);
   V3 axis_0 = v3(0, 0, 0), axis_1 = v3(0, 0, 0); Q4 qrot = q4(0, 0, 0, 0);
@@ -1578,6 +1606,7 @@ DEV void convex_convex_contact_staged(const Model& m, const E& e, int i_ga, int 
       qrot = rotvec_to_quat(m.mc_perturbation * axis, EPS);
       rotate_frame(ga_pos_o, ga_quat_o, contact_pos_0, qrot, pr.pos_a, pr.quat_a);
       rotate_frame(gb_pos_o, gb_quat_o, contact_pos_0, inv_quat(qrot), pr.pos_b, pr.quat_b);
+      pair_set_rots(pr);
     }
     if ((multi_contact && is_col_0) || (i_detection == 0)) {
       bool is_mpr_updated = false;
@@ -1602,7 +1631,7 @@ DEV void convex_convex_contact_staged(const Model& m, const E& e, int i_ga, int 
         atomicAdd(&e.gjk_fallback()[0], 1);
         DgPair dp;                                                 // the out-of-line callee takes a reference: this record only exists on the cold
         dp.m = &m; dp.i_ga = pr.i_ga; dp.i_gb = pr.i_gb; dp.pos_a = pr.pos_a; dp.quat_a = pr.quat_a; dp.pos_b = pr.pos_b; dp.quat_b = pr.quat_b;   // path, `pr` stays in registers
-        dp.ga = pr.ga; dp.gb = pr.gb;
+        dp.ga = pr.ga; dp.gb = pr.gb; dp.ra = pr.ra; dp.rb = pr.rb;
         dp.discrete = type_a == GEOM_BOX && type_b == GEOM_BOX;     // func_is_discrete_geoms, collider/utils.py:105-126
 #if defined(GO2SIM_REPEAT_PHASE) && GO2SIM_REPEAT_PHASE == 34
         { const DgResult g0 = gjk_query(dp, gjk_slots, gjk_slot_mask, gjk_full, m.eps); if (g0.penetration == 12345.0f) penetration = 0.0f; }
@@ -1657,6 +1686,7 @@ DEV bool terrain_pair_setup(const Model& m, const E& e, int i_ga, int i_gb, TP& 
   t.center_a = transform_by_trans_quat(m.geoms[i_ga].center, t.pos_a, t.quat_a);
   t.i_ga = i_ga;
   GeomLite gl = geom_lite(m, i_ga);
+  const Rot t_rot = make_rot(t.quat_a);
   float xyz_max_min[6];
 #pragma unroll
   for (int i_axis = 0; i_axis < 3; ++i_axis)
@@ -1664,7 +1694,7 @@ DEV bool terrain_pair_setup(const Model& m, const E& e, int i_ga, int i_gb, TP& 
     for (int i_m = 0; i_m < 2; ++i_m) {
       V3 direction = v3(0, 0, 0);
       vset(direction, i_axis, (i_m == 0) ? 1.0f : -1.0f);
-      V3 v1 = support_driver(m, direction, i_ga, gl, t.pos_a, t.quat_a);
+      V3 v1 = support_driver(m, direction, i_ga, gl, t.pos_a, t_rot);
       xyz_max_min[3 * i_m + i_axis] = vget(v1, i_axis);
     }
   const float* tmm = m.terrain_xyz_maxmin;
@@ -1705,6 +1735,7 @@ DEV bool terrain_prism_contact(const Model& m, const E& e, const TP& t, int i_gb
   }
   Pair pr; pr.i_ga = t.i_ga; pr.i_gb = i_gb; pr.prism = prism; pr.pos_a = t.pos_a; pr.quat_a = t.quat_a; pr.pos_b = v3(0, 0, 0); pr.quat_b = qident();
   pr.ga = geom_lite(m, t.i_ga); pr.gb = geom_lite(m, i_gb);
+  pair_set_rots(pr);
   V3 center_b = v3(0, 0, 0);
   for (int i_p = 0; i_p < 6; ++i_p) center_b = center_b + prism[i_p];
   center_b = center_b / 6.0f;
@@ -2095,14 +2126,17 @@ DEV void team_serial_sum(const float (&x)[NQ], const float (&base)[NQ], int tl, 
 template <int T, class S, class MT>
 DEV void ts_update_constraint(const MT& m, S* s, int tl, int n_con, float& cost, float& prev_cost, float& gauss) {
   prev_cost = cost;
+  float row_cost = 0.0f;                                               // 0.5 * Jaref^2 * D * active of the lane's row (rows one per lane)
   for (int c = tl; c < n_con; c += T) {
     s->prev_active[c] = s->active[c];
     float Ja = s->Jaref[c];
     int act = Ja < 0.0f;
     s->active[c] = act;
     float D = s->efc_D[c];
-    s->DA[c] = D * (float)act;
+    const float DA = D * (float)act;
+    s->DA[c] = DA;
     s->efc_force[c] = 0.0f + (-Ja * D * (float)act);
+    row_cost = 0.5f * (Ja * Ja * DA);
   }
   team_sync();
   for (int d = tl; d < ND; d += T) {
@@ -2111,16 +2145,33 @@ DEV void ts_update_constraint(const MT& m, S* s, int tl, int n_con, float& cost,
     for (int c = 0; c < n_con; ++c) q = q + s->J[c * DS + d] * s->efc_force[c];
     s->qfrc[d] = q;
   }
-  float cost_i = 0.0f, gauss_i = 0.0f;
-#pragma unroll
-  for (int d = 0; d < ND; ++d) {
-    float v = 0.5f * (s->Ma[d] - s->force[d]) * (s->qacc[d] - s->acc_smooth[d]);
-    gauss_i = gauss_i + v;
-    cost_i = cost_i + v;
+  bool done = false;
+  if constexpr (T >= 32) {
+    const int n_wave = __builtin_amdgcn_readfirstlane(imx(__shfl(n_con, 0), __shfl(n_con, T == 64 ? 0 : 32)));
+    if (n_wave <= T) {                                                 // serial-order lane scans: the 18 dof terms, then the rows on top of them
+      const int d = tl < ND ? tl : ND - 1;
+      const float v = 0.5f * (s->Ma[d] - s->force[d]) * (s->qacc[d] - s->acc_smooth[d]);
+      const float xd[1] = {tl < ND ? v : 0.0f}, zero[1] = {0.0f};
+      float g[1], ct[1];
+      team_serial_sum<T, 1>(xd, zero, tl, 2, g);
+      const float xr[1] = {tl < n_con ? row_cost : 0.0f};
+      team_serial_sum<T, 1>(xr, g, tl, (n_wave + 15) / 16, ct);
+      gauss = g[0]; cost = (n_wave > 0) ? ct[0] : g[0];
+      done = true;
+    }
   }
+  if (!done) {
+    float cost_i = 0.0f, gauss_i = 0.0f;
+#pragma unroll
+    for (int d = 0; d < ND; ++d) {
+      float v = 0.5f * (s->Ma[d] - s->force[d]) * (s->qacc[d] - s->acc_smooth[d]);
+      gauss_i = gauss_i + v;
+      cost_i = cost_i + v;
+    }
 #pragma unroll 16
-  for (int c = 0; c < n_con; ++c) { float Ja = s->Jaref[c]; cost_i = cost_i + 0.5f * (Ja * Ja * s->DA[c]); }
-  gauss = gauss_i; cost = cost_i;
+    for (int c = 0; c < n_con; ++c) { float Ja = s->Jaref[c]; cost_i = cost_i + 0.5f * (Ja * Ja * s->DA[c]); }
+    gauss = gauss_i; cost = cost_i;
+  }
   team_sync();
 }
 
@@ -2469,8 +2520,16 @@ DEV float ts_linesearch(const MT& m, S* s, int tl, int n_con, float gauss) {
 #pragma unroll
   for (int d = 0; d < ND; ++d) sr[d] = s->search[d];
   float snorm = 0.0f;
+  if constexpr (T >= 32) {
+    const float my = s->search[tl < ND ? tl : ND - 1];
+    const float xq[1] = {tl < ND ? my * my : 0.0f}, zero[1] = {0.0f};
+    float tot[1];
+    team_serial_sum<T, 1>(xq, zero, tl, 2, tot);
+    snorm = tot[0];
+  } else {
 #pragma unroll
-  for (int jd = 0; jd < ND; ++jd) snorm = snorm + sr[jd] * sr[jd];
+    for (int jd = 0; jd < ND; ++jd) snorm = snorm + sr[jd] * sr[jd];
+  }
   snorm = dm_sqrt(snorm);
   float scale = m.meaninertia * (float)imx(1, ND);
   float gtol = m.tolerance * m.ls_tolerance * snorm * scale;
@@ -2502,11 +2561,20 @@ DEV float ts_linesearch(const MT& m, S* s, int tl, int n_con, float gauss) {
   }
   team_sync();
   float qg1 = 0.0f, qg2 = 0.0f;
+  if constexpr (T >= 32) {
+    const int d = tl < ND ? tl : ND - 1;
+    const float sd = s->search[d];
+    const float xq[2] = {tl < ND ? (sd * s->Ma[d] - sd * s->force[d]) : 0.0f, tl < ND ? 0.5f * sd * s->mv[d] : 0.0f}, zero[2] = {0.0f, 0.0f};
+    float tot[2];
+    team_serial_sum<T, 2>(xq, zero, tl, 2, tot);
+    qg1 = tot[0]; qg2 = tot[1];
+  } else {
 #pragma unroll
-  for (int d = 0; d < ND; ++d) {
-    float sd = sr[d];
-    qg1 = qg1 + (sd * s->Ma[d] - sd * s->force[d]);
-    qg2 = qg2 + 0.5f * sd * s->mv[d];
+    for (int d = 0; d < ND; ++d) {
+      float sd = sr[d];
+      qg1 = qg1 + (sd * s->Ma[d] - sd * s->force[d]);
+      qg2 = qg2 + 0.5f * sd * s->mv[d];
+    }
   }
   const float qg0 = gauss;
   LsPoint p0;
@@ -2728,8 +2796,16 @@ DEV int ts_solve(const MT& m, const E& e, S* s, int tl, int nc, int n_con, unsig
       if (it > 0) {
         float improvement = prev_cost - cost;
         float grad_norm = 0.0f;
+        if constexpr (T >= 32) {
+          const float g = s->grad[tl < ND ? tl : ND - 1];
+          const float xq[1] = {tl < ND ? g * g : 0.0f}, zero[1] = {0.0f};
+          float tot[1];
+          team_serial_sum<T, 1>(xq, zero, tl, 2, tot);
+          grad_norm = tot[0];
+        } else {
 #pragma unroll
-        for (int d = 0; d < ND; ++d) { float g = s->grad[d]; grad_norm = grad_norm + g * g; }
+          for (int d = 0; d < ND; ++d) { float g = s->grad[d]; grad_norm = grad_norm + g * g; }
+        }
         grad_norm = dm_sqrt(grad_norm);
         bool improved = (grad_norm > tol_scaled) && (improvement > tol_scaled);
         if (!improved) break;
@@ -2884,10 +2960,11 @@ __global__ __launch_bounds__(64) void k_debug_narrowphase(const Model* __restric
   bool is_col = false; V3 normal = v3(0, 0, 0), pos = v3(0, 0, 0); float pen = 0.0f;
   if (which == 0) {
     Pair pr; pr.i_ga = i_ga; pr.i_gb = i_gb; pr.pos_a = pa; pr.quat_a = qa; pr.pos_b = pb; pr.quat_b = qb; pr.prism = nullptr; pr.ga = geom_lite(m, i_ga); pr.gb = geom_lite(m, i_gb);
+    pair_set_rots(pr);
     mpr_contact(m, pr, v3(0, 0, 0), is_col, normal, pen, pos);
   } else {
     DgPair dp; dp.m = mp; dp.i_ga = i_ga; dp.i_gb = i_gb; dp.pos_a = pa; dp.quat_a = qa; dp.pos_b = pb; dp.quat_b = qb;
-    dp.ga = geom_lite(m, i_ga); dp.gb = geom_lite(m, i_gb);
+    dp.ga = geom_lite(m, i_ga); dp.gb = geom_lite(m, i_gb); dp.ra = make_rot(qa); dp.rb = make_rot(qb);
     dp.discrete = m.geoms[i_ga].type == GEOM_BOX && m.geoms[i_gb].type == GEOM_BOX;
     const DgResult r = (which == 1) ? gjk_query(dp, slots, &mask, full, m.eps) : gjk_query(dp, nullptr, &mask, full, m.eps);
     is_col = r.is_col; pen = r.penetration; normal = r.normal; pos = r.pos;

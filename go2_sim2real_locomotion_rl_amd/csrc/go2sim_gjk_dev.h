@@ -56,31 +56,31 @@ struct DgResult { bool is_col, overflow; float penetration; V3 normal, pos; };
 
 // ---- geometry of the pair: world-frame support points with vertex ids (gjk_support.py:62-186, support_field.py:183-306) ----
 struct DgPair {
-  const Model* m; int i_ga, i_gb; V3 pos_a; Q4 quat_a; V3 pos_b; Q4 quat_b; bool discrete; GeomLite ga, gb;   // type / size of the two geoms, read once
-  DEV V3 support_one(V3 d, int i_g, const GeomLite& gl, V3 pos, Q4 quat, int& vid) const { return gjk_support_driver(*m, d, i_g, gl, pos, quat, vid); }
+  const Model* m; int i_ga, i_gb; V3 pos_a; Q4 quat_a; V3 pos_b; Q4 quat_b; bool discrete; GeomLite ga, gb; Rot ra, rb;   // type / size of the two geoms and the rotation coefficients of their poses, set up once
+  DEV V3 support_one(V3 d, int i_g, const GeomLite& gl, V3 pos, const Rot& rot, int& vid) const { return gjk_support_driver(*m, d, i_g, gl, pos, rot, vid); }
   DG_OUTLINE void support_into(V3 d, DgVert* out) const {                   // the one copy of the support code of a query
     PHD_BEGIN
     DgVert r;
-    r.o1 = support_one(d, i_ga, ga, pos_a, quat_a, r.id1);
-    r.o2 = support_one(-d, i_gb, gb, pos_b, quat_b, r.id2);
+    r.o1 = support_one(d, i_ga, ga, pos_a, ra, r.id1);
+    r.o2 = support_one(-d, i_gb, gb, pos_b, rb, r.id2);
     r.mk = r.o1 - r.o2;
     *out = r;
     PHD(48)
   }
   DEV DgVert support(V3 d) const { DgVert r; support_into(d, &r); return r; }
   // count_support_driver, gjk.py:1854-1877: only a box can have several support points (a face / edge exactly normal to the direction)
-  DEV int count_one(V3 d, const GeomLite& gl, Q4 quat) const {
+  DEV int count_one(V3 d, const GeomLite& gl, const Rot& rot) const {
     if (gl.type != GEOM_BOX) return 1;
-    V3 db = inv_transform_by_quat(d, quat);
+    V3 db = rot_apply_inv(rot, d);
     return 1 << ((db.x == 0.0f) + (db.y == 0.0f) + (db.z == 0.0f));
   }
-  DG_OUTLINE int count(V3 d) const { return count_one(d, ga, quat_a) * count_one(-d, gb, quat_b); }
+  DG_OUTLINE int count(V3 d) const { return count_one(d, ga, ra) * count_one(-d, gb, rb); }
   // func_get_discrete_geom_vertex (BOX), gjk.py:1666-1700
   DEV void box_vertex(bool second, int i_v, V3& obj, int& id) const {
     const int i_g = second ? i_gb : i_ga;
     const GeomLite& G = second ? gb : ga;
     V3 loc = v3(((i_v & 1) ? 1.0f : -1.0f) * G.d0 * 0.5f, ((i_v & 2) ? 1.0f : -1.0f) * G.d1 * 0.5f, ((i_v & 4) ? 1.0f : -1.0f) * G.d2 * 0.5f);
-    obj = transform_by_trans_quat(loc, second ? pos_b : pos_a, second ? quat_b : quat_a);
+    obj = rot_apply(second ? rb : ra, loc) + (second ? pos_b : pos_a);
     id = 64 * i_g + i_v;
   }
 };
