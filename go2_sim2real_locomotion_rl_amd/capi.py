@@ -228,6 +228,11 @@ class Go2Sim:
         self._call("errno_poll_result", ctypes.byref(v), ctypes.byref(ready))
         return (v.value if ready.value else None)
 
+    def errno_poll_wait(self):
+        v = ctypes.c_int()
+        self._call("errno_poll_wait", ctypes.byref(v))
+        return v.value
+
     def graph_status(self):
         using, nfb = ctypes.c_int(), ctypes.c_int()
         self._call("graph_status", ctypes.byref(using), ctypes.byref(nfb))

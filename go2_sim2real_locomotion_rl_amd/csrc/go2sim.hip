@@ -685,11 +685,13 @@ __device__ unsigned long long g_phase_cycles[PH_MAX_WG * 64];
 // the same inside lane-divergent code: the first active lane of the wavefront accounts the section (all active lanes run it together)
 #define PHD_BEGIN unsigned long long phd_t = __builtin_readcyclecounter();
 #define PHD(i) { unsigned long long phd_n = __builtin_readcyclecounter(); const unsigned long long phd_a = __ballot(1); if ((int)threadIdx.x == __ffsll((long long)phd_a) - 1 && blockIdx.x < PH_MAX_WG) { atomicAdd(&g_phase_cycles[blockIdx.x * 64 + (i)], phd_n - phd_t); atomicAdd(&g_phase_cycles[blockIdx.x * 64 + (i) + 1], 1ull); } phd_t = __builtin_readcyclecounter(); }
+#define PHC(i, n) { if (threadIdx.x == 0 && blockIdx.x < PH_MAX_WG) g_phase_cycles[blockIdx.x * 64 + (i)] += (unsigned long long)(n); }   // event counter
 #else
 #define PH_BEGIN
 #define PH(i)
 #define PHD_BEGIN
 #define PHD(i)
+#define PHC(i, n)
 #endif
 
 // -DGO2SIM_REPEAT_PHASE=k (profiling builds, tools/repeat_probe.py): phase k runs twice; every such phase is idempotent, so the results
@@ -727,6 +729,17 @@ struct KinData {
   int valid;
 };
 
+struct DynData {
+  float cinr_I[NL * 9], cinr_pos[NL * 3], cinr_mass[NL];
+  float crb_I[NL * 9], crb_pos[NL * 3], crb_mass[NL];
+  float cdof_ang[ND * 3], cdof_vel[ND * 3], cdofd_ang[ND * 3], cdofd_vel[ND * 3];
+  float cd_vel[NL * 3], cd_ang[NL * 3], cdd_vel[NL * 3], cdd_ang[NL * 3], cfrc_vel[NL * 3], cfrc_ang[NL * 3];
+  float f_ang[ND * 3], f_vel[ND * 3];
+  float vel[ND], qf_applied[ND], qf_passive[ND], force[ND], out[ND], Dinv[ND];
+  float M[ND * ND], L[ND * ND];
+  int ctrl_mode[ND];
+};
+
 template <int T>
 DEV void tk_stage_links(const E& e, KinData* s, int tl) {
   team_for<NL, T>(tl, [&](int i_l) { st3(s->l_pos, i_l, e.l_pos()[i_l]); st4(s->l_quat, i_l, e.l_quat()[i_l]); });
@@ -734,8 +747,10 @@ DEV void tk_stage_links(const E& e, KinData* s, int tl) {
 // update_cartesian_space + forward_velocity of the state held in s->qpos / s->vel
 // (func_forward_kinematics_entity :463-618, func_COM_links_entity :224-459, func_update_geoms_entity :709-744,
 //  func_forward_velocity_entity :871-994 of forward_kinematics.py)
+// `dk` (optional): the working set of the forward dynamics that follow in the same kernel (k_integrate_fk_dynamics_team): everything the dynamics would
+// otherwise read back from HBM is also left there
 template <int T, class MT>
-DEV void tk_kinematics(const MT& m, const E& e, KinData* s, int tl, bool force_update_fixed) {
+DEV void tk_kinematics(const MT& m, const E& e, KinData* s, int tl, bool force_update_fixed, DynData* dk = nullptr) {
   // s->l_pos / s->l_quat hold the current link poses (tk_stage_links, issued with the kernel's other staging loads)
   for (int lev = 0; lev < m.n_levels; ++lev) {
     for (int k = m.level_start[lev] + tl; k < m.level_start[lev + 1]; k += T) {
@@ -759,6 +774,7 @@ DEV void tk_kinematics(const MT& m, const E& e, KinData* s, int tl, bool force_u
           quat_ = q4(quat_.w / n, quat_.x / n, quat_.y / n, quat_.z / n);
           pos = pos_; quat = quat_;
           gstore(e, FO(dof_pos), dof_start + 0, pos.x); gstore(e, FO(dof_pos), dof_start + 1, pos.y); gstore(e, FO(dof_pos), dof_start + 2, pos.z);
+          if (dk) { dk->out[dof_start] = pos.x; dk->out[dof_start + 1] = pos.y; dk->out[dof_start + 2] = pos.z; }
         } else if (J.type == JOINT_REVOLUTE) {
           V3 axis = m.dofs[dof_start].motion_ang;
           V3 anchor = transform_by_quat(J.pos, quat) + pos;
@@ -766,6 +782,7 @@ DEV void tk_kinematics(const MT& m, const E& e, KinData* s, int tl, bool force_u
           st3(s->xaxis, i_j, transform_by_quat(axis, quat));
           float dp = s->qpos[q_start] - m.qpos0[q_start];
           gstore(e, FO(dof_pos), dof_start, dp);
+          if (dk) dk->out[dof_start] = dp;
           Q4 qloc = rotvec_to_quat(axis * dp, m.eps);
           quat = transform_quat_by_quat(qloc, quat);
           pos = anchor - transform_by_quat(J.pos, quat);
@@ -808,6 +825,7 @@ DEV void tk_kinematics(const MT& m, const E& e, KinData* s, int tl, bool force_u
     M3 oI; V3 op;
     transform_inertia_by_trans_quat(L.inertial_i, i_mass, ip, iq, m.eps, oI, op);
     e.cinr_inertial()[i_l] = oI; e.cinr_pos()[i_l] = op; e.cinr_mass()[i_l] = i_mass;
+    if (dk) { st9(dk->cinr_I, i_l, oI); st9(dk->crb_I, i_l, oI); st3(dk->cinr_pos, i_l, op); st3(dk->crb_pos, i_l, op); dk->cinr_mass[i_l] = i_mass; dk->crb_mass[i_l] = i_mass; }
   }
   for (int i_j = tl; i_j < NJ; i_j += T) {
     const Joint& J = m.joints[i_j];
@@ -821,12 +839,14 @@ DEV void tk_kinematics(const MT& m, const E& e, KinData* s, int tl, bool force_u
       V3 cv = cross(ax, offset_pos);
       st3(s->cdof_ang, ds, ax); st3(s->cdof_vel, ds, cv);
       e.cdof_ang()[ds] = ax; e.cdof_vel()[ds] = cv;
+      if (dk) { st3(dk->cdof_ang, ds, ax); st3(dk->cdof_vel, ds, cv); }
     } else if (J.type == JOINT_FREE) {
       for (int i = 0; i < 3; ++i) {
         V3 cv = v3(0, 0, 0);
         vset(cv, i, 1.0f);
         st3(s->cdof_ang, i + ds, v3(0, 0, 0)); st3(s->cdof_vel, i + ds, cv);
         e.cdof_ang()[i + ds] = v3(0, 0, 0); e.cdof_vel()[i + ds] = cv;
+        if (dk) { st3(dk->cdof_ang, i + ds, v3(0, 0, 0)); st3(dk->cdof_vel, i + ds, cv); }
       }
       M3 xmat_T = transpose(quat_to_R(ld4(s->l_quat, J.link), m.eps));
 #pragma unroll
@@ -835,6 +855,7 @@ DEV void tk_kinematics(const MT& m, const E& e, KinData* s, int tl, bool force_u
         V3 cv = cross(row, offset_pos);
         st3(s->cdof_ang, i + ds + 3, row); st3(s->cdof_vel, i + ds + 3, cv);
         e.cdof_ang()[i + ds + 3] = row; e.cdof_vel()[i + ds + 3] = cv;
+        if (dk) { st3(dk->cdof_ang, i + ds + 3, row); st3(dk->cdof_vel, i + ds + 3, cv); }
       }
     }
   }
@@ -866,9 +887,11 @@ DEV void tk_kinematics(const MT& m, const E& e, KinData* s, int tl, bool force_u
           }
           for (int i = 0; i < 3; ++i) {
             e.cdofd_ang()[ds + i] = v3(0, 0, 0); e.cdofd_vel()[ds + i] = v3(0, 0, 0);
+            if (dk) { st3(dk->cdofd_ang, ds + i, v3(0, 0, 0)); st3(dk->cdofd_vel, ds + i, v3(0, 0, 0)); }
             V3 oa, ov;
             motion_cross_motion(cvel_ang, cvel_vel, ld3(s->cdof_ang, ds + i + 3), ld3(s->cdof_vel, ds + i + 3), oa, ov);
             e.cdofd_ang()[ds + i + 3] = oa; e.cdofd_vel()[ds + i + 3] = ov;
+            if (dk) { st3(dk->cdofd_ang, ds + i + 3, oa); st3(dk->cdofd_vel, ds + i + 3, ov); }
           }
           for (int i = 0; i < 3; ++i) {
             float v = s->vel[ds + i + 3];
@@ -880,6 +903,7 @@ DEV void tk_kinematics(const MT& m, const E& e, KinData* s, int tl, bool force_u
             V3 oa, ov;
             motion_cross_motion(cvel_ang, cvel_vel, ld3(s->cdof_ang, i_d), ld3(s->cdof_vel, i_d), oa, ov);
             e.cdofd_ang()[i_d] = oa; e.cdofd_vel()[i_d] = ov;
+            if (dk) { st3(dk->cdofd_ang, i_d, oa); st3(dk->cdofd_vel, i_d, ov); }
           }
           for (int i_d = ds; i_d < J.dof_end; ++i_d) {
             float v = s->vel[i_d];
@@ -890,34 +914,15 @@ DEV void tk_kinematics(const MT& m, const E& e, KinData* s, int tl, bool force_u
       }
       st3(s->cd_vel, i_l, cvel_vel); st3(s->cd_ang, i_l, cvel_ang);
       e.cd_vel()[i_l] = cvel_vel; e.cd_ang()[i_l] = cvel_ang;
+      if (dk) { st3(dk->cd_vel, i_l, cvel_vel); st3(dk->cd_ang, i_l, cvel_ang); }
     }
     team_sync();
   }
 }
 
-// kernel_step_2 (rigid_solver.py:3072-3180): func_integrate (forward_dynamics.py:1558-1699) + func_copy_next_to_curr
-// (abd/diff.py:25-54) + FK / forward velocity of the new state
-template <int T>
-__global__ __launch_bounds__(64) void k_integrate_fk_team(Pool P, const ModelS* __restrict__ mp) {
-  constexpr int EPW = 64 / T;
-  __shared__ KinData lds[EPW];
-  __shared__ alignas(16) char ms_raw[MODELS_LDS_BYTES];
-  const ModelS& ms = *(const ModelS*)ms_raw;
-  wg_dma_to_lds<(int)sizeof(ModelS)>(ms_raw, mp);
-  const int tl = threadIdx.x % T, slot = threadIdx.x / T;
-  const int b = blockIdx.x * EPW + slot;
-  const ModelView m(&ms, mp);
-  E e(P, b < P.B ? b : P.B - 1);
-  KinData* s = &lds[slot];
-  PH_BEGIN
-  team_stage<ND, T>(tl, [&](int d) { return gload(e, FO(vel), d); }, [&](int d, float v) { s->vel[d] = v; });
-  team_stage<ND, T>(tl, [&](int d) { return aload(e, AO(acc), d); }, [&](int d, float a) { s->vel_next[d] = a; });
-  team_stage<NQ, T>(tl, [&](int q) { return gload(e, FO(qpos), q); }, [&](int q, float v) { s->qpos[q] = v; });
-  team_for<ND, T>(tl, [&](int d) { s->vel_next[d] = s->vel[d] + s->vel_next[d] * m.substep_dt; });
-  if (tl == 0) s->valid = 1;
-  tk_stage_links<T>(e, s, tl);
-  team_sync();
-  if (b >= P.B) return;
+// func_integrate (forward_dynamics.py:1558-1699) + func_copy_next_to_curr (abd/diff.py:25-54) on the staged state: s->vel_next holds v + a dt
+template <int T, class MT>
+DEV void tk_integrate(const MT& m, const E& e, KinData* s, int tl) {
   for (int i_l = tl; i_l < NL; i_l += T) {
     const auto& L = m.links[i_l];
     if (L.n_dofs == 0) continue;
@@ -950,6 +955,32 @@ __global__ __launch_bounds__(64) void k_integrate_fk_team(Pool P, const ModelS* 
     atomicOr(&e.err()[0], GO2SIM_ERR_INVALID_ACC_NAN);
   }
   team_sync();
+}
+
+// kernel_step_2 (rigid_solver.py:3072-3180): func_integrate (forward_dynamics.py:1558-1699) + func_copy_next_to_curr
+// (abd/diff.py:25-54) + FK / forward velocity of the new state
+template <int T>
+__global__ __launch_bounds__(64) void k_integrate_fk_team(Pool P, const ModelS* __restrict__ mp) {
+  constexpr int EPW = 64 / T;
+  __shared__ KinData lds[EPW];
+  __shared__ alignas(16) char ms_raw[MODELS_LDS_BYTES];
+  const ModelS& ms = *(const ModelS*)ms_raw;
+  wg_dma_to_lds<(int)sizeof(ModelS)>(ms_raw, mp);
+  const int tl = threadIdx.x % T, slot = threadIdx.x / T;
+  const int b = blockIdx.x * EPW + slot;
+  const ModelView m(&ms, mp);
+  E e(P, b < P.B ? b : P.B - 1);
+  KinData* s = &lds[slot];
+  PH_BEGIN
+  team_stage<ND, T>(tl, [&](int d) { return gload(e, FO(vel), d); }, [&](int d, float v) { s->vel[d] = v; });
+  team_stage<ND, T>(tl, [&](int d) { return aload(e, AO(acc), d); }, [&](int d, float a) { s->vel_next[d] = a; });
+  team_stage<NQ, T>(tl, [&](int q) { return gload(e, FO(qpos), q); }, [&](int q, float v) { s->qpos[q] = v; });
+  team_for<ND, T>(tl, [&](int d) { s->vel_next[d] = s->vel[d] + s->vel_next[d] * m.substep_dt; });
+  if (tl == 0) s->valid = 1;
+  tk_stage_links<T>(e, s, tl);
+  team_sync();
+  if (b >= P.B) return;
+  tk_integrate<T>(m, e, s, tl);
   PH(40)
   tk_kinematics<T>(m, e, s, tl, false);
   PH(41)
@@ -977,59 +1008,14 @@ __global__ __launch_bounds__(64) void k_fk_team(Pool P, const ModelS* __restrict
   tk_kinematics<T>(m, e, s, tl, force_update_fixed != 0);
 }
 
-struct DynData {
-  float cinr_I[NL * 9], cinr_pos[NL * 3], cinr_mass[NL];
-  float crb_I[NL * 9], crb_pos[NL * 3], crb_mass[NL];
-  float cdof_ang[ND * 3], cdof_vel[ND * 3], cdofd_ang[ND * 3], cdofd_vel[ND * 3];
-  float cd_vel[NL * 3], cd_ang[NL * 3], cdd_vel[NL * 3], cdd_ang[NL * 3], cfrc_vel[NL * 3], cfrc_ang[NL * 3];
-  float f_ang[ND * 3], f_vel[ND * 3];
-  float vel[ND], qf_applied[ND], qf_passive[ND], force[ND], out[ND], Dinv[ND];
-  float M[ND * ND], L[ND * ND];
-  int ctrl_mode[ND];
-};
-
 // kernel_step_1 without the (already fresh) FK, rigid_solver.py:3008-3069: func_compute_mass_matrix (forward_dynamics.py:291-541),
 // func_factor_mass :560-604, func_torque_and_passive_force :961-1174, func_update_acc/force/bias_force :1177-1478,
 // func_solve_mass_entity :818-900
-template <int T>
-__global__ __launch_bounds__(64) void k_dynamics_team(Pool P, const ModelS* __restrict__ mp) {
-  constexpr int EPW = 64 / T;
-  __shared__ DynData lds[EPW];
-  __shared__ alignas(16) char ms_raw[MODELS_LDS_BYTES];
-  const ModelS& ms = *(const ModelS*)ms_raw;
-  wg_dma_to_lds<(int)sizeof(ModelS)>(ms_raw, mp);
-  {  // ---- stage the SoA inputs cooperatively (adjacent lanes = adjacent envs), before any lane retires ----
-    const int b0 = blockIdx.x * EPW;
-    wg_load<EPW, NL * 3>(P, b0, FO(cd_vel), [&](int ev, int k, float v) { lds[ev].cd_vel[k] = v; });
-    wg_load<EPW, NL * 3>(P, b0, FO(cd_ang), [&](int ev, int k, float v) { lds[ev].cd_ang[k] = v; });
-    wg_load<EPW, ND>(P, b0, FO(vel), [&](int ev, int k, float v) { lds[ev].vel[k] = v; });
-  }
-  const int tl = threadIdx.x % T, slot = threadIdx.x / T;
-  const int b = blockIdx.x * EPW + slot;
-  const bool env_valid = b < P.B;
-  const ModelView m(&ms, mp);
-  E e(P, env_valid ? b : P.B - 1);
-  DynData* s = &lds[slot];
+// (the computation proper; the inputs are in the LDS working set `s`: staged from HBM by k_dynamics_team, or left there by the kinematics of
+//  the same kernel in k_integrate_fk_dynamics_team)
+template <int T, class MT>
+DEV void tk_dynamics(const MT& m, const E& e, DynData* s, int tl, bool env_valid) {
   PH_BEGIN
-  // AoS record: the team reads consecutive words
-  team_stage<NL * 9, T>(tl, [&](int k) { return aload(e, AO(cinr_inertial), k); }, [&](int k, float v) { s->cinr_I[k] = v; s->crb_I[k] = v; });
-  team_stage<NL * 3, T>(tl, [&](int k) { return aload(e, AO(cinr_pos), k); }, [&](int k, float v) { s->cinr_pos[k] = v; s->crb_pos[k] = v; });
-  team_stage<NL, T>(tl, [&](int k) { return aload(e, AO(cinr_mass), k); }, [&](int k, float v) { s->cinr_mass[k] = v; s->crb_mass[k] = v; });
-  team_stage<ND, T>(tl, [&](int d) { return __int_as_float((int)e.ctrl_mode()[d]); }, [&](int d, float v) { s->ctrl_mode[d] = __float_as_int(v); });
-  team_stage<ND * 3, T>(tl, [&](int k) { return aload(e, AO(cdof_ang), k); }, [&](int k, float v) { s->cdof_ang[k] = v; });
-  team_stage<ND * 3, T>(tl, [&](int k) { return aload(e, AO(cdof_vel), k); }, [&](int k, float v) { s->cdof_vel[k] = v; });
-  team_stage<ND * 3, T>(tl, [&](int k) { return aload(e, AO(cdofd_ang), k); }, [&](int k, float v) { s->cdofd_ang[k] = v; });
-  team_stage<ND * 3, T>(tl, [&](int k) { return aload(e, AO(cdofd_vel), k); }, [&](int k, float v) { s->cdofd_vel[k] = v; });
-  // inputs of the later phases, parked in LDS slots that are only written afterwards (by the same lane that reads the parked value):
-  // control targets -> qf_applied / qf_passive / force / out, external link forces -> cfrc_ang / cfrc_vel
-  team_stage<ND, T>(tl, [&](int d) { return gload(e, FO(ctrl_force), d); }, [&](int d, float v) { s->qf_applied[d] = v; });
-  team_stage<ND, T>(tl, [&](int d) { return gload(e, FO(ctrl_pos), d); }, [&](int d, float v) { s->qf_passive[d] = v; });
-  team_stage<ND, T>(tl, [&](int d) { return gload(e, FO(ctrl_vel), d); }, [&](int d, float v) { s->force[d] = v; });
-  team_stage<ND, T>(tl, [&](int d) { return gload(e, FO(dof_pos), d); }, [&](int d, float v) { s->out[d] = v; });
-  team_stage<NL * 6, T>(tl, [&](int k) { return gload(e, FO(ext), k); },
-                        [&](int k, float v) { int i_l = k / 6, c = k % 6; if (c < 3) s->cfrc_ang[3 * i_l + c] = v; else s->cfrc_vel[3 * i_l + c - 3] = v; });
-  team_sync();
-  PH(20)
   // ---- composite rigid bodies, leaf -> root ----
   for (int lev = m.n_levels - 2; lev >= 0; --lev) {
     int n_par = m.level_start[lev + 1] - m.level_start[lev];
@@ -1186,6 +1172,95 @@ __global__ __launch_bounds__(64) void k_dynamics_team(Pool P, const ModelS* __re
   if (env_valid) for (int i_d = tl; i_d < ND; i_d += T) { float a = s->out[i_d]; astore(e, AO(acc_smooth), i_d, a); astore(e, AO(acc), i_d, a); }
   if (env_valid) for (int k = tl; k < ND * ND; k += T) astore(e, AO(mass_mat), k, s->M[k]);
   PH(25)
+}
+
+template <int T>
+__global__ __launch_bounds__(64) void k_dynamics_team(Pool P, const ModelS* __restrict__ mp) {
+  constexpr int EPW = 64 / T;
+  __shared__ DynData lds[EPW];
+  __shared__ alignas(16) char ms_raw[MODELS_LDS_BYTES];
+  const ModelS& ms = *(const ModelS*)ms_raw;
+  wg_dma_to_lds<(int)sizeof(ModelS)>(ms_raw, mp);
+  {  // ---- stage the SoA inputs cooperatively (adjacent lanes = adjacent envs), before any lane retires ----
+    const int b0 = blockIdx.x * EPW;
+    wg_load<EPW, NL * 3>(P, b0, FO(cd_vel), [&](int ev, int k, float v) { lds[ev].cd_vel[k] = v; });
+    wg_load<EPW, NL * 3>(P, b0, FO(cd_ang), [&](int ev, int k, float v) { lds[ev].cd_ang[k] = v; });
+    wg_load<EPW, ND>(P, b0, FO(vel), [&](int ev, int k, float v) { lds[ev].vel[k] = v; });
+  }
+  const int tl = threadIdx.x % T, slot = threadIdx.x / T;
+  const int b = blockIdx.x * EPW + slot;
+  const bool env_valid = b < P.B;
+  const ModelView m(&ms, mp);
+  E e(P, env_valid ? b : P.B - 1);
+  DynData* s = &lds[slot];
+  PH_BEGIN
+  // AoS record: the team reads consecutive words
+  team_stage<NL * 9, T>(tl, [&](int k) { return aload(e, AO(cinr_inertial), k); }, [&](int k, float v) { s->cinr_I[k] = v; s->crb_I[k] = v; });
+  team_stage<NL * 3, T>(tl, [&](int k) { return aload(e, AO(cinr_pos), k); }, [&](int k, float v) { s->cinr_pos[k] = v; s->crb_pos[k] = v; });
+  team_stage<NL, T>(tl, [&](int k) { return aload(e, AO(cinr_mass), k); }, [&](int k, float v) { s->cinr_mass[k] = v; s->crb_mass[k] = v; });
+  team_stage<ND, T>(tl, [&](int d) { return __int_as_float((int)e.ctrl_mode()[d]); }, [&](int d, float v) { s->ctrl_mode[d] = __float_as_int(v); });
+  team_stage<ND * 3, T>(tl, [&](int k) { return aload(e, AO(cdof_ang), k); }, [&](int k, float v) { s->cdof_ang[k] = v; });
+  team_stage<ND * 3, T>(tl, [&](int k) { return aload(e, AO(cdof_vel), k); }, [&](int k, float v) { s->cdof_vel[k] = v; });
+  team_stage<ND * 3, T>(tl, [&](int k) { return aload(e, AO(cdofd_ang), k); }, [&](int k, float v) { s->cdofd_ang[k] = v; });
+  team_stage<ND * 3, T>(tl, [&](int k) { return aload(e, AO(cdofd_vel), k); }, [&](int k, float v) { s->cdofd_vel[k] = v; });
+  // inputs of the later phases, parked in LDS slots that are only written afterwards (by the same lane that reads the parked value):
+  // control targets -> qf_applied / qf_passive / force / out, external link forces -> cfrc_ang / cfrc_vel
+  team_stage<ND, T>(tl, [&](int d) { return gload(e, FO(ctrl_force), d); }, [&](int d, float v) { s->qf_applied[d] = v; });
+  team_stage<ND, T>(tl, [&](int d) { return gload(e, FO(ctrl_pos), d); }, [&](int d, float v) { s->qf_passive[d] = v; });
+  team_stage<ND, T>(tl, [&](int d) { return gload(e, FO(ctrl_vel), d); }, [&](int d, float v) { s->force[d] = v; });
+  team_stage<ND, T>(tl, [&](int d) { return gload(e, FO(dof_pos), d); }, [&](int d, float v) { s->out[d] = v; });
+  team_stage<NL * 6, T>(tl, [&](int k) { return gload(e, FO(ext), k); },
+                        [&](int k, float v) { int i_l = k / 6, c = k % 6; if (c < 3) s->cfrc_ang[3 * i_l + c] = v; else s->cfrc_vel[3 * i_l + c - 3] = v; });
+  team_sync();
+  PH(20)
+  tk_dynamics<T>(m, e, s, tl, env_valid);
+}
+
+
+// kernel_step_2 of substep i followed by kernel_step_1 of substep i + 1 (rigid_solver.py:3072-3180, 3008-3069) in one launch: integrate, commit, FK,
+// COM / cinr / cdof, geoms, forward velocity -- and straight on to the forward dynamics of the new state, whose inputs stay in LDS instead of making
+// an HBM round trip between two kernels (the FK outputs are still written out: the collision kernel, the solver and the env kernels read them).
+// Between the two halves nothing else runs in a scene step; the control inputs of the dynamics do not depend on the kinematics and are requested at
+// the top of the kernel.
+template <int T>
+__global__ __launch_bounds__(64) void k_integrate_fk_dynamics_team(Pool P, const ModelS* __restrict__ mp) {
+  constexpr int EPW = 64 / T;
+  __shared__ DynData lds_d[EPW];
+  __shared__ alignas(16) char ms_raw[MODELS_LDS_BYTES];
+  const ModelS& ms = *(const ModelS*)ms_raw;
+  wg_dma_to_lds<(int)sizeof(ModelS)>(ms_raw, mp);
+  const int tl = threadIdx.x % T, slot = threadIdx.x / T;
+  const int b = blockIdx.x * EPW + slot;
+  const ModelView m(&ms, mp);
+  E e(P, b < P.B ? b : P.B - 1);
+  DynData* d = &lds_d[slot];
+  // the kinematics working set lives in the M | L words of the dynamics record, which the dynamics only start writing (mass matrix, then its factor)
+  // after the kinematics are done: same LDS footprint, hence the same 8 workgroups per CU, as k_dynamics_team alone
+  static_assert(offsetof(DynData, L) == offsetof(DynData, M) + sizeof(float) * ND * ND && sizeof(KinData) <= 2 * sizeof(float) * ND * ND, "KinData overlay");
+  KinData* s = (KinData*)d->M;
+  PH_BEGIN
+  team_stage<ND, T>(tl, [&](int i) { return gload(e, FO(vel), i); }, [&](int i, float v) { s->vel[i] = v; });
+  team_stage<ND, T>(tl, [&](int i) { return aload(e, AO(acc), i); }, [&](int i, float a) { s->vel_next[i] = a; });
+  team_stage<NQ, T>(tl, [&](int q) { return gload(e, FO(qpos), q); }, [&](int q, float v) { s->qpos[q] = v; });
+  // control inputs of the dynamics half (parked exactly as k_dynamics_team parks them)
+  team_stage<ND, T>(tl, [&](int i) { return __int_as_float((int)e.ctrl_mode()[i]); }, [&](int i, float v) { d->ctrl_mode[i] = __float_as_int(v); });
+  team_stage<ND, T>(tl, [&](int i) { return gload(e, FO(ctrl_force), i); }, [&](int i, float v) { d->qf_applied[i] = v; });
+  team_stage<ND, T>(tl, [&](int i) { return gload(e, FO(ctrl_pos), i); }, [&](int i, float v) { d->qf_passive[i] = v; });
+  team_stage<ND, T>(tl, [&](int i) { return gload(e, FO(ctrl_vel), i); }, [&](int i, float v) { d->force[i] = v; });
+  team_stage<NL * 6, T>(tl, [&](int k) { return gload(e, FO(ext), k); },
+                        [&](int k, float v) { int i_l = k / 6, c = k % 6; if (c < 3) d->cfrc_ang[3 * i_l + c] = v; else d->cfrc_vel[3 * i_l + c - 3] = v; });
+  team_for<ND, T>(tl, [&](int i) { s->vel_next[i] = s->vel[i] + s->vel_next[i] * m.substep_dt; });
+  if (tl == 0) s->valid = 1;
+  tk_stage_links<T>(e, s, tl);
+  team_sync();
+  if (b >= P.B) return;                                               // (team_sync is a fence, not a barrier: a team may leave early)
+  tk_integrate<T>(m, e, s, tl);
+  PH(40)
+  tk_kinematics<T>(m, e, s, tl, false, d);
+  team_for<ND, T>(tl, [&](int i) { d->vel[i] = s->vel[i]; });
+  team_sync();
+  PH(41)
+  tk_dynamics<T>(m, e, d, tl, true);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2065,6 +2140,7 @@ struct alignas(16) SolverData {
   alignas(16) float efc_D[R]; alignas(16) float Jaref[R]; alignas(16) float jv[R]; alignas(16) float efc_force[R];
   alignas(16) float qf0[R]; alignas(16) float qf1[R]; alignas(16) float qf2[R]; alignas(16) float DA[R];
   alignas(16) int active[R]; alignas(16) int prev_active[R];
+  alignas(16) float rot[ND][4];   // pipelined rank-1 updates: rotation (c, 1/c, s) computed by the lane that owns a column, read by the rows below it
 };
 
 // value of lane k of the caller's team (k is a compile-time constant after unrolling): v_readlane through an SGPR instead of a
@@ -2240,7 +2316,9 @@ DEV bool ts_cholesky_incremental_reg(const MT& m, S* s, int tl, int n_con) {
     const bool flip = c_me < n_con && ((s->active[c_me] != 0) != (s->prev_active[c_me] != 0));
     const unsigned long long bal = __ballot(flip);
     unsigned long long mask = (T == 64) ? bal : ((bal >> ((threadIdx.x / T) * T)) & ((1ull << (T & 63)) - 1ull));
+    PHC(50, 1)
     while (mask != 0ull && !degenerated) {
+      PHC(51, 1)
       const int c = base + __ffsll((long long)mask) - 1;
       mask &= mask - 1ull;
       touched = true;
@@ -2289,6 +2367,7 @@ DEV bool ts_cholesky_incremental_pipelined(const MT& m, S* s, int tl, int n_con)
   bool degenerated = false;
   const int row = tl < ND ? tl : ND - 1;
   const bool own = tl < ND;
+  const unsigned urow = own ? (unsigned)row : 0u;                       // "column k lies left of my row" is (unsigned)k < urow (never true for spare lanes)
   float Ld = s->H[row * DS + row];                                     // my diagonal element
   for (int base = 0; base < n_con && !degenerated; base += T) {
     const int c_me = base + tl;
@@ -2296,28 +2375,31 @@ DEV bool ts_cholesky_incremental_pipelined(const MT& m, S* s, int tl, int n_con)
     const unsigned long long bal = __ballot(flip);
     unsigned long long mask = (T == 64) ? bal : ((bal >> ((threadIdx.x / T) * T)) & ((1ull << (T & 63)) - 1ull));
     while (mask != 0ull && !degenerated) {                              // batches of up to FMAX flipped rows, in row order
-      float W[FMAX]; unsigned sgn = 0u; int nb = 0;
+      float W[FMAX], sg[FMAX]; int nb = 0;                              // update vectors (my element), sign of each update (0 = slot unused)
 #pragma unroll
       for (int f = 0; f < FMAX; ++f) {
-        W[f] = 0.0f;
+        W[f] = 0.0f; sg[f] = 0.0f;
         if (mask != 0ull) {
           const int c = base + __ffsll((long long)mask) - 1;
           mask &= mask - 1ull;
           W[f] = s->J[c * DS + row] * dm_sqrt(s->efc_D[c]);
-          if (s->active[c] != 0) sgn |= 1u << f;
+          sg[f] = (s->active[c] != 0) ? 1.0f : -1.0f;
           nb = f + 1;
         }
       }
       const int nb_wave = __builtin_amdgcn_readfirstlane(imx(__shfl(nb, 0), __shfl(nb, T == 64 ? 0 : 32)));   // both teams (nb is team-uniform)
+      PHC(52, 1) PHC(53, nb_wave) PHC(54, ND - 1 + nb_wave)
       for (int t = 0; t < ND - 1 + nb_wave && !degenerated; ++t) {
+        // ---- factor elements of my row at the columns of this step's pairs: requested first, they arrive while the rotations are computed ----
+        float hcur[FMAX];
+#pragma unroll
+        for (int f = 0; f < FMAX; ++f) hcur[f] = s->H[row * DS + imn(imx(t - f, 0), ND - 2)];
         // ---- my pair of this step: row f_me at my own column ----
         const int f_me = t - row;
-        const bool valid = own && f_me >= 0 && f_me < nb;
-        float dv = 0.0f;
+        float dv = 0.0f, sg_me = 0.0f;
 #pragma unroll
-        for (int f = 0; f < FMAX; ++f) dv = (f_me == f) ? W[f] : dv;
-        const float sg_me = ((sgn >> (f_me & 31)) & 1u) ? 1.0f : -1.0f;
-        const bool rot = valid && dm_abs(dv) > m.eps;
+        for (int f = 0; f < FMAX; ++f) { dv = (f_me == f) ? W[f] : dv; sg_me = (f_me == f) ? sg[f] : sg_me; }
+        const bool rot = own && sg_me != 0.0f && dm_abs(dv) > m.eps;     // (sg_me == 0: no pair at my column in this step)
         const float tmp = Ld * Ld + sg_me * (dv * dv);
         const bool deg = rot && tmp < m.eps;
         const float r = dm_sqrt(tmp);
@@ -2331,24 +2413,36 @@ DEV bool ts_cholesky_incremental_pipelined(const MT& m, S* s, int tl, int n_con)
           if (mine != 0ull) { degenerated = true; break; }
         }
         if (rot) { Ld = r; s->H[row * DS + row] = r; }
-        // ---- hand every pair's rotation to the rows below its column ----
+        // ---- hand every pair's rotation to the rows below its column: the owner publishes (c, 1/c, s) of its column in LDS, every row reads the
+        //      column of each slot (a broadcast read).  Branch-free over the slots of the batch: one LDS round trip per step, no EXEC juggling
+        //      (a pair that does not apply to a lane stores into a spare word instead of the factor). ----
+        if (own) *(float4*)&s->rot[row][0] = make_float4(cc, cinv, sk, 0.0f);
+        team_sync();
+        float4 rp[FMAX];
+#pragma unroll
+        for (int f = 0; f < FMAX; ++f) rp[f] = *(const float4*)&s->rot[imn(imx(t - f, 0), ND - 2)][0];
 #pragma unroll
         for (int f = 0; f < FMAX; ++f) {
-          const int k = t - f;                                           // wave-uniform
-          if (f < nb_wave && k >= 0 && k < ND - 1) {
-            const float bcc = team_bcast_dyn<T>(cc, k), bci = team_bcast_dyn<T>(cinv, k), bsk = team_bcast_dyn<T>(sk, k);
-            if (own && f < nb && row > k && bci != 0.0f) {
-              const float sgf = ((sgn >> f) & 1u) ? 1.0f : -1.0f;
-              const float hik = (s->H[row * DS + k] + bsk * W[f] * sgf) * bci;
-              s->H[row * DS + k] = hik; s->H[k * DS + row] = hik;
-              W[f] = W[f] * bcc - bsk * hik;
-            }
-          }
+          const int k = t - f;
+          const bool on = (unsigned)k < urow && sg[f] != 0.0f && rp[f].y != 0.0f;   // k >= 0 (unsigned compare), left of my row, slot in use, pair rotates
+          const float hik = (hcur[f] + rp[f].z * W[f] * sg[f]) * rp[f].y;
+          const float wn = W[f] * rp[f].x - rp[f].z * hik;
+          float* dst = on ? &s->H[row * DS + k] : &s->rot[row][3];       // (a slot that does not apply here stores into the lane's spare word)
+          *dst = hik;
+          W[f] = on ? wn : W[f];
         }
       }
     }
   }
   team_sync();
+  if (!degenerated) {                                                   // the strict upper triangle mirrors the lower one (the triangular solves read columns as rows)
+    for (int idx = tl; idx < NTRI; idx += T) {
+      int i, j;
+      tri_index(m, idx, i, j);
+      if (i != j) s->H[j * DS + i] = s->H[i * DS + j];
+    }
+    team_sync();
+  }
   return degenerated;
 }
 template <int T, class S, class MT>
@@ -2359,15 +2453,24 @@ DEV bool ts_cholesky_incremental(const MT& m, S* s, int tl, int n_con) {
     // instruction stream; several -> the pipelined form is 17 + n steps long instead of 18 n
     int n_flip = 0;
     for (int c = tl; c < n_con; c += T) n_flip += ((s->active[c] != 0) != (s->prev_active[c] != 0)) ? 1 : 0;
-    unsigned long long any2;
+    unsigned long long any2, n_mine;
     {
       const unsigned long long fb = __ballot(n_flip > 0);
       // flipped rows of my team = bits of my team's lanes (each lane holds at most ceil(n_con / T) of them: count lanes, a lower bound that is
       // exact whenever n_con <= T, which is the LDS-resident case)
       const unsigned long long mine = (T == 64) ? fb : ((fb >> ((threadIdx.x / T) * T)) & ((1ull << (T & 63)) - 1ull));
       any2 = __ballot(__popcll(mine) >= 2);
+      n_mine = mine;
     }
-    if (any2 != 0ull) return ts_cholesky_incremental_pipelined<T, 8>(m, s, tl, n_con);
+    if (any2 != 0ull) {                                                 // slots per batch sized to the larger flip count of the wavefront
+      const int n_team = __popcll(n_mine);
+      const int n_wave = __builtin_amdgcn_readfirstlane(imx(__shfl(n_team, 0), __shfl(n_team, T == 64 ? 0 : 32)));
+      if (n_wave <= 2) return ts_cholesky_incremental_pipelined<T, 2>(m, s, tl, n_con);
+      if (n_wave <= 3) return ts_cholesky_incremental_pipelined<T, 3>(m, s, tl, n_con);
+      if (n_wave <= 4) return ts_cholesky_incremental_pipelined<T, 4>(m, s, tl, n_con);
+      if (n_wave <= 6) return ts_cholesky_incremental_pipelined<T, 6>(m, s, tl, n_con);
+      return ts_cholesky_incremental_pipelined<T, 8>(m, s, tl, n_con);
+    }
 #endif
     return ts_cholesky_incremental_reg<T>(m, s, tl, n_con);
   }
@@ -2470,8 +2573,13 @@ DEV LsPoint ts_ls_point(const MT& m, S* s, int tl, int n_con, int nseg, const Ls
   return p;
 }
 // func_ls_point_fn_3alphas_opt, solver.py:2080-2209
+#ifdef GO2SIM_LS3_NOINLINE
+#define GO2SIM_LS3_ATTR DEVN
+#else
+#define GO2SIM_LS3_ATTR DEV
+#endif
 template <int T, class S, class MT>
-DEV void ts_ls_point3(const MT& m, S* s, int tl, int n_con, int nseg, const LsRow& rw, const float a[3], float qg0, float qg1, float qg2, float costs[3], float grads[3],
+GO2SIM_LS3_ATTR void ts_ls_point3(const MT& m, S* s, int tl, int n_con, int nseg, const LsRow& rw, const float a[3], float qg0, float qg1, float qg2, float costs[3], float grads[3],
                       float hess[3]) {
   float b0 = qg0 + 0.0f, b1 = qg1 + 0.0f, b2 = qg2 + 0.0f;
   float t[3][3] = {{b0, b1, b2}, {b0, b1, b2}, {b0, b1, b2}};
@@ -2633,7 +2741,13 @@ DEV float ts_linesearch(const MT& m, S* s, int tl, int n_con, float gauss) {
       if (dm_abs(grads[i]) < gtol && (!best_found || costs[i] < best_cost)) { best_alpha = al[i]; best_cost = costs[i]; best_found = true; }
     if (best_found) return best_alpha;
     int b1 = update_bracket(p1, al, costs, grads, hess, p1_next_alpha);
+#ifdef GO2SIM_BRACKET_FENCE   // investigation builds (tools/repro_bracket/README.md): value barriers around the inlined bracket step
+    asm volatile("" : "+v"(p1.alpha), "+v"(p1.cost), "+v"(p1.grad), "+v"(p1.hess), "+v"(p1_next_alpha), "+v"(b1));
+#endif
     int b2 = update_bracket(p2, al, costs, grads, hess, p2_next_alpha);
+#ifdef GO2SIM_BRACKET_FENCE
+    asm volatile("" : "+v"(p2.alpha), "+v"(p2.cost), "+v"(p2.grad), "+v"(p2.hess), "+v"(p2_next_alpha), "+v"(b2));
+#endif
     if (b1 == 0 && b2 == 0) return al[2];
     al[0] = p1_next_alpha; al[1] = p2_next_alpha; al[2] = (p1.alpha + p2.alpha) * 0.5f;
   }
@@ -4166,6 +4280,7 @@ struct go2sim {
   } sg;
   bool use_graph = true;
   int graph_fallbacks = 0;                  // times the graph path was abandoned for plain launches (go2sim_graph_status)
+  bool fuse_fk_dyn = true;                  // k_integrate_fk_dynamics_team between the substeps of a scene step (GO2SIM_NO_FUSE=1: separate launches)
   int dyn_team = 32;                        // lanes per environment in k_dynamics_team
   int fk_team = 16;                         // lanes per environment in k_integrate_fk_team / k_fk_team
   int collide_team = 16;                    // lanes per environment in k_collide_team
@@ -4207,16 +4322,16 @@ static void launch_fk_team(go2sim* h, hipStream_t s, int force_update_fixed, con
   else hipLaunchKernelGGL(k_fk_team<64>, gd, b, 0, s, h->P, h->dms, force_update_fixed, cond);
 }
 
-static int launch_substep(go2sim* h, hipStream_t s) {
-  dim3 g = grid_for(h->B), b(WG);
-  {
-    ScopedTimer t(h, s, T_DYN);
-    const int T = h->dyn_team;
-    dim3 gd((h->B + 64 / T - 1) / (64 / T));
-    if (T == 16) hipLaunchKernelGGL(k_dynamics_team<16>, gd, b, 0, s, h->P, h->dms);
-    else if (T == 32) hipLaunchKernelGGL(k_dynamics_team<32>, gd, b, 0, s, h->P, h->dms);
-    else hipLaunchKernelGGL(k_dynamics_team<64>, gd, b, 0, s, h->P, h->dms);
-  }
+static void launch_dynamics(go2sim* h, hipStream_t s) {
+  ScopedTimer t(h, s, T_DYN);
+  const int T = h->dyn_team;
+  dim3 gd((h->B + 64 / T - 1) / (64 / T)), b(WG);
+  if (T == 16) hipLaunchKernelGGL(k_dynamics_team<16>, gd, b, 0, s, h->P, h->dms);
+  else if (T == 32) hipLaunchKernelGGL(k_dynamics_team<32>, gd, b, 0, s, h->P, h->dms);
+  else hipLaunchKernelGGL(k_dynamics_team<64>, gd, b, 0, s, h->P, h->dms);
+}
+static void launch_collide_solve(go2sim* h, hipStream_t s) {
+  dim3 b(WG);
   {
     ScopedTimer t(h, s, T_COLLIDE);
     const int T = h->collide_team;
@@ -4238,16 +4353,35 @@ static int launch_substep(go2sim* h, hipStream_t s) {
       else hipLaunchKernelGGL((k_constraint_solve_team<64, RL>), gs, b, 0, s, h->P, h->dm, h->dms, h->solver_ovf);
     }
   }
-  {
-    ScopedTimer t(h, s, T_INTEGRATE);
-    const int T = h->fk_team;
-    dim3 gd((h->B + 64 / T - 1) / (64 / T));
-    if (T == 16) hipLaunchKernelGGL(k_integrate_fk_team<16>, gd, b, 0, s, h->P, h->dms);
-    else if (T == 32) hipLaunchKernelGGL(k_integrate_fk_team<32>, gd, b, 0, s, h->P, h->dms);
-    else hipLaunchKernelGGL(k_integrate_fk_team<64>, gd, b, 0, s, h->P, h->dms);
+}
+static void launch_integrate(go2sim* h, hipStream_t s) {
+  ScopedTimer t(h, s, T_INTEGRATE);
+  const int T = h->fk_team;
+  dim3 gd((h->B + 64 / T - 1) / (64 / T)), b(WG);
+  if (T == 16) hipLaunchKernelGGL(k_integrate_fk_team<16>, gd, b, 0, s, h->P, h->dms);
+  else if (T == 32) hipLaunchKernelGGL(k_integrate_fk_team<32>, gd, b, 0, s, h->P, h->dms);
+  else hipLaunchKernelGGL(k_integrate_fk_team<64>, gd, b, 0, s, h->P, h->dms);
+}
+// integrate + FK of one substep and the forward dynamics of the next one in a single launch (accounted with the integrate class)
+static void launch_integrate_dynamics(go2sim* h, hipStream_t s) {
+  ScopedTimer t(h, s, T_INTEGRATE);
+  const int T = h->dyn_team == 64 ? 64 : 32;
+  dim3 gd((h->B + 64 / T - 1) / (64 / T)), b(WG);
+  if (T == 32) hipLaunchKernelGGL(k_integrate_fk_dynamics_team<32>, gd, b, 0, s, h->P, h->dms);
+  else hipLaunchKernelGGL(k_integrate_fk_dynamics_team<64>, gd, b, 0, s, h->P, h->dms);
+}
+// n substeps of RigidSolver.substep (rigid_solver.py:1116-1184): dynamics | collide, solve | integrate+FK, where the integrate of substep i and the
+// dynamics of substep i + 1 share a launch
+static int launch_substeps(go2sim* h, hipStream_t s, int n) {
+  launch_dynamics(h, s);
+  for (int i = 0; i < n; ++i) {
+    launch_collide_solve(h, s);
+    if (i + 1 < n && h->fuse_fk_dyn) launch_integrate_dynamics(h, s);
+    else { launch_integrate(h, s); if (i + 1 < n) launch_dynamics(h, s); }
   }
   return GO2SIM_E_OK;
 }
+static int launch_substep(go2sim* h, hipStream_t s) { return launch_substeps(h, s, 1); }
 
 // ---- hipGraph of one env step -----------------------------------------------------------------------------------------------------
 static void step_graph_destroy(go2sim* h) {
@@ -4293,12 +4427,25 @@ static bool step_graph_build(go2sim* h, const float* actions, float* obs, float*
   g.a_actions = (const float**)sl[4]; g.a_pre_step = (uint32_t*)sl[6]; g.a_pre_widx = (int*)sl[7];
   auto team_grid = [&](int T) { return dim3((h->B + 64 / T - 1) / (64 / T)); };
   const int substeps = h->hcfg.i[GO2SIM_IC_SUBSTEPS];
-  for (int i = 0; i < substeps && ok; ++i) {
-    { const int T = h->dyn_team; const dim3 gd = team_grid(T);
-      ok = T == 16 ? graph_add_kernel(h, last, k_dynamics_team<16>, gd, b64, nullptr, nullptr, nullptr, h->P, h->dms)
+  auto add_dynamics = [&]() {
+    const int T = h->dyn_team; const dim3 gd = team_grid(T);
+    return T == 16 ? graph_add_kernel(h, last, k_dynamics_team<16>, gd, b64, nullptr, nullptr, nullptr, h->P, h->dms)
          : T == 32 ? graph_add_kernel(h, last, k_dynamics_team<32>, gd, b64, nullptr, nullptr, nullptr, h->P, h->dms)
-                   : graph_add_kernel(h, last, k_dynamics_team<64>, gd, b64, nullptr, nullptr, nullptr, h->P, h->dms); }
-    if (!ok) break;
+                   : graph_add_kernel(h, last, k_dynamics_team<64>, gd, b64, nullptr, nullptr, nullptr, h->P, h->dms);
+  };
+  auto add_integrate = [&]() {
+    const int T = h->fk_team; const dim3 gd = team_grid(T);
+    return T == 16 ? graph_add_kernel(h, last, k_integrate_fk_team<16>, gd, b64, nullptr, nullptr, nullptr, h->P, h->dms)
+         : T == 32 ? graph_add_kernel(h, last, k_integrate_fk_team<32>, gd, b64, nullptr, nullptr, nullptr, h->P, h->dms)
+                   : graph_add_kernel(h, last, k_integrate_fk_team<64>, gd, b64, nullptr, nullptr, nullptr, h->P, h->dms);
+  };
+  auto add_integrate_dynamics = [&]() {
+    const int T = h->dyn_team == 64 ? 64 : 32; const dim3 gd = team_grid(T);
+    return T == 32 ? graph_add_kernel(h, last, k_integrate_fk_dynamics_team<32>, gd, b64, nullptr, nullptr, nullptr, h->P, h->dms)
+                   : graph_add_kernel(h, last, k_integrate_fk_dynamics_team<64>, gd, b64, nullptr, nullptr, nullptr, h->P, h->dms);
+  };
+  ok = add_dynamics();
+  for (int i = 0; i < substeps && ok; ++i) {                               // same order as launch_substeps
     { const int T = h->collide_team; const dim3 gc = team_grid(T);
       ok = T == 16 ? graph_add_kernel(h, last, k_collide_team<16>, gc, b64, nullptr, nullptr, nullptr, h->P, h->dm, h->gjk_scratch)
          : T == 32 ? graph_add_kernel(h, last, k_collide_team<32>, gc, b64, nullptr, nullptr, nullptr, h->P, h->dm, h->gjk_scratch)
@@ -4313,10 +4460,8 @@ static bool step_graph_build(go2sim* h, const float* actions, float* obs, float*
                    : graph_add_kernel(h, last, k_constraint_solve_team<64, RL>, gs, b64, nullptr, nullptr, nullptr, h->P, h->dm, h->dms, h->solver_ovf);
     }
     if (!ok) break;
-    { const int T = h->fk_team; const dim3 gd = team_grid(T);
-      ok = T == 16 ? graph_add_kernel(h, last, k_integrate_fk_team<16>, gd, b64, nullptr, nullptr, nullptr, h->P, h->dms)
-         : T == 32 ? graph_add_kernel(h, last, k_integrate_fk_team<32>, gd, b64, nullptr, nullptr, nullptr, h->P, h->dms)
-                   : graph_add_kernel(h, last, k_integrate_fk_team<64>, gd, b64, nullptr, nullptr, nullptr, h->P, h->dms); }
+    if (i + 1 < substeps && h->fuse_fk_dyn) ok = add_integrate_dynamics();
+    else { ok = add_integrate(); if (ok && i + 1 < substeps) ok = add_dynamics(); }
   }
   if (!ok) return false;
   ok = graph_add_kernel(h, last, k_env_post_a, ge, be, &g.n_post_a, &g.p_post_a, &sl, h->P, h->dm, h->hcfg, h->dglob, h->dacc, h->seed, h->step_count);
@@ -4394,6 +4539,7 @@ int go2sim_create(const void* blob, size_t nbytes, int n_envs, int device, uint6
     CK(hipMalloc((void**)&h->solver_ovf, (size_t)n_envs * sizeof(SolverData<MAXR>)));
     if (const char* t = getenv("GO2SIM_DYN_TEAM")) { int v = atoi(t); if (v == 16 || v == 32 || v == 64) h->dyn_team = v; }
     if (const char* t = getenv("GO2SIM_NO_GRAPH")) { if (atoi(t) != 0) h->use_graph = false; }
+    if (const char* t = getenv("GO2SIM_NO_FUSE")) { if (atoi(t) != 0) h->fuse_fk_dyn = false; }
     if (const char* t = getenv("GO2SIM_FK_TEAM")) { int v = atoi(t); if (v == 16 || v == 32 || v == 64) h->fk_team = v; }
     if (const char* t = getenv("GO2SIM_COLLIDE_TEAM")) { int v = atoi(t); if (v == 16 || v == 32 || v == 64) h->collide_team = v; }
     CK(hipMalloc((void**)&h->gjk_scratch, (size_t)n_envs * h->collide_team * sizeof(GjkStoreFull)));   // ~20 KB per narrow-phase lane
@@ -4443,7 +4589,7 @@ int go2sim_substep(go2sim_t* h, void* stream) {
 int go2sim_scene_step(go2sim_t* h, int substeps, void* stream) {
   if (!h || substeps <= 0) return GO2SIM_E_BADARG;
   hipStream_t s = (hipStream_t)stream;
-  for (int i = 0; i < substeps; ++i) launch_substep(h, s);
+  launch_substeps(h, s, substeps);
   { ScopedTimer t(h, s, T_MISC); hipLaunchKernelGGL(k_clear_ext, grid_for(h->B), dim3(WG), 0, s, h->P); }
   HIPCHK(hipGetLastError());
   return GO2SIM_E_OK;
@@ -4689,8 +4835,7 @@ int go2sim_env_step(go2sim_t* h, const float* actions, float* obs, float* priv, 
   if (h->timing && h->ev_n + 64 > TIMING_RING) timing_flush(h);   // all pending events belong to completed launches
   ScopedTimer total(h, s, T_TOTAL);
   { ScopedTimer t(h, s, T_ENV_PRE); hipLaunchKernelGGL(k_env_pre, g, b, 0, s, h->P, h->dm, h->hcfg, h->dglob, actions, h->seed, h->step_count, h->action_write_idx); }
-  int substeps = h->hcfg.i[GO2SIM_IC_SUBSTEPS];
-  for (int i = 0; i < substeps; ++i) launch_substep(h, s);
+  launch_substeps(h, s, h->hcfg.i[GO2SIM_IC_SUBSTEPS]);
   {
     ScopedTimer t(h, s, T_ENV_POST);
     hipLaunchKernelGGL(k_env_post_a, g, b, 0, s, h->P, h->dm, h->hcfg, h->dglob, h->dacc, h->seed, h->step_count);
@@ -4779,6 +4924,15 @@ int go2sim_errno_poll_result(go2sim_t* h, int* errno_host, int* ready) {
   HIPCHK(q);
   h->errno_poll_pending = false;
   *ready = 1; *errno_host = h->herr_pinned[0];
+  return GO2SIM_E_OK;
+}
+int go2sim_errno_poll_wait(go2sim_t* h, int* errno_host) {
+  if (!h || !errno_host) return GO2SIM_E_BADARG;
+  *errno_host = 0;
+  if (!h->errno_poll_pending) return GO2SIM_E_OK;
+  HIPCHK(hipEventSynchronize(h->ev_errno));
+  h->errno_poll_pending = false;
+  *errno_host = h->herr_pinned[0];
   return GO2SIM_E_OK;
 }
 int go2sim_graph_status(go2sim_t* h, int* using_graph, int* n_fallbacks) {

@@ -15,7 +15,7 @@ Differences that are deliberate (DESIGN.md "boundary"):
   * ``extras["episode"]`` / ``extras["curriculum"]`` / ``extras["domain_randomization"]`` values are 0-dim device tensors
     (views of one per-step snapshot of the device globals) instead of python floats (rsl_rl accepts both);
   * the errno poll of ``scene.step`` (simulator.py:267, every 10 substeps = 5 env steps) is asynchronous: the reduction is
-    enqueued after the step and examined one step later, so the loop never waits for the device;
+    enqueued after the step and examined at the following steps (at the latest when the next poll is due), so the loop does not wait for the device;
   * random numbers come from the counter-based Philox stream of the C ABI (include/go2sim.h), not from
     torch's global generator.
 """
@@ -147,7 +147,8 @@ class Go2Env:
         poll = self._steps_since_poll >= self.errno_poll_every             # RATE_CHECK_ERRNO = 10 substeps, simulator.py:45,267
         if poll:
             self._steps_since_poll = 0
-            self._sim.errno_poll_begin(stream)
+            self._raise_on_errno(self._sim.errno_poll_wait())              # the previous poll is a whole cadence old: this practically never blocks,
+            self._sim.errno_poll_begin(stream)                             # and an error surfaces at most 2 x errno_poll_every steps after it happened
         self.extras["time_outs"] = self._time_outs
         self.extras["observations"]["critic"] = self.privileged_obs_buf if self.num_privileged_obs else self.obs_buf
         if self.log_extras:

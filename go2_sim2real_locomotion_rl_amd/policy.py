@@ -131,6 +131,22 @@ class ActorCritic:
     def state_dict(self):
         return dict(self._state)
 
+    def load_checkpoint(self, path, strict=False):
+        """Load ``model_<it>.pt`` of a training run (rsl_rl 2.2.4 ``OnPolicyRunner.save`` layout), read with ``torch.load(weights_only=True)``.
+        strict=False is the eval scripts' compatibility load (go2_eval_stairs.py:368-450): layers whose shapes differ from this model -- a critic
+        trained with another privileged-observation width -- keep their current values, everything else (the actor in particular) is taken from the
+        file.  -> (loaded keys, skipped {key: reason}, iteration)"""
+        from .eval_io import compatible_state_dict, read_checkpoint
+
+        ckpt = read_checkpoint(path)
+        saved = ckpt["model_state_dict"]
+        if strict:
+            self.load_state_dict(saved)
+            return sorted(saved), {}, int(ckpt.get("iter", 0) or 0)
+        merged, loaded, skipped = compatible_state_dict(self.state_dict(), saved)
+        self.load_state_dict(merged)
+        return loaded, skipped, int(ckpt.get("iter", 0) or 0)
+
     # ---- rsl_rl ActorCritic surface (inference side) ---------------------------------------------------
     def _buf(self, name, shape):
         t = self._bufs.get(name)

@@ -314,6 +314,9 @@ int go2sim_check_errno(go2sim_t* h, int* errno_host, void* stream);
  * pinned host memory on `stream`; _result sets *ready = 1 and *errno_host once that copy has completed (never waits). */
 int go2sim_errno_poll_begin(go2sim_t* h, void* stream);
 int go2sim_errno_poll_result(go2sim_t* h, int* errno_host, int* ready);
+/* waits for the poll in flight (if any) and returns its value: bounds the staleness when the host runs ahead of the device -- the caller waits
+ * on a poll that is a whole cadence old before starting the next one, which in practice never blocks */
+int go2sim_errno_poll_wait(go2sim_t* h, int* errno_host);
 /* whether go2sim_env_step currently replays its hipGraph (1) or issues plain launches (0), and how often the graph path was abandoned */
 int go2sim_graph_status(go2sim_t* h, int* using_graph, int* n_fallbacks);
 

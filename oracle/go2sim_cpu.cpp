@@ -2785,6 +2785,7 @@ int go2sim_cpu_errno_poll_result(go2sim* h, int* errno_host, int* ready) {
   *ready = 1;
   return go2sim_cpu_check_errno(h, errno_host, nullptr);
 }
+int go2sim_cpu_errno_poll_wait(go2sim* h, int* errno_host) { return (h && errno_host) ? go2sim_cpu_check_errno(h, errno_host, nullptr) : GO2SIM_E_BADARG; }
 int go2sim_cpu_graph_status(go2sim* h, int* using_graph, int* n_fallbacks) {
   if (!h) return GO2SIM_E_BADARG;
   if (using_graph) *using_graph = 0;

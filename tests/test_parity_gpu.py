@@ -237,7 +237,8 @@ def test_go2env_class_matches_c_abi(hip_lib, blob):
         env.step(torch.zeros(B, 12, device=env.device))
 
 
-@pytest.mark.parametrize("task,n_envs,steps,kind,seed", [("crouch", 70, 120, "0.5", 3), ("jump", 33, 160, "mixed", 8), ("jump_dr", 40, 140, "0.5", 9)])
+@pytest.mark.parametrize("task,n_envs,steps,kind,seed", [("crouch", 70, 120, "0.5", 3), ("jump", 33, 160, "mixed", 8), ("jump_dr", 40, 140, "0.5", 9), ("crouch_dr", 48, 100, "mixed", 10),
+                                                           ("jump_dr", 4096, 10, "0.5", 12)])
 def test_base_env_bit_exact(oracle_lib, hip_lib, blob, task, n_envs, steps, kind, seed):
     """go2_env_base.py (crouch / jump): engine PD, reset before reward, 45 observations -- GPU vs oracle, tolerance 0."""
     cpu, gpu = CpuEnv(oracle_lib, blob, n_envs, seed=seed, task=task), GpuEnv(hip_lib, blob, n_envs, seed=seed, task=task)
@@ -253,7 +254,7 @@ def test_base_env_bit_exact(oracle_lib, hip_lib, blob, task, n_envs, steps, kind
         n_resets += int(dc.sum())
     _compare_fields(cpu, gpu, "final")
     _compare_globals(cpu, gpu)
-    assert n_resets > 0
+    assert n_resets > 0 or steps < 100
 
 
 def test_go2env_class_base_family(hip_lib, blob):
@@ -299,3 +300,60 @@ def test_gs_surface_on_hip_backend(oracle_lib):
         res.append([t.cpu().numpy() for t in (robot.get_pos(), robot.get_quat(), robot.get_dofs_position(motors), robot.get_links_net_contact_force())])
     for a, b in zip(*res):
         assert bits_equal(a, b)
+
+
+def test_go2env_step_returns_fresh_observation_tensors_and_logs(hip_lib, blob):
+    """rsl_rl's PPO keeps `transition.observations = obs` by reference across env.step (storage.add_transitions copies it afterwards), so a step must
+    not overwrite the tensor it returned before: like the reference (`self.obs_buf = torch.cat(...)`, go2_env_walk.py:1084) every step hands out new
+    observation tensors.  Also: the extras keys of the reference (go2_env_walk.py:674-686, 756, 813, 1228-1235)."""
+    import torch
+
+    from go2_sim2real_locomotion_rl_amd import Go2Env, init
+    from go2_sim2real_locomotion_rl_amd.configs import get_walk_cfgs
+
+    init(seed=5)
+    env = Go2Env(32, *get_walk_cfgs())
+    g = torch.Generator(device="cpu").manual_seed(0)
+    a = (0.3 * torch.randn(32, 16, generator=g)).to(env.device)
+    o1, r1, d1, ex1 = env.step(a)
+    c1 = ex1["observations"]["critic"]
+    keep_o, keep_c = o1.clone(), c1.clone()
+    o2, _, _, ex2 = env.step(a)
+    torch.cuda.synchronize()
+    assert o2.data_ptr() != o1.data_ptr() and ex2["observations"]["critic"].data_ptr() != c1.data_ptr()
+    assert torch.equal(o1, keep_o) and torch.equal(c1, keep_c), "a later step overwrote an observation tensor it had returned"
+    assert not torch.equal(o1, o2)
+    assert set(ex2["episode"]) == {"rew_" + n for n in env.reward_scales}
+    for _ in range(6):                                                     # curriculum / DR logs refresh at the errno-poll cadence (5 steps)
+        _, _, _, ex = env.step(a)
+    assert {"level", "timeout_rate_ema", "tracking_ema", "fall_rate_ema", "obs_noise_level_cur", "push_enable", "delay_max_cur", "cmd_ranges"} <= set(ex["curriculum"])
+    assert {"friction", "mass_shift", "com_shift", "leg_mass_shift"} <= set(ex["domain_randomization"])
+    assert float(ex["curriculum"]["level"]) == pytest.approx(0.10) and env.graph_status() == (True, 0)
+    # reset_idx on a subset through the class
+    env.reset_idx(torch.tensor([1, 5], device=env.device))
+    assert int(env.episode_length_buf[1]) == 0 and int(env.episode_length_buf[5]) == 0 and int(env.episode_length_buf[0]) > 0
+
+
+def test_go2env_errno_poll_raises_like_scene_step(hip_lib, blob):
+    """simulator.py:267 polls errno every 10 substeps and scene.step raises (rigid_solver.py:1189-1213).  Go2Env.step enqueues the poll every 5 env
+    steps and raises at the following step -- no env is silently frozen by the NaN guard."""
+    import torch
+
+    from go2_sim2real_locomotion_rl_amd import Go2Env, Go2SimError, init
+    from go2_sim2real_locomotion_rl_amd.capi import C
+    from go2_sim2real_locomotion_rl_amd.configs import get_walk_cfgs
+
+    init(seed=2)
+    env = Go2Env(16, *get_walk_cfgs())
+    a = torch.zeros(16, 16, device=env.device)
+    for _ in range(7):
+        env.step(a)                                                        # healthy: the polls come back clean
+    vel = torch.zeros(18, 16, device=env.device)
+    env._sim.get_field(C["GO2SIM_F_VEL"], vel)
+    vel[3, 4] = float("nan")                                               # one env with a NaN velocity: its state commit is skipped, errno set
+    env._sim.set_field(C["GO2SIM_F_VEL"], vel)
+    with pytest.raises(Go2SimError, match="nan"):
+        for _ in range(12):
+            env.step(a)
+    with pytest.raises(Go2SimError):
+        env.check_errno()

@@ -41,6 +41,15 @@ for name, i in (("GJK / EPA query", 34), ("  of which GJK", 38), ("  of which EP
     cyc, cnt = a[:, i], a[:, i + 1]
     if cnt.sum() > 0:
         print(f"-- {name}: {cnt.sum() / launches:8.1f} executions per launch (wave level), {cyc.sum() / cnt.sum():9.0f} cycles each; per WG-launch mean {cyc.mean() * PH_MAX_WG / max(1, (cyc > 0).sum()) / launches:9.0f}, slowest 1% {np.sort(cyc)[-max(1, int((cyc > 0).sum()) // 100):].mean() / launches:9.0f}")
+cnt = a[:, 50:55].sum(0) / launches
+if cnt.sum() > 0:
+    wg = max(1, int((a[:, 0] > 0).sum()))
+    print(f"-- incremental Cholesky per WG-launch: serial-form calls {cnt[0] / wg:.2f} with {cnt[1] / wg:.2f} flipped-row passes; pipelined batches {cnt[2] / wg:.2f} "
+          f"with {cnt[3] / wg:.2f} flipped rows (larger team) in {cnt[4] / wg:.1f} time steps")
+    tot50 = a[:, 50:55]
+    order = np.argsort(-a[:, 8])[:max(1, wg // 100)]
+    c1 = tot50[order].mean(0) / launches
+    print(f"   slowest 1% (by incremental time): serial calls {c1[0]:.2f} / passes {c1[1]:.2f}; pipelined batches {c1[2]:.2f} / rows {c1[3]:.2f} / time steps {c1[4]:.1f}")
 for g, ids in GROUPS.items():
     sub = a[:, ids]
     tot = sub.sum(1)
