@@ -103,7 +103,7 @@ def pmc_traffic_bytes(kernel, n_envs):
     rec = doc.get("kernels", {}).get(kernel)
     if rec is None:
         return None, f"kernel {kernel} not in the traffic file"
-    return int((2 * rec["fetch_size_kb"] + rec["write_size_kb"]) * 1000), None
+    return int((2 * rec["fetch_size_kb"] + rec["write_size_kb"]) * 1024), None
 
 
 def make_sim(lib, n_envs, device_index, seed, workload, freeze_curriculum=True):

@@ -719,6 +719,18 @@ DEV void st9(float* p, int i, const M3& r) {
 #pragma unroll
   for (int k = 0; k < 9; ++k) p[9 * i + k] = r.m[k / 3][k % 3]; }
 
+// Workgroups are dealt to the 8 XCDs round-robin (workgroups i and i + 8 share an XCD) and every XCD has its own L2.  With the plain blockIdx -> env
+// map the 8 (T = 16) or 16 (T = 32) workgroups whose envs share one 128-byte line of a [feature][env] row sit on 8 different XCDs: every L2 fetches
+// the whole line for 4 or 8 of its bytes and writes it back piecemeal.  Logical block ids are handed out so that the workgroups of one XCD cover one
+// contiguous range of envs (speed only: any placement gives the same results).
+DEV int xcd_block() {
+#ifdef GO2SIM_NO_XCD_REMAP
+  return (int)blockIdx.x;
+#endif
+  const int n = (int)gridDim.x, q = n >> 3, r = n & 7, x = (int)blockIdx.x & 7, i = (int)blockIdx.x >> 3;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+}
+
 struct KinData {
   float qpos[NQ], vel[ND], qpos_next[NQ], vel_next[ND];
   float l_pos[NL * 3], l_quat[NL * 4], i_pos[NL * 3], i_quat[NL * 4];
@@ -967,7 +979,7 @@ __global__ __launch_bounds__(64) void k_integrate_fk_team(Pool P, const ModelS* 
   const ModelS& ms = *(const ModelS*)ms_raw;
   wg_dma_to_lds<(int)sizeof(ModelS)>(ms_raw, mp);
   const int tl = threadIdx.x % T, slot = threadIdx.x / T;
-  const int b = blockIdx.x * EPW + slot;
+  const int b = xcd_block() * EPW + slot;
   const ModelView m(&ms, mp);
   E e(P, b < P.B ? b : P.B - 1);
   KinData* s = &lds[slot];
@@ -996,7 +1008,7 @@ __global__ __launch_bounds__(64) void k_fk_team(Pool P, const ModelS* __restrict
   if (cond && *cond <= 0) return;
   wg_dma_to_lds<(int)sizeof(ModelS)>(ms_raw, mp);
   const int tl = threadIdx.x % T, slot = threadIdx.x / T;
-  const int b = blockIdx.x * EPW + slot;
+  const int b = xcd_block() * EPW + slot;
   const ModelView m(&ms, mp);
   E e(P, b < P.B ? b : P.B - 1);
   KinData* s = &lds[slot];
@@ -1182,13 +1194,13 @@ __global__ __launch_bounds__(64) void k_dynamics_team(Pool P, const ModelS* __re
   const ModelS& ms = *(const ModelS*)ms_raw;
   wg_dma_to_lds<(int)sizeof(ModelS)>(ms_raw, mp);
   {  // ---- stage the SoA inputs cooperatively (adjacent lanes = adjacent envs), before any lane retires ----
-    const int b0 = blockIdx.x * EPW;
+    const int b0 = xcd_block() * EPW;
     wg_load<EPW, NL * 3>(P, b0, FO(cd_vel), [&](int ev, int k, float v) { lds[ev].cd_vel[k] = v; });
     wg_load<EPW, NL * 3>(P, b0, FO(cd_ang), [&](int ev, int k, float v) { lds[ev].cd_ang[k] = v; });
     wg_load<EPW, ND>(P, b0, FO(vel), [&](int ev, int k, float v) { lds[ev].vel[k] = v; });
   }
   const int tl = threadIdx.x % T, slot = threadIdx.x / T;
-  const int b = blockIdx.x * EPW + slot;
+  const int b = xcd_block() * EPW + slot;
   const bool env_valid = b < P.B;
   const ModelView m(&ms, mp);
   E e(P, env_valid ? b : P.B - 1);
@@ -1230,7 +1242,7 @@ __global__ __launch_bounds__(64) void k_integrate_fk_dynamics_team(Pool P, const
   const ModelS& ms = *(const ModelS*)ms_raw;
   wg_dma_to_lds<(int)sizeof(ModelS)>(ms_raw, mp);
   const int tl = threadIdx.x % T, slot = threadIdx.x / T;
-  const int b = blockIdx.x * EPW + slot;
+  const int b = xcd_block() * EPW + slot;
   const ModelView m(&ms, mp);
   E e(P, b < P.B ? b : P.B - 1);
   DynData* d = &lds_d[slot];
@@ -1647,7 +1659,7 @@ struct CollideData {
     GjkStoreLds gjk[GJK_SLOTS];
     Terrain tr;
   };
-  int pair_sorted[MAXB];
+  unsigned short pair_sorted[MAXB];                   // geom a | geom b << 8
   float stage[T][5][7];
   int cnt[T];
   unsigned gjk_slot_mask;                             // bit i set = gjk[i] is taken
@@ -1830,7 +1842,7 @@ __global__ __launch_bounds__(64) void k_collide_team(Pool P, const Model* __rest
   constexpr int EPW = 64 / T;
   __shared__ CollideData<T> lds[EPW];
   const int tl = threadIdx.x % T, slot = threadIdx.x / T;
-  const int b = blockIdx.x * EPW + slot;
+  const int b = xcd_block() * EPW + slot;
   if (b >= P.B) return;
   const Model& m = *mp;
   E e(P, b);
@@ -1952,7 +1964,7 @@ __global__ __launch_bounds__(64) void k_collide_team(Pool P, const Model* __rest
   for (int c = tl; c < n_cand; c += T) {
     int key = s->bp.cand_key[c], r = 0;
     for (int j = 0; j < n_cand; ++j) r += s->bp.cand_key[j] < key;
-    s->pair_sorted[r] = s->bp.cand_pair[c];
+    s->pair_sorted[r] = (unsigned short)s->bp.cand_pair[c];
   }
   const int n_broad = imn(n_cand, m.max_broad_pairs);
   team_sync();
@@ -3030,7 +3042,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   PH_BEGIN
   wg_dma_to_lds<SOLVER_BLOCK_BYTES>(blk_raw, mp->links);
   const int tl = threadIdx.x % T, slot = threadIdx.x / T;
-  const int b = blockIdx.x * EPW + slot;
+  const int b = xcd_block() * EPW + slot;
   const bool env_valid = b < P.B;
   E e(P, env_valid ? b : P.B - 1);
   const int nc = e.n_contacts()[0];
@@ -3999,7 +4011,7 @@ __global__ __launch_bounds__(64) void k_env_post_b_team(Pool P, const Model* __r
   const bool fk_needed = gp->n_reset_now > 0;
   if (fk_needed) wg_dma_to_lds<(int)sizeof(ModelS)>(ms_raw, msp);
   const int tl = threadIdx.x % T, slot = threadIdx.x / T;
-  const int b = blockIdx.x * EPW + slot;
+  const int b = xcd_block() * EPW + slot;
   if (b >= P.B) return;
   const Model& m = *mp; const DCfg& c = *cp; const Glob& g = *gp;
   E e(P, b);

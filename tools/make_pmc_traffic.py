@@ -1,0 +1,28 @@
+#!/usr/bin/env python3
+"""profiles/rNN_pmc_traffic.json from the two --pmc passes of tools/profile_round.sh, stamped with bench.source_hash() so that bench.py refuses it
+for any other build of the kernels.   usage: make_pmc_traffic.py FETCH.json WRITE.json OUT.json "<command line that was profiled>" """
+import json, os, re, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import source_hash
+
+fetch, write = json.load(open(sys.argv[1])), json.load(open(sys.argv[2]))
+CLASS = [("k_constraint_solve", r"^k_constraint_solve_team"), ("k_collide", r"^k_collide_team"), ("k_dynamics", r"^k_dynamics_team"),
+         ("k_integrate_fk", r"^k_integrate_fk_team"), ("k_integrate_fk_dynamics", r"^k_integrate_fk_dynamics_team"), ("k_env_pre", r"^k_env_pre"),
+         ("k_env_post_a", r"^k_env_post_a"), ("k_env_post_b", r"^k_env_post_b"), ("k_env_globals", r"^k_env_globals")]
+kernels = {}
+for name, pat in CLASS:
+    f = [v for k, v in fetch.items() if re.match(pat, k)]
+    w = [v for k, v in write.items() if re.match(pat, k)]
+    if f and w:
+        kernels[name] = {"fetch_size_kb": round(f[0]["FETCH_SIZE"], 1), "write_size_kb": round(w[0]["WRITE_SIZE"], 1), "launches_averaged": f[0]["n"],
+                         "avg_us_under_pmc": round(f[0]["avg_us"], 1)}
+per_step = {"k_constraint_solve": 2, "k_collide": 2, "k_dynamics": 1, "k_integrate_fk": 1, "k_integrate_fk_dynamics": 1, "k_env_pre": 1, "k_env_post_a": 1,
+            "k_env_post_b": 1, "k_env_globals": 1}
+step_bytes = sum((2 * v["fetch_size_kb"] + v["write_size_kb"]) * 1024 * per_step[k] for k, v in kernels.items())
+doc = {"_comment": "HBM-side traffic per launch, rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (MI355X_MICROARCH.md, HBM): "
+                   "bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 -- FETCH_SIZE is doubled (gfx950 tallies 128-B requests at 64 B); 4-byte-per-lane "
+                   "accesses are outside the guide's calibration, and Infinity-Cache hits are counted, so read it as L2-miss traffic, +-2x.",
+       "command": sys.argv[4], "source_sha256": source_hash(), "kernels": kernels,
+       "env_step_bytes": int(step_bytes), "env_step_launches": per_step}
+json.dump(doc, open(sys.argv[3], "w"), indent=1)
+print(json.dumps(doc, indent=1))
