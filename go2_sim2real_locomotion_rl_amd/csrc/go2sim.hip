@@ -1686,7 +1686,9 @@ DEV void convex_convex_contact_staged(const Model& m, const E& e, int i_ga, int 
   V3 axis_0 = v3(0, 0, 0), axis_1 = v3(0, 0, 0); Q4 qrot = q4(0, 0, 0, 0);
   int i_pair = (i_ga > i_gb) ? m.pair_idx[i_gb][i_ga] : m.pair_idx[i_ga][i_gb];
   auto normal_cache = e.normal_cache();
+  PHD_BEGIN
   for (int i_detection = 0; i_detection < 5; ++i_detection) {
+    if (i_detection == 1) { PHD(44) }
     bool prefer_gjk = false;
     if (multi_contact && is_col_0) {
       V3 axis = (float)(2 * (i_detection % 2) - 1) * axis_0 + (float)(1 - 2 * ((i_detection / 2) % 2)) * axis_1;
@@ -1761,6 +1763,7 @@ DEV void convex_convex_contact_staged(const Model& m, const E& e, int i_ga, int 
       }
     }
   }
+  PHD(46)
 }
 
 // func_contact_mpr_terrain, narrowphase.py:345-490, split for one-lane-per-prism execution.
@@ -3357,6 +3360,145 @@ __global__ __launch_bounds__(WG) void k_env_pre(Pool P, const Model* __restrict_
   }
 }
 
+// k_env_pre and the forward dynamics of the first substep in one launch: the pre-physics part of Go2Env.step is element-wise over the 12 motors
+// (lane i = action / motor i; the push bookkeeping on one lane), its outputs are exactly the control inputs the dynamics stage -- they go to
+// the pool (the second substep, the post kernels and get_field read them there) and straight into the dynamics working set in LDS.
+// Same arithmetic per element as k_env_pre (go2_env_walk.py:985-1023, _apply_push :872-906).
+template <int T>
+__global__ __launch_bounds__(64) void k_pre_dynamics_team(Pool P, const ModelS* __restrict__ mp, const DCfg cv, const Glob* __restrict__ gp,
+                                                          const float* __restrict__ actions_in, uint64_t seed, uint32_t step_count, int write_idx) {
+  static_assert(T >= NA, "one lane per action");
+  constexpr int EPW = 64 / T;
+  __shared__ DynData lds[EPW];
+  __shared__ alignas(16) char ms_raw[MODELS_LDS_BYTES];
+  const ModelS& ms = *(const ModelS*)ms_raw;
+  wg_dma_to_lds<(int)sizeof(ModelS)>(ms_raw, mp);
+  {
+    const int b0 = xcd_block() * EPW;
+    wg_load<EPW, NL * 3>(P, b0, FO(cd_vel), [&](int ev, int k, float v) { lds[ev].cd_vel[k] = v; });
+    wg_load<EPW, NL * 3>(P, b0, FO(cd_ang), [&](int ev, int k, float v) { lds[ev].cd_ang[k] = v; });
+    wg_load<EPW, ND>(P, b0, FO(vel), [&](int ev, int k, float v) { lds[ev].vel[k] = v; });
+  }
+  const int tl = threadIdx.x % T, slot = threadIdx.x / T;
+  const int b = xcd_block() * EPW + slot;
+  const bool env_valid = b < P.B;
+  const ModelView m(&ms, mp);
+  E e(P, env_valid ? b : P.B - 1);
+  DynData* s = &lds[slot];
+  const DCfg& c = cv; const Glob& g = *gp;
+  PH_BEGIN
+  // ---- loads of the pre-physics part (lane i: action / motor i) ----
+  const int na = c.i[GO2SIM_IC_NUM_ACTIONS];
+  const int ia = tl < NA ? tl : NA - 1, im = tl < NM ? tl : NM - 1;
+  const int eb = env_valid ? b : P.B - 1;
+  auto hist = e.action_history();
+  const int delay = e.delay_steps()[0];
+  const float a_in = (ia < na) ? actions_in[(size_t)eb * na + ia] : 0.0f;
+  const float h0_ = hist[0][ia], h1_ = hist[1][ia];
+  const float kpf = e.kp_factors()[im], kdf = e.kd_factors()[im], mst = e.motor_strength()[im], dp = e.e_dof_pos()[im], dv = e.e_dof_vel()[im];
+  const bool manual_pd = c.i[GO2SIM_IC_MANUAL_PD] != 0, pls = c.i[GO2SIM_IC_PLS_ENABLE] != 0;
+  const bool push_on = c.i[GO2SIM_IC_HAS_PUSH] && g.push_enable;
+  const int pl = c.i[GO2SIM_IC_PUSH_LINK];
+  auto psf = e.push_stored_force(); auto prem = e.push_remaining(); auto cpf = e.current_push_force(); auto ext = e.ext();
+  float psf_[3] = {psf[0], psf[1], psf[2]}; int rem0 = prem[0];
+  const V3 pl_pos = e.l_pos()[pl], pl_com = e.root_com()[pl];
+  float ext_[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) ext_[k] = ext[6 * pl + k];
+  // ---- staging of the dynamics inputs, as k_dynamics_team ----
+  team_stage<NL * 9, T>(tl, [&](int k) { return aload(e, AO(cinr_inertial), k); }, [&](int k, float v) { s->cinr_I[k] = v; s->crb_I[k] = v; });
+  team_stage<NL * 3, T>(tl, [&](int k) { return aload(e, AO(cinr_pos), k); }, [&](int k, float v) { s->cinr_pos[k] = v; s->crb_pos[k] = v; });
+  team_stage<NL, T>(tl, [&](int k) { return aload(e, AO(cinr_mass), k); }, [&](int k, float v) { s->cinr_mass[k] = v; s->crb_mass[k] = v; });
+  team_stage<ND, T>(tl, [&](int d) { return __int_as_float((int)e.ctrl_mode()[d]); }, [&](int d, float v) { s->ctrl_mode[d] = __float_as_int(v); });
+  team_stage<ND * 3, T>(tl, [&](int k) { return aload(e, AO(cdof_ang), k); }, [&](int k, float v) { s->cdof_ang[k] = v; });
+  team_stage<ND * 3, T>(tl, [&](int k) { return aload(e, AO(cdof_vel), k); }, [&](int k, float v) { s->cdof_vel[k] = v; });
+  team_stage<ND * 3, T>(tl, [&](int k) { return aload(e, AO(cdofd_ang), k); }, [&](int k, float v) { s->cdofd_ang[k] = v; });
+  team_stage<ND * 3, T>(tl, [&](int k) { return aload(e, AO(cdofd_vel), k); }, [&](int k, float v) { s->cdofd_vel[k] = v; });
+  team_stage<ND, T>(tl, [&](int d) { return gload(e, FO(ctrl_force), d); }, [&](int d, float v) { s->qf_applied[d] = v; });
+  team_stage<ND, T>(tl, [&](int d) { return gload(e, FO(ctrl_pos), d); }, [&](int d, float v) { s->qf_passive[d] = v; });
+  team_stage<ND, T>(tl, [&](int d) { return gload(e, FO(ctrl_vel), d); }, [&](int d, float v) { s->force[d] = v; });
+  team_stage<ND, T>(tl, [&](int d) { return gload(e, FO(dof_pos), d); }, [&](int d, float v) { s->out[d] = v; });
+  team_stage<NL * 6, T>(tl, [&](int k) { return gload(e, FO(ext), k); },
+                        [&](int k, float v) { int i_l = k / 6, cc = k % 6; if (cc < 3) s->cfrc_ang[3 * i_l + cc] = v; else s->cfrc_vel[3 * i_l + cc - 3] = v; });
+  team_sync();
+  // ---- the pre-physics part; the parked control inputs of the motor dofs and the external force of the pushed link are replaced in LDS ----
+  if (env_valid) {
+    const float clip = c.f[GO2SIM_FC_CLIP_ACTIONS];
+    const int w_after = (write_idx + 1) % 2;
+    const int read_idx = (((w_after - 1 - delay) % 2) + 2) % 2;
+    float delayed = 0.0f;
+    if (tl < NA && tl < na) {
+      const float a = fmn(fmx(a_in, -clip), clip);
+      e.actions()[tl] = a;
+      const float h0 = (write_idx == 0) ? a : h0_, h1 = (write_idx == 1) ? a : h1_;
+      hist[write_idx][tl] = a;
+      delayed = (read_idx == 0) ? h0 : h1;
+      e.applied_actions()[tl] = delayed;
+    }
+    const float delayed_leg = __shfl(delayed, NM + im / 3, T);            // per-leg stiffness action of the PLS policy (actions 12..15)
+    if (tl < NM) {
+      float target = delayed * c.f[GO2SIM_FC_ACTION_SCALE] + c.f[GO2SIM_FC_DEFAULT_DOF_POS0 + tl];
+      if (g.action_noise_std_cur > 0.0f) {
+        dm_u4 r = rng4(seed, RNG_ACTION_NOISE, b, step_count, tl / 4);
+        float n0, n1;
+        if ((tl & 2) == 0) dm_normal2(r.v[0], r.v[1], &n0, &n1); else dm_normal2(r.v[2], r.v[3], &n0, &n1);
+        target = target + ((tl & 1) ? n1 : n0) * g.action_noise_std_cur;
+      }
+      e.target_dof_pos()[tl] = target;
+      const int d = c.i[GO2SIM_IC_MOTOR_DOF0 + tl];
+      if (!manual_pd) {                                                  // go2_env_base.py:127: control_dofs_position (engine PD)
+        e.ctrl_mode()[d] = CTRL_POSITION; e.ctrl_pos()[d] = target; e.ctrl_vel()[d] = 0.0f; e.ctrl_force()[d] = 0.0f;
+        e.torque()[tl] = 0.0f;
+        s->ctrl_mode[d] = CTRL_POSITION; s->qf_passive[d] = target; s->force[d] = 0.0f; s->qf_applied[d] = 0.0f;
+      } else {
+        float eff_kp, eff_kd;
+        if (pls) {                                                       // _compute_pls_kp_kd :969-979
+          float kp_leg = c.f[GO2SIM_FC_PLS_KP_DEFAULT] + delayed_leg * c.f[GO2SIM_FC_PLS_KP_ACTION_SCALE];
+          kp_leg = fmn(fmx(kp_leg, c.f[GO2SIM_FC_PLS_KP_MIN]), c.f[GO2SIM_FC_PLS_KP_MAX]);
+          const float kd_j = 0.2f * dm_sqrt(kp_leg);
+          eff_kp = kp_leg * kpf * mst;
+          eff_kd = kd_j * kdf;
+        } else {
+          eff_kp = c.f[GO2SIM_FC_KP] * kpf; eff_kd = c.f[GO2SIM_FC_KD] * kdf;
+        }
+        const float pos_error = target - dp;
+        float torque = eff_kp * pos_error - eff_kd * dv;
+        const float lim = c.f[GO2SIM_FC_TORQUE_LIMIT0 + tl];
+        torque = fmn(fmx(torque, -lim), lim);
+        e.torque()[tl] = torque;
+        e.ctrl_mode()[d] = CTRL_FORCE; e.ctrl_force()[d] = torque;
+        s->ctrl_mode[d] = CTRL_FORCE; s->qf_applied[d] = torque;
+      }
+    }
+    if (tl == T - 1) {                                                   // push bookkeeping (a lane without a motor)
+      if (!push_on) {
+        cpf[0] = 0.0f; cpf[1] = 0.0f; cpf[2] = 0.0f;
+      } else {
+        if (g.push_counter % g.push_interval == 0) {
+          dm_u4 r = rng4(seed, RNG_PUSH, b, step_count, 0);
+          psf_[0] = rand_float(g.push_force_lo, g.push_force_hi, r.v[0]);
+          psf_[1] = rand_float(g.push_force_lo, g.push_force_hi, r.v[1]);
+          psf_[2] = 0.0f;
+          psf[0] = psf_[0]; psf[1] = psf_[1]; psf[2] = psf_[2];
+          rem0 = rand_int(c.i[GO2SIM_IC_PUSH_DUR_LO], c.i[GO2SIM_IC_PUSH_DUR_HI], r.v[2]);
+        }
+        const float active = (rem0 > 0) ? 1.0f : 0.0f;
+        const V3 force = v3(psf_[0] * active, psf_[1] * active, psf_[2] * active);
+        cpf[0] = force.x; cpf[1] = force.y; cpf[2] = force.z;
+        prem[0] = imx(rem0 - 1, 0);
+        const V3 tq = cross(pl_pos - pl_com, force);                      // func_apply_link_external_force ref=link_origin, abd/misc.py:695-715
+        const float x0 = ext_[0] - tq.x, x1 = ext_[1] - tq.y, x2 = ext_[2] - tq.z, x3 = ext_[3] - force.x, x4 = ext_[4] - force.y, x5 = ext_[5] - force.z;
+        ext[6 * pl + 0] = x0; ext[6 * pl + 1] = x1; ext[6 * pl + 2] = x2; ext[6 * pl + 3] = x3; ext[6 * pl + 4] = x4; ext[6 * pl + 5] = x5;
+        s->cfrc_ang[3 * pl + 0] = x0; s->cfrc_ang[3 * pl + 1] = x1; s->cfrc_ang[3 * pl + 2] = x2;
+        s->cfrc_vel[3 * pl + 0] = x3; s->cfrc_vel[3 * pl + 1] = x4; s->cfrc_vel[3 * pl + 2] = x5;
+      }
+    }
+  }
+  team_sync();
+  PH(20)
+  tk_dynamics<T>(m, e, s, tl, env_valid);
+}
+
 struct RewCtx { float link_vel_xy[8], foot_z[4], foot_xy[8]; float vel_world[3]; int was_reset; };
 // Everything the reward terms read, held in registers: the loads are issued together ahead of the (serial) term loop, so the loop itself
 // never waits on memory.  Terms that mutate env buffers (feet_air_time, forward_progress) update the copy; the caller writes it back.
@@ -4334,10 +4476,17 @@ static void launch_fk_team(go2sim* h, hipStream_t s, int force_update_fixed, con
   else hipLaunchKernelGGL(k_fk_team<64>, gd, b, 0, s, h->P, h->dms, force_update_fixed, cond);
 }
 
-static void launch_dynamics(go2sim* h, hipStream_t s) {
+// `actions` != nullptr: the first dynamics launch of an env step, with the pre-physics part of the step in the same kernel (k_pre_dynamics_team)
+static bool fuse_pre(const go2sim* h) { return h->fuse_fk_dyn && h->dyn_team >= 32; }
+static void launch_dynamics(go2sim* h, hipStream_t s, const float* actions = nullptr) {
   ScopedTimer t(h, s, T_DYN);
   const int T = h->dyn_team;
   dim3 gd((h->B + 64 / T - 1) / (64 / T)), b(WG);
+  if (actions) {
+    if (T == 32) hipLaunchKernelGGL(k_pre_dynamics_team<32>, gd, b, 0, s, h->P, h->dms, h->hcfg, h->dglob, actions, h->seed, h->step_count, h->action_write_idx);
+    else hipLaunchKernelGGL(k_pre_dynamics_team<64>, gd, b, 0, s, h->P, h->dms, h->hcfg, h->dglob, actions, h->seed, h->step_count, h->action_write_idx);
+    return;
+  }
   if (T == 16) hipLaunchKernelGGL(k_dynamics_team<16>, gd, b, 0, s, h->P, h->dms);
   else if (T == 32) hipLaunchKernelGGL(k_dynamics_team<32>, gd, b, 0, s, h->P, h->dms);
   else hipLaunchKernelGGL(k_dynamics_team<64>, gd, b, 0, s, h->P, h->dms);
@@ -4384,8 +4533,8 @@ static void launch_integrate_dynamics(go2sim* h, hipStream_t s) {
 }
 // n substeps of RigidSolver.substep (rigid_solver.py:1116-1184): dynamics | collide, solve | integrate+FK, where the integrate of substep i and the
 // dynamics of substep i + 1 share a launch
-static int launch_substeps(go2sim* h, hipStream_t s, int n) {
-  launch_dynamics(h, s);
+static int launch_substeps(go2sim* h, hipStream_t s, int n, const float* pre_actions = nullptr) {
+  launch_dynamics(h, s, pre_actions);
   for (int i = 0; i < n; ++i) {
     launch_collide_solve(h, s);
     if (i + 1 < n && h->fuse_fk_dyn) launch_integrate_dynamics(h, s);
@@ -4434,10 +4583,14 @@ static bool step_graph_build(go2sim* h, const float* actions, float* obs, float*
   hipGraphNode_t last = nullptr;
   const dim3 ge = grid_for(h->B), be(WG), b64(64);
   void** sl = nullptr;
-  bool ok = graph_add_kernel(h, last, k_env_pre, ge, be, &g.n_pre, &g.p_pre, &sl, h->P, h->dm, h->hcfg, h->dglob, actions, h->seed, h->step_count, h->action_write_idx);
+  auto team_grid = [&](int T) { return dim3((h->B + 64 / T - 1) / (64 / T)); };
+  // first node: the pre-physics part, alone (k_env_pre) or in front of the first dynamics (k_pre_dynamics_team); same per-step argument slots
+  bool ok;
+  if (!fuse_pre(h)) ok = graph_add_kernel(h, last, k_env_pre, ge, be, &g.n_pre, &g.p_pre, &sl, h->P, h->dm, h->hcfg, h->dglob, actions, h->seed, h->step_count, h->action_write_idx);
+  else if (h->dyn_team == 32) ok = graph_add_kernel(h, last, k_pre_dynamics_team<32>, team_grid(32), b64, &g.n_pre, &g.p_pre, &sl, h->P, h->dms, h->hcfg, h->dglob, actions, h->seed, h->step_count, h->action_write_idx);
+  else ok = graph_add_kernel(h, last, k_pre_dynamics_team<64>, team_grid(64), b64, &g.n_pre, &g.p_pre, &sl, h->P, h->dms, h->hcfg, h->dglob, actions, h->seed, h->step_count, h->action_write_idx);
   if (!ok) return false;
   g.a_actions = (const float**)sl[4]; g.a_pre_step = (uint32_t*)sl[6]; g.a_pre_widx = (int*)sl[7];
-  auto team_grid = [&](int T) { return dim3((h->B + 64 / T - 1) / (64 / T)); };
   const int substeps = h->hcfg.i[GO2SIM_IC_SUBSTEPS];
   auto add_dynamics = [&]() {
     const int T = h->dyn_team; const dim3 gd = team_grid(T);
@@ -4456,7 +4609,7 @@ static bool step_graph_build(go2sim* h, const float* actions, float* obs, float*
     return T == 32 ? graph_add_kernel(h, last, k_integrate_fk_dynamics_team<32>, gd, b64, nullptr, nullptr, nullptr, h->P, h->dms)
                    : graph_add_kernel(h, last, k_integrate_fk_dynamics_team<64>, gd, b64, nullptr, nullptr, nullptr, h->P, h->dms);
   };
-  ok = add_dynamics();
+  if (!fuse_pre(h)) ok = add_dynamics();
   for (int i = 0; i < substeps && ok; ++i) {                               // same order as launch_substeps
     { const int T = h->collide_team; const dim3 gc = team_grid(T);
       ok = T == 16 ? graph_add_kernel(h, last, k_collide_team<16>, gc, b64, nullptr, nullptr, nullptr, h->P, h->dm, h->gjk_scratch)
@@ -4846,8 +4999,8 @@ int go2sim_env_step(go2sim_t* h, const float* actions, float* obs, float* priv, 
   }
   if (h->timing && h->ev_n + 64 > TIMING_RING) timing_flush(h);   // all pending events belong to completed launches
   ScopedTimer total(h, s, T_TOTAL);
-  { ScopedTimer t(h, s, T_ENV_PRE); hipLaunchKernelGGL(k_env_pre, g, b, 0, s, h->P, h->dm, h->hcfg, h->dglob, actions, h->seed, h->step_count, h->action_write_idx); }
-  launch_substeps(h, s, h->hcfg.i[GO2SIM_IC_SUBSTEPS]);
+  if (!fuse_pre(h)) { ScopedTimer t(h, s, T_ENV_PRE); hipLaunchKernelGGL(k_env_pre, g, b, 0, s, h->P, h->dm, h->hcfg, h->dglob, actions, h->seed, h->step_count, h->action_write_idx); }
+  launch_substeps(h, s, h->hcfg.i[GO2SIM_IC_SUBSTEPS], fuse_pre(h) ? actions : nullptr);
   {
     ScopedTimer t(h, s, T_ENV_POST);
     hipLaunchKernelGGL(k_env_post_a, g, b, 0, s, h->P, h->dm, h->hcfg, h->dglob, h->dacc, h->seed, h->step_count);
