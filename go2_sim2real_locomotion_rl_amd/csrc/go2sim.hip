@@ -488,7 +488,7 @@ constexpr int MODELS_LDS_BYTES = lds_dma_bytes((int)sizeof(ModelS));
 #define GO2SIM_FLOAT_FIELDS(X)                                                                                       \
   X(qpos, NQ) X(vel, ND) X(ctrl_force, ND) X(ext, NL * 6) X(mass_shift, NL) X(com_shift, NL * 3)                        \
   X(friction_ratio, NG) X(l_pos, NL * 3) X(l_quat, NL * 4) X(cd_vel, NL * 3) X(cd_ang, NL * 3) X(root_com, NL * 3)     \
-  X(contact_force, NL * 3) X(normal_cache, NPAIR * 3) X(geom_friction, NG) X(ctrl_pos, ND) X(ctrl_vel, ND) X(dof_pos, ND) \
+  X(contact_force, NL * 3) X(geom_friction, NG) X(ctrl_pos, ND) X(ctrl_vel, ND) X(dof_pos, ND) \
   /* ---- Go2Env buffers ---- */                                                                                     \
   X(actions, NA) X(last_actions, NA) X(applied_actions, NA) X(action_history, 2 * NA) X(target_dof_pos, NM)            \
   X(e_dof_pos, NM) X(e_dof_vel, NM) X(last_dof_vel, NM) X(torque, NM) X(base_pos, 3) X(base_quat, 4) X(base_lin_vel, 3) \
@@ -506,9 +506,12 @@ constexpr int MODELS_LDS_BYTES = lds_dma_bytes((int)sizeof(ModelS));
   X(cdof_ang, ND * 3) X(cdof_vel, ND * 3) X(cdofd_ang, ND * 3) X(cdofd_vel, ND * 3) X(cinr_inertial, NL * 9)            \
   X(cinr_pos, NL * 3) X(cinr_mass, NL) X(i_pos, NL * 3) X(i_quat, NL * 4) X(g_pos, NG * 3) X(g_quat, NG * 4)              \
   X(sort_value, 2 * NG) X(c_pos, MAXC * 3) X(c_normal, MAXC * 3) X(c_pen, MAXC) X(c_friction, MAXC) X(c_sol, MAXC * 7)    \
-  X(c_force, MAXC * 3) X(efc_force, MAXR)
+  X(c_force, MAXC * 3) X(efc_force, MAXR) X(normal_cache, NPAIR * 3)
 
-#define GO2SIM_AOS_INT_FIELDS(X) X(sort_ig, 2 * NG) X(broad, MAXB * 2) X(c_geom, 2 * MAXC) X(c_link, 2 * MAXC)
+// ncache_valid: one bit per geom pair, set = normal_cache[pair] holds the contact normal of the last narrow phase; clear = the cache entry reads as the
+// zero vector (func_broad_phase / func_convex_convex_contact write zeros there: here they clear a bit of a mask the kernel keeps in LDS)
+constexpr int NCV = (NPAIR + 31) / 32;
+#define GO2SIM_AOS_INT_FIELDS(X) X(sort_ig, 2 * NG) X(broad, MAXB * 2) X(c_geom, 2 * MAXC) X(c_link, 2 * MAXC) X(ncache_valid, NCV)
 
 enum FOff : int {
 #define X(n, c) FO_##n##_, FO_##n##_end = FO_##n##_ + (c) - 1,
@@ -598,7 +601,7 @@ struct E {
 #define AA2(name, W) DEV Arr2<W> name() const { return Arr2<W>{fa + AO(name), 1}; }
 #define AIA(name) DEV Arr<int> name() const { return Arr<int>{ia + AIO(name), 1}; }
   FA(qpos) FA(vel) FA(ctrl_force) FA(ctrl_pos) FA(ctrl_vel) FA(ext) FA(mass_shift) FA3(com_shift) FA(friction_ratio)
-  FA(geom_friction) FA3(normal_cache) FA3(l_pos) FA4(l_quat) FA3(root_com) FA(dof_pos) FA3(cd_vel) FA3(cd_ang) FA3(contact_force)
+  FA(geom_friction) FA3(l_pos) FA4(l_quat) FA3(root_com) FA(dof_pos) FA3(cd_vel) FA3(cd_ang) FA3(contact_force)
   FA(actions) FA(last_actions) FA(applied_actions) FA2(action_history, NA) FA(target_dof_pos) FA(e_dof_pos) FA(e_dof_vel) FA(last_dof_vel)
   FA(torque) FA(base_pos) FA(base_quat) FA(base_lin_vel) FA(base_ang_vel) FA(projected_gravity) FA(base_euler) FA(commands) FA(time_out)
   FA(kp_factors) FA(kd_factors) FA(motor_strength) FA(gravity_offset) FA(current_push_force) FA(push_stored_force) FA(feet_air_time) FA(base_vel_world) FA(last_base_pos_x)
@@ -607,8 +610,8 @@ struct E {
   IA(gjk_fallback) IA(delay_steps) IA(episode_length) IA(reset_buf) IA(push_remaining) IA(foot_contact) IA(last_foot_contact) IA(terrain_row) IA(terrain_key)
   AA(acc) AA(qacc_ws) AA(force) AA(qf_smooth) AA(acc_smooth) AA(qfrc_constraint) AA2(mass_mat, ND) AA3(cdof_ang) AA3(cdof_vel) AA3(cdofd_ang)
   AA3(cdofd_vel) AA9(cinr_inertial) AA3(cinr_pos) AA(cinr_mass) AA3(i_pos) AA4(i_quat) AA3(g_pos) AA4(g_quat) AA(sort_value) AA3(c_pos) AA3(c_normal)
-  AA(c_pen) AA(c_friction) AA2(c_sol, 7) AA3(c_force) AA(efc_force)
-  AIA(sort_ig) AIA(broad) AIA(c_geom) AIA(c_link)
+  AA(c_pen) AA(c_friction) AA2(c_sol, 7) AA3(c_force) AA(efc_force) AA3(normal_cache)
+  AIA(sort_ig) AIA(broad) AIA(c_geom) AIA(c_link) AIA(ncache_valid)
 #undef FA
 #undef FA3
 #undef FA4
@@ -1663,6 +1666,7 @@ struct CollideData {
   float stage[T][5][7];
   int cnt[T];
   unsigned gjk_slot_mask;                             // bit i set = gjk[i] is taken
+  unsigned ncv[NCV];                                  // ncache_valid of this env for the duration of the kernel
 };
 struct ContactStage { float* st; int n; };   // per-lane staging of the (<= 5) contacts of one pair
 
@@ -1673,7 +1677,7 @@ DEV void stage_contact(ContactStage& cs, V3 normal, V3 pos, float pen) {
 }
 
 // func_convex_convex_contact (CCD_ALGORITHM_CODE.MPR branch), narrowphase.py:514-961; contacts go to the lane's staging buffer
-DEV void convex_convex_contact_staged(const Model& m, const E& e, int i_ga, int i_gb, ContactStage& cs, GjkStoreLds* gjk_slots, unsigned* gjk_slot_mask, GjkStoreFull* gjk_full) {
+DEV void convex_convex_contact_staged(const Model& m, const E& e, int i_ga, int i_gb, ContactStage& cs, GjkStoreLds* gjk_slots, unsigned* gjk_slot_mask, GjkStoreFull* gjk_full, unsigned* ncv) {
   const float EPS = m.eps;
   int type_a = m.geoms[i_ga].type, type_b = m.geoms[i_gb].type;
   bool multi_contact = (type_a != GEOM_SPHERE) && (type_b != GEOM_SPHERE);
@@ -1699,7 +1703,7 @@ DEV void convex_convex_contact_staged(const Model& m, const E& e, int i_ga, int 
     }
     if ((multi_contact && is_col_0) || (i_detection == 0)) {
       bool is_mpr_updated = false;
-      V3 normal_ws = normal_cache[i_pair];
+      V3 normal_ws = ((ncv[i_pair >> 5] >> (i_pair & 31)) & 1u) ? (V3)normal_cache[i_pair] : v3(0, 0, 0);
       bool guess_available = (dm_abs(normal_ws.x) > EPS) || (dm_abs(normal_ws.y) > EPS) || (dm_abs(normal_ws.z) > EPS);
       for (int i_mpr = 0; i_mpr < 2; ++i_mpr) {
         if (i_mpr == 1) {
@@ -1738,9 +1742,9 @@ DEV void convex_convex_contact_staged(const Model& m, const E& e, int i_ga, int 
       if (is_col_0) {
         stage_contact(cs, normal, contact_pos, penetration);
         if (multi_contact) contact_orthogonals(m, e, i_ga, i_gb, normal, axis_0, axis_1);
-        normal_cache[i_pair] = normal;
+        normal_cache[i_pair] = normal; atomicOr(&ncv[i_pair >> 5], 1u << (i_pair & 31));
       } else {
-        normal_cache[i_pair] = v3(0, 0, 0);
+        atomicAnd(&ncv[i_pair >> 5], ~(1u << (i_pair & 31)));          // normal_cache[i_pair] := 0
       }
     } else if (multi_contact && is_col) {
       V3 contact_point_a = transform_by_quat((contact_pos - 0.5f * penetration * normal) - contact_pos_0, inv_quat(qrot)) + contact_pos_0;
@@ -1852,6 +1856,7 @@ __global__ __launch_bounds__(64) void k_collide_team(Pool P, const Model* __rest
   CollideData<T>* s = &lds[slot];
   const float inf = dm_bits2f(0x7f800000u);
   if (tl == 0) s->gjk_slot_mask = 0u;                                   // made visible by the barriers of the broad phase
+  for (int i = tl; i < NCV; i += T) s->ncv[i] = (unsigned)e.ncache_valid()[i];
   PH_BEGIN
   // ---- loads of the prologue first: previous contact count, first-step flag, the persistent sort order, geom poses ----
   const int nc_old = e.n_contacts()[0];
@@ -1940,7 +1945,7 @@ __global__ __launch_bounds__(64) void k_collide_team(Pool P, const Model* __rest
     if (packed >= 0 && rs < rmax_first) {
       bool any1 = (amx.x <= bmn.x) || (amx.y <= bmn.y) || (amx.z <= bmn.z);
       bool any2 = (amn.x >= bmx.x) || (amn.y >= bmx.y) || (amn.z >= bmx.z);
-      if (any1 || any2) e.normal_cache()[pidx] = v3(0, 0, 0);
+      if (any1 || any2) atomicAnd(&s->ncv[pidx >> 5], ~(1u << (pidx & 31)));   // normal_cache[pidx] := 0
       else cmask |= 1u << it;
     }
   }
@@ -1986,7 +1991,7 @@ __global__ __launch_bounds__(64) void k_collide_team(Pool P, const Model* __rest
       i_ga = pk & 0xff; i_gb = pk >> 8;
       if (m.geoms[i_ga].type > m.geoms[i_gb].type) { int t = i_ga; i_ga = i_gb; i_gb = t; }
       const bool with_terrain = m.geoms[i_gb].type == GEOM_TERRAIN;
-      if (!with_terrain) convex_convex_contact_staged(m, e, i_ga, i_gb, cs, s->gjk, &s->gjk_slot_mask, &gjk_scratch[(size_t)b * T + tl]);
+      if (!with_terrain) convex_convex_contact_staged(m, e, i_ga, i_gb, cs, s->gjk, &s->gjk_slot_mask, &gjk_scratch[(size_t)b * T + tl], s->ncv);
     }
     s->cnt[tl] = cs.n;
     team_sync();
@@ -2105,6 +2110,8 @@ __global__ __launch_bounds__(64) void k_collide_team(Pool P, const Model* __rest
     }
   }
   if (tl == 0) { e.n_broad()[0] = n_broad; e.n_contacts()[0] = imn(nc_run, m.max_contact_pairs); }
+  team_sync();
+  for (int i = tl; i < NCV; i += T) e.ncache_valid()[i] = (int)s->ncv[i];
   PH(33)
 }
 
@@ -3897,7 +3904,7 @@ __global__ __launch_bounds__(WG) void k_env_respawn(Pool P, const Model* __restr
   for (int d = 0; d < ND; ++d) vel[d] = 0.0f;
   e.err()[0] = 0; e.is_warmstart()[0] = 0;                              // set_dofs_position: rigid_solver.py:2403-2410
   { auto qacc_ws = e.qacc_ws(); for (int d = 0; d < ND; ++d) qacc_ws[d] = 0.0f; }
-  { auto ncache = e.normal_cache(); for (int p = 0; p < NPAIR; ++p) ncache[p] = v3(0, 0, 0); }
+  { auto ncv = e.ncache_valid(); for (int p = 0; p < NCV; ++p) ncv[p] = 0; }   // normal cache := zeros
   float bq[4];
   for (int k = 0; k < 4; ++k) bq[k] = quat ? quat[4 * t + k] : c.f[GO2SIM_FC_BASE_INIT_QUAT0 + k];
   auto base_pos = e.base_pos(); auto base_quat = e.base_quat();
@@ -4018,7 +4025,7 @@ DEV void env_reset_one(const Model& m, const DCfg& c, const Glob& g, const E& e,
   for (int d = 0; d < ND; ++d) vel[d] = 0.0f;
   e.err()[0] = 0; e.is_warmstart()[0] = 0;
   { auto qacc_ws = e.qacc_ws(); for (int d = 0; d < ND; ++d) qacc_ws[d] = 0.0f; }
-  { auto ncache = e.normal_cache(); for (int p = 0; p < NPAIR; ++p) ncache[p] = v3(0, 0, 0); }
+  { auto ncv = e.ncache_valid(); for (int p = 0; p < NCV; ++p) ncv[p] = 0; }   // normal cache := zeros
   float bpx = c.f[GO2SIM_FC_BASE_INIT_POS0], bpy = c.f[GO2SIM_FC_BASE_INIT_POS0 + 1], bpz = c.f[GO2SIM_FC_BASE_INIT_POS0 + 2];
   float bq[4] = {c.f[GO2SIM_FC_BASE_INIT_QUAT0], c.f[GO2SIM_FC_BASE_INIT_QUAT0 + 1], c.f[GO2SIM_FC_BASE_INIT_QUAT0 + 2], c.f[GO2SIM_FC_BASE_INIT_QUAT0 + 3]};
   if (c.i[GO2SIM_IC_USE_TERRAIN]) {                                    // _get_terrain_spawn_pos, go2_env_stair.py:856-871, :1531-1540
@@ -4324,8 +4331,8 @@ __global__ __launch_bounds__(WG) void k_scene_reset_clear(Pool P) {   // RigidSo
   E e(P, b);
   auto vel = e.vel(); auto acc = e.acc(); auto qacc_ws = e.qacc_ws();
   for (int d = 0; d < ND; ++d) { vel[d] = 0.0f; acc[d] = 0.0f; qacc_ws[d] = 0.0f; }
-  auto ncache = e.normal_cache();
-  for (int p = 0; p < NPAIR; ++p) ncache[p] = v3(0, 0, 0);
+  auto ncv = e.ncache_valid();
+  for (int p = 0; p < NCV; ++p) ncv[p] = 0;                               // normal cache := zeros
   int nc = e.n_contacts()[0];
   for (int i_c = 0; i_c < nc; ++i_c) { e.c_link()[i_c] = -1; e.c_link()[MAXC + i_c] = -1; e.c_geom()[i_c] = -1; e.c_geom()[MAXC + i_c] = -1; e.c_pen()[i_c] = 0.0f; e.c_pos()[i_c] = v3(0, 0, 0); e.c_normal()[i_c] = v3(0, 0, 0); e.c_force()[i_c] = v3(0, 0, 0); }
   e.n_contacts()[0] = 0; e.err()[0] = 0; e.is_warmstart()[0] = 0; e.n_con()[0] = 0;
@@ -4341,8 +4348,8 @@ __global__ __launch_bounds__(WG) void k_reset_caches(Pool P, const int* __restri
   e.err()[0] = 0; e.is_warmstart()[0] = 0;
   auto qacc_ws = e.qacc_ws();
   for (int d = 0; d < ND; ++d) qacc_ws[d] = 0.0f;
-  auto ncache = e.normal_cache();
-  for (int p = 0; p < NPAIR; ++p) ncache[p] = v3(0, 0, 0);
+  auto ncv = e.ncache_valid();
+  for (int p = 0; p < NCV; ++p) ncv[p] = 0;                               // normal cache := zeros
 }
 __global__ __launch_bounds__(WG) void k_set_friction(Pool P, float mu) {
   int b = blockIdx.x * WG + threadIdx.x;
@@ -4379,6 +4386,22 @@ __global__ void k_rows_to_aos(const int* __restrict__ rows, int* __restrict__ re
   if (t >= k * B) return;
   int j = t / B, b = t % B;
   rec[(size_t)b * stride + off + j] = rows[t];
+}
+// F_NORMAL_CACHE through the field API: rows of pairs whose valid bit is clear read as zeros; a set_field makes every uploaded entry valid
+__global__ void k_ncache_mask_rows(Pool P, float* __restrict__ rows) {
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= NPAIR * P.B) return;
+  int p = t / P.B, b = t % P.B;
+  E e(P, b);
+  if (!(((unsigned)e.ncache_valid()[p >> 5] >> (p & 31)) & 1u)) { rows[(size_t)(3 * p) * P.B + b] = 0.0f; rows[(size_t)(3 * p + 1) * P.B + b] = 0.0f; rows[(size_t)(3 * p + 2) * P.B + b] = 0.0f; }
+}
+__global__ void k_ncache_set_valid(Pool P) {
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= NCV * P.B) return;
+  int w = t / P.B, b = t % P.B;
+  E e(P, b);
+  const int n = NPAIR - 32 * w;
+  e.ncache_valid()[w] = (int)(n >= 32 ? 0xffffffffu : ((1u << n) - 1u));
 }
 __global__ void k_gather(const void* __restrict__ src, void* __restrict__ dst, int k, int B) {
   int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -4793,7 +4816,7 @@ static int field_lookup(int field, int* k, int* is_int, int* off, int* is_aos = 
     case GO2SIM_F_CONTACT_POS: kk = MAXC * 3; oo = AO(c_pos); aa = 1; break;
     case GO2SIM_F_CONTACT_NORMAL: kk = MAXC * 3; oo = AO(c_normal); aa = 1; break;
     case GO2SIM_F_CONTACT_PEN: kk = MAXC; oo = AO(c_pen); aa = 1; break;
-    case GO2SIM_F_NORMAL_CACHE: kk = NPAIR * 3; oo = FO(normal_cache); break;
+    case GO2SIM_F_NORMAL_CACHE: kk = NPAIR * 3; oo = AO(normal_cache); aa = 1; break;   // masked by ncache_valid: go2sim_get_field / go2sim_set_field
     case GO2SIM_F_SORT_VALUE: kk = 2 * NG; oo = AO(sort_value); aa = 1; break;
     case GO2SIM_F_GEOM_FRICTION: kk = NG; oo = FO(geom_friction); break;
     case GO2SIM_F_EFC_FORCE: kk = MAXR; oo = AO(efc_force); aa = 1; break;
@@ -4835,6 +4858,7 @@ int go2sim_get_field(go2sim_t* h, int field, void* dst, void* stream) {
   if (aa) {
     const int* rec = ii ? h->P.ia : (const int*)h->P.fa;
     hipLaunchKernelGGL(k_aos_to_rows, dim3((k * h->B + 255) / 256), dim3(256), 0, s, rec, ii ? AISTRIDE : ASTRIDE, off, k, h->B, (int*)dst);
+    if (field == GO2SIM_F_NORMAL_CACHE) hipLaunchKernelGGL(k_ncache_mask_rows, dim3((NPAIR * h->B + 255) / 256), dim3(256), 0, s, h->P, (float*)dst);
     HIPCHK(hipGetLastError());
   } else {
     void* p = ii ? (void*)(h->P.i + (size_t)off * h->B) : (void*)(h->P.f + (size_t)off * h->B);
@@ -4849,6 +4873,7 @@ int go2sim_set_field(go2sim_t* h, int field, const void* src, void* stream) {
   if (aa) {
     int* rec = ii ? h->P.ia : (int*)h->P.fa;
     hipLaunchKernelGGL(k_rows_to_aos, dim3((k * h->B + 255) / 256), dim3(256), 0, s, (const int*)src, rec, ii ? AISTRIDE : ASTRIDE, off, k, h->B);
+    if (field == GO2SIM_F_NORMAL_CACHE) hipLaunchKernelGGL(k_ncache_set_valid, dim3((NCV * h->B + 255) / 256), dim3(256), 0, s, h->P);
     HIPCHK(hipGetLastError());
   } else {
     void* p = ii ? (void*)(h->P.i + (size_t)off * h->B) : (void*)(h->P.f + (size_t)off * h->B);
@@ -4878,8 +4903,8 @@ __global__ void k_set_link0_pose(Pool P, V3 pos) {
   E e(P, b);
   e.l_pos()[0] = pos; e.l_quat()[0] = qident();
   e.first_time()[0] = 1; e.is_warmstart()[0] = 0;
-  auto nc = e.normal_cache();
-  for (int p = 0; p < NPAIR; ++p) nc[p] = v3(0, 0, 0);
+  auto ncv = e.ncache_valid();
+  for (int p = 0; p < NCV; ++p) ncv[p] = 0;
 }
 int go2sim_set_terrain(go2sim_t* h, const int16_t* hf, int rows, int cols, float horizontal_scale, float vertical_scale, const float* origin, void* stream) {
   if (!h || !hf || rows < 2 || cols < 2 || !origin || !(horizontal_scale > 0.0f)) return GO2SIM_E_BADARG;

@@ -357,3 +357,33 @@ def test_go2env_errno_poll_raises_like_scene_step(hip_lib, blob):
             env.step(a)
     with pytest.raises(Go2SimError):
         env.check_errno()
+
+
+def test_normal_cache_field_semantics(oracle_lib, hip_lib, blob):
+    """The contact-normal cache (collider `contact_cache.normal`, narrowphase.py:689-760) is kept on the device as per-env records plus a valid-bit
+    mask instead of explicit zero vectors.  Through the field API it must behave like the plain array of the reference: an uploaded array reads
+    back unchanged (zeros included), continues the simulation exactly like the oracle given the same upload, and reset_caches zeroes it."""
+    n = 32
+    cpu, gpu = CpuEnv(oracle_lib, blob, n, seed=5), GpuEnv(hip_lib, blob, n, seed=5)
+    cpu.reset(); gpu.reset()
+    acts = make_actions(12, n, seed=5, kind="0.5")
+    for a in acts[:6]:
+        cpu.step(a); gpu.step(a)
+    nc = cpu.field("F_NORMAL_CACHE")
+    assert np.abs(nc).max() > 0 and bits_equal(nc, gpu.field("F_NORMAL_CACHE"))
+    rng = np.random.default_rng(0)
+    up = nc.copy()
+    up[:, ::2] = 0.0                                             # wipe the guesses of every other env
+    sel = rng.integers(0, up.shape[0] // 3, 20)
+    for p in sel:                                                # and plant (non-unit) guesses for a few more pairs
+        up[3 * p:3 * p + 3, 1::2] = rng.standard_normal((3, 1)).astype(np.float32)
+    cpu.sim.set_field_np(F("F_NORMAL_CACHE"), up); gpu.set_field("F_NORMAL_CACHE", up)
+    assert bits_equal(gpu.field("F_NORMAL_CACHE"), up)
+    for s, a in enumerate(acts[6:]):
+        oc, pc, rc, dc, tc = cpu.step(a)
+        og, pg, rg, dg, tg = gpu.step(a)
+        assert bits_equal(oc, og) and bits_equal(rc, rg) and np.array_equal(dc, dg), s
+        assert bits_equal(cpu.field("F_NORMAL_CACHE"), gpu.field("F_NORMAL_CACHE")), s
+        assert bits_equal(cpu.field("F_CONTACT_PEN"), gpu.field("F_CONTACT_PEN")), s
+    gpu.sim.reset_caches(None, 0); cpu.sim.reset_caches(None, 0)
+    assert not gpu.field("F_NORMAL_CACHE").any() and not cpu.field("F_NORMAL_CACHE").any()
