@@ -45,6 +45,20 @@ def build_hip(force=False, verbose=True):
     return HIP_LIB
 
 
+def build_hip_variant(name, extra_flags, force=False, verbose=True):
+    """A diagnostic BUILD of the product library with extra -D flags (tools/lib_<name>.so); test infrastructure for builds the
+    product does not ship -- e.g. ("bracket_inline", ["-DGO2SIM_BRACKET_INLINE"]), see DESIGN.md "update_bracket"."""
+    out = os.path.join(REPO_ROOT, "tools", f"lib_{name}.so")
+    if not force and _newer(out, HIP_SRC, HIP_SRC_POLICY, HIP_HDR_GJK, *_headers()):
+        return out
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    cmd = [hipcc, *HIP_FLAGS, *extra_flags, HIP_SRC, HIP_SRC_POLICY, "-o", out]
+    if verbose:
+        print("[build]", " ".join(cmd), file=sys.stderr)
+    subprocess.run(cmd, check=True)
+    return out
+
+
 def build_oracle(force=False, verbose=True):
     if not force and _newer(ORACLE_LIB, ORACLE_SRC, ORACLE_SRC_POLICY, os.path.join(REPO_ROOT, "oracle", "gjk_epa_cpu.h"), *_headers()):
         return ORACLE_LIB

@@ -369,11 +369,13 @@ DG_NOUNROLL
   for (int k = 0; k < DG_EPA_MAX_IT; ++k) {
     const int prev = nearest;
     float lower2 = DG_FLOAT_MAX * DG_FLOAT_MAX;
+    { PHD_BEGIN
     for (int i = 0; i < c.nmap; ++i) {                                   // candidate face closest to the origin
       const int i_f = st.map[i];
       const float d2 = st.f[i_f].d2;
       if (d2 < lower2) { lower2 = d2; nearest = i_f; }
     }
+    PHD(56) }
     if (lower2 > upper2 || nearest == -1) { nearest = prev; break; }
     lower = dm_sqrt(lower2);
     const V3 dir = st.f[nearest].n;
@@ -390,13 +392,16 @@ DG_NOUNROLL
       for (int i = 0; i < c.nv && !repeated; ++i) repeated = (i != wi) && st.v[i].id1 == st.v[wi].id1 && st.v[i].id2 == st.v[wi].id2;
       if (repeated) break;
     }
+    { PHD_BEGIN
     dg_horizon(st, c, nearest, w);
+    PHD(58) }
     if (c.overflow) return 0.0f;
     if (c.hz_n < 3) { nearest = -1; break; }
     const int nfaces = c.nf, nedges = c.hz_n;
     if (nfaces + nedges >= DG_MAX_FACES) break;                          // the reference's capacity rule (part of the algorithm)
     if (nfaces + nedges > S::CAP_F) { c.overflow = true; return 0.0f; }   // this store is too small: the caller reruns on the full one
     bool ok = true;
+    { PHD_BEGIN
     for (int i = 0; i < nedges; ++i) {
       const int f0 = nfaces + i, f1 = nfaces + (i + 1) % nedges;
       const int h_f = st.hz_f[i], h_e = st.hz_e[i];
@@ -408,6 +413,7 @@ DG_NOUNROLL
       const float d2 = st.f[c.nf - 1].d2;
       if (d2 >= lower2 - eps && d2 <= upper2 + eps) { st.map[c.nmap] = (short)f0; st.f[f0].map_idx = (short)c.nmap; c.nmap += 1; }
     }
+    PHD(60) }
     if (!ok) { nearest = -1; break; }
     c.hz_n = 0;
     if (c.nmap == 0 || nearest == -1) { nearest = -1; break; }

@@ -7,6 +7,7 @@ from bench import source_hash
 
 fetch, write = json.load(open(sys.argv[1])), json.load(open(sys.argv[2]))
 CLASS = [("k_constraint_solve", r"^k_constraint_solve_team"), ("k_collide", r"^k_collide_team"), ("k_dynamics", r"^k_dynamics_team"),
+         ("k_pre_dynamics", r"^k_pre_dynamics_team"),
          ("k_integrate_fk", r"^k_integrate_fk_team"), ("k_integrate_fk_dynamics", r"^k_integrate_fk_dynamics_team"), ("k_env_pre", r"^k_env_pre"),
          ("k_env_post_a", r"^k_env_post_a"), ("k_env_post_b", r"^k_env_post_b"), ("k_env_globals", r"^k_env_globals")]
 kernels = {}
@@ -16,13 +17,14 @@ for name, pat in CLASS:
     if f and w:
         kernels[name] = {"fetch_size_kb": round(f[0]["FETCH_SIZE"], 1), "write_size_kb": round(w[0]["WRITE_SIZE"], 1), "launches_averaged": f[0]["n"],
                          "avg_us_under_pmc": round(f[0]["avg_us"], 1)}
-per_step = {"k_constraint_solve": 2, "k_collide": 2, "k_dynamics": 1, "k_integrate_fk": 1, "k_integrate_fk_dynamics": 1, "k_env_pre": 1, "k_env_post_a": 1,
-            "k_env_post_b": 1, "k_env_globals": 1}
+# launches per env step (2 substeps): k_dynamics / k_env_pre / k_env_globals only run outside the fused step (scene_step, GO2SIM_NO_FUSE, reset)
+per_step = {"k_constraint_solve": 2, "k_collide": 2, "k_pre_dynamics": 1, "k_integrate_fk": 1, "k_integrate_fk_dynamics": 1, "k_env_post_a": 1, "k_env_post_b": 1,
+            "k_dynamics": 0, "k_env_pre": 0, "k_env_globals": 0}
 step_bytes = sum((2 * v["fetch_size_kb"] + v["write_size_kb"]) * 1024 * per_step[k] for k, v in kernels.items())
 doc = {"_comment": "HBM-side traffic per launch, rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (MI355X_MICROARCH.md, HBM): "
                    "bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 -- FETCH_SIZE is doubled (gfx950 tallies 128-B requests at 64 B); 4-byte-per-lane "
                    "accesses are outside the guide's calibration, and Infinity-Cache hits are counted, so read it as L2-miss traffic, +-2x.",
        "command": sys.argv[4], "source_sha256": source_hash(), "kernels": kernels,
-       "env_step_bytes": int(step_bytes), "env_step_launches": per_step}
+       "env_step_bytes": int(step_bytes), "env_step_launches": {k: v for k, v in per_step.items() if v and k in kernels}}
 json.dump(doc, open(sys.argv[3], "w"), indent=1)
 print(json.dumps(doc, indent=1))
