@@ -1647,6 +1647,7 @@ struct CollideData {
   struct Broad {
     alignas(16) float amin[NG * 4], amax[NG * 4];   // xyz + pad: one 128-bit LDS read per corner
     float sval[2 * NG], sval_sorted[2 * NG];
+    alignas(16) unsigned long long skey[2 * NG];      // (order-preserving integer image of the endpoint value) << 8 | position before the sort
     int sig[2 * NG], sig_sorted[2 * NG];
     alignas(8) int rank_mm[NG * 2];                  // (rank of the min endpoint, rank of the max endpoint) per geom
     int cand_key[MAXB], cand_pair[MAXB];
@@ -1904,14 +1905,22 @@ __global__ __launch_bounds__(64) void k_collide_team(Pool P, const Model* __rest
     int sg = first ? ((i >> 1) | ((i & 1) ? 0x100 : 0)) : s->bp.sig[i];
     int g = sg & 0xff;
     s->bp.sig[i] = sg;
-    s->bp.sval[i] = (sg & 0x100) ? s->bp.amax[4 * g] : s->bp.amin[4 * g];
+    const float v = (sg & 0x100) ? s->bp.amax[4 * g] : s->bp.amin[4 * g];
+    s->bp.sval[i] = v;
+    // rank of endpoint i = #{j : w_j < v  or  (w_j == v and j < i)}  =  #{j : key_j < key_i} with key = (image(value), position): one 64-bit
+    // compare per pair instead of two float compares and the tie logic.  image() is monotone on the non-NaN floats and maps -0 and +0 to one value
+    // (v + 0.0f), like the float compares it replaces.
+    unsigned u = (unsigned)__float_as_int(v + 0.0f);
+    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+    s->bp.skey[i] = ((unsigned long long)u << 8) | (unsigned long long)i;
   }
   team_sync();
   for (int i = tl; i < n2; i += T) {
     float v = s->bp.sval[i];
+    const unsigned long long key = s->bp.skey[i];
     int r = 0;
 #pragma unroll
-    for (int j = 0; j < 2 * NG; ++j) { float w = s->bp.sval[j]; r += (w < v) || (w == v && j < i); }
+    for (int j = 0; j < 2 * NG; ++j) r += (s->bp.skey[j] < key) ? 1 : 0;
     int sg = s->bp.sig[i];
     s->bp.sval_sorted[r] = v; s->bp.sig_sorted[r] = sg;
     s->bp.rank_mm[2 * (sg & 0xff) + ((sg & 0x100) ? 1 : 0)] = r;
