@@ -1070,21 +1070,62 @@ DEV void tk_dynamics(const MT& m, const E& e, DynData* s, int tl, bool env_valid
   }
   team_sync();
   PH(22)
-  // ---- reverse-order LDL^T ----
+  // ---- reverse-order LDL^T (func_factor_mass, forward_dynamics.py) ----
+  if constexpr (T >= ND) {
+    // Lane j keeps row j of the factor in registers.  Step i (i = ND-1 .. 0): lane i publishes its (final, unscaled) row in its LDS home, every
+    // row j < i reads it and does L[j][k] -= (L[i][j] * D_inv) * L[i][k] for k <= j -- the same operands in the same order as the element loop of
+    // the reference, one LDS round trip and one fence per step.  Row i's own scaling by D_inv touches nothing a later step reads, so every
+    // lane applies it to its registers at the end.  (Register entries right of the diagonal are don't-care values: they are never published.)
+    const int row = tl < ND ? tl : ND - 1;
+    float Lr[ND];
 #pragma unroll
-  for (int i_d_ = 0; i_d_ < ND; ++i_d_) {
-    const int i_d = ND - i_d_ - 1;
-    float D_inv = 1.0f / s->L[i_d * ND + i_d];
-    for (int idx = tl; idx < i_d * (i_d + 1) / 2; idx += T) {
-      int j_d, k_d;
-      tri_index(m, idx, j_d, k_d);
-      float a = s->L[i_d * ND + j_d] * D_inv;
-      s->L[j_d * ND + k_d] -= a * s->L[i_d * ND + k_d];
+    for (int k = 0; k < ND; ++k) Lr[k] = s->L[row * ND + k];
+    float dinv_own = 0.0f;
+#pragma unroll
+    for (int i_d_ = 0; i_d_ < ND; ++i_d_) {
+      const int i_d = ND - i_d_ - 1;
+      if (i_d_ > 0) {                                                     // (the last row has not changed: its LDS copy is current)
+        if (tl == i_d) {
+#pragma unroll
+          for (int k = 0; k <= i_d; ++k) s->L[i_d * ND + k] = Lr[k];
+        }
+        team_sync();
+      }
+      float ri[ND];
+#pragma unroll
+      for (int k = 0; k <= i_d; ++k) ri[k] = s->L[i_d * ND + k];
+      const float lij = s->L[i_d * ND + (row < i_d ? row : 0)];
+      const float D_inv = 1.0f / ri[i_d];
+      if (row == i_d) dinv_own = D_inv;
+      const bool act = row < i_d;
+      const float a = lij * D_inv;
+#pragma unroll
+      for (int k = 0; k < i_d; ++k) { const float nv = Lr[k] - a * ri[k]; Lr[k] = act ? nv : Lr[k]; }
     }
     team_sync();
-    for (int j_d = tl; j_d < i_d; j_d += T) s->L[i_d * ND + j_d] = s->L[i_d * ND + j_d] * D_inv;
-    if (tl == 0) { s->Dinv[i_d] = D_inv; s->L[i_d * ND + i_d] = 1.0f; }
+    if (tl < ND) {
+#pragma unroll
+      for (int k = 0; k < ND; ++k) if (k < row) s->L[row * ND + k] = Lr[k] * dinv_own;
+      s->L[row * ND + row] = 1.0f;
+      s->Dinv[row] = dinv_own;
+    }
     team_sync();
+  } else {
+#pragma unroll
+    for (int i_d_ = 0; i_d_ < ND; ++i_d_) {
+      const int i_d = ND - i_d_ - 1;
+      float D_inv = 1.0f / s->L[i_d * ND + i_d];
+      for (int idx = tl; idx < i_d * (i_d + 1) / 2; idx += T) {
+        int j_d, k_d;
+        tri_index(m, idx, j_d, k_d);
+        float a = s->L[i_d * ND + j_d] * D_inv;
+        s->L[j_d * ND + k_d] -= a * s->L[i_d * ND + k_d];
+      }
+      team_sync();
+      for (int j_d = tl; j_d < i_d; j_d += T) s->L[i_d * ND + j_d] = s->L[i_d * ND + j_d] * D_inv;
+      if (tl == 0) { s->Dinv[i_d] = D_inv; s->L[i_d * ND + i_d] = 1.0f; }
+      team_sync();
+    }
   }
   PH(23)
   // ---- applied / passive joint forces ----
