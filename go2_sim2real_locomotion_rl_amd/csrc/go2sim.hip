@@ -3590,13 +3590,21 @@ DEV void load_rew_state(const DCfg& c, const E& e, RewState& rs) {
   }
 }
 // reward terms, go2_env_walk.py:1251-1366
-DEV float reward_term(const Model& m, const DCfg& c, RewState& rs, int id, const RewCtx& rc) {
+// the command gates shared by several terms (evaluated once per env and step, not once per term)
+struct RewGates { float still, moving; };
+DEV RewGates reward_gates(const RewState& rs) {
+  const float c0 = rs.cmd[0], c1 = rs.cmd[1], c2 = rs.cmd[2];
+  const float cmd_norm = dm_sqrt(c0 * c0 + c1 * c1 + c2 * c2);
+  RewGates g;
+  g.still = (cmd_norm < 0.1f) ? 1.0f : 0.0f;
+  g.moving = (dm_sqrt(c0 * c0 + c1 * c1) > 0.1f) ? 1.0f : 0.0f;
+  return g;
+}
+DEV float reward_term(const Model& m, const DCfg& c, RewState& rs, int id, const RewCtx& rc, const RewGates& gt) {
   const float dt = c.f[GO2SIM_FC_DT];
   const float* cmd = rs.cmd; const float* blv = rs.blv; const float* bav = rs.bav; const float* dof_pos = rs.dof_pos; const float* dof_vel = rs.dof_vel;
   float c0 = cmd[0], c1 = cmd[1], c2 = cmd[2];
-  float cmd_norm = dm_sqrt(c0 * c0 + c1 * c1 + c2 * c2);
-  float still = (cmd_norm < 0.1f) ? 1.0f : 0.0f;
-  float moving = (dm_sqrt(c0 * c0 + c1 * c1) > 0.1f) ? 1.0f : 0.0f;
+  const float still = gt.still, moving = gt.moving;
   switch (id) {
     case GO2SIM_R_TRACKING_LIN_VEL: { float d0 = c0 - blv[0], d1 = c1 - blv[1]; return dm_exp(-(d0 * d0 + d1 * d1) / c.f[GO2SIM_FC_TRACKING_SIGMA]); }
     case GO2SIM_R_TRACKING_ANG_VEL: { float d = c2 - bav[2]; return dm_exp(-(d * d) / c.f[GO2SIM_FC_TRACKING_SIGMA]); }
@@ -3747,6 +3755,7 @@ __global__ __launch_bounds__(WG) void k_env_post_a(Pool P, const Model* __restri
   E e(P, b);
   const int nrew = c.i[GO2SIM_IC_N_REWARDS];
   const bool base_env = c.i[GO2SIM_IC_ENV_KIND] == 1;               // base env: rewards follow the reset (k_env_post_b_team)
+  PH_BEGIN
   // ---- loads ----
   int ep_len = e.episode_length()[0] + 1;
   int bl = c.i[GO2SIM_IC_BASE_LINK];
@@ -3779,6 +3788,7 @@ __global__ __launch_bounds__(WG) void k_env_post_a(Pool P, const Model* __restri
 #pragma unroll
     for (int k = 0; k < NREW; ++k) s_es[k][ln] = es_[k];
   }
+  PH(12)
   // ---- stores start here ----
   { auto ext = e.ext(); for (int i = 0; i < NL * 6; ++i) ext[i] = 0.0f; }
   e.episode_length()[0] = ep_len;
@@ -3833,13 +3843,17 @@ __global__ __launch_bounds__(WG) void k_env_post_a(Pool P, const Model* __restri
   e.time_out()[0] = time_out;
   float rew = 0.0f;
   float tracking_int = 0.0f;
+  PH(13)
   const float fat0[4] = {rs.fat[0], rs.fat[1], rs.fat[2], rs.fat[3]};
   const float last_x0 = rs.last_x;
+  const RewGates gates = reward_gates(rs);
+  int id_next = c.i[GO2SIM_IC_REWARD_ID0]; float scale_next = c.f[GO2SIM_FC_REWARD_SCALE0];
   for (int k = 0; k < nrew; ++k) {
-    int id = c.i[GO2SIM_IC_REWARD_ID0 + k];
+    const int id = id_next; const float scale = scale_next;
+    { const int kn = (k + 1 < NREW) ? k + 1 : k; id_next = c.i[GO2SIM_IC_REWARD_ID0 + kn]; scale_next = c.f[GO2SIM_FC_REWARD_SCALE0 + kn]; }   // the table reads of the next term overlap this one
     float es = s_es[k][ln];
     if (!base_env) {
-      float r = reward_term(m, c, rs, id, rc) * c.f[GO2SIM_FC_REWARD_SCALE0 + k];
+      float r = reward_term(m, c, rs, id, rc, gates) * scale;
       s_r[k][ln] = r;
       rew = rew + r;
       es = es + r;
@@ -3847,15 +3861,7 @@ __global__ __launch_bounds__(WG) void k_env_post_a(Pool P, const Model* __restri
     }
     if (id == GO2SIM_R_TRACKING_LIN_VEL || id == GO2SIM_R_TRACKING_ANG_VEL) tracking_int = tracking_int + es;
   }
-  if (!base_env) {
-    e.rew()[0] = rew;
-    auto rew_terms = e.rew_terms(); auto episode_sums = e.episode_sums();
-    for (int k = 0; k < nrew; ++k) { rew_terms[k] = s_r[k][ln]; episode_sums[k] = s_es[k][ln]; }
-    auto fat = e.feet_air_time();
-#pragma unroll
-    for (int i = 0; i < 4; ++i) if (rs.fat[i] != fat0[i]) fat[i] = rs.fat[i];
-    if (rs.last_x != last_x0) e.last_base_pos_x()[0] = rs.last_x;
-  }
+  PH(14)
   if (rst) {
     float ep_steps = fmx((float)ep_len, 1.0f);
     float ep_seconds = ep_steps * c.f[GO2SIM_FC_DT];
@@ -3866,8 +3872,10 @@ __global__ __launch_bounds__(WG) void k_env_post_a(Pool P, const Model* __restri
   }
   // The single-thread part of the step (curriculum state machine, "global" DR draws: the quantities the reference keeps in Python scalars)
   // runs in whichever workgroup finishes last, instead of in a kernel of its own.
+  PH(15)
   __threadfence();
   __syncthreads();
+  PH(16)
   if (threadIdx.x == 0) {
     const int ticket = atomicAdd(&acc->done, 1);
     if (ticket == (int)gridDim.x - 1) {
@@ -3875,6 +3883,17 @@ __global__ __launch_bounds__(WG) void k_env_post_a(Pool P, const Model* __restri
       acc->done = 0;
       env_globals_body(c, *gp, acc, seed, 1);
     }
+  }
+  PH(17)
+  // the per-term outputs go out last: nothing in this kernel reads them back, and the fence above then only waits for the statistics
+  if (!base_env) {
+    e.rew()[0] = rew;
+    auto rew_terms = e.rew_terms(); auto episode_sums = e.episode_sums();
+    for (int k = 0; k < nrew; ++k) { rew_terms[k] = s_r[k][ln]; episode_sums[k] = s_es[k][ln]; }
+    auto fat = e.feet_air_time();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) if (rs.fat[i] != fat0[i]) fat[i] = rs.fat[i];
+    if (rs.last_x != last_x0) e.last_base_pos_x()[0] = rs.last_x;
   }
 }
 
@@ -4253,9 +4272,10 @@ __global__ __launch_bounds__(64) void k_env_post_b_team(Pool P, const Model* __r
         for (int k = 0; k < 4; ++k) rs.fc[k] = fc[k];
       }
       float rew = 0.0f;
+      const RewGates gates = reward_gates(rs);
       auto rew_terms = e.rew_terms(); auto episode_sums = e.episode_sums();
       for (int k = 0; k < c.i[GO2SIM_IC_N_REWARDS]; ++k) {
-        float r = reward_term(m, c, rs, c.i[GO2SIM_IC_REWARD_ID0 + k], rc) * c.f[GO2SIM_FC_REWARD_SCALE0 + k];
+        float r = reward_term(m, c, rs, c.i[GO2SIM_IC_REWARD_ID0 + k], rc, gates) * c.f[GO2SIM_FC_REWARD_SCALE0 + k];
         rew_terms[k] = r;
         rew = rew + r;
         episode_sums[k] = episode_sums[k] + r;

@@ -28,7 +28,7 @@ for s in range(W):
 PH_MAX_WG = 8192
 out = (ctypes.c_ulonglong * (64 * PH_MAX_WG))()
 lib.lib.go2sim_debug_phases(sim.h, out, 1)
-GROUPS_ = {"solver": [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 11], "dynamics": list(range(20, 26)), "collide": list(range(30, 34)), "integrate_fk": [40, 41]}
+GROUPS_ = {"post_a": [12, 13, 14, 15, 16, 17], "solver": [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 11], "dynamics": list(range(20, 26)), "collide": list(range(30, 34)), "integrate_fk": [40, 41]}
 if len(sys.argv) > 3 and sys.argv[3] == "each":
     # one read-out per env step: what a single launch waits for is its slowest workgroup, which per-run sums average away
     rows = {g: [] for g in GROUPS_}
@@ -38,14 +38,14 @@ if len(sys.argv) > 3 and sys.argv[3] == "each":
         lib.lib.go2sim_debug_phases(sim.h, out, 1)
         a = np.frombuffer(out, dtype=np.uint64).reshape(PH_MAX_WG, 64).astype(np.float64)
         for g, ids in GROUPS_.items():
-            tot = a[:, ids].sum(1) / 2                                  # two launches per env step (fused kernels: their phases land in both groups)
+            tot = a[:, ids].sum(1) / (1 if g == "post_a" else 2)                                  # two launches per env step (fused kernels: their phases land in both groups)
             used = tot > 0
             if not used.any(): continue
             srt = np.sort(tot[used])
             rows[g].append((srt.mean(), srt[int(0.99 * len(srt))], srt[int(0.999 * len(srt))], srt[-1]))
             i = int(np.argmax(tot))
             if worst[g] is None or tot[i] > worst[g][0]:
-                worst[g] = (tot[i], {k: a[i, k] / 2 for k in ids}, {k: a[i, k] for k in (range(50, 55) if g == "solver" else list(range(34, 50)) + list(range(56, 62)))})
+                worst[g] = (tot[i], {k: a[i, k] / (1 if g == "post_a" else 2) for k in ids}, {k: a[i, k] for k in (range(50, 55) if g == "solver" else list(range(34, 50)) + list(range(56, 62)))})
     for g, r in rows.items():
         if not r: continue
         r = np.array(r)
