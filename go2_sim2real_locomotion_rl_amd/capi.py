@@ -51,19 +51,20 @@ DECLARED_FUNCS = DECLARED_FUNCS + _DECL_POLICY
 
 class EnvGlobals(ctypes.Structure):
     _fields_ = [
-        ("level", ctypes.c_float), ("timeout_rate_ema", ctypes.c_float), ("tracking_ema", ctypes.c_float),
-        ("fall_rate_ema", ctypes.c_float), ("ema_valid", ctypes.c_int), ("ready_streak", ctypes.c_int),
-        ("hard_streak", ctypes.c_int), ("cooldown", ctypes.c_int), ("curr_ep_total", ctypes.c_int),
-        ("curr_timeout_total", ctypes.c_float), ("curr_tracking_sum", ctypes.c_float), ("curr_tracking_n", ctypes.c_int),
-        ("obs_noise_level_cur", ctypes.c_float), ("action_noise_std_cur", ctypes.c_float), ("push_enable", ctypes.c_int),
-        ("push_force_lo", ctypes.c_float), ("push_force_hi", ctypes.c_float), ("push_interval", ctypes.c_int),
-        ("push_counter", ctypes.c_int), ("delay_max_cur", ctypes.c_int),
-        ("cmd_x_lo", ctypes.c_float), ("cmd_x_hi", ctypes.c_float), ("cmd_y_lo", ctypes.c_float), ("cmd_y_hi", ctypes.c_float),
-        ("cmd_yaw_lo", ctypes.c_float), ("cmd_yaw_hi", ctypes.c_float), ("global_dr_reset_counter", ctypes.c_int),
-        ("friction", ctypes.c_float), ("mass_shift", ctypes.c_float), ("com_shift", ctypes.c_float * 3),
-        ("leg_mass_shift", ctypes.c_float * 4), ("action_write_idx", ctypes.c_int), ("step_count", ctypes.c_uint),
-        ("reset_calls", ctypes.c_uint), ("last_reset_count", ctypes.c_int), ("last_episode_rew", ctypes.c_float * 32),
-        ("n_reset_now", ctypes.c_int), ("ep_acc", ctypes.c_float * 32), ("t_sample", ctypes.c_float), ("terrain_mean_row", ctypes.c_float), ("terrain_row_sum", ctypes.c_int),
+        ("level", ctypes.c_double), ("timeout_rate_ema", ctypes.c_double), ("tracking_ema", ctypes.c_double), ("fall_rate_ema", ctypes.c_double),
+        ("curr_timeout_total", ctypes.c_double), ("curr_tracking_sum", ctypes.c_double),
+        ("obs_noise_level_cur", ctypes.c_double), ("action_noise_std_cur", ctypes.c_double),
+        ("push_force_lo", ctypes.c_double), ("push_force_hi", ctypes.c_double),
+        ("cmd_x_lo", ctypes.c_double), ("cmd_x_hi", ctypes.c_double), ("cmd_y_lo", ctypes.c_double), ("cmd_y_hi", ctypes.c_double),
+        ("cmd_yaw_lo", ctypes.c_double), ("cmd_yaw_hi", ctypes.c_double), ("t_sample", ctypes.c_double),
+        ("ema_valid", ctypes.c_int), ("ready_streak", ctypes.c_int), ("hard_streak", ctypes.c_int), ("cooldown", ctypes.c_int),
+        ("curr_ep_total", ctypes.c_int), ("curr_tracking_n", ctypes.c_int),
+        ("push_enable", ctypes.c_int), ("push_interval", ctypes.c_int), ("push_counter", ctypes.c_int), ("delay_max_cur", ctypes.c_int),
+        ("global_dr_reset_counter", ctypes.c_int),
+        ("friction", ctypes.c_float), ("mass_shift", ctypes.c_float), ("com_shift", ctypes.c_float * 3), ("leg_mass_shift", ctypes.c_float * 4),
+        ("action_write_idx", ctypes.c_int), ("step_count", ctypes.c_uint), ("reset_calls", ctypes.c_uint),
+        ("last_reset_count", ctypes.c_int), ("last_episode_rew", ctypes.c_float * 32),
+        ("n_reset_now", ctypes.c_int), ("ep_acc", ctypes.c_float * 32), ("terrain_mean_row", ctypes.c_float), ("terrain_row_sum", ctypes.c_int),
         ("lock_terrain_rows", ctypes.c_int),
     ]
 
@@ -197,7 +198,7 @@ class Go2Sim:
 
     # ---- env level -----------------------------------------------------------------------------
     def env_configure(self, fcfg: np.ndarray, icfg: np.ndarray):
-        fcfg = np.ascontiguousarray(fcfg, dtype=np.float32)
+        fcfg = np.ascontiguousarray(fcfg, dtype=np.float64)
         icfg = np.ascontiguousarray(icfg, dtype=np.int32)
         self._call("env_configure", _ptr(fcfg), ctypes.c_int(fcfg.size), _ptr(icfg), ctypes.c_int(icfg.size))
 
@@ -258,7 +259,7 @@ class Go2Sim:
         return p.value
 
     def env_set_level(self, level, stream=None):
-        self._call("env_set_level", ctypes.c_float(level), _ptr(stream))
+        self._call("env_set_level", ctypes.c_double(level), _ptr(stream))
 
     def enable_timing(self, enable=True):
         self._call("enable_timing", ctypes.c_int(int(enable)))

@@ -92,7 +92,7 @@ def flatten_walk_cfg(num_envs, env_cfg, obs_cfg, reward_cfg, command_cfg, *, mod
     model = load_model_json() if model is None else model
     links, joints = _name_maps(model)
     env_cfg = copy.deepcopy(env_cfg)
-    f = np.zeros(C["GO2SIM_FC_COUNT"], dtype=np.float32)
+    f = np.zeros(C["GO2SIM_FC_COUNT"], dtype=np.float64)   # python floats of the cfg dicts, unrounded (include/go2sim.h: host scalars)
     i = np.zeros(C["GO2SIM_IC_COUNT"], dtype=np.int32)
     dt = 0.02
     F = lambda name: C["GO2SIM_FC_" + name]
@@ -193,8 +193,8 @@ def flatten_walk_cfg(num_envs, env_cfg, obs_cfg, reward_cfg, command_cfg, *, mod
     i[I("MIN_DELAY")] = int(env_cfg.get("min_delay_steps", 0))
     i[I("MAX_DELAY")] = int(env_cfg.get("max_delay_steps", 2))
     i[I("DELAY_EASY_MAX")] = int(curr.get("delay_easy_max_steps", 1))
-    if i[I("MAX_DELAY")] > 1:
-        raise NotImplementedError("max_delay_steps > 1 needs a deeper action ring (reference walk cfg uses 1)")
+    if not 0 <= i[I("MAX_DELAY")] < C["GO2SIM_ACTION_RING_MAX"]:
+        raise ValueError(f"max_delay_steps must be in [0, {C['GO2SIM_ACTION_RING_MAX'] - 1}] (the action ring is max_delay_steps + 1 deep, go2_env_walk.py:373-380)")
 
     i[I("CURR_ENABLED")] = int(bool(curr.get("enabled", False)))
     f[F("CURR_LEVEL_INIT")] = curr.get("level_init", 0.0)
@@ -327,7 +327,7 @@ def flatten_base_cfg(num_envs, env_cfg, obs_cfg, reward_cfg, command_cfg, *, mod
     latency, no domain randomisation / noise / pushes / curriculum, reset before the reward, 45 observations."""
     model = load_model_json() if model is None else model
     links, joints = _name_maps(model)
-    f = np.zeros(C["GO2SIM_FC_COUNT"], dtype=np.float32)
+    f = np.zeros(C["GO2SIM_FC_COUNT"], dtype=np.float64)   # python floats of the cfg dicts, unrounded (include/go2sim.h: host scalars)
     i = np.zeros(C["GO2SIM_IC_COUNT"], dtype=np.int32)
     dt = 0.02
     F = lambda name: C["GO2SIM_FC_" + name]

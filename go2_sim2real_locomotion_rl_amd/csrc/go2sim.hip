@@ -490,7 +490,7 @@ constexpr int MODELS_LDS_BYTES = lds_dma_bytes((int)sizeof(ModelS));
   X(friction_ratio, NG) X(l_pos, NL * 3) X(l_quat, NL * 4) X(cd_vel, NL * 3) X(cd_ang, NL * 3) X(root_com, NL * 3)     \
   X(contact_force, NL * 3) X(geom_friction, NG) X(ctrl_pos, ND) X(ctrl_vel, ND) X(dof_pos, ND) \
   /* ---- Go2Env buffers ---- */                                                                                     \
-  X(actions, NA) X(last_actions, NA) X(applied_actions, NA) X(action_history, 2 * NA) X(target_dof_pos, NM)            \
+  X(actions, NA) X(last_actions, NA) X(applied_actions, NA) X(action_history, GO2SIM_ACTION_RING_MAX * NA) X(target_dof_pos, NM)            \
   X(e_dof_pos, NM) X(e_dof_vel, NM) X(last_dof_vel, NM) X(torque, NM) X(base_pos, 3) X(base_quat, 4) X(base_lin_vel, 3) \
   X(base_ang_vel, 3) X(projected_gravity, 3) X(base_euler, 3) X(commands, 3) X(time_out, 1) X(kp_factors, NM)          \
   X(kd_factors, NM) X(motor_strength, NM) X(gravity_offset, 3) X(current_push_force, 3) X(push_stored_force, 3)       \
@@ -3171,7 +3171,8 @@ __global__ __launch_bounds__(WG) void k_clear_ext(Pool P) {             // kerne
 // around the physics plus one single-thread kernel for the quantities the reference keeps in Python
 // scalars (curriculum state machine, "global" domain-randomisation draws).
 // ---------------------------------------------------------------------------------------------
-struct DCfg { float f[GO2SIM_FC_COUNT]; int i[GO2SIM_IC_COUNT]; };
+// d[]: the host scalars in double (include/go2sim.h enum go2sim_fcfg, entries below GO2SIM_FC_N_HOST); f[]: every entry rounded to float32
+struct DCfg { double d[GO2SIM_FC_N_HOST]; float f[GO2SIM_FC_COUNT]; int i[GO2SIM_IC_COUNT]; };
 struct Acc { double timeouts, tracking, ep[NREW]; int n_reset_now; int done; };   // done: workgroups of k_env_post_a that have finished
 typedef go2sim_env_globals_t Glob;
 
@@ -3179,12 +3180,15 @@ enum { RNG_ACTION_NOISE = 1, RNG_PUSH = 2, RNG_CMD = 3, RNG_OBS_NOISE = 4, RNG_R
 DEV dm_u4 rng4(uint64_t seed, uint32_t purpose, uint32_t env, uint32_t step, uint32_t idx) {
   return dm_philox(env, step, purpose, idx, (uint32_t)seed, (uint32_t)(seed >> 32));
 }
-DEV float rand_float(float lower, float upper, uint32_t r) { return (upper - lower) * dm_u01(r) + lower; }   // gs_rand_float, go2_env_walk.py:7-8
+// gs_rand_float, go2_env_walk.py:7-8: `(upper - lower) * torch.rand(...) + lower` with python-float bounds: the difference is formed in float64 and
+// both scalars are rounded to float32 where they meet the float32 tensor
+DEV float rand_float(double lower, double upper, uint32_t r) { return (float)(upper - lower) * dm_u01(r) + (float)lower; }
 DEV int rand_int(int lower, int upper, uint32_t r) { return lower + (int)(r % (uint32_t)(upper - lower + 1)); }   // gs_rand_int, :11-13
 __host__ __device__ inline double clamp01d(double x) { return x < 0.0 ? 0.0 : (x > 1.0 ? 1.0 : x); }
 __host__ __device__ inline double lerpd(double a, double b, double t) { t = clamp01d(t); return a + (b - a) * t; }
-DEV float lerp_lo(const DCfg& c, int easy_lo, float t) { return (float)lerpd(c.f[easy_lo], c.f[easy_lo + 2], t); }
-DEV float lerp_hi(const DCfg& c, int easy_lo, float t) { return (float)lerpd(c.f[easy_lo + 1], c.f[easy_lo + 3], t); }
+// _lerp_range(easy, hard, t_sample), go2_env_walk.py:37-39: python floats
+DEV double lerp_lo(const DCfg& c, int easy_lo, double t) { return lerpd(c.d[easy_lo], c.d[easy_lo + 2], t); }
+DEV double lerp_hi(const DCfg& c, int easy_lo, double t) { return lerpd(c.d[easy_lo + 1], c.d[easy_lo + 3], t); }
 
 // torch-side helpers of genesis/utils/geom.py used by Go2Env (evaluation order of the torch code)
 DEV Q4 tc_quat_mul(Q4 u, Q4 v) {                                   // geom.py:989-1007
@@ -3221,7 +3225,7 @@ DEV V3 tc_quat_to_xyz_rpy_deg(Q4 q, float eps) {                   // geom.py:71
 // _get_dr_level, go2_env_stair.py:972-988 (two-phase DR schedule coupled to the terrain level)
 __host__ __device__ inline double dr_level(const DCfg& c, double terrain_level) {
   if (!c.i[GO2SIM_IC_DR_SCHEDULE]) return terrain_level;
-  double gate = c.f[GO2SIM_FC_DR_TERRAIN_GATE], p1 = c.f[GO2SIM_FC_DR_PHASE1_LEVEL];
+  double gate = c.d[GO2SIM_FC_DR_TERRAIN_GATE], p1 = c.d[GO2SIM_FC_DR_PHASE1_LEVEL];
   if (terrain_level < gate) return p1;
   double den = 1.0 - gate; if (den < 1e-6) den = 1e-6;
   double progress = clamp01d((terrain_level - gate) / den);
@@ -3237,65 +3241,65 @@ DEV float terrain_height(const Model& m, const DCfg& c, float x, float y) {
   return m.terrain_hf[(size_t)col * m.terrain_cols + row];
 }
 __host__ __device__ inline void apply_curriculum_level(const DCfg& c, Glob& g) {
-  double lvl_terrain = c.i[GO2SIM_IC_CURR_ENABLED] ? (double)g.level : 1.0;
+  double lvl_terrain = c.i[GO2SIM_IC_CURR_ENABLED] ? g.level : 1.0;
   double lvl = dr_level(c, lvl_terrain);   // noise / pushes / delay follow the DR level; the command ranges follow the curriculum level
-  g.obs_noise_level_cur = (float)lerpd(0.0, c.i[GO2SIM_IC_HAS_OBS_NOISE] ? c.f[GO2SIM_FC_OBS_NOISE_LEVEL_MAX] : 0.0, lvl);
-  g.action_noise_std_cur = (float)lerpd(0.0, c.f[GO2SIM_FC_ACTION_NOISE_STD_MAX], lvl);
-  double dt = c.f[GO2SIM_FC_DT];
+  g.obs_noise_level_cur = lerpd(0.0, c.i[GO2SIM_IC_HAS_OBS_NOISE] ? c.d[GO2SIM_FC_OBS_NOISE_LEVEL_MAX] : 0.0, lvl);
+  g.action_noise_std_cur = lerpd(0.0, c.d[GO2SIM_FC_ACTION_NOISE_STD_MAX], lvl);
+  double dt = c.d[GO2SIM_FC_DT];
   if (!c.i[GO2SIM_IC_HAS_PUSH]) {
-    g.push_enable = 0; g.push_force_lo = g.push_force_hi = 0.0f; g.push_interval = 1000000000;
+    g.push_enable = 0; g.push_force_lo = g.push_force_hi = 0.0; g.push_interval = 1000000000;
   } else {
-    double push_start = c.f[GO2SIM_FC_PUSH_START];
+    double push_start = c.d[GO2SIM_FC_PUSH_START];
     if (lvl < push_start) {
-      g.push_enable = 0; g.push_force_lo = g.push_force_hi = 0.0f;
-      g.push_interval = (int)((double)c.f[GO2SIM_FC_PUSH_INTERVAL_S_EASY] / dt);
+      g.push_enable = 0; g.push_force_lo = g.push_force_hi = 0.0;
+      g.push_interval = (int)(c.d[GO2SIM_FC_PUSH_INTERVAL_S_EASY] / dt);
     } else {
       double den = 1.0 - push_start; if (den < 1e-6) den = 1e-6;
       double s = clamp01d((lvl - push_start) / den);
-      g.push_force_lo = (float)((double)c.f[GO2SIM_FC_PUSH_FORCE_LO] * s);
-      g.push_force_hi = (float)((double)c.f[GO2SIM_FC_PUSH_FORCE_HI] * s);
-      double interval_s = lerpd(c.f[GO2SIM_FC_PUSH_INTERVAL_S_EASY], c.f[GO2SIM_FC_PUSH_INTERVAL_S_HARD], s);
+      g.push_force_lo = c.d[GO2SIM_FC_PUSH_FORCE_LO] * s;
+      g.push_force_hi = c.d[GO2SIM_FC_PUSH_FORCE_HI] * s;
+      double interval_s = lerpd(c.d[GO2SIM_FC_PUSH_INTERVAL_S_EASY], c.d[GO2SIM_FC_PUSH_INTERVAL_S_HARD], s);
       int iv = (int)(interval_s / dt);
       g.push_interval = iv < 1 ? 1 : iv;
       g.push_enable = 1;
     }
   }
   g.delay_max_cur = (int)rint(lerpd((double)c.i[GO2SIM_IC_DELAY_EASY_MAX], (double)c.i[GO2SIM_IC_MAX_DELAY], lvl));
-  double frac = c.i[GO2SIM_IC_CMD_CURRICULUM] ? lerpd(c.f[GO2SIM_FC_CMD_START_FRAC], 1.0, lvl_terrain) : 1.0;
+  double frac = c.i[GO2SIM_IC_CMD_CURRICULUM] ? lerpd(c.d[GO2SIM_FC_CMD_START_FRAC], 1.0, lvl_terrain) : 1.0;
   {
-    double lo = c.f[GO2SIM_FC_CMD_X_LO], hi = c.f[GO2SIM_FC_CMD_X_HI], center = (lo + hi) / 2.0, half = (hi - lo) / 2.0;
-    g.cmd_x_lo = (float)(center - half * frac); g.cmd_x_hi = (float)(center + half * frac);
-    lo = c.f[GO2SIM_FC_CMD_Y_LO]; hi = c.f[GO2SIM_FC_CMD_Y_HI]; center = (lo + hi) / 2.0; half = (hi - lo) / 2.0;
-    g.cmd_y_lo = (float)(center - half * frac); g.cmd_y_hi = (float)(center + half * frac);
-    lo = c.f[GO2SIM_FC_CMD_YAW_LO]; hi = c.f[GO2SIM_FC_CMD_YAW_HI]; center = (lo + hi) / 2.0; half = (hi - lo) / 2.0;
-    g.cmd_yaw_lo = (float)(center - half * frac); g.cmd_yaw_hi = (float)(center + half * frac);
+    double lo = c.d[GO2SIM_FC_CMD_X_LO], hi = c.d[GO2SIM_FC_CMD_X_HI], center = (lo + hi) / 2.0, half = (hi - lo) / 2.0;
+    g.cmd_x_lo = center - half * frac; g.cmd_x_hi = center + half * frac;
+    lo = c.d[GO2SIM_FC_CMD_Y_LO]; hi = c.d[GO2SIM_FC_CMD_Y_HI]; center = (lo + hi) / 2.0; half = (hi - lo) / 2.0;
+    g.cmd_y_lo = center - half * frac; g.cmd_y_hi = center + half * frac;
+    lo = c.d[GO2SIM_FC_CMD_YAW_LO]; hi = c.d[GO2SIM_FC_CMD_YAW_HI]; center = (lo + hi) / 2.0; half = (hi - lo) / 2.0;
+    g.cmd_yaw_lo = center - half * frac; g.cmd_yaw_hi = center + half * frac;
   }
 }
 
 // CurriculumManager.update, go2_env_walk.py:101-142
 DEV bool curriculum_update(const DCfg& c, Glob& g, double timeout_rate, double tracking_per_sec, double fall_rate) {
-  double a = c.f[GO2SIM_FC_CURR_EMA_ALPHA];
-  if (!g.ema_valid) { g.timeout_rate_ema = (float)timeout_rate; g.tracking_ema = (float)tracking_per_sec; g.fall_rate_ema = (float)fall_rate; g.ema_valid = 1; }
+  double a = c.d[GO2SIM_FC_CURR_EMA_ALPHA];
+  if (!g.ema_valid) { g.timeout_rate_ema = timeout_rate; g.tracking_ema = tracking_per_sec; g.fall_rate_ema = fall_rate; g.ema_valid = 1; }
   else {
-    g.timeout_rate_ema = (float)((1.0 - a) * g.timeout_rate_ema + a * timeout_rate);
-    g.tracking_ema = (float)((1.0 - a) * g.tracking_ema + a * tracking_per_sec);
-    g.fall_rate_ema = (float)((1.0 - a) * g.fall_rate_ema + a * fall_rate);
+    g.timeout_rate_ema = (1.0 - a) * g.timeout_rate_ema + a * timeout_rate;
+    g.tracking_ema = (1.0 - a) * g.tracking_ema + a * tracking_per_sec;
+    g.fall_rate_ema = (1.0 - a) * g.fall_rate_ema + a * fall_rate;
   }
   if (g.cooldown > 0) g.cooldown -= 1;
-  bool ready = g.timeout_rate_ema >= c.f[GO2SIM_FC_CURR_READY_TIMEOUT_RATE] && g.tracking_ema >= c.f[GO2SIM_FC_CURR_READY_TRACKING] &&
-               g.fall_rate_ema <= c.f[GO2SIM_FC_CURR_READY_FALL_RATE];
-  bool hard = g.fall_rate_ema >= c.f[GO2SIM_FC_CURR_HARD_FALL_RATE];
+  bool ready = g.timeout_rate_ema >= c.d[GO2SIM_FC_CURR_READY_TIMEOUT_RATE] && g.tracking_ema >= c.d[GO2SIM_FC_CURR_READY_TRACKING] &&
+               g.fall_rate_ema <= c.d[GO2SIM_FC_CURR_READY_FALL_RATE];
+  bool hard = g.fall_rate_ema >= c.d[GO2SIM_FC_CURR_HARD_FALL_RATE];
   g.ready_streak = ready ? g.ready_streak + 1 : 0;
   g.hard_streak = hard ? g.hard_streak + 1 : 0;
-  float old_level = g.level;
+  double old_level = g.level;
   if (g.hard_streak >= c.i[GO2SIM_IC_CURR_HARD_STREAK]) {
-    g.level = fmx(c.f[GO2SIM_FC_CURR_LEVEL_MIN], g.level - c.f[GO2SIM_FC_CURR_STEP_DOWN]);
+    { double lo = c.d[GO2SIM_FC_CURR_LEVEL_MIN], v = g.level - c.d[GO2SIM_FC_CURR_STEP_DOWN]; g.level = (lo < v) ? v : lo; }      // std::max(lo, v)
     g.hard_streak = 0; g.ready_streak = 0; g.cooldown = c.i[GO2SIM_IC_CURR_COOLDOWN];
   } else if (g.ready_streak >= c.i[GO2SIM_IC_CURR_READY_STREAK] && g.cooldown == 0) {
-    g.level = fmn(c.f[GO2SIM_FC_CURR_LEVEL_MAX], g.level + c.f[GO2SIM_FC_CURR_STEP_UP]);
+    { double hi = c.d[GO2SIM_FC_CURR_LEVEL_MAX], v = g.level + c.d[GO2SIM_FC_CURR_STEP_UP]; g.level = (v < hi) ? v : hi; }        // std::min(hi, v)
     g.ready_streak = 0; g.cooldown = c.i[GO2SIM_IC_CURR_COOLDOWN];
   }
-  g.level = fmx(0.0f, fmn(1.0f, g.level));
+  g.level = clamp01d(g.level);
   return g.level != old_level;
 }
 
@@ -3317,11 +3321,17 @@ __global__ __launch_bounds__(WG) void k_env_pre(Pool P, const Model* __restrict_
   const int pl = c.i[GO2SIM_IC_PUSH_LINK];
   // ---- loads first (one wave per 64 envs: the kernel's duration is its chain of memory round trips) ----
   int delay = e.delay_steps()[0];
-  float a_in[NA], h0_[NA], h1_[NA];
+  // the ring of the walk / stair envs (_action_history[B, max_delay_steps + 1, A], go2_env_walk.py:373-380, 916-923); the base env has none:
+  // it executes last_actions, which reset_idx zeroes and the end of the same step overwrites (go2_env_base.py:124-125, 187, 225)
+  const bool base_env = c.i[GO2SIM_IC_ENV_KIND] == 1;
+  const int depth = c.i[GO2SIM_IC_MAX_DELAY] + 1;
+  const int read_idx = (((write_idx - delay) % depth) + depth) % depth;
+  auto last_a = e.last_actions();
+  float a_in[NA], h_[NA];
 #pragma unroll
   for (int i = 0; i < NA; ++i) {
     a_in[i] = (i < na) ? actions_in[(size_t)b * na + i] : 0.0f;
-    h0_[i] = hist[0][i]; h1_[i] = hist[1][i];
+    h_[i] = base_env ? last_a[i] : hist[read_idx][i];
   }
   float kpf[NM], kdf[NM], mst[NM], dp[NM], dv[NM];
 #pragma unroll
@@ -3332,17 +3342,15 @@ __global__ __launch_bounds__(WG) void k_env_pre(Pool P, const Model* __restrict_
 #pragma unroll
   for (int k = 0; k < 6; ++k) ext_[k] = ext[6 * pl + k];
   // ---- compute + stores ----
-  int w_after = (write_idx + 1) % 2;
-  int read_idx = (((w_after - 1 - delay) % 2) + 2) % 2;
   float delayed[NA];
 #pragma unroll
   for (int i = 0; i < NA; ++i) {
     if (i < na) {
       float a = fmn(fmx(a_in[i], -clip), clip);
       actions[i] = a;
-      float h0 = (write_idx == 0) ? a : h0_[i], h1 = (write_idx == 1) ? a : h1_[i];
-      hist[write_idx][i] = a;
-      float d = (read_idx == 0) ? h0 : h1;
+      float d;
+      if (base_env) d = (depth > 1) ? h_[i] : a;
+      else { hist[write_idx][i] = a; d = (read_idx == write_idx) ? a : h_[i]; }
       delayed[i] = d; applied[i] = d;
     } else {
       delayed[i] = 0.0f;
@@ -3351,16 +3359,16 @@ __global__ __launch_bounds__(WG) void k_env_pre(Pool P, const Model* __restrict_
   float target[NM];
 #pragma unroll
   for (int i = 0; i < NM; ++i) target[i] = delayed[i] * c.f[GO2SIM_FC_ACTION_SCALE] + c.f[GO2SIM_FC_DEFAULT_DOF_POS0 + i];
-  if (g.action_noise_std_cur > 0.0f) {
+  if (g.action_noise_std_cur > 0.0) {
 #pragma unroll
     for (int blk = 0; blk < 3; ++blk) {
       dm_u4 r = rng4(seed, RNG_ACTION_NOISE, b, step_count, blk);
       float n0, n1, n2, n3;
       dm_normal2(r.v[0], r.v[1], &n0, &n1); dm_normal2(r.v[2], r.v[3], &n2, &n3);
-      target[4 * blk + 0] = target[4 * blk + 0] + n0 * g.action_noise_std_cur;
-      target[4 * blk + 1] = target[4 * blk + 1] + n1 * g.action_noise_std_cur;
-      target[4 * blk + 2] = target[4 * blk + 2] + n2 * g.action_noise_std_cur;
-      target[4 * blk + 3] = target[4 * blk + 3] + n3 * g.action_noise_std_cur;
+      target[4 * blk + 0] = target[4 * blk + 0] + n0 * (float)g.action_noise_std_cur;
+      target[4 * blk + 1] = target[4 * blk + 1] + n1 * (float)g.action_noise_std_cur;
+      target[4 * blk + 2] = target[4 * blk + 2] + n2 * (float)g.action_noise_std_cur;
+      target[4 * blk + 3] = target[4 * blk + 3] + n3 * (float)g.action_noise_std_cur;
     }
   }
   if (!manual_pd) {                                                  // go2_env_base.py:127: control_dofs_position (engine PD)
@@ -3451,7 +3459,10 @@ __global__ __launch_bounds__(64) void k_pre_dynamics_team(Pool P, const ModelS* 
   auto hist = e.action_history();
   const int delay = e.delay_steps()[0];
   const float a_in = (ia < na) ? actions_in[(size_t)eb * na + ia] : 0.0f;
-  const float h0_ = hist[0][ia], h1_ = hist[1][ia];
+  const bool base_env = c.i[GO2SIM_IC_ENV_KIND] == 1;                     // see k_env_pre: ring (walk / stairs) vs last_actions (base env)
+  const int depth = c.i[GO2SIM_IC_MAX_DELAY] + 1;
+  const int read_idx = (((write_idx - delay) % depth) + depth) % depth;
+  const float h_ = base_env ? e.last_actions()[ia] : hist[read_idx][ia];
   const float kpf = e.kp_factors()[im], kdf = e.kd_factors()[im], mst = e.motor_strength()[im], dp = e.e_dof_pos()[im], dv = e.e_dof_vel()[im];
   const bool manual_pd = c.i[GO2SIM_IC_MANUAL_PD] != 0, pls = c.i[GO2SIM_IC_PLS_ENABLE] != 0;
   const bool push_on = c.i[GO2SIM_IC_HAS_PUSH] && g.push_enable;
@@ -3481,25 +3492,22 @@ __global__ __launch_bounds__(64) void k_pre_dynamics_team(Pool P, const ModelS* 
   // ---- the pre-physics part; the parked control inputs of the motor dofs and the external force of the pushed link are replaced in LDS ----
   if (env_valid) {
     const float clip = c.f[GO2SIM_FC_CLIP_ACTIONS];
-    const int w_after = (write_idx + 1) % 2;
-    const int read_idx = (((w_after - 1 - delay) % 2) + 2) % 2;
     float delayed = 0.0f;
     if (tl < NA && tl < na) {
       const float a = fmn(fmx(a_in, -clip), clip);
       e.actions()[tl] = a;
-      const float h0 = (write_idx == 0) ? a : h0_, h1 = (write_idx == 1) ? a : h1_;
-      hist[write_idx][tl] = a;
-      delayed = (read_idx == 0) ? h0 : h1;
+      if (base_env) delayed = (depth > 1) ? h_ : a;
+      else { hist[write_idx][tl] = a; delayed = (read_idx == write_idx) ? a : h_; }
       e.applied_actions()[tl] = delayed;
     }
     const float delayed_leg = __shfl(delayed, NM + im / 3, T);            // per-leg stiffness action of the PLS policy (actions 12..15)
     if (tl < NM) {
       float target = delayed * c.f[GO2SIM_FC_ACTION_SCALE] + c.f[GO2SIM_FC_DEFAULT_DOF_POS0 + tl];
-      if (g.action_noise_std_cur > 0.0f) {
+      if (g.action_noise_std_cur > 0.0) {
         dm_u4 r = rng4(seed, RNG_ACTION_NOISE, b, step_count, tl / 4);
         float n0, n1;
         if ((tl & 2) == 0) dm_normal2(r.v[0], r.v[1], &n0, &n1); else dm_normal2(r.v[2], r.v[3], &n0, &n1);
-        target = target + ((tl & 1) ? n1 : n0) * g.action_noise_std_cur;
+        target = target + ((tl & 1) ? n1 : n0) * (float)g.action_noise_std_cur;
       }
       e.target_dof_pos()[tl] = target;
       const int d = c.i[GO2SIM_IC_MOTOR_DOF0 + tl];
@@ -3983,7 +3991,7 @@ __global__ __launch_bounds__(WG) void k_env_respawn(Pool P, const Model* __restr
     auto blv = e.base_lin_vel(); auto bav = e.base_ang_vel();
     for (int k = 0; k < 3; ++k) { blv[k] = 0.0f; bav[k] = 0.0f; }
     auto la = e.last_actions(); auto aa = e.applied_actions(); auto hist = e.action_history();
-    for (int i = 0; i < NA; ++i) { la[i] = 0.0f; aa[i] = 0.0f; hist[0][i] = 0.0f; hist[1][i] = 0.0f; }
+    for (int i = 0; i < NA; ++i) { la[i] = 0.0f; aa[i] = 0.0f; for (int k = 0; k < GO2SIM_ACTION_RING_MAX; ++k) hist[k][i] = 0.0f; }
     { auto ldv = e.last_dof_vel(); for (int i = 0; i < NM; ++i) ldv[i] = 0.0f; }
     e.last_base_pos_x()[0] = pos[3 * t];
   }
@@ -4002,29 +4010,30 @@ DEV void env_globals_body(const DCfg& c, Glob& g, Acc* acc, uint64_t seed, int c
   g.n_reset_now = n;
   if (n > 0) {
     if (c.i[GO2SIM_IC_CURR_ENABLED] && !c.i[GO2SIM_IC_FREEZE_CURRICULUM]) {
-      g.curr_ep_total += n; g.curr_timeout_total += (float)acc->timeouts; g.curr_tracking_sum += (float)acc->tracking; g.curr_tracking_n += n;
+      // `float(tensor.sum().item())` of float32 tensors (:698, :710) added to python floats
+      g.curr_ep_total += n; g.curr_timeout_total += (double)(float)acc->timeouts; g.curr_tracking_sum += (double)(float)acc->tracking; g.curr_tracking_n += n;
       if (g.curr_ep_total >= c.i[GO2SIM_IC_CURR_UPDATE_EVERY]) {
-        double timeout_rate = (double)g.curr_timeout_total / (double)imx(1, g.curr_ep_total);
+        double timeout_rate = g.curr_timeout_total / (double)imx(1, g.curr_ep_total);
         double fall_rate = 1.0 - timeout_rate;
-        double tracking_avg = (double)g.curr_tracking_sum / (double)imx(1, g.curr_tracking_n);
+        double tracking_avg = g.curr_tracking_sum / (double)imx(1, g.curr_tracking_n);
         if (curriculum_update(c, g, timeout_rate, tracking_avg, fall_rate)) apply_curriculum_level(c, g);
-        g.curr_ep_total = 0; g.curr_timeout_total = 0.0f; g.curr_tracking_sum = 0.0f; g.curr_tracking_n = 0;
+        g.curr_ep_total = 0; g.curr_timeout_total = 0.0; g.curr_tracking_sum = 0.0; g.curr_tracking_n = 0;
       }
     }
     dm_u4 r0 = rng4(seed, RNG_GLOBAL_DR, 0xffffffffu, g.reset_calls, 0);
     dm_u4 r1 = rng4(seed, RNG_GLOBAL_DR, 0xffffffffu, g.reset_calls, 1);
     dm_u4 r2 = rng4(seed, RNG_GLOBAL_DR, 0xffffffffu, g.reset_calls, 2);
     double t;
-    if (c.i[GO2SIM_IC_DR_SCHEDULE]) t = dr_level(c, c.i[GO2SIM_IC_CURR_ENABLED] ? (double)g.level : 1.0);   // go2_env_stair.py:1506-1507
+    if (c.i[GO2SIM_IC_DR_SCHEDULE]) t = dr_level(c, c.i[GO2SIM_IC_CURR_ENABLED] ? g.level : 1.0);   // go2_env_stair.py:1506-1507
     else if (!c.i[GO2SIM_IC_CURR_ENABLED]) t = 1.0;
     else if (dm_u01(r0.v[0]) < c.f[GO2SIM_FC_CURR_MIX_PROB_CURRENT]) t = clamp01d(g.level);
     else {
-      double hi = (double)g.level < (double)c.f[GO2SIM_FC_CURR_MIX_LEVEL_HIGH] ? (double)g.level : (double)c.f[GO2SIM_FC_CURR_MIX_LEVEL_HIGH];
-      double lo = (double)c.f[GO2SIM_FC_CURR_MIX_LEVEL_LOW] < hi ? (double)c.f[GO2SIM_FC_CURR_MIX_LEVEL_LOW] : hi;
+      double hi = c.d[GO2SIM_FC_CURR_MIX_LEVEL_HIGH] < g.level ? c.d[GO2SIM_FC_CURR_MIX_LEVEL_HIGH] : g.level;          // std::min(level, high)
+      double lo = hi < c.d[GO2SIM_FC_CURR_MIX_LEVEL_LOW] ? hi : c.d[GO2SIM_FC_CURR_MIX_LEVEL_LOW];                   // std::min(low, hi)
       t = clamp01d(lo + (hi - lo) * (double)dm_u01(r0.v[1]));
     }
-    g.t_sample = (float)t;
-    float ts = g.t_sample;
+    g.t_sample = t;
+    double ts = g.t_sample;
     if (c.i[GO2SIM_IC_HAS_FRICTION_DR]) {
       g.global_dr_reset_counter += n;
       if (g.global_dr_reset_counter >= c.i[GO2SIM_IC_GLOBAL_DR_INTERVAL]) {
@@ -4040,7 +4049,7 @@ DEV void env_globals_body(const DCfg& c, Glob& g, Acc* acc, uint64_t seed, int c
     g.last_reset_count = n;
     g.terrain_row_sum = 0;   // accumulated by k_env_terrain_rows
     for (int k = 0; k < NREW; ++k)
-      g.last_episode_rew[k] = (c.i[GO2SIM_IC_ENV_KIND] == 1) ? (float)((double)(float)(acc->ep[k] / (double)n) / (double)c.f[GO2SIM_FC_EPISODE_LENGTH_S]) : (float)(acc->ep[k] / (double)n);
+      g.last_episode_rew[k] = (c.i[GO2SIM_IC_ENV_KIND] == 1) ? (float)((double)(float)(acc->ep[k] / (double)n) / c.d[GO2SIM_FC_EPISODE_LENGTH_S]) : (float)(acc->ep[k] / (double)n);
     g.reset_calls += 1;
     // consumed: clear the accumulators for the next reset call (they are only ever non-zero when n > 0)
     acc->timeouts = 0.0; acc->tracking = 0.0; acc->n_reset_now = 0;
@@ -4056,7 +4065,7 @@ __global__ void k_env_globals(const DCfg* __restrict__ cp, Glob* gp, Acc* acc, u
 // per-env part of reset_idx (go2_env_walk.py:1156-1240)
 DEV void env_reset_one(const Model& m, const DCfg& c, const Glob& g, const E& e, int b, uint64_t seed) {
   uint32_t rc = g.reset_calls - 1;
-  float ts = g.t_sample;
+  double ts = g.t_sample;
   auto kp_factors = e.kp_factors(); auto kd_factors = e.kd_factors(); auto motor_strength = e.motor_strength(); auto gravity_offset = e.gravity_offset();
   if (c.i[GO2SIM_IC_HAS_KPF_DR])
     for (int blk = 0; blk < 3; ++blk) { dm_u4 r = rng4(seed, RNG_RESET_DR, b, rc, blk); for (int k = 0; k < 4; ++k) kp_factors[4 * blk + k] = rand_float(lerp_lo(c, GO2SIM_FC_KPF_EASY_LO, ts), lerp_hi(c, GO2SIM_FC_KPF_EASY_LO, ts), r.v[k]); }
@@ -4102,12 +4111,12 @@ DEV void env_reset_one(const Model& m, const DCfg& c, const Glob& g, const E& e,
     float init_z = c.f[GO2SIM_FC_BASE_INIT_POS0 + 2];
     float spawn_z = rcn[2] + init_z;
     bpx = rcn[0]; bpy = rcn[1]; bpz = spawn_z;
-    if (c.i[GO2SIM_IC_HAS_INIT_Z]) bpz = ((spawn_z + rand_float(c.f[GO2SIM_FC_INIT_Z_LO], c.f[GO2SIM_FC_INIT_Z_HI], rp.v[0])) - init_z) + init_z;
+    if (c.i[GO2SIM_IC_HAS_INIT_Z]) bpz = ((spawn_z + rand_float(c.d[GO2SIM_FC_INIT_Z_LO], c.d[GO2SIM_FC_INIT_Z_HI], rp.v[0])) - init_z) + init_z;
   } else
-  if (c.i[GO2SIM_IC_HAS_INIT_Z]) bpz = rand_float(c.f[GO2SIM_FC_INIT_Z_LO], c.f[GO2SIM_FC_INIT_Z_HI], rp.v[0]);
+  if (c.i[GO2SIM_IC_HAS_INIT_Z]) bpz = rand_float(c.d[GO2SIM_FC_INIT_Z_LO], c.d[GO2SIM_FC_INIT_Z_HI], rp.v[0]);
   if (c.i[GO2SIM_IC_HAS_INIT_EULER]) {                                 // euler_to_quat_wxyz, go2_env_walk.py:16-25
-    const float D2R = 0.017453292519943295f;
-    float lo = c.f[GO2SIM_FC_INIT_EULER_LO_DEG] * D2R, hi = c.f[GO2SIM_FC_INIT_EULER_HI_DEG] * D2R;
+    const double D2R = 3.141592653589793 / 180.0;                       // math.radians: x * (pi / 180) in float64
+    double lo = c.d[GO2SIM_FC_INIT_EULER_LO_DEG] * D2R, hi = c.d[GO2SIM_FC_INIT_EULER_HI_DEG] * D2R;
     float roll = rand_float(lo, hi, rp.v[1]), pitch = rand_float(lo, hi, rp.v[2]), yaw = 0.0f;
     float sr, cr, sp, cpp, sy, cy;
     dm_sincos(roll / 2.0f, &sr, &cr); dm_sincos(pitch / 2.0f, &sp, &cpp); dm_sincos(yaw / 2.0f, &sy, &cy);
@@ -4121,7 +4130,7 @@ DEV void env_reset_one(const Model& m, const DCfg& c, const Glob& g, const E& e,
   auto blv = e.base_lin_vel(); auto bav = e.base_ang_vel();
   for (int k = 0; k < 3; ++k) { blv[k] = 0.0f; bav[k] = 0.0f; }
   auto la = e.last_actions(); auto aa = e.applied_actions(); auto hist = e.action_history();
-  for (int i = 0; i < NA; ++i) { la[i] = 0.0f; aa[i] = 0.0f; hist[0][i] = 0.0f; hist[1][i] = 0.0f; }
+  for (int i = 0; i < NA; ++i) { la[i] = 0.0f; aa[i] = 0.0f; for (int k = 0; k < GO2SIM_ACTION_RING_MAX; ++k) hist[k][i] = 0.0f; }
   { auto ldv = e.last_dof_vel(); for (int i = 0; i < NM; ++i) ldv[i] = 0.0f; }
   e.last_base_pos_x()[0] = bpx;                                       // go2_env_stair.py:1557
   { auto psf = e.push_stored_force(); for (int k = 0; k < 3; ++k) psf[k] = 0.0f; }
@@ -4166,7 +4175,7 @@ __global__ __launch_bounds__(256) void k_env_terrain_rows(Pool P, const DCfg* __
   const int n = g.n_reset_now;
   int row = e.terrain_row()[0];
   if (n_rows > 1 && !g.lock_terrain_rows) {                            // `if not self._lock_terrain_rows`, go2_env_stair.py:1513
-    double level = c.i[GO2SIM_IC_CURR_ENABLED] ? (double)g.level : 1.0;
+    double level = c.i[GO2SIM_IC_CURR_ENABLED] ? g.level : 1.0;
     int max_row = (int)(level * (double)(n_rows - 1));
     max_row = imx(0, imn(max_row, n_rows - 1));
     int n_frontier = (int)((double)n * 0.40), n_near = (int)((double)n * 0.30);
@@ -4311,8 +4320,8 @@ __global__ __launch_bounds__(64) void k_env_post_b_team(Pool P, const Model* __r
   float* src = pb_src[slot];
   team_stage<PB_N, T>(tl, [&](int k) { return gload(e, post_b_src_off(k), 0); }, [&](int k, float v) { src[k] = v; });
   team_sync();
-  const bool noisy = c.i[GO2SIM_IC_HAS_OBS_NOISE] && c.f[GO2SIM_FC_OBS_NOISE_LEVEL_MAX] > 0.0f;
-  const float lvl = g.obs_noise_level_cur;
+  const bool noisy = c.i[GO2SIM_IC_HAS_OBS_NOISE] && c.d[GO2SIM_FC_OBS_NOISE_LEVEL_MAX] > 0.0;
+  const double lvl = g.obs_noise_level_cur;          // python-float products, rounded on assignment into the float32 noise vector
   for (int blk = tl; blk * 4 < nobs; blk += T) {
     float n[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     if (noisy) {
@@ -4324,11 +4333,11 @@ __global__ __launch_bounds__(64) void k_env_post_b_team(Pool P, const Model* __r
       int i = 4 * blk + k;
       if (i < nobs) {
         float v, nv = 0.0f;
-        if (i < 3) { v = src[PB_BAV + i] * c.f[GO2SIM_FC_OBS_SCALE_ANG_VEL]; nv = c.f[GO2SIM_FC_OBS_NOISE_ANG_VEL] * c.f[GO2SIM_FC_OBS_SCALE_ANG_VEL] * lvl; }
-        else if (i < 6) { v = src[PB_PG + i - 3] + src[PB_GOFF + i - 3]; nv = c.f[GO2SIM_FC_OBS_NOISE_GRAVITY] * lvl; }
+        if (i < 3) { v = src[PB_BAV + i] * c.f[GO2SIM_FC_OBS_SCALE_ANG_VEL]; nv = (float)(c.d[GO2SIM_FC_OBS_NOISE_ANG_VEL] * c.d[GO2SIM_FC_OBS_SCALE_ANG_VEL] * lvl); }
+        else if (i < 6) { v = src[PB_PG + i - 3] + src[PB_GOFF + i - 3]; nv = (float)(c.d[GO2SIM_FC_OBS_NOISE_GRAVITY] * lvl); }
         else if (i < 9) { v = src[PB_CMD + i - 6] * ((i - 6 < 2) ? c.f[GO2SIM_FC_OBS_SCALE_LIN_VEL] : c.f[GO2SIM_FC_OBS_SCALE_ANG_VEL]); nv = 0.0f; }
-        else if (i < 21) { v = (src[PB_DP + i - 9] - c.f[GO2SIM_FC_DEFAULT_DOF_POS0 + i - 9]) * c.f[GO2SIM_FC_OBS_SCALE_DOF_POS]; nv = c.f[GO2SIM_FC_OBS_NOISE_DOF_POS] * c.f[GO2SIM_FC_OBS_SCALE_DOF_POS] * lvl; }
-        else if (i < 33) { v = src[PB_DV + i - 21] * c.f[GO2SIM_FC_OBS_SCALE_DOF_VEL]; nv = c.f[GO2SIM_FC_OBS_NOISE_DOF_VEL] * c.f[GO2SIM_FC_OBS_SCALE_DOF_VEL] * lvl; }
+        else if (i < 21) { v = (src[PB_DP + i - 9] - c.f[GO2SIM_FC_DEFAULT_DOF_POS0 + i - 9]) * c.f[GO2SIM_FC_OBS_SCALE_DOF_POS]; nv = (float)(c.d[GO2SIM_FC_OBS_NOISE_DOF_POS] * c.d[GO2SIM_FC_OBS_SCALE_DOF_POS] * lvl); }
+        else if (i < 33) { v = src[PB_DV + i - 21] * c.f[GO2SIM_FC_OBS_SCALE_DOF_VEL]; nv = (float)(c.d[GO2SIM_FC_OBS_NOISE_DOF_VEL] * c.d[GO2SIM_FC_OBS_SCALE_DOF_VEL] * lvl); }
         else { v = (i - 33 < na) ? src[PB_ACT + i - 33] : gload(e, FO(obs), i); }
         if (noisy) v = v + n[k] * nv;
         gstore(e, FO(obs), i, v); gstore(e, FO(priv), i, v);
@@ -5021,13 +5030,15 @@ int go2sim_check_errno(go2sim_t* h, int* out, void* stream) {
   return GO2SIM_E_OK;
 }
 
-int go2sim_env_configure(go2sim_t* h, const float* f, int nf, const int* i, int ni) {
+int go2sim_env_configure(go2sim_t* h, const double* f, int nf, const int* i, int ni) {
   if (!h || !f || !i || nf != GO2SIM_FC_COUNT || ni != GO2SIM_IC_COUNT) return GO2SIM_E_BADARG;
   {                                                                       // validate a local copy: a rejected configuration leaves the handle as it was
     DCfg c;
-    memcpy(c.f, f, sizeof(float) * nf); memcpy(c.i, i, sizeof(int) * ni);
+    for (int k = 0; k < GO2SIM_FC_N_HOST; ++k) c.d[k] = f[k];
+    for (int k = 0; k < nf; ++k) c.f[k] = (float)f[k];
+    memcpy(c.i, i, sizeof(int) * ni);
     if (c.i[GO2SIM_IC_NUM_ACTIONS] > NA || c.i[GO2SIM_IC_NUM_ACTIONS] < NM || c.i[GO2SIM_IC_NUM_OBS] > NOBS_MAX || c.i[GO2SIM_IC_NUM_PRIV_OBS] > NPRIV_MAX ||
-        c.i[GO2SIM_IC_N_REWARDS] > NREW || c.i[GO2SIM_IC_N_REWARDS] < 0 || c.i[GO2SIM_IC_MAX_DELAY] > 1 || c.i[GO2SIM_IC_NUM_OBS] < 33 + c.i[GO2SIM_IC_NUM_ACTIONS] ||
+        c.i[GO2SIM_IC_N_REWARDS] > NREW || c.i[GO2SIM_IC_N_REWARDS] < 0 || c.i[GO2SIM_IC_MAX_DELAY] >= GO2SIM_ACTION_RING_MAX || c.i[GO2SIM_IC_MAX_DELAY] < 0 || c.i[GO2SIM_IC_NUM_OBS] < 33 + c.i[GO2SIM_IC_NUM_ACTIONS] ||
         c.i[GO2SIM_IC_SUBSTEPS] < 1 || c.i[GO2SIM_IC_SUBSTEPS] > 16 || c.i[GO2SIM_IC_RESAMPLE_STEPS] < 1 || c.i[GO2SIM_IC_N_TERRAIN_ROWS] > 16 || c.i[GO2SIM_IC_SCAN_N] > 80 ||
         c.i[GO2SIM_IC_SCAN_N] < 0)
       return GO2SIM_E_BADARG;
@@ -5042,7 +5053,7 @@ int go2sim_env_configure(go2sim_t* h, const float* f, int nf, const int* i, int 
   HIPCHK(hipSetDevice(h->device));
   HIPCHK(hipMemcpy(h->dcfg, &h->hcfg, sizeof(DCfg), hipMemcpyHostToDevice));
   Glob g; memset(&g, 0, sizeof(g));
-  g.level = c.f[GO2SIM_FC_CURR_LEVEL_INIT]; g.friction = 1.0f;
+  g.level = c.d[GO2SIM_FC_CURR_LEVEL_INIT]; g.friction = 1.0f;
   apply_curriculum_level(c, g);
   HIPCHK(hipMemcpy(h->dglob, &g, sizeof(Glob), hipMemcpyHostToDevice));
   // zero the env buffers
@@ -5083,7 +5094,7 @@ int go2sim_env_step(go2sim_t* h, const float* actions, float* obs, float* priv, 
                             hipGraphExecKernelNodeSetParams(sg.exec, sg.n_post_a, &sg.p_post_a) == hipSuccess &&
                             hipGraphExecKernelNodeSetParams(sg.exec, sg.n_post_b, &sg.p_post_b) == hipSuccess && hipGraphLaunch(sg.exec, s) == hipSuccess;
       if (launched) {
-        h->action_write_idx = (h->action_write_idx + 1) % 2;
+        h->action_write_idx = (h->action_write_idx + 1) % (h->hcfg.i[GO2SIM_IC_MAX_DELAY] + 1);
         h->step_count += 1;
         return GO2SIM_E_OK;
       }
@@ -5103,7 +5114,7 @@ int go2sim_env_step(go2sim_t* h, const float* actions, float* obs, float* priv, 
     hipLaunchKernelGGL(k_env_post_b_team<16>, dim3((h->B + 3) / 4), dim3(64), 0, s, h->P, h->dm, h->dms, h->dcfg, h->dglob, h->seed, h->step_count, obs, priv, rew, reset, timeout);
   }
   HIPCHK(hipGetLastError());
-  h->action_write_idx = (h->action_write_idx + 1) % 2;
+  h->action_write_idx = (h->action_write_idx + 1) % (h->hcfg.i[GO2SIM_IC_MAX_DELAY] + 1);
   h->step_count += 1;
   return GO2SIM_E_OK;
 }
@@ -5255,7 +5266,7 @@ int go2sim_env_globals_ptr(go2sim_t* h, void** ptr_out) {
   *ptr_out = h->dglob;
   return GO2SIM_E_OK;
 }
-int go2sim_env_set_level(go2sim_t* h, float level, void* stream) {
+int go2sim_env_set_level(go2sim_t* h, double level, void* stream) {
   if (!h || !h->cfg_set) return GO2SIM_E_BADARG;
   hipStream_t s = (hipStream_t)stream;
   Glob g;

@@ -26,7 +26,7 @@ tc_float, tc_int = torch.float32, torch.int32
 device = None
 _lib = None
 _seed = 1
-EPS = 1e-15
+EPS = float(np.finfo(np.float32).eps)     # gs.EPS = max(1e-15, eps of the float type) (genesis/__init__.py:62,229), precision "32"
 
 
 class GenesisException(Exception):
@@ -57,32 +57,58 @@ constraint_solver = types.SimpleNamespace(Newton="Newton", CG="CG")
 morphs = types.SimpleNamespace(URDF=lambda **kw: _Opt(kind="urdf", **kw), Terrain=lambda **kw: _Opt(kind="terrain", **kw))
 
 
-# ---- genesis.utils.geom helpers used by Go2Env (torch; genesis/utils/geom.py) -------------------------------------------------------
+# ---- genesis.utils.geom helpers used by Go2Env (torch branch of genesis/utils/geom.py; same operation order, so an env file that runs on
+# the shim sees the values it would see on Genesis) --------------------------------------------------------------------------------------
 def inv_quat(q):
+    """Conjugate (geom.py `inv_quat`: the sign of the vector part flips; unit quaternions assumed)."""
     return torch.cat([q[..., :1], -q[..., 1:]], dim=-1)
 
 
 def transform_quat_by_quat(v, u):
-    """quat_mul(u, v), normalised (geom.py:989-1007)."""
+    """quat_mul(u, v) followed by a normalisation (geom.py:989-1023, the 8-multiplication product of `_tc_quat_mul`)."""
     w1, x1, y1, z1 = u.unbind(-1)
     w2, x2, y2, z2 = v.unbind(-1)
-    out = torch.stack([w1 * w2 - x1 * x2 - y1 * y2 - z1 * z2, w1 * x2 + x1 * w2 + y1 * z2 - z1 * y2,
-                       w1 * y2 - x1 * z2 + y1 * w2 + z1 * x2, w1 * z2 + x1 * y2 - y1 * x2 + z1 * w2], dim=-1)
-    return out / out.norm(dim=-1, keepdim=True)
+    ww = (z1 + x1) * (x2 + y2)
+    yy = (w1 - y1) * (w2 + z2)
+    zz = (w1 + y1) * (w2 - z2)
+    xx = ww + yy + zz
+    qq = 0.5 * (xx + (z1 - x1) * (x2 - y2))
+    out = torch.stack([qq - ww + (z1 - y1) * (y2 - z2), qq - xx + (x1 + w1) * (x2 + w2),
+                       qq - yy + (w1 - x1) * (y2 + z2), qq - zz + (z1 + y1) * (w2 - x2)], dim=-1)
+    return out / torch.linalg.vector_norm(out, ord=2, dim=-1, keepdim=True)
+
+
+def _quat_products(q):
+    w, x, y, z = q[..., :1], q[..., 1:2], q[..., 2:3], q[..., 3:]
+    return w * w, w * x, w * y, w * z, x * x, x * y, x * z, y * y, y * z, z * z
 
 
 def transform_by_quat(v, q):
-    qw, qv = q[..., :1], q[..., 1:]
-    t = 2.0 * torch.cross(qv, v, dim=-1)
-    return v + qw * t + torch.cross(qv, t, dim=-1)
+    """Rotation-matrix form with the division by |q|^2 applied to v first (geom.py:1048-1070, `_tc_transform_by_quat`)."""
+    ww, wx, wy, wz, xx, xy, xz, yy, yz, zz = _quat_products(q)
+    vs = v / (ww + xx + yy + zz)
+    vx, vy, vz = vs[..., :1], vs[..., 1:2], vs[..., 2:]
+    return torch.cat([vx * (xx + ww - yy - zz) + vy * (2.0 * xy - 2.0 * wz) + vz * (2.0 * xz + 2.0 * wy),
+                      vx * (2.0 * wz + 2.0 * xy) + vy * (ww - xx + yy - zz) + vz * (2.0 * yz - 2.0 * wx),
+                      vx * (2.0 * xz - 2.0 * wy) + vy * (2.0 * wx + 2.0 * yz) + vz * (ww - xx - yy + zz)], dim=-1)
 
 
-def quat_to_xyz(q, rpy=True, degrees=False):
-    qw, qx, qy, qz = q.unbind(-1)
-    roll = torch.atan2(2 * (qw * qx + qy * qz), 1 - 2 * (qx * qx + qy * qy))
-    pitch = torch.asin(torch.clamp(2 * (qw * qy - qz * qx), -1.0, 1.0))
-    yaw = torch.atan2(2 * (qw * qz + qx * qy), 1 - 2 * (qy * qy + qz * qz))
-    out = torch.stack([roll, pitch, yaw], dim=-1)
+def quat_to_xyz(q, rpy=False, degrees=False):
+    """Euler angles by atan2 of half-scaled products, with the cos(pitch) < EPS branch (geom.py:717-774, `_tc_quat_to_xyz`).  `rpy` defaults
+    to False like the reference; the Go2Env files pass rpy=True."""
+    ww, wx, wy, wz, xx, xy, xz, yy, yz, zz = _quat_products(q)
+    if rpy:
+        sinp, sinrcosp, sinycosp = wy - xz, wx + yz, wz + xy
+    else:
+        sinp, sinrcosp, sinycosp = xz + wy, wx - yz, wz - xy
+    cosrcosp = (ww - xx - yy + zz) / 2
+    cosycosp = (ww + xx - yy - zz) / 2
+    cosp = torch.sqrt(cosycosp**2 + sinycosp**2)
+    roll, pitch, yaw = torch.atan2(sinrcosp, cosrcosp), torch.atan2(sinp, cosp), torch.atan2(sinycosp, cosycosp)
+    singular = cosp < EPS
+    roll = roll.masked_fill(singular, 0.0)
+    yaw = torch.where(singular, torch.atan2((wz - xy) if rpy else (wz + xy), (ww - xx + yy - zz) / 2), yaw)
+    out = torch.cat([roll, pitch, yaw], dim=-1)
     return torch.rad2deg(out) if degrees else out
 
 
@@ -92,6 +118,39 @@ utils = types.SimpleNamespace(geom=types.SimpleNamespace(inv_quat=inv_quat, tran
 
 def _F(name):
     return C["GO2SIM_" + name]
+
+
+def _broadcast(values, shape):
+    """What the reference's setters do to their value argument before the accessor kernel runs (rigid_solver.py:1835-1871 ->
+    genesis/utils/misc.py `broadcast_tensor`): a value with fewer dimensions than (n_envs(sel), n_idx(, k)) is matched right-aligned when
+    that fits, otherwise its dimensions are assigned to the expected ones preferring the leading ones, and size-1 dimensions expand.
+    So `set_mass_shift([s], [0])` and `set_COM_shift([[x, y, z]], [0])` with envs_idx=None reach every env (go2_env_walk.py:810,820,843),
+    and a [B, 3] force for one link becomes [B, 1, 3]."""
+    import itertools
+
+    t = torch.as_tensor(values, dtype=torch.float32, device=device)
+    shape = tuple(int(n) for n in shape)
+    if t.ndim == 0:
+        t = t[None]
+    elif t.ndim > len(shape):
+        raise GenesisException(f"Invalid input shape: {tuple(t.shape)}. Expecting at most {len(shape)}D tensor.")
+    elif t.ndim < len(shape) and any(a != b for a, b in zip(t.shape, shape[-t.ndim:])):
+        for keep in reversed(list(itertools.combinations(range(len(shape)), t.ndim))):
+            dims, k = [], 0
+            for i, n in enumerate(shape):
+                if i in keep:
+                    if t.shape[k] not in (n, 1):
+                        break
+                    dims.append(t.shape[k]); k += 1
+                else:
+                    dims.append(1)
+            else:
+                t = t.reshape(dims)
+                break
+    try:
+        return t.expand(shape)
+    except RuntimeError as e:
+        raise GenesisException(f"Invalid input shape: {tuple(t.shape)}. Expected shape: {shape}.") from e
 
 
 class _Named:
@@ -210,7 +269,7 @@ class RigidEntity:
     def _write_dofs(self, field, values, dofs_idx_local, envs_idx, mode=None):
         d, e = self._dofs(dofs_idx_local), self._envs(envs_idx)
         cur = self._get(field)
-        cur[d[:, None], e[None, :]] = torch.as_tensor(values, device=device, dtype=torch.float32).reshape(len(e), len(d)).t()
+        cur[d[:, None], e[None, :]] = _broadcast(values, (len(e), len(d))).t()
         self._set(field, cur)
         if mode is not None:
             m = self._get("I_CTRL_MODE")
@@ -244,7 +303,7 @@ class RigidEntity:
         q = self._get("F_QPOS")
         qpos0 = torch.tensor(self._scene._model["qpos0"], device=device)
         qi = d + 1                                                                       # revolute dof d <-> qpos index d + 1 (free joint: 7 q, 6 dofs)
-        vals = torch.as_tensor(position, device=device, dtype=torch.float32).reshape(len(e), len(d)).t()
+        vals = _broadcast(position, (len(e), len(d))).t()
         q[qi[:, None], e[None, :]] = qpos0[qi][:, None] + vals
         self._set("F_QPOS", q)
         if zero_velocity:
@@ -262,7 +321,7 @@ class RigidEntity:
     def _set_base(self, val, lo, hi, zero_velocity, envs_idx):
         e = self._envs(envs_idx)
         q = self._get("F_QPOS")
-        q[lo:hi, e] = torch.as_tensor(val, device=device, dtype=torch.float32).reshape(len(e), hi - lo).t()
+        q[lo:hi, e] = _broadcast(val, (len(e), hi - lo)).t()
         self._set("F_QPOS", q)
         if zero_velocity:
             self.zero_all_dofs_velocity(envs_idx)
@@ -287,13 +346,13 @@ class RigidEntity:
     def set_mass_shift(self, mass_shift, links_idx_local=None, envs_idx=None):
         l, e = self._links(links_idx_local), self._envs(envs_idx)
         cur = self._get("F_MASS_SHIFT")
-        cur[l[:, None], e[None, :]] = torch.as_tensor(mass_shift, device=device, dtype=torch.float32).reshape(len(e), len(l)).t()
+        cur[l[:, None], e[None, :]] = _broadcast(mass_shift, (len(e), len(l))).t()
         self._set("F_MASS_SHIFT", cur)
 
     def set_COM_shift(self, com_shift, links_idx_local=None, envs_idx=None):
         l, e = self._links(links_idx_local), self._envs(envs_idx)
         cur = self._get("F_COM_SHIFT").reshape(-1, 3, self._sim.n_envs)
-        cur[l[:, None], :, e[None, :]] = torch.as_tensor(com_shift, device=device, dtype=torch.float32).reshape(len(e), len(l), 3).permute(1, 0, 2)
+        cur[l[:, None], :, e[None, :]] = _broadcast(com_shift, (len(e), len(l), 3)).permute(1, 0, 2)
         self._set("F_COM_SHIFT", cur.reshape(-1, self._sim.n_envs))
 
 
@@ -307,7 +366,7 @@ class _RigidSolver:
         robot = scene._robot
         e = robot._envs(envs_idx)
         l = torch.as_tensor(links_idx, device=device).long().reshape(-1)
-        f = torch.as_tensor(force, device=device, dtype=torch.float32).reshape(len(e), len(l), 3)
+        f = _broadcast(force, (len(e), len(l), 3))
         ext = robot._get("F_EXT_FORCE").reshape(-1, 6, scene._sim.n_envs)                  # [link, (ang3, vel3), B]
         pos = robot._link_vec("F_LINK_POS", 3)[e][:, l]
         torque = torch.cross(pos - robot._root_com()[e][:, None, :], f, dim=-1)

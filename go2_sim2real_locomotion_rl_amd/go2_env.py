@@ -115,8 +115,9 @@ class Go2Env:
         gptr = self._sim.env_globals_ptr()
         self._glob_f32 = _as_device_tensor(gptr, (ctypes.sizeof(EnvGlobals) // 4,), torch.float32, dev)
         self._ep_off = EnvGlobals.last_episode_rew.offset // 4
-        self._level_off = EnvGlobals.level.offset // 4
-        self._goff = {name: getattr(EnvGlobals, name).offset // 4 for name, _ in EnvGlobals._fields_}
+        self._glob_f64 = self._glob_f32.view(torch.float64)     # the python-float state of the reference is kept in double (include/go2sim.h)
+        self._level_off = EnvGlobals.level.offset // 8
+        self._goff = {name: getattr(EnvGlobals, name).offset // (8 if ct is ctypes.c_double else 4) for name, ct in EnvGlobals._fields_}
         self._episode_keys = ["rew_" + n for n in self._reward_names]
         self._use_terrain = hasattr(self, "_terrain_info")
         self._terrain_rows_locked = False
@@ -167,16 +168,16 @@ class Go2Env:
             self.extras["episode"]["terrain_mean_row"] = rows[self._goff["terrain_row_sum"]].float() / rows[self._goff["last_reset_count"]].clamp(min=1).float()
         if self.is_base_env or not full:
             return
-        f, i = snap, snap.view(torch.int32)
+        f, i, d = snap, snap.view(torch.int32), snap.view(torch.float64)
         g = self._goff
         self.extras["curriculum"] = {
-            "level": f[g["level"]], "timeout_rate_ema": f[g["timeout_rate_ema"]], "tracking_ema": f[g["tracking_ema"]],
-            "fall_rate_ema": f[g["fall_rate_ema"]], "ready_streak": i[g["ready_streak"]], "hard_streak": i[g["hard_streak"]],
-            "cooldown": i[g["cooldown"]], "obs_noise_level_cur": f[g["obs_noise_level_cur"]], "action_noise_std_cur": f[g["action_noise_std_cur"]],
-            "push_enable": i[g["push_enable"]], "push_force_range_cur": f[g["push_force_lo"]:g["push_force_lo"] + 2],
+            "level": d[g["level"]], "timeout_rate_ema": d[g["timeout_rate_ema"]], "tracking_ema": d[g["tracking_ema"]],
+            "fall_rate_ema": d[g["fall_rate_ema"]], "ready_streak": i[g["ready_streak"]], "hard_streak": i[g["hard_streak"]],
+            "cooldown": i[g["cooldown"]], "obs_noise_level_cur": d[g["obs_noise_level_cur"]], "action_noise_std_cur": d[g["action_noise_std_cur"]],
+            "push_enable": i[g["push_enable"]], "push_force_range_cur": d[g["push_force_lo"]:g["push_force_lo"] + 2],
             "push_interval_steps": i[g["push_interval"]], "delay_max_cur": i[g["delay_max_cur"]],
-            "cmd_ranges": {"lin_vel_x_range": f[g["cmd_x_lo"]:g["cmd_x_lo"] + 2], "lin_vel_y_range": f[g["cmd_y_lo"]:g["cmd_y_lo"] + 2],
-                           "ang_vel_range": f[g["cmd_yaw_lo"]:g["cmd_yaw_lo"] + 2]},
+            "cmd_ranges": {"lin_vel_x_range": d[g["cmd_x_lo"]:g["cmd_x_lo"] + 2], "lin_vel_y_range": d[g["cmd_y_lo"]:g["cmd_y_lo"] + 2],
+                           "ang_vel_range": d[g["cmd_yaw_lo"]:g["cmd_yaw_lo"] + 2]},
         }
         self.extras["domain_randomization"] = {"friction": f[g["friction"]], "mass_shift": f[g["mass_shift"]],
                                                "com_shift": f[g["com_shift"]:g["com_shift"] + 3],
@@ -296,7 +297,7 @@ class Go2Env:
 
     @property
     def curriculum_level(self):
-        return self._glob_f32[self._level_off]
+        return self._glob_f64[self._level_off]
 
     def curriculum_state(self):
         """extras["curriculum"] of the reference (go2_env_walk.py:674-690); this call synchronises the stream."""

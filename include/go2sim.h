@@ -131,21 +131,13 @@ enum go2sim_field {
  * Mirrors the cfg dicts of examples/locomotion/final/go2_train_walk.py:68-372 as consumed by
  * examples/locomotion/final/go2_env_walk.py:155-525. */
 enum go2sim_fcfg {
-  GO2SIM_FC_DT = 0, GO2SIM_FC_ACTION_SCALE, GO2SIM_FC_CLIP_ACTIONS,
-  GO2SIM_FC_KP, GO2SIM_FC_KD,
-  GO2SIM_FC_PLS_KP_MIN, GO2SIM_FC_PLS_KP_MAX, GO2SIM_FC_PLS_KP_DEFAULT, GO2SIM_FC_PLS_KP_ACTION_SCALE,
-  GO2SIM_FC_TORQUE_LIMIT0, /* 12 values, env joint order */
-  GO2SIM_FC_DEFAULT_DOF_POS0 = GO2SIM_FC_TORQUE_LIMIT0 + 12, /* 12 values */
-  GO2SIM_FC_TERM_PITCH_DEG = GO2SIM_FC_DEFAULT_DOF_POS0 + 12, GO2SIM_FC_TERM_ROLL_DEG,
-  GO2SIM_FC_TERM_ZVEL, GO2SIM_FC_TERM_YVEL,
-  GO2SIM_FC_BASE_INIT_POS0, GO2SIM_FC_BASE_INIT_QUAT0 = GO2SIM_FC_BASE_INIT_POS0 + 3,
-  GO2SIM_FC_INIT_Z_LO = GO2SIM_FC_BASE_INIT_QUAT0 + 4, GO2SIM_FC_INIT_Z_HI,
-  GO2SIM_FC_INIT_EULER_LO_DEG, GO2SIM_FC_INIT_EULER_HI_DEG,
+  /* ---- host scalars: values that Go2Env keeps as python floats and combines in float64 before anything reaches a float32 tensor (the
+     curriculum state machine, `_lerp_range(easy, hard, level)`, `_apply_curriculum_level`, `math.radians(init_euler_range)`, the obs-noise vector).
+     The library keeps entries [0, GO2SIM_FC_N_HOST) in double precision as well and does that arithmetic in double. ---- */
+  GO2SIM_FC_DT = 0,
+  GO2SIM_FC_INIT_Z_LO, GO2SIM_FC_INIT_Z_HI, GO2SIM_FC_INIT_EULER_LO_DEG, GO2SIM_FC_INIT_EULER_HI_DEG,
   GO2SIM_FC_OBS_SCALE_LIN_VEL, GO2SIM_FC_OBS_SCALE_ANG_VEL, GO2SIM_FC_OBS_SCALE_DOF_POS, GO2SIM_FC_OBS_SCALE_DOF_VEL,
-  GO2SIM_FC_TRACKING_SIGMA, GO2SIM_FC_BASE_HEIGHT_TARGET, GO2SIM_FC_FEET_HEIGHT_TARGET,
-  GO2SIM_FC_FEET_AIR_TIME_TARGET, GO2SIM_FC_FOOT_CONTACT_THRESHOLD,
-  GO2SIM_FC_REWARD_SCALE0, /* 32 values: reward_scales[name] * dt in evaluation order */
-  GO2SIM_FC_CMD_X_LO = GO2SIM_FC_REWARD_SCALE0 + 32, GO2SIM_FC_CMD_X_HI, GO2SIM_FC_CMD_Y_LO, GO2SIM_FC_CMD_Y_HI,
+  GO2SIM_FC_CMD_X_LO, GO2SIM_FC_CMD_X_HI, GO2SIM_FC_CMD_Y_LO, GO2SIM_FC_CMD_Y_HI,
   GO2SIM_FC_CMD_YAW_LO, GO2SIM_FC_CMD_YAW_HI, GO2SIM_FC_CMD_START_FRAC,
   GO2SIM_FC_FRICTION_EASY_LO, GO2SIM_FC_FRICTION_EASY_HI, GO2SIM_FC_FRICTION_HARD_LO, GO2SIM_FC_FRICTION_HARD_HI,
   GO2SIM_FC_KPF_EASY_LO, GO2SIM_FC_KPF_EASY_HI, GO2SIM_FC_KPF_HARD_LO, GO2SIM_FC_KPF_HARD_HI,
@@ -165,10 +157,25 @@ enum go2sim_fcfg {
   GO2SIM_FC_CURR_READY_TIMEOUT_RATE, GO2SIM_FC_CURR_READY_TRACKING, GO2SIM_FC_CURR_READY_FALL_RATE,
   GO2SIM_FC_CURR_HARD_FALL_RATE, GO2SIM_FC_CURR_STEP_UP, GO2SIM_FC_CURR_STEP_DOWN,
   GO2SIM_FC_CURR_MIX_PROB_CURRENT, GO2SIM_FC_CURR_MIX_LEVEL_LOW, GO2SIM_FC_CURR_MIX_LEVEL_HIGH,
-  /* base env (go2_env_base.py): episode-log normalisation and jump rewards */
-  GO2SIM_FC_EPISODE_LENGTH_S, GO2SIM_FC_JUMP_APEX_HEIGHT, GO2SIM_FC_JUMP_APEX_SIGMA,
-  /* stair env (go2_env_stair.py): terrain-relative rewards, two-phase DR schedule, spawn rows, height scan */
-  GO2SIM_FC_LIN_VEL_Z_DEADZONE, GO2SIM_FC_DR_PHASE1_LEVEL, GO2SIM_FC_DR_TERRAIN_GATE,
+  GO2SIM_FC_EPISODE_LENGTH_S,                               /* base env (go2_env_base.py:232-236): episode-log normalisation */
+  GO2SIM_FC_DR_PHASE1_LEVEL, GO2SIM_FC_DR_TERRAIN_GATE,     /* stair env: two-phase DR schedule (go2_env_stair.py:972-988) */
+  GO2SIM_FC_N_HOST,
+  /* ---- constants of the per-env float32 arithmetic (python floats that meet a float32 tensor directly) ---- */
+  GO2SIM_FC_ACTION_SCALE = GO2SIM_FC_N_HOST, GO2SIM_FC_CLIP_ACTIONS,
+  GO2SIM_FC_KP, GO2SIM_FC_KD,
+  GO2SIM_FC_PLS_KP_MIN, GO2SIM_FC_PLS_KP_MAX, GO2SIM_FC_PLS_KP_DEFAULT, GO2SIM_FC_PLS_KP_ACTION_SCALE,
+  GO2SIM_FC_TORQUE_LIMIT0, /* 12 values, env joint order */
+  GO2SIM_FC_DEFAULT_DOF_POS0 = GO2SIM_FC_TORQUE_LIMIT0 + 12, /* 12 values */
+  GO2SIM_FC_TERM_PITCH_DEG = GO2SIM_FC_DEFAULT_DOF_POS0 + 12, GO2SIM_FC_TERM_ROLL_DEG,
+  GO2SIM_FC_TERM_ZVEL, GO2SIM_FC_TERM_YVEL,
+  GO2SIM_FC_BASE_INIT_POS0, GO2SIM_FC_BASE_INIT_QUAT0 = GO2SIM_FC_BASE_INIT_POS0 + 3,
+  GO2SIM_FC_TRACKING_SIGMA = GO2SIM_FC_BASE_INIT_QUAT0 + 4, GO2SIM_FC_BASE_HEIGHT_TARGET, GO2SIM_FC_FEET_HEIGHT_TARGET,
+  GO2SIM_FC_FEET_AIR_TIME_TARGET, GO2SIM_FC_FOOT_CONTACT_THRESHOLD,
+  GO2SIM_FC_REWARD_SCALE0, /* 32 values: reward_scales[name] * dt (the float64 product) in evaluation order */
+  /* base env (go2_env_base.py): jump rewards */
+  GO2SIM_FC_JUMP_APEX_HEIGHT = GO2SIM_FC_REWARD_SCALE0 + 32, GO2SIM_FC_JUMP_APEX_SIGMA,
+  /* stair env (go2_env_stair.py): terrain-relative rewards, spawn rows, height scan */
+  GO2SIM_FC_LIN_VEL_Z_DEADZONE,
   GO2SIM_FC_TERRAIN_ORIGIN_X, GO2SIM_FC_TERRAIN_ORIGIN_Y, GO2SIM_FC_TERRAIN_H_SCALE,
   GO2SIM_FC_ROW_CENTER0,                                   /* 16 x (x, y, z) spawn centres of the difficulty rows */
   GO2SIM_FC_SCAN_X0 = GO2SIM_FC_ROW_CENTER0 + 48,          /* 80 body-frame x offsets of the height-scan grid (row-major nx x ny) */
@@ -238,24 +245,32 @@ enum go2sim_env_buf {
   GO2SIM_EB_COUNT
 };
 
+/* Depth limit of the per-env action ring of the walk / stair envs: `_action_history[B, max_delay_steps + 1, A]`
+   (go2_env_walk.py:373-380, 916-923).  env_cfg["max_delay_steps"] <= GO2SIM_ACTION_RING_MAX - 1; the reference's walk cfg uses 1, the
+   env's own default is 2. */
+#define GO2SIM_ACTION_RING_MAX 4
+
 /* device-side env globals (curriculum + "global" DR scalars), host-readable snapshot */
 typedef struct go2sim_env_globals {
-  float level;                 /* CurriculumManager.level (go2_env_walk.py:54) */
-  float timeout_rate_ema, tracking_ema, fall_rate_ema;
+  /* python-float (float64) state of Go2Env / CurriculumManager, kept in double like the reference keeps it */
+  double level;                /* CurriculumManager.level (go2_env_walk.py:54) */
+  double timeout_rate_ema, tracking_ema, fall_rate_ema;
+  double curr_timeout_total, curr_tracking_sum;            /* _curr_timeout_total, _curr_tracking_sum (:461-462) */
+  double obs_noise_level_cur, action_noise_std_cur;         /* :634-635 */
+  double push_force_lo, push_force_hi;                      /* _push_force_range_cur (:651) */
+  double cmd_x_lo, cmd_x_hi, cmd_y_lo, cmd_y_hi, cmd_yaw_lo, cmd_yaw_hi;   /* _cmd_cur_ranges (:662-672) */
+  double t_sample;                                          /* level handed to the DR helpers by reset_idx (:1162) */
   int   ema_valid, ready_streak, hard_streak, cooldown;
-  int   curr_ep_total; float curr_timeout_total, curr_tracking_sum; int curr_tracking_n;
-  float obs_noise_level_cur, action_noise_std_cur;
-  int   push_enable; float push_force_lo, push_force_hi; int push_interval, push_counter;
+  int   curr_ep_total, curr_tracking_n;
+  int   push_enable, push_interval, push_counter;
   int   delay_max_cur;
-  float cmd_x_lo, cmd_x_hi, cmd_y_lo, cmd_y_hi, cmd_yaw_lo, cmd_yaw_hi;
   int   global_dr_reset_counter;
-  float friction, mass_shift, com_shift[3], leg_mass_shift[4];
+  float friction, mass_shift, com_shift[3], leg_mass_shift[4];   /* float(tensor.item()) of float32 draws (:750, :809, :817-819, :841) */
   int   action_write_idx;
   unsigned int step_count, reset_calls;
   /* extras["episode"]: mean per-second reward of the envs reset in the last reset call */
   int   last_reset_count; float last_episode_rew[32];
   int   n_reset_now; float ep_acc[32]; /* scratch accumulators */
-  float t_sample;
   float terrain_mean_row;      /* extras["episode"]["terrain_mean_row"] of the last reset call (go2_env_stair.py:1588-1590);
                                   filled by go2sim_env_globals() from terrain_row_sum / last_reset_count */
   int   terrain_row_sum;
@@ -322,7 +337,9 @@ int go2sim_graph_status(go2sim_t* h, int* using_graph, int* n_fallbacks);
 
 /* ---- fused Go2Env fast path (examples/locomotion/final/go2_env_walk.py) ------------------------ */
 /* Go2Env.__init__ buffers + cfg (go2_env_walk.py:155-525) */
-int go2sim_env_configure(go2sim_t* h, const float* fcfg_host, int n_f, const int* icfg_host, int n_i);
+/* fcfg_host: float64 [GO2SIM_FC_COUNT] (enum go2sim_fcfg; the cfg dicts hold python floats: entries below GO2SIM_FC_N_HOST keep their double value,
+ * all entries are also kept rounded to float32 for the per-env arithmetic); icfg_host: int32 [GO2SIM_IC_COUNT] */
+int go2sim_env_configure(go2sim_t* h, const double* fcfg_host, int n_f, const int* icfg_host, int n_i);
 /* Go2Env.step (go2_env_walk.py:985-1109): actions [n_envs][num_actions] -> obs [n_envs][num_obs],
  * priv [n_envs][num_priv_obs], rew [n_envs], reset [n_envs] (u8 bool), time_outs [n_envs] f32. */
 int go2sim_env_step(go2sim_t* h, const float* actions_dev, float* obs_dev, float* priv_dev, float* rew_dev,
@@ -347,7 +364,7 @@ int go2sim_env_get(go2sim_t* h, int env_buf, void* dst_dev, void* stream);
 int go2sim_env_set_episode_length(go2sim_t* h, const int* ep_len_dev, void* stream); /* rsl_rl init_at_random_ep_len */
 int go2sim_env_set_commands(go2sim_t* h, const float* cmd_dev, void* stream);
 int go2sim_env_globals(go2sim_t* h, go2sim_env_globals_t* out_host, void* stream);
-int go2sim_env_set_level(go2sim_t* h, float level, void* stream);
+int go2sim_env_set_level(go2sim_t* h, double level, void* stream);
 /* zero-copy address of the live go2sim_env_globals_t (device memory for the HIP library): lets the host shim expose
  * extras["episode"] / extras["curriculum"] (go2_env_Omni_walk_16output.py:674-690, 1229-1234) as device tensors
  * without a stream synchronisation. */

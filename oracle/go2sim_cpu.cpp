@@ -1752,7 +1752,7 @@ void substep(const Model& m, Env& e) {
 constexpr int NA = 16, NM = 12, NOBS_MAX = 64, NPRIV_MAX = 192, NREW = 32;
 
 struct EnvBuf {
-  real actions[NA], last_actions[NA], applied_actions[NA], action_history[2][NA]; int delay_steps;
+  real actions[NA], last_actions[NA], applied_actions[NA], action_history[GO2SIM_ACTION_RING_MAX][NA]; int delay_steps;
   real target_dof_pos[NM], dof_pos[NM], dof_vel[NM], last_dof_vel[NM], torque[NM];
   real base_pos[3], base_quat[4], base_lin_vel[3], base_ang_vel[3], projected_gravity[3], base_euler[3];
   real commands[3]; int episode_length, reset_buf; real time_out;
@@ -1799,7 +1799,8 @@ inline V3 tc_quat_to_xyz_rpy_deg(Q4 q, real eps) {               // geom.py:717-
   return v3(x * R2D, y * R2D, z * R2D);
 }
 
-struct Cfg { float f[GO2SIM_FC_COUNT]; int i[GO2SIM_IC_COUNT]; bool set; };
+// d[]: the host scalars in double (include/go2sim.h enum go2sim_fcfg, entries below GO2SIM_FC_N_HOST); f[]: every entry rounded to float32
+struct Cfg { double d[GO2SIM_FC_N_HOST]; float f[GO2SIM_FC_COUNT]; int i[GO2SIM_IC_COUNT]; bool set; };
 
 inline double clamp01d(double x) { return std::max(0.0, std::min(1.0, x)); }
 inline double lerpd(double a, double b, double t) { t = clamp01d(t); return a + (b - a) * t; }
@@ -1823,14 +1824,16 @@ inline dm_u4 rng4(const go2sim* h, uint32_t purpose, uint32_t env, uint32_t step
   return dm_philox(env, step, purpose, idx, (uint32_t)h->seed, (uint32_t)(h->seed >> 32));
 }
 enum { RNG_ACTION_NOISE = 1, RNG_PUSH = 2, RNG_CMD = 3, RNG_OBS_NOISE = 4, RNG_RESET_DR = 5, RNG_GLOBAL_DR = 6, RNG_RESET_CMD = 7, RNG_RESET_POSE = 8, RNG_TERRAIN_ROW = 9, RNG_TERRAIN_PERM = 10 };
-inline real rand_float(real lower, real upper, uint32_t r) { return (upper - lower) * dm_u01(r) + lower; }   // gs_rand_float, go2_env_walk.py:7-8
+// gs_rand_float, go2_env_walk.py:7-8: `(upper - lower) * torch.rand(...) + lower` with python-float bounds: the difference is formed in float64 and
+// both scalars are rounded to float32 where they meet the float32 tensor
+inline real rand_float(double lower, double upper, uint32_t r) { return (real)(upper - lower) * dm_u01(r) + (real)lower; }
 inline int rand_int(int lower, int upper, uint32_t r) { return lower + (int)(r % (uint32_t)(upper - lower + 1)); }   // gs_rand_int, :11-13
 
 // Go2Env._apply_curriculum_level, go2_env_walk.py:628-686 (python float64 arithmetic)
 // _get_dr_level, go2_env_stair.py:972-988 (two-phase DR schedule coupled to the terrain level)
 inline double dr_level(const Cfg& c, double terrain_level) {
   if (!c.i[GO2SIM_IC_DR_SCHEDULE]) return terrain_level;
-  double gate = c.f[GO2SIM_FC_DR_TERRAIN_GATE], p1 = c.f[GO2SIM_FC_DR_PHASE1_LEVEL];
+  double gate = c.d[GO2SIM_FC_DR_TERRAIN_GATE], p1 = c.d[GO2SIM_FC_DR_PHASE1_LEVEL];
   if (terrain_level < gate) return p1;
   double progress = clamp01d((terrain_level - gate) / std::max(1e-6, 1.0 - gate));
   return lerpd(p1, 1.0, progress);
@@ -1846,68 +1849,69 @@ inline real terrain_height(const go2sim* h, real x, real y) {
 }
 void apply_curriculum_level(go2sim* h) {
   const Cfg& c = h->cfg; go2sim_env_globals_t& g = h->g;
-  double lvl_terrain = c.i[GO2SIM_IC_CURR_ENABLED] ? (double)g.level : 1.0;
+  double lvl_terrain = c.i[GO2SIM_IC_CURR_ENABLED] ? g.level : 1.0;
   double lvl = dr_level(c, lvl_terrain);   // noise / pushes / delay follow the DR level; the command ranges follow the curriculum level
-  g.obs_noise_level_cur = (float)lerpd(0.0, c.i[GO2SIM_IC_HAS_OBS_NOISE] ? c.f[GO2SIM_FC_OBS_NOISE_LEVEL_MAX] : 0.0, lvl);
-  g.action_noise_std_cur = (float)lerpd(0.0, c.f[GO2SIM_FC_ACTION_NOISE_STD_MAX], lvl);
-  double dt = c.f[GO2SIM_FC_DT];
+  g.obs_noise_level_cur = lerpd(0.0, c.i[GO2SIM_IC_HAS_OBS_NOISE] ? c.d[GO2SIM_FC_OBS_NOISE_LEVEL_MAX] : 0.0, lvl);
+  g.action_noise_std_cur = lerpd(0.0, c.d[GO2SIM_FC_ACTION_NOISE_STD_MAX], lvl);
+  double dt = c.d[GO2SIM_FC_DT];
   if (!c.i[GO2SIM_IC_HAS_PUSH]) {
-    g.push_enable = 0; g.push_force_lo = g.push_force_hi = 0.0f; g.push_interval = 1000000000;
+    g.push_enable = 0; g.push_force_lo = g.push_force_hi = 0.0; g.push_interval = 1000000000;
   } else {
-    double push_start = c.f[GO2SIM_FC_PUSH_START];
+    double push_start = c.d[GO2SIM_FC_PUSH_START];
     if (lvl < push_start) {
-      g.push_enable = 0; g.push_force_lo = g.push_force_hi = 0.0f;
-      g.push_interval = (int)((double)c.f[GO2SIM_FC_PUSH_INTERVAL_S_EASY] / dt);
+      g.push_enable = 0; g.push_force_lo = g.push_force_hi = 0.0;
+      g.push_interval = (int)(c.d[GO2SIM_FC_PUSH_INTERVAL_S_EASY] / dt);
     } else {
       double s = clamp01d((lvl - push_start) / std::max(1e-6, 1.0 - push_start));
-      g.push_force_lo = (float)((double)c.f[GO2SIM_FC_PUSH_FORCE_LO] * s);
-      g.push_force_hi = (float)((double)c.f[GO2SIM_FC_PUSH_FORCE_HI] * s);
-      double interval_s = lerpd(c.f[GO2SIM_FC_PUSH_INTERVAL_S_EASY], c.f[GO2SIM_FC_PUSH_INTERVAL_S_HARD], s);
+      g.push_force_lo = c.d[GO2SIM_FC_PUSH_FORCE_LO] * s;
+      g.push_force_hi = c.d[GO2SIM_FC_PUSH_FORCE_HI] * s;
+      double interval_s = lerpd(c.d[GO2SIM_FC_PUSH_INTERVAL_S_EASY], c.d[GO2SIM_FC_PUSH_INTERVAL_S_HARD], s);
       g.push_interval = std::max(1, (int)(interval_s / dt));
       g.push_enable = 1;
     }
   }
   g.delay_max_cur = (int)nearbyint(lerpd((double)c.i[GO2SIM_IC_DELAY_EASY_MAX], (double)c.i[GO2SIM_IC_MAX_DELAY], lvl));
-  double frac = c.i[GO2SIM_IC_CMD_CURRICULUM] ? lerpd(c.f[GO2SIM_FC_CMD_START_FRAC], 1.0, lvl_terrain) : 1.0;
+  double frac = c.i[GO2SIM_IC_CMD_CURRICULUM] ? lerpd(c.d[GO2SIM_FC_CMD_START_FRAC], 1.0, lvl_terrain) : 1.0;
   const int lo_idx[3] = {GO2SIM_FC_CMD_X_LO, GO2SIM_FC_CMD_Y_LO, GO2SIM_FC_CMD_YAW_LO};
-  float* out[3][2] = {{&g.cmd_x_lo, &g.cmd_x_hi}, {&g.cmd_y_lo, &g.cmd_y_hi}, {&g.cmd_yaw_lo, &g.cmd_yaw_hi}};
+  double* out[3][2] = {{&g.cmd_x_lo, &g.cmd_x_hi}, {&g.cmd_y_lo, &g.cmd_y_hi}, {&g.cmd_yaw_lo, &g.cmd_yaw_hi}};
   for (int k = 0; k < 3; ++k) {
-    double lo = c.f[lo_idx[k]], hi = c.f[lo_idx[k] + 1];
+    double lo = c.d[lo_idx[k]], hi = c.d[lo_idx[k] + 1];
     double center = (lo + hi) / 2.0, half = (hi - lo) / 2.0;
-    *out[k][0] = (float)(center - half * frac); *out[k][1] = (float)(center + half * frac);
+    *out[k][0] = center - half * frac; *out[k][1] = center + half * frac;
   }
 }
 
 // CurriculumManager.update, go2_env_walk.py:101-142
 bool curriculum_update(go2sim* h, double timeout_rate, double tracking_per_sec, double fall_rate) {
   const Cfg& c = h->cfg; go2sim_env_globals_t& g = h->g;
-  double a = c.f[GO2SIM_FC_CURR_EMA_ALPHA];
-  if (!g.ema_valid) { g.timeout_rate_ema = (float)timeout_rate; g.tracking_ema = (float)tracking_per_sec; g.fall_rate_ema = (float)fall_rate; g.ema_valid = 1; }
+  double a = c.d[GO2SIM_FC_CURR_EMA_ALPHA];
+  if (!g.ema_valid) { g.timeout_rate_ema = timeout_rate; g.tracking_ema = tracking_per_sec; g.fall_rate_ema = fall_rate; g.ema_valid = 1; }
   else {
-    g.timeout_rate_ema = (float)((1.0 - a) * g.timeout_rate_ema + a * timeout_rate);
-    g.tracking_ema = (float)((1.0 - a) * g.tracking_ema + a * tracking_per_sec);
-    g.fall_rate_ema = (float)((1.0 - a) * g.fall_rate_ema + a * fall_rate);
+    g.timeout_rate_ema = (1.0 - a) * g.timeout_rate_ema + a * timeout_rate;
+    g.tracking_ema = (1.0 - a) * g.tracking_ema + a * tracking_per_sec;
+    g.fall_rate_ema = (1.0 - a) * g.fall_rate_ema + a * fall_rate;
   }
   if (g.cooldown > 0) g.cooldown -= 1;
-  bool ready = g.timeout_rate_ema >= c.f[GO2SIM_FC_CURR_READY_TIMEOUT_RATE] && g.tracking_ema >= c.f[GO2SIM_FC_CURR_READY_TRACKING] &&
-               g.fall_rate_ema <= c.f[GO2SIM_FC_CURR_READY_FALL_RATE];
-  bool hard = g.fall_rate_ema >= c.f[GO2SIM_FC_CURR_HARD_FALL_RATE];
+  bool ready = g.timeout_rate_ema >= c.d[GO2SIM_FC_CURR_READY_TIMEOUT_RATE] && g.tracking_ema >= c.d[GO2SIM_FC_CURR_READY_TRACKING] &&
+               g.fall_rate_ema <= c.d[GO2SIM_FC_CURR_READY_FALL_RATE];
+  bool hard = g.fall_rate_ema >= c.d[GO2SIM_FC_CURR_HARD_FALL_RATE];
   g.ready_streak = ready ? g.ready_streak + 1 : 0;
   g.hard_streak = hard ? g.hard_streak + 1 : 0;
-  float old_level = g.level;
+  double old_level = g.level;
   if (g.hard_streak >= c.i[GO2SIM_IC_CURR_HARD_STREAK]) {
-    g.level = std::max(c.f[GO2SIM_FC_CURR_LEVEL_MIN], g.level - c.f[GO2SIM_FC_CURR_STEP_DOWN]);
+    g.level = std::max(c.d[GO2SIM_FC_CURR_LEVEL_MIN], g.level - c.d[GO2SIM_FC_CURR_STEP_DOWN]);
     g.hard_streak = 0; g.ready_streak = 0; g.cooldown = c.i[GO2SIM_IC_CURR_COOLDOWN];
   } else if (g.ready_streak >= c.i[GO2SIM_IC_CURR_READY_STREAK] && g.cooldown == 0) {
-    g.level = std::min(c.f[GO2SIM_FC_CURR_LEVEL_MAX], g.level + c.f[GO2SIM_FC_CURR_STEP_UP]);
+    g.level = std::min(c.d[GO2SIM_FC_CURR_LEVEL_MAX], g.level + c.d[GO2SIM_FC_CURR_STEP_UP]);
     g.ready_streak = 0; g.cooldown = c.i[GO2SIM_IC_CURR_COOLDOWN];
   }
-  g.level = std::max(0.0f, std::min(1.0f, g.level));
+  g.level = clamp01d(g.level);
   return g.level != old_level;
 }
 
-inline real lerp_lo(const Cfg& c, int easy_lo, real t) { return (real)lerpd(c.f[easy_lo], c.f[easy_lo + 2], t); }
-inline real lerp_hi(const Cfg& c, int easy_lo, real t) { return (real)lerpd(c.f[easy_lo + 1], c.f[easy_lo + 3], t); }
+// _lerp_range(easy, hard, t_sample), go2_env_walk.py:37-39: python floats
+inline double lerp_lo(const Cfg& c, int easy_lo, double t) { return lerpd(c.d[easy_lo], c.d[easy_lo + 2], t); }
+inline double lerp_hi(const Cfg& c, int easy_lo, double t) { return lerpd(c.d[easy_lo + 1], c.d[easy_lo + 3], t); }
 
 // Go2Env.step, pre-physics part: go2_env_walk.py:985-1023 (+ _apply_push :872-906)
 void env_pre(go2sim* h, int b, const real* actions) {
@@ -1916,21 +1920,28 @@ void env_pre(go2sim* h, int b, const real* actions) {
   const int na = c.i[GO2SIM_IC_NUM_ACTIONS];
   real clip = c.f[GO2SIM_FC_CLIP_ACTIONS];
   for (int i = 0; i < na; ++i) x.actions[i] = std::min(std::max(actions[i], -clip), clip);
-  int w = g.action_write_idx;
-  for (int i = 0; i < na; ++i) x.action_history[w][i] = x.actions[i];                 // _store_action :916-918
-  int w_after = (w + 1) % 2;
-  int read_idx = (((w_after - 1 - x.delay_steps) % 2) + 2) % 2;                          // _get_delayed_action :920-923
   real delayed[NA];
-  for (int i = 0; i < na; ++i) { delayed[i] = x.action_history[read_idx][i]; x.applied_actions[i] = delayed[i]; }
+  if (c.i[GO2SIM_IC_ENV_KIND] == 1) {
+    // go2_env_base.py:124-125: exec_actions = last_actions (one step of latency) or the fresh actions.  last_actions is zeroed by reset_idx (:225)
+    // and then overwritten with the step's actions (:187), so the step after a reset executes the action of the reset step -- there is no ring.
+    for (int i = 0; i < na; ++i) { delayed[i] = c.i[GO2SIM_IC_MAX_DELAY] > 0 ? x.last_actions[i] : x.actions[i]; x.applied_actions[i] = delayed[i]; }
+  } else {
+    const int depth = c.i[GO2SIM_IC_MAX_DELAY] + 1;                                       // _delay_buf_size = max_delay_steps + 1, :375
+    int w = g.action_write_idx;
+    for (int i = 0; i < na; ++i) x.action_history[w][i] = x.actions[i];                 // _store_action :916-918
+    int w_after = (w + 1) % depth;
+    int read_idx = (((w_after - 1 - x.delay_steps) % depth) + depth) % depth;            // _get_delayed_action :920-923
+    for (int i = 0; i < na; ++i) { delayed[i] = x.action_history[read_idx][i]; x.applied_actions[i] = delayed[i]; }
+  }
   real target[NM];
   for (int i = 0; i < NM; ++i) target[i] = delayed[i] * c.f[GO2SIM_FC_ACTION_SCALE] + c.f[GO2SIM_FC_DEFAULT_DOF_POS0 + i];
-  if (g.action_noise_std_cur > 0.0f) {
+  if (g.action_noise_std_cur > 0.0) {                                                  // randn_like(target) * python float: the scalar meets the tensor as float32
     for (int blk = 0; blk < 3; ++blk) {
       dm_u4 r = rng4(h, RNG_ACTION_NOISE, b, g.step_count, blk);
       real n0, n1, n2, n3;
       dm_normal2(r.v[0], r.v[1], &n0, &n1); dm_normal2(r.v[2], r.v[3], &n2, &n3);
       real nn[4] = {n0, n1, n2, n3};
-      for (int k = 0; k < 4; ++k) target[4 * blk + k] = target[4 * blk + k] + nn[k] * g.action_noise_std_cur;
+      for (int k = 0; k < 4; ++k) target[4 * blk + k] = target[4 * blk + k] + nn[k] * (real)g.action_noise_std_cur;
     }
   }
   for (int i = 0; i < NM; ++i) x.target_dof_pos[i] = target[i];
@@ -2175,29 +2186,30 @@ void env_globals_update(go2sim* h, bool count_push) {
   int n = g.n_reset_now;
   if (n > 0) {
     if (c.i[GO2SIM_IC_CURR_ENABLED] && !c.i[GO2SIM_IC_FREEZE_CURRICULUM]) {                // _maybe_update_curriculum_on_reset
-      g.curr_ep_total += n; g.curr_timeout_total += (float)h->acc_timeouts; g.curr_tracking_sum += (float)h->acc_tracking; g.curr_tracking_n += n;
+      // `float(tensor.sum().item())` of float32 tensors (:698, :710) added to python floats
+      g.curr_ep_total += n; g.curr_timeout_total += (double)(float)h->acc_timeouts; g.curr_tracking_sum += (double)(float)h->acc_tracking; g.curr_tracking_n += n;
       if (g.curr_ep_total >= c.i[GO2SIM_IC_CURR_UPDATE_EVERY]) {
-        double timeout_rate = (double)g.curr_timeout_total / std::max(1, g.curr_ep_total);
+        double timeout_rate = g.curr_timeout_total / std::max(1, g.curr_ep_total);
         double fall_rate = 1.0 - timeout_rate;
-        double tracking_avg = (double)g.curr_tracking_sum / std::max(1, g.curr_tracking_n);
+        double tracking_avg = g.curr_tracking_sum / std::max(1, g.curr_tracking_n);
         if (curriculum_update(h, timeout_rate, tracking_avg, fall_rate)) apply_curriculum_level(h);
-        g.curr_ep_total = 0; g.curr_timeout_total = 0.0f; g.curr_tracking_sum = 0.0f; g.curr_tracking_n = 0;
+        g.curr_ep_total = 0; g.curr_timeout_total = 0.0; g.curr_tracking_sum = 0.0; g.curr_tracking_n = 0;
       }
     }
     dm_u4 r0 = rng4(h, RNG_GLOBAL_DR, 0xffffffffu, g.reset_calls, 0);
     dm_u4 r1 = rng4(h, RNG_GLOBAL_DR, 0xffffffffu, g.reset_calls, 1);
     dm_u4 r2 = rng4(h, RNG_GLOBAL_DR, 0xffffffffu, g.reset_calls, 2);
     double t;                                                                             // CurriculumManager.sample_level :85-93
-    if (c.i[GO2SIM_IC_DR_SCHEDULE]) t = dr_level(c, c.i[GO2SIM_IC_CURR_ENABLED] ? (double)g.level : 1.0);   // go2_env_stair.py:1506-1507
+    if (c.i[GO2SIM_IC_DR_SCHEDULE]) t = dr_level(c, c.i[GO2SIM_IC_CURR_ENABLED] ? g.level : 1.0);   // go2_env_stair.py:1506-1507
     else if (!c.i[GO2SIM_IC_CURR_ENABLED]) t = 1.0;
     else if (dm_u01(r0.v[0]) < c.f[GO2SIM_FC_CURR_MIX_PROB_CURRENT]) t = clamp01d(g.level);
     else {
-      double hi = std::min((double)g.level, (double)c.f[GO2SIM_FC_CURR_MIX_LEVEL_HIGH]);
-      double lo = std::min((double)c.f[GO2SIM_FC_CURR_MIX_LEVEL_LOW], hi);
+      double hi = std::min(g.level, c.d[GO2SIM_FC_CURR_MIX_LEVEL_HIGH]);
+      double lo = std::min(c.d[GO2SIM_FC_CURR_MIX_LEVEL_LOW], hi);
       t = clamp01d(lo + (hi - lo) * (double)dm_u01(r0.v[1]));
     }
-    g.t_sample = (float)t;
-    real ts = g.t_sample;
+    g.t_sample = t;
+    double ts = g.t_sample;
     if (c.i[GO2SIM_IC_HAS_FRICTION_DR]) {                                                  // _randomize_friction :737-756
       g.global_dr_reset_counter += n;
       if (g.global_dr_reset_counter >= c.i[GO2SIM_IC_GLOBAL_DR_INTERVAL]) {
@@ -2213,7 +2225,7 @@ void env_globals_update(go2sim* h, bool count_push) {
       for (int k = 0; k < 4; ++k) g.leg_mass_shift[k] = rand_float(lerp_lo(c, GO2SIM_FC_LEGM_EASY_LO, ts), lerp_hi(c, GO2SIM_FC_LEGM_EASY_LO, ts), r2.v[k]);
     g.last_reset_count = n;
     for (int k = 0; k < NREW; ++k)
-      g.last_episode_rew[k] = (c.i[GO2SIM_IC_ENV_KIND] == 1) ? (float)((double)(float)(h->acc_ep[k] / (double)n) / (double)c.f[GO2SIM_FC_EPISODE_LENGTH_S]) : (float)(h->acc_ep[k] / (double)n);
+      g.last_episode_rew[k] = (c.i[GO2SIM_IC_ENV_KIND] == 1) ? (float)((double)(float)(h->acc_ep[k] / (double)n) / c.d[GO2SIM_FC_EPISODE_LENGTH_S]) : (float)(h->acc_ep[k] / (double)n);
     g.reset_calls += 1;
   }
 }
@@ -2223,7 +2235,7 @@ void env_reset_one(go2sim* h, int b) {
   const Model& m = h->m; const Cfg& c = h->cfg; const go2sim_env_globals_t& g = h->g;
   Env& e = h->envs[b]; EnvBuf& x = h->eb[b];
   uint32_t rc = g.reset_calls - 1;  // id of the current reset call (already advanced by env_globals_update)
-  real ts = g.t_sample;
+  double ts = g.t_sample;
   if (c.i[GO2SIM_IC_HAS_KPF_DR])                                                          // _randomize_kp_kd (PLS branch) :763-773
     for (int blk = 0; blk < 3; ++blk) { dm_u4 r = rng4(h, RNG_RESET_DR, b, rc, blk); for (int k = 0; k < 4; ++k) x.kp_factors[4 * blk + k] = rand_float(lerp_lo(c, GO2SIM_FC_KPF_EASY_LO, ts), lerp_hi(c, GO2SIM_FC_KPF_EASY_LO, ts), r.v[k]); }
   if (c.i[GO2SIM_IC_HAS_KDF_DR])
@@ -2266,12 +2278,12 @@ void env_reset_one(go2sim* h, int b) {
     real init_z = c.f[GO2SIM_FC_BASE_INIT_POS0 + 2];
     real spawn_z = rcn[2] + init_z;
     x.base_pos[0] = rcn[0]; x.base_pos[1] = rcn[1]; x.base_pos[2] = spawn_z;
-    if (c.i[GO2SIM_IC_HAS_INIT_Z]) x.base_pos[2] = ((spawn_z + rand_float(c.f[GO2SIM_FC_INIT_Z_LO], c.f[GO2SIM_FC_INIT_Z_HI], rp.v[0])) - init_z) + init_z;
+    if (c.i[GO2SIM_IC_HAS_INIT_Z]) x.base_pos[2] = ((spawn_z + rand_float(c.d[GO2SIM_FC_INIT_Z_LO], c.d[GO2SIM_FC_INIT_Z_HI], rp.v[0])) - init_z) + init_z;
   } else
-  if (c.i[GO2SIM_IC_HAS_INIT_Z]) x.base_pos[2] = rand_float(c.f[GO2SIM_FC_INIT_Z_LO], c.f[GO2SIM_FC_INIT_Z_HI], rp.v[0]);
+  if (c.i[GO2SIM_IC_HAS_INIT_Z]) x.base_pos[2] = rand_float(c.d[GO2SIM_FC_INIT_Z_LO], c.d[GO2SIM_FC_INIT_Z_HI], rp.v[0]);
   if (c.i[GO2SIM_IC_HAS_INIT_EULER]) {                                                     // :1191-1199, euler_to_quat_wxyz :16-25
-    const real D2R = 0.017453292519943295f;
-    real lo = c.f[GO2SIM_FC_INIT_EULER_LO_DEG] * D2R, hi = c.f[GO2SIM_FC_INIT_EULER_HI_DEG] * D2R;
+    const double D2R = 3.141592653589793 / 180.0;                                          // math.radians: x * (pi / 180) in float64
+    double lo = c.d[GO2SIM_FC_INIT_EULER_LO_DEG] * D2R, hi = c.d[GO2SIM_FC_INIT_EULER_HI_DEG] * D2R;
     real roll = rand_float(lo, hi, rp.v[1]), pitch = rand_float(lo, hi, rp.v[2]), yaw = 0.0f;
     real sr, cr, sp, cp, sy, cy;
     dm_sincos(roll / 2.0f, &sr, &cr); dm_sincos(pitch / 2.0f, &sp, &cp); dm_sincos(yaw / 2.0f, &sy, &cy);
@@ -2281,7 +2293,7 @@ void env_reset_one(go2sim* h, int b) {
   for (int k = 0; k < 3; ++k) e.qpos[k] = x.base_pos[k];
   for (int k = 0; k < 4; ++k) e.qpos[3 + k] = x.base_quat[k];
   for (int k = 0; k < 3; ++k) { x.base_lin_vel[k] = 0.0f; x.base_ang_vel[k] = 0.0f; }
-  for (int i = 0; i < NA; ++i) { x.last_actions[i] = 0.0f; x.applied_actions[i] = 0.0f; x.action_history[0][i] = 0.0f; x.action_history[1][i] = 0.0f; }
+  for (int i = 0; i < NA; ++i) { x.last_actions[i] = 0.0f; x.applied_actions[i] = 0.0f; for (int k = 0; k < GO2SIM_ACTION_RING_MAX; ++k) x.action_history[k][i] = 0.0f; }
   for (int i = 0; i < NM; ++i) x.last_dof_vel[i] = 0.0f;
   x.last_base_pos_x = x.base_pos[0];                                                       // go2_env_stair.py:1557
   for (int k = 0; k < 3; ++k) x.push_stored_force[k] = 0.0f;
@@ -2346,8 +2358,8 @@ void env_post_b(go2sim* h, int b, real* obs, real* priv) {
   for (int i = 0; i < NM; ++i) o[9 + i] = (x.dof_pos[i] - c.f[GO2SIM_FC_DEFAULT_DOF_POS0 + i]) * c.f[GO2SIM_FC_OBS_SCALE_DOF_POS];
   for (int i = 0; i < NM; ++i) o[21 + i] = x.dof_vel[i] * c.f[GO2SIM_FC_OBS_SCALE_DOF_VEL];
   for (int i = 0; i < na; ++i) o[33 + i] = x.applied_actions[i];
-  if (c.i[GO2SIM_IC_HAS_OBS_NOISE] && c.f[GO2SIM_FC_OBS_NOISE_LEVEL_MAX] > 0.0f) {          // _add_obs_noise :908-910, _rebuild_obs_noise_vec :611-626
-    real lvl = g.obs_noise_level_cur;
+  if (c.i[GO2SIM_IC_HAS_OBS_NOISE] && c.d[GO2SIM_FC_OBS_NOISE_LEVEL_MAX] > 0.0) {          // _add_obs_noise :908-910, _rebuild_obs_noise_vec :611-626
+    double lvl = g.obs_noise_level_cur;                                                     // python-float products, rounded on assignment into the float32 vector
     for (int blk = 0; blk * 4 < nobs; ++blk) {
       dm_u4 r = rng4(h, RNG_OBS_NOISE, b, g.step_count, blk);
       real n[4];
@@ -2356,11 +2368,11 @@ void env_post_b(go2sim* h, int b, real* obs, real* priv) {
         int i = 4 * blk + k;
         if (i >= nobs) break;
         real nv = 0.0f;
-        if (i < 3) nv = c.f[GO2SIM_FC_OBS_NOISE_ANG_VEL] * c.f[GO2SIM_FC_OBS_SCALE_ANG_VEL] * lvl;
-        else if (i < 6) nv = c.f[GO2SIM_FC_OBS_NOISE_GRAVITY] * lvl;
+        if (i < 3) nv = (real)(c.d[GO2SIM_FC_OBS_NOISE_ANG_VEL] * c.d[GO2SIM_FC_OBS_SCALE_ANG_VEL] * lvl);
+        else if (i < 6) nv = (real)(c.d[GO2SIM_FC_OBS_NOISE_GRAVITY] * lvl);
         else if (i < 9) nv = 0.0f;
-        else if (i < 21) nv = c.f[GO2SIM_FC_OBS_NOISE_DOF_POS] * c.f[GO2SIM_FC_OBS_SCALE_DOF_POS] * lvl;
-        else if (i < 33) nv = c.f[GO2SIM_FC_OBS_NOISE_DOF_VEL] * c.f[GO2SIM_FC_OBS_SCALE_DOF_VEL] * lvl;
+        else if (i < 21) nv = (real)(c.d[GO2SIM_FC_OBS_NOISE_DOF_POS] * c.d[GO2SIM_FC_OBS_SCALE_DOF_POS] * lvl);
+        else if (i < 33) nv = (real)(c.d[GO2SIM_FC_OBS_NOISE_DOF_VEL] * c.d[GO2SIM_FC_OBS_SCALE_DOF_VEL] * lvl);
         o[i] = o[i] + n[k] * nv;
       }
     }
@@ -2621,15 +2633,17 @@ int go2sim_cpu_check_errno(go2sim* h, int* out, void*) {
   return GO2SIM_E_OK;
 }
 
-int go2sim_cpu_env_configure(go2sim* h, const float* f, int nf, const int* i, int ni) {
+int go2sim_cpu_env_configure(go2sim* h, const double* f, int nf, const int* i, int ni) {
   if (!h || !f || !i || nf != GO2SIM_FC_COUNT || ni != GO2SIM_IC_COUNT) return GO2SIM_E_BADARG;
-  memcpy(h->cfg.f, f, sizeof(float) * nf); memcpy(h->cfg.i, i, sizeof(int) * ni); h->cfg.set = true;
+  for (int k = 0; k < GO2SIM_FC_N_HOST; ++k) h->cfg.d[k] = f[k];
+  for (int k = 0; k < nf; ++k) h->cfg.f[k] = (float)f[k];
+  memcpy(h->cfg.i, i, sizeof(int) * ni); h->cfg.set = true;
   const Cfg& c = h->cfg;
   if (c.i[GO2SIM_IC_NUM_ACTIONS] > NA || c.i[GO2SIM_IC_NUM_OBS] > NOBS_MAX || c.i[GO2SIM_IC_NUM_PRIV_OBS] > NPRIV_MAX || c.i[GO2SIM_IC_N_REWARDS] > NREW ||
-      c.i[GO2SIM_IC_MAX_DELAY] > 1)
+      c.i[GO2SIM_IC_MAX_DELAY] >= GO2SIM_ACTION_RING_MAX || c.i[GO2SIM_IC_MAX_DELAY] < 0)
     return GO2SIM_E_BADARG;
   memset(&h->g, 0, sizeof(h->g));
-  h->g.level = c.f[GO2SIM_FC_CURR_LEVEL_INIT];
+  h->g.level = c.d[GO2SIM_FC_CURR_LEVEL_INIT];
   h->g.friction = 1.0f;
   apply_curriculum_level(h);
   for (int b = 0; b < h->B; ++b) {
@@ -2655,7 +2669,7 @@ static void assign_terrain_rows(go2sim* h) {
   const int n = (int)idx.size();
   double mean_row = 0.0;
   if (n_rows > 1 && !g.lock_terrain_rows) {                        // `if not self._lock_terrain_rows`, go2_env_stair.py:1513
-    double level = c.i[GO2SIM_IC_CURR_ENABLED] ? (double)g.level : 1.0;
+    double level = c.i[GO2SIM_IC_CURR_ENABLED] ? g.level : 1.0;
     int max_row = (int)(level * (double)(n_rows - 1));
     max_row = std::max(0, std::min(max_row, n_rows - 1));
     int n_frontier = (int)((double)n * 0.40), n_near = (int)((double)n * 0.30);
@@ -2708,7 +2722,7 @@ int go2sim_cpu_env_step(go2sim* h, const float* actions, float* obs, float* priv
     for (int l = 0; l < NL; ++l) { e.ext_ang[l] = v3(0, 0, 0); e.ext_vel[l] = v3(0, 0, 0); }
     env_post_a(h, b);
   }
-  h->g.action_write_idx = (h->g.action_write_idx + 1) % 2;
+  h->g.action_write_idx = (h->g.action_write_idx + 1) % (c.i[GO2SIM_IC_MAX_DELAY] + 1);
   reset_call(h, true);
 #pragma omp parallel for schedule(static)
   for (int b = 0; b < h->B; ++b) {
@@ -2758,7 +2772,7 @@ int go2sim_cpu_env_respawn(go2sim* h, const int* envs_idx, int n_sel, const floa
     for (int k = 0; k < 4; ++k) { real q = quat ? quat[4 * t + k] : c.f[GO2SIM_FC_BASE_INIT_QUAT0 + k]; x.base_quat[k] = q; e.qpos[3 + k] = q; }
     if (clear_buffers) {
       for (int k = 0; k < 3; ++k) { x.base_lin_vel[k] = 0.0f; x.base_ang_vel[k] = 0.0f; }
-      for (int i = 0; i < NA; ++i) { x.last_actions[i] = 0.0f; x.applied_actions[i] = 0.0f; x.action_history[0][i] = 0.0f; x.action_history[1][i] = 0.0f; }
+      for (int i = 0; i < NA; ++i) { x.last_actions[i] = 0.0f; x.applied_actions[i] = 0.0f; for (int k = 0; k < GO2SIM_ACTION_RING_MAX; ++k) x.action_history[k][i] = 0.0f; }
       for (int i = 0; i < NM; ++i) x.last_dof_vel[i] = 0.0f;
       x.last_base_pos_x = pos[3 * t];
     }
@@ -2839,7 +2853,7 @@ int go2sim_cpu_env_globals_ptr(go2sim* h, void** ptr_out) {
   *ptr_out = &h->g;
   return GO2SIM_E_OK;
 }
-int go2sim_cpu_env_set_level(go2sim* h, float level, void*) {
+int go2sim_cpu_env_set_level(go2sim* h, double level, void*) {
   if (!h || !h->cfg.set) return GO2SIM_E_BADARG;
   h->g.level = level;
   apply_curriculum_level(h);

@@ -97,3 +97,49 @@ def test_genesis_alias_package(oracle_lib):
     import inspect
 
     assert "_backend_lib" not in inspect.signature(gs.init).parameters
+
+
+def test_setters_take_the_reference_call_shapes(oracle_lib):
+    """The global-DR calls of go2_env_walk.py:810,820,843 / go2_env_stair.py:1161,1169,1189: one value, one link, envs_idx=None; the reference's
+    setters broadcast it over every env (rigid_solver.py:2051-2071 -> _sanitize_io_variables -> genesis/utils/misc.py broadcast_tensor)."""
+    B = 5
+    scene, robot = _build(oracle_lib, B, get_jump_cfgs()[0])
+    robot.set_mass_shift([1.25], [0])
+    robot.set_COM_shift([[0.01, -0.02, 0.03]], [0])
+    for hip in (1, 2, 3, 4):
+        robot.set_mass_shift([0.1 * hip], [hip])                                         # _randomize_leg_mass, :840-846
+    ms = robot._get("F_MASS_SHIFT").t()                                                  # [B, 14] (global link index: the plane is link 0)
+    cs = robot._get("F_COM_SHIFT").reshape(-1, 3, B).permute(2, 0, 1)
+    assert torch.equal(ms[:, 1], torch.full((B,), 1.25)) and torch.allclose(ms[:, 2:6], torch.tensor([0.1, 0.2, 0.3, 0.4]).expand(B, 4))
+    assert torch.allclose(cs[:, 1], torch.tensor([0.01, -0.02, 0.03]).expand(B, 3)) and float(cs[:, 2:].abs().max()) == 0.0
+    robot.set_mass_shift(torch.arange(B, dtype=torch.float32)[:, None], [0])             # per-env values keep working
+    assert torch.equal(robot._get("F_MASS_SHIFT").t()[:, 1], torch.arange(B, dtype=torch.float32))
+    robot.set_mass_shift([7.0], [0], envs_idx=[3])
+    assert robot._get("F_MASS_SHIFT").t()[:, 1].tolist() == [0.0, 1.0, 2.0, 7.0, 4.0]
+    # _apply_push (:893-898): force [B, 3], one link, all envs -> [B, 1, 3]
+    scene.rigid_solver.apply_links_external_force(force=torch.zeros(B, 3), links_idx=[2], envs_idx=torch.arange(B, dtype=torch.int32))
+    robot.control_dofs_position(torch.zeros(12), list(range(6, 18)))                     # a [12] target reaches every env
+    assert robot._get("F_CTRL_POS").t()[:, 6:].abs().max() == 0
+    with pytest.raises(gs.GenesisException):
+        robot.set_mass_shift(torch.zeros(B, 2, 2), [0])
+    scene.step()
+
+
+def test_quat_to_xyz_is_the_reference_formulation():
+    """geom.py:717-774 (`_tc_quat_to_xyz`): atan2 forms, the cos(pitch) < EPS branch, rpy default False; checked against scipy's rotation
+    conventions (extrinsic xyz = roll / pitch / yaw for rpy=True, intrinsic XYZ for rpy=False)."""
+    from scipy.spatial.transform import Rotation
+
+    rng = np.random.default_rng(0)
+    q = rng.standard_normal((200, 4)); q /= np.linalg.norm(q, axis=1, keepdims=True)
+    rot = Rotation.from_quat(q[:, [1, 2, 3, 0]])
+    ours = gs.quat_to_xyz(torch.from_numpy(q.astype(np.float32)), rpy=True, degrees=True).numpy()
+    assert np.abs(ours - rot.as_euler("xyz", degrees=True)).max() < 2e-3
+    ours = gs.quat_to_xyz(torch.from_numpy(q.astype(np.float32))).numpy()               # rpy defaults to False like the reference
+    assert np.abs(ours - rot.as_euler("XYZ")).max() < 5e-5
+    # pitch beyond +-90 degrees is where asin(2 (wy - zx)) (the former shim) and the reference differ: none of the angles may exceed 90 in pitch,
+    # and the singular pose takes the cosp < EPS branch: roll = 0, yaw from the remaining terms
+    up = torch.tensor([[np.cos(np.pi / 4), 0.0, np.sin(np.pi / 4), 0.0]], dtype=torch.float32)   # pitch = 90 degrees exactly
+    e = gs.quat_to_xyz(up, rpy=True, degrees=True)[0]
+    assert float(e[0]) == 0.0 and abs(float(e[1]) - 90.0) < 1e-3 and abs(float(e[2])) < 1e-3
+    assert gs.EPS == float(np.finfo(np.float32).eps)
