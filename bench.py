@@ -111,7 +111,7 @@ def pmc_traffic_bytes(kernel, n_envs):
     return int((2 * rec["fetch_size_kb"] + rec["write_size_kb"]) * 1024), None
 
 
-def make_sim(lib, n_envs, device_index, seed, workload, freeze_curriculum=True):
+def make_sim(lib, n_envs, device_index, seed, workload, freeze_curriculum=True, shared_globals=False):
     """Configured handle: walk (flat plane) or stairs (go2_train_stair.py terrain + cfg), curriculum frozen at its initial level."""
     sim = Go2Sim(lib, pack_model(), n_envs, device_index, seed)
     if workload == "jump_dr":       # BASELINE configs[4]: base env (go2_train_jump.py) + per-env friction / base-mass randomisation
@@ -123,7 +123,7 @@ def make_sim(lib, n_envs, device_index, seed, workload, freeze_curriculum=True):
     if workload == "stairs":
         hf, info = build_stair_terrain(cfgs[0]["terrain"])
         sim.set_terrain(hf, info["horizontal_scale"], info["vertical_scale"], info["terrain_origin"])
-    f, i, _ = flatten_walk_cfg(n_envs, *cfgs, freeze_curriculum=freeze_curriculum)
+    f, i, _ = flatten_walk_cfg(n_envs, *cfgs, freeze_curriculum=freeze_curriculum, shared_globals=shared_globals)
     sim.env_configure(f, i)
     sim.env_reset()
     return sim
@@ -214,6 +214,44 @@ def ref_protocol(B, device, local_rank, stream, warm=1000, steps=1000):
     return out
 
 
+def go2env_class_run(B, device, local_rank, seed, W, K):
+    """The headline window through the Go2Env CLASS (go2_env.Go2Env.step: fresh observation tensors per step, extras, errno poll), i.e. what
+    rsl_rl's OnPolicyRunner sees; same cfg, seed and action tape as `value`, with the per-step extras snapshot on and off."""
+    from go2_sim2real_locomotion_rl_amd import go2_env
+
+    go2_env.init(seed=seed, device_index=local_rank)
+    out = {}
+    for key, log in (("log_extras_on", True), ("log_extras_off", False)):
+        env = go2_env.Go2Env(B, *get_walk_cfgs(), seed=seed, device=device, freeze_curriculum=True, log_extras=log)
+        env.reset()
+        act = make_actions(W + K, B, device)
+        for s in range(W):
+            env.step(act[s])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for s in range(W, W + K):
+            env.step(act[s])
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        out[key] = {"value": round(B * K / dt, 1), "ms_per_step": round(dt / K * 1e3, 4)}
+        del env
+    out["note"] = f"Go2Env.step x {K} after {W} warm-up steps from the reset; `value` of the headline times the C ABI underneath"
+    return out
+
+
+def ref_logged():
+    """The only throughput figures the reference tree holds for this path (logs/test1 TensorBoard scalars of a 4096-env stairs run, hardware
+    unstated), extracted by tools/extract_ref_tb_scalars.py into tests/golden/ref_test1_tb_scalars.json."""
+    p = os.path.join(ROOT, "tests", "golden", "ref_test1_tb_scalars.json")
+    if not os.path.exists(p):
+        return None
+    d = json.load(open(p)).get("derived", {})
+    rows = d.get("per_iteration", [])
+    return {"source": "logs/test1/events.out.tfevents.* (go2_train_stair.py run, 4096 envs x 24 steps per iteration, policy inference included, hardware unstated)",
+            "collection_env_steps_per_s": [round(r["collection_env_steps_per_s"], 1) for r in rows],
+            "total_fps": [r["total_fps"] for r in rows], "compare_with": "workloads.stairs (env step only) and `--workload stairs --rollout` (policy + storage included)"}
+
+
 def cpu_baseline(n_envs, steps, warmup, threads=None):
     from go2_sim2real_locomotion_rl_amd.capi import load_cpu_oracle_lib
 
@@ -299,7 +337,8 @@ def main():
     if args.rollout:                      # information-only mode: no per-kernel replay, no CPU baseline
         args.no_profile_pass = args.no_cpu_baseline = args.no_extras = True
     B = args.envs_per_gpu
-    sim = make_sim(load_hip_lib(), B, local_rank, 1 + rank, WORKLOAD)
+    # N > 1: one batch sharded over the ranks keeps ONE curriculum level and ONE set of global DR scalars: distributed.sync_env_globals
+    sim = make_sim(load_hip_lib(), B, local_rank, 1 + rank, WORKLOAD, shared_globals=(world > 1 and WORKLOAD != "jump_dr"))
     K, W = args.steps, args.warmup
     SS_SETTLE, SS_STEPS, SS_KSTEPS = 150, 1000, 200
     n_tape = K + W + (max(0, SS_SETTLE - (K + W)) + SS_STEPS + SS_KSTEPS if world == 1 else 0)
@@ -325,6 +364,11 @@ def main():
         policy = ActorCritic(NOBS[WORKLOAD], NPRIV[WORKLOAD], NACT[WORKLOAD], [512, 256, 128], [512, 256, 128], activation="elu", init_noise_std=0.3,
                              device=device, seed=1 + rank)
 
+    if world > 1:
+        from go2_sim2real_locomotion_rl_amd import distributed as _d
+
+        _sync_globals = _d.sync_env_globals                              # moves host tensors under gloo (rehearsal), device tensors under nccl
+
     def step(s):
         if policy is not None:                                           # closed loop: policy -> env -> storage (-> returns every 24 steps)
             a = policy.act(obs, priv)
@@ -341,6 +385,8 @@ def main():
             sim.env_step(actions[s], obs, priv, storage.rewards[t], storage.dones[t], to, stream)
             if t == ROLLOUT_LEN - 1:
                 storage.compute_returns(zeros_B, 0.99, 0.95)
+                if WORKLOAD != "jump_dr":                                    # all-reduce of the curriculum counters + broadcast of rank 0's global DR draws
+                    _sync_globals(sim, None, stream)
             return
         sim.env_step(actions[s], obs, priv, rew, rst, to, stream)
 
@@ -404,9 +450,10 @@ def main():
         roofline = roofline_of(ms, cnt, K, B, WORKLOAD, value)
         del sim2
 
-    action_sets = curriculum_live = workloads = refp = None
+    action_sets = curriculum_live = workloads = refp = envcls = None
     if extras_on:
         del sim
+        envcls = go2env_class_run(B, device, local_rank, 1 + rank, W, K)
         action_sets = {k: protocol_run(B, device, local_rank, 1, "walk", k, 200, 1000, stream) for k in ("A", "B", "C")}
         action_sets["note"] = "SURVEY 8d: A zeros (standing), B 0.5*N(0,1) (falls / resets), C open-loop sine gait; 200 warm-up + 1000 timed steps each, curriculum frozen at 0.10"
         curriculum_live = protocol_run(B, device, local_rank, 1, "walk", "C", 200, 1000, stream, freeze=False)
@@ -439,7 +486,7 @@ def main():
                                 "env step, open-loop actions" + ("; rewards / dones land in the rollout storage, GAE + RCCL all-gather of the advantage moments every 24 steps"
                                                                  if world > 1 else ""))},
             "roofline": roofline, "cpu_baseline": cpu, "steady_state": steady, "action_sets": action_sets, "curriculum_live": curriculum_live,
-            "workloads": workloads, "ref_protocol_fps": refp,
+            "workloads": workloads, "ref_protocol_fps": refp, "go2env_class": envcls, "ref_logged": ref_logged(),
         }
         print(json.dumps(out), flush=True)
     if dist is not None:

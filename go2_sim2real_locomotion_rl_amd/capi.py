@@ -65,7 +65,7 @@ class EnvGlobals(ctypes.Structure):
         ("action_write_idx", ctypes.c_int), ("step_count", ctypes.c_uint), ("reset_calls", ctypes.c_uint),
         ("last_reset_count", ctypes.c_int), ("last_episode_rew", ctypes.c_float * 32),
         ("n_reset_now", ctypes.c_int), ("ep_acc", ctypes.c_float * 32), ("terrain_mean_row", ctypes.c_float), ("terrain_row_sum", ctypes.c_int),
-        ("lock_terrain_rows", ctypes.c_int),
+        ("lock_terrain_rows", ctypes.c_int), ("sync_calls", ctypes.c_int), ("shard_counters", ctypes.c_double * 5),
     ]
 
     def as_dict(self):
@@ -257,6 +257,20 @@ class Go2Sim:
         p = ctypes.c_void_p()
         self._call("env_globals_ptr", ctypes.byref(p))
         return p.value
+
+    def env_sync_counters(self, stream=None):
+        out = (ctypes.c_double * 5)()
+        self._call("env_sync_counters", out, _ptr(stream))
+        return np.array(out[:], np.float64)
+
+    def env_sync_apply(self, summed_counters, stream=None):
+        c = (ctypes.c_double * 5)(*[float(v) for v in summed_counters])
+        dr = (ctypes.c_double * 10)()
+        self._call("env_sync_apply", c, dr, _ptr(stream))
+        return np.array(dr[:], np.float64)
+
+    def env_set_global_dr(self, dr10, stream=None):
+        self._call("env_set_global_dr", (ctypes.c_double * 10)(*[float(v) for v in dr10]), _ptr(stream))
 
     def env_set_level(self, level, stream=None):
         self._call("env_set_level", ctypes.c_double(level), _ptr(stream))

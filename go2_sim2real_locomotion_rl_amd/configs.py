@@ -86,7 +86,7 @@ def _name_maps(model):
 
 
 def flatten_walk_cfg(num_envs, env_cfg, obs_cfg, reward_cfg, command_cfg, *, model=None, per_env_global_dr=False,
-                     freeze_curriculum=False):
+                     freeze_curriculum=False, shared_globals=False):
     """Go2Env.__init__ (go2_env_walk.py:155-525) as data: returns (fcfg float32[FC_COUNT], icfg int32[IC_COUNT],
     reward_names) for go2sim_env_configure."""
     model = load_model_json() if model is None else model
@@ -233,6 +233,7 @@ def flatten_walk_cfg(num_envs, env_cfg, obs_cfg, reward_cfg, command_cfg, *, mod
     i[I("PUSH_LINK")] = robot_links[1]  # `self.robot.links[1].idx` (go2_env_walk.py:339-342): first depth-1 link, not the base
     i[I("PER_ENV_GLOBAL_DR")] = int(per_env_global_dr)
     i[I("FREEZE_CURRICULUM")] = int(freeze_curriculum)
+    i[I("SHARED_GLOBALS")] = int(shared_globals)       # one shard of a larger batch: distributed.sync_env_globals combines the shards
 
     # ---- stair env extras (go2_env_stair.py:352-398, 972-988, 1615-1626) ----
     f[F("LIN_VEL_Z_DEADZONE")] = float(reward_cfg.get("lin_vel_z_deadzone", 0.0))

@@ -3177,18 +3177,18 @@ struct Acc { double timeouts, tracking, ep[NREW]; int n_reset_now; int done; }; 
 typedef go2sim_env_globals_t Glob;
 
 enum { RNG_ACTION_NOISE = 1, RNG_PUSH = 2, RNG_CMD = 3, RNG_OBS_NOISE = 4, RNG_RESET_DR = 5, RNG_GLOBAL_DR = 6, RNG_RESET_CMD = 7, RNG_RESET_POSE = 8, RNG_TERRAIN_ROW = 9, RNG_TERRAIN_PERM = 10 };
-DEV dm_u4 rng4(uint64_t seed, uint32_t purpose, uint32_t env, uint32_t step, uint32_t idx) {
+__host__ __device__ inline dm_u4 rng4(uint64_t seed, uint32_t purpose, uint32_t env, uint32_t step, uint32_t idx) {
   return dm_philox(env, step, purpose, idx, (uint32_t)seed, (uint32_t)(seed >> 32));
 }
 // gs_rand_float, go2_env_walk.py:7-8: `(upper - lower) * torch.rand(...) + lower` with python-float bounds: the difference is formed in float64 and
 // both scalars are rounded to float32 where they meet the float32 tensor
-DEV float rand_float(double lower, double upper, uint32_t r) { return (float)(upper - lower) * dm_u01(r) + (float)lower; }
+__host__ __device__ inline float rand_float(double lower, double upper, uint32_t r) { return (float)(upper - lower) * dm_u01(r) + (float)lower; }
 DEV int rand_int(int lower, int upper, uint32_t r) { return lower + (int)(r % (uint32_t)(upper - lower + 1)); }   // gs_rand_int, :11-13
 __host__ __device__ inline double clamp01d(double x) { return x < 0.0 ? 0.0 : (x > 1.0 ? 1.0 : x); }
 __host__ __device__ inline double lerpd(double a, double b, double t) { t = clamp01d(t); return a + (b - a) * t; }
 // _lerp_range(easy, hard, t_sample), go2_env_walk.py:37-39: python floats
-DEV double lerp_lo(const DCfg& c, int easy_lo, double t) { return lerpd(c.d[easy_lo], c.d[easy_lo + 2], t); }
-DEV double lerp_hi(const DCfg& c, int easy_lo, double t) { return lerpd(c.d[easy_lo + 1], c.d[easy_lo + 3], t); }
+__host__ __device__ inline double lerp_lo(const DCfg& c, int easy_lo, double t) { return lerpd(c.d[easy_lo], c.d[easy_lo + 2], t); }
+__host__ __device__ inline double lerp_hi(const DCfg& c, int easy_lo, double t) { return lerpd(c.d[easy_lo + 1], c.d[easy_lo + 3], t); }
 
 // torch-side helpers of genesis/utils/geom.py used by Go2Env (evaluation order of the torch code)
 DEV Q4 tc_quat_mul(Q4 u, Q4 v) {                                   // geom.py:989-1007
@@ -3277,7 +3277,7 @@ __host__ __device__ inline void apply_curriculum_level(const DCfg& c, Glob& g) {
 }
 
 // CurriculumManager.update, go2_env_walk.py:101-142
-DEV bool curriculum_update(const DCfg& c, Glob& g, double timeout_rate, double tracking_per_sec, double fall_rate) {
+__host__ __device__ inline bool curriculum_update(const DCfg& c, Glob& g, double timeout_rate, double tracking_per_sec, double fall_rate) {
   double a = c.d[GO2SIM_FC_CURR_EMA_ALPHA];
   if (!g.ema_valid) { g.timeout_rate_ema = timeout_rate; g.tracking_ema = tracking_per_sec; g.fall_rate_ema = fall_rate; g.ema_valid = 1; }
   else {
@@ -4003,49 +4003,63 @@ __global__ __launch_bounds__(WG) void k_env_set_terrain_rows(Pool P, const int* 
   P.i[(size_t)IO(terrain_row) * P.B + b] = r < 0 ? 0 : (r >= n_rows ? n_rows - 1 : r);
 }
 
+// the update step of _maybe_update_curriculum_on_reset (go2_env_walk.py:717-729) on the accumulated counters
+__host__ __device__ inline void globals_curriculum_check(const DCfg& c, Glob& g) {
+  if (g.curr_ep_total < c.i[GO2SIM_IC_CURR_UPDATE_EVERY]) return;
+  double timeout_rate = g.curr_timeout_total / (double)(g.curr_ep_total < 1 ? 1 : g.curr_ep_total);
+  double fall_rate = 1.0 - timeout_rate;
+  double tracking_avg = g.curr_tracking_sum / (double)(g.curr_tracking_n < 1 ? 1 : g.curr_tracking_n);
+  if (curriculum_update(c, g, timeout_rate, tracking_avg, fall_rate)) apply_curriculum_level(c, g);
+  g.curr_ep_total = 0; g.curr_timeout_total = 0.0; g.curr_tracking_sum = 0.0; g.curr_tracking_n = 0;
+}
+// t_sample (CurriculumManager.sample_level :85-93) and the "global" DR draws (:737-756, 803-848) of one reset call; `n_throttle` resets are counted
+// for the friction throttle, `key` numbers the call in the Philox stream
+__host__ __device__ inline void globals_draws(const DCfg& c, Glob& g, uint64_t seed, int n_throttle, uint32_t key) {
+  dm_u4 r0 = rng4(seed, RNG_GLOBAL_DR, 0xffffffffu, key, 0);
+  dm_u4 r1 = rng4(seed, RNG_GLOBAL_DR, 0xffffffffu, key, 1);
+  dm_u4 r2 = rng4(seed, RNG_GLOBAL_DR, 0xffffffffu, key, 2);
+  double t;
+  if (c.i[GO2SIM_IC_DR_SCHEDULE]) t = dr_level(c, c.i[GO2SIM_IC_CURR_ENABLED] ? g.level : 1.0);   // go2_env_stair.py:1506-1507
+  else if (!c.i[GO2SIM_IC_CURR_ENABLED]) t = 1.0;
+  else if (dm_u01(r0.v[0]) < c.f[GO2SIM_FC_CURR_MIX_PROB_CURRENT]) t = clamp01d(g.level);
+  else {
+    double hi = c.d[GO2SIM_FC_CURR_MIX_LEVEL_HIGH] < g.level ? c.d[GO2SIM_FC_CURR_MIX_LEVEL_HIGH] : g.level;          // std::min(level, high)
+    double lo = hi < c.d[GO2SIM_FC_CURR_MIX_LEVEL_LOW] ? hi : c.d[GO2SIM_FC_CURR_MIX_LEVEL_LOW];                   // std::min(low, hi)
+    t = clamp01d(lo + (hi - lo) * (double)dm_u01(r0.v[1]));
+  }
+  g.t_sample = t;
+  double ts = g.t_sample;
+  if (c.i[GO2SIM_IC_HAS_FRICTION_DR]) {
+    g.global_dr_reset_counter += n_throttle;
+    if (g.global_dr_reset_counter >= c.i[GO2SIM_IC_GLOBAL_DR_INTERVAL]) {
+      g.global_dr_reset_counter = 0;
+      g.friction = rand_float(lerp_lo(c, GO2SIM_FC_FRICTION_EASY_LO, ts), lerp_hi(c, GO2SIM_FC_FRICTION_EASY_LO, ts), r0.v[2]);
+    }
+  }
+  if (c.i[GO2SIM_IC_HAS_MASS_DR]) g.mass_shift = rand_float(lerp_lo(c, GO2SIM_FC_MASS_EASY_LO, ts), lerp_hi(c, GO2SIM_FC_MASS_EASY_LO, ts), r0.v[3]);
+  if (c.i[GO2SIM_IC_HAS_COM_DR])
+    for (int k = 0; k < 3; ++k) g.com_shift[k] = rand_float(lerp_lo(c, GO2SIM_FC_COM_EASY_LO, ts), lerp_hi(c, GO2SIM_FC_COM_EASY_LO, ts), r1.v[k]);
+  if (c.i[GO2SIM_IC_HAS_LEGM_DR])
+    for (int k = 0; k < 4; ++k) g.leg_mass_shift[k] = rand_float(lerp_lo(c, GO2SIM_FC_LEGM_EASY_LO, ts), lerp_hi(c, GO2SIM_FC_LEGM_EASY_LO, ts), r2.v[k]);
+}
+
 // single-instance part of reset_idx: curriculum, t_sample, "global" DR (go2_env_walk.py:688-756,803-848,1160-1171)
 DEV void env_globals_body(const DCfg& c, Glob& g, Acc* acc, uint64_t seed, int count_push) {
   if (count_push && c.i[GO2SIM_IC_HAS_PUSH] && g.push_enable) g.push_counter += 1;
   int n = acc->n_reset_now;
   g.n_reset_now = n;
   if (n > 0) {
-    if (c.i[GO2SIM_IC_CURR_ENABLED] && !c.i[GO2SIM_IC_FREEZE_CURRICULUM]) {
-      // `float(tensor.sum().item())` of float32 tensors (:698, :710) added to python floats
-      g.curr_ep_total += n; g.curr_timeout_total += (double)(float)acc->timeouts; g.curr_tracking_sum += (double)(float)acc->tracking; g.curr_tracking_n += n;
-      if (g.curr_ep_total >= c.i[GO2SIM_IC_CURR_UPDATE_EVERY]) {
-        double timeout_rate = g.curr_timeout_total / (double)imx(1, g.curr_ep_total);
-        double fall_rate = 1.0 - timeout_rate;
-        double tracking_avg = g.curr_tracking_sum / (double)imx(1, g.curr_tracking_n);
-        if (curriculum_update(c, g, timeout_rate, tracking_avg, fall_rate)) apply_curriculum_level(c, g);
-        g.curr_ep_total = 0; g.curr_timeout_total = 0.0; g.curr_tracking_sum = 0.0; g.curr_tracking_n = 0;
+    // `float(tensor.sum().item())` of float32 tensors (:698, :710) added to python floats
+    const double timeouts = (double)(float)acc->timeouts, tracking = (double)(float)acc->tracking;
+    if (c.i[GO2SIM_IC_SHARED_GLOBALS]) {              // one shard of a larger batch: the increments are combined by the host (go2sim_env_sync_*)
+      g.shard_counters[0] += n; g.shard_counters[1] += timeouts; g.shard_counters[2] += tracking; g.shard_counters[3] += n; g.shard_counters[4] += n;
+    } else {
+      if (c.i[GO2SIM_IC_CURR_ENABLED] && !c.i[GO2SIM_IC_FREEZE_CURRICULUM]) {
+        g.curr_ep_total += n; g.curr_timeout_total += timeouts; g.curr_tracking_sum += tracking; g.curr_tracking_n += n;
+        globals_curriculum_check(c, g);
       }
+      globals_draws(c, g, seed, n, g.reset_calls);
     }
-    dm_u4 r0 = rng4(seed, RNG_GLOBAL_DR, 0xffffffffu, g.reset_calls, 0);
-    dm_u4 r1 = rng4(seed, RNG_GLOBAL_DR, 0xffffffffu, g.reset_calls, 1);
-    dm_u4 r2 = rng4(seed, RNG_GLOBAL_DR, 0xffffffffu, g.reset_calls, 2);
-    double t;
-    if (c.i[GO2SIM_IC_DR_SCHEDULE]) t = dr_level(c, c.i[GO2SIM_IC_CURR_ENABLED] ? g.level : 1.0);   // go2_env_stair.py:1506-1507
-    else if (!c.i[GO2SIM_IC_CURR_ENABLED]) t = 1.0;
-    else if (dm_u01(r0.v[0]) < c.f[GO2SIM_FC_CURR_MIX_PROB_CURRENT]) t = clamp01d(g.level);
-    else {
-      double hi = c.d[GO2SIM_FC_CURR_MIX_LEVEL_HIGH] < g.level ? c.d[GO2SIM_FC_CURR_MIX_LEVEL_HIGH] : g.level;          // std::min(level, high)
-      double lo = hi < c.d[GO2SIM_FC_CURR_MIX_LEVEL_LOW] ? hi : c.d[GO2SIM_FC_CURR_MIX_LEVEL_LOW];                   // std::min(low, hi)
-      t = clamp01d(lo + (hi - lo) * (double)dm_u01(r0.v[1]));
-    }
-    g.t_sample = t;
-    double ts = g.t_sample;
-    if (c.i[GO2SIM_IC_HAS_FRICTION_DR]) {
-      g.global_dr_reset_counter += n;
-      if (g.global_dr_reset_counter >= c.i[GO2SIM_IC_GLOBAL_DR_INTERVAL]) {
-        g.global_dr_reset_counter = 0;
-        g.friction = rand_float(lerp_lo(c, GO2SIM_FC_FRICTION_EASY_LO, ts), lerp_hi(c, GO2SIM_FC_FRICTION_EASY_LO, ts), r0.v[2]);
-      }
-    }
-    if (c.i[GO2SIM_IC_HAS_MASS_DR]) g.mass_shift = rand_float(lerp_lo(c, GO2SIM_FC_MASS_EASY_LO, ts), lerp_hi(c, GO2SIM_FC_MASS_EASY_LO, ts), r0.v[3]);
-    if (c.i[GO2SIM_IC_HAS_COM_DR])
-      for (int k = 0; k < 3; ++k) g.com_shift[k] = rand_float(lerp_lo(c, GO2SIM_FC_COM_EASY_LO, ts), lerp_hi(c, GO2SIM_FC_COM_EASY_LO, ts), r1.v[k]);
-    if (c.i[GO2SIM_IC_HAS_LEGM_DR])
-      for (int k = 0; k < 4; ++k) g.leg_mass_shift[k] = rand_float(lerp_lo(c, GO2SIM_FC_LEGM_EASY_LO, ts), lerp_hi(c, GO2SIM_FC_LEGM_EASY_LO, ts), r2.v[k]);
     g.last_reset_count = n;
     g.terrain_row_sum = 0;   // accumulated by k_env_terrain_rows
     for (int k = 0; k < NREW; ++k)
@@ -5276,6 +5290,72 @@ int go2sim_env_set_level(go2sim_t* h, double level, void* stream) {
   apply_curriculum_level(h->hcfg, g);
   HIPCHK(hipMemcpyAsync(h->dglob, &g, sizeof(Glob), hipMemcpyHostToDevice, s));
   HIPCHK(hipStreamSynchronize(s));
+  return GO2SIM_E_OK;
+}
+// ---- one batch sharded over several handles (GO2SIM_IC_SHARED_GLOBALS), include/go2sim.h ----
+__global__ __launch_bounds__(WG) void k_env_apply_global_dr(Pool P, const DCfg* __restrict__ cp, const Glob* __restrict__ gp) {
+  int b = blockIdx.x * WG + threadIdx.x;
+  if (b >= P.B) return;
+  const DCfg& c = *cp; const Glob& g = *gp;
+  E e(P, b);
+  const bool per_env = c.i[GO2SIM_IC_PER_ENV_GLOBAL_DR] != 0;
+  if (c.i[GO2SIM_IC_HAS_FRICTION_DR] && !per_env) { auto gf = e.geom_friction(); for (int i = 0; i < NG; ++i) gf[i] = g.friction; }
+  int bl = c.i[GO2SIM_IC_BASE_LINK];
+  if (c.i[GO2SIM_IC_HAS_MASS_DR] && !per_env) e.mass_shift()[bl] = g.mass_shift;
+  if (c.i[GO2SIM_IC_HAS_COM_DR]) e.com_shift()[bl] = v3(g.com_shift[0], g.com_shift[1], g.com_shift[2]);
+  if (c.i[GO2SIM_IC_HAS_LEGM_DR]) for (int k = 0; k < 4; ++k) e.mass_shift()[c.i[GO2SIM_IC_HIP_LINK0 + k]] = g.leg_mass_shift[k];
+}
+static int glob_download(go2sim_t* h, Glob& g, hipStream_t s) {
+  HIPCHK(hipMemcpyAsync(&g, h->dglob, sizeof(Glob), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  return GO2SIM_E_OK;
+}
+static int glob_upload(go2sim_t* h, const Glob& g, hipStream_t s) {
+  HIPCHK(hipMemcpyAsync(h->dglob, &g, sizeof(Glob), hipMemcpyHostToDevice, s));
+  HIPCHK(hipStreamSynchronize(s));
+  return GO2SIM_E_OK;
+}
+int go2sim_env_sync_counters(go2sim_t* h, double* out5, void* stream) {
+  if (!h || !h->cfg_set || !out5) return GO2SIM_E_BADARG;
+  hipStream_t s = (hipStream_t)stream;
+  Glob g; int rc = glob_download(h, g, s); if (rc) return rc;
+  for (int k = 0; k < 5; ++k) { out5[k] = g.shard_counters[k]; g.shard_counters[k] = 0.0; }
+  return glob_upload(h, g, s);
+}
+int go2sim_env_sync_apply(go2sim_t* h, const double* s5, double* dr_out10, void* stream) {
+  if (!h || !h->cfg_set || !s5) return GO2SIM_E_BADARG;
+  hipStream_t s = (hipStream_t)stream;
+  const DCfg& c = h->hcfg;
+  Glob g; int rc = glob_download(h, g, s); if (rc) return rc;
+  const int n = (int)s5[0];
+  if (n > 0) {
+    if (c.i[GO2SIM_IC_CURR_ENABLED] && !c.i[GO2SIM_IC_FREEZE_CURRICULUM]) {
+      g.curr_ep_total += n; g.curr_timeout_total += s5[1]; g.curr_tracking_sum += s5[2]; g.curr_tracking_n += (int)s5[3];
+      globals_curriculum_check(c, g);
+    }
+    globals_draws(c, g, h->seed, (int)s5[4], (uint32_t)g.sync_calls);
+    g.sync_calls += 1;
+  }
+  if (dr_out10) {
+    dr_out10[0] = g.friction; dr_out10[1] = g.mass_shift;
+    for (int k = 0; k < 3; ++k) dr_out10[2 + k] = g.com_shift[k];
+    for (int k = 0; k < 4; ++k) dr_out10[5 + k] = g.leg_mass_shift[k];
+    dr_out10[9] = g.t_sample;
+  }
+  return glob_upload(h, g, s);
+}
+int go2sim_env_set_global_dr(go2sim_t* h, const double* dr10, void* stream) {
+  if (!h || !h->cfg_set || !dr10) return GO2SIM_E_BADARG;
+  hipStream_t s = (hipStream_t)stream;
+  Glob g; int rc = glob_download(h, g, s); if (rc) return rc;
+  g.friction = (float)dr10[0]; g.mass_shift = (float)dr10[1];
+  for (int k = 0; k < 3; ++k) g.com_shift[k] = (float)dr10[2 + k];
+  for (int k = 0; k < 4; ++k) g.leg_mass_shift[k] = (float)dr10[5 + k];
+  g.t_sample = dr10[9];
+  rc = glob_upload(h, g, s); if (rc) return rc;
+  hipLaunchKernelGGL(k_env_apply_global_dr, grid_for(h->B), dim3(WG), 0, s, h->P, h->dcfg, h->dglob);
+  launch_fk_team(h, s, 1, nullptr);
+  HIPCHK(hipGetLastError());
   return GO2SIM_E_OK;
 }
 int go2sim_enable_timing(go2sim_t* h, int enable) {

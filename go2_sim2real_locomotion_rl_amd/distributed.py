@@ -1,5 +1,9 @@
 """Multi-GPU sharding helpers.
 
+Besides the advantage statistics, the reference's env has ONE curriculum level and ONE set of "global" DR scalars for all its envs
+(go2_env_walk.py:458-463, 737-756, 803-848).  `sync_env_globals` keeps that true for a batch sharded over ranks: an all-reduce of the four
+curriculum counters (+ the friction-throttle counter), the same state machine on every rank, and a broadcast of rank 0's draws.
+
 Environments are fully independent, so the hot path shards as contiguous blocks of envs per GPU with NO
 physics traffic.  The only collective the path needs is the rollout advantage-normalisation statistics:
 an all-gather of [sum, sum of squares, count] (3 floats per rank) over RCCL/xGMI (backend "nccl" on ROCm,
@@ -58,3 +62,26 @@ def allgather_moments(moments3: torch.Tensor, group=None) -> torch.Tensor:
             g = g + out[r]
         return g
     return moments3
+
+
+def sync_env_globals(sim, group=None, stream=None):
+    """One batch sharded over ranks, one curriculum / one set of global DR scalars.  `sim` is a capi.Go2Sim configured with
+    ``shared_globals=True`` (GO2SIM_IC_SHARED_GLOBALS).  Call it on every rank at the same cadence (once per rollout):
+      1. this shard's increments of [episodes, time-outs, tracking sum, tracking n, throttle resets] (go2_env_walk.py:460-463, 712-715, 744)
+      2. all-reduce(sum) of those 5 float64 (RCCL over xGMI with backend "nccl"; gloo in the CPU tests)
+      3. every rank runs _maybe_update_curriculum_on_reset / sample_level / the global DR draws on the SAME summed counters
+      4. broadcast of rank 0's draws (friction, mass shift, COM shift, leg-mass shifts and the sampled DR level t_sample: 10 float64), applied
+         to all envs of every shard.
+    Returns (summed counters, the 10 scalars now in force).  Without a process group it degenerates to the single-shard case."""
+    dev = torch.device("cuda", torch.cuda.current_device()) if (dist.is_available() and dist.is_initialized() and dist.get_backend(group) == "nccl") else torch.device("cpu")
+    counters = torch.from_numpy(sim.env_sync_counters(stream)).to(dev)
+    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    if multi:
+        dist.all_reduce(counters, op=dist.ReduceOp.SUM, group=group)
+    summed = counters.cpu().numpy()
+    dr = torch.from_numpy(sim.env_sync_apply(summed, stream)).to(dev)
+    if multi:
+        dist.broadcast(dr, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    dr = dr.cpu().numpy()
+    sim.env_set_global_dr(dr, stream)
+    return summed, dr

@@ -65,7 +65,7 @@ def _as_device_tensor(ptr, shape, dtype, device):
 
 class Go2Env:
     def __init__(self, num_envs, env_cfg, obs_cfg, reward_cfg, command_cfg, show_viewer=False, *, seed=None, device=None,
-                 freeze_curriculum=False, log_extras=True, errno_poll_every=5):
+                 freeze_curriculum=False, log_extras=True, errno_poll_every=5, shared_globals=False):
         if show_viewer:
             raise Go2SimError("the viewer is outside the accelerated path (SURVEY.md section 8f)")
         self.device = device if device is not None else (_DEVICE if _DEVICE is not None else init())
@@ -91,7 +91,7 @@ class Go2Env:
             self.num_privileged_obs = None
         else:
             fcfg, icfg, self._reward_names = flatten_walk_cfg(num_envs, env_cfg, obs_cfg, reward_cfg, command_cfg,
-                                                              freeze_curriculum=freeze_curriculum)
+                                                              freeze_curriculum=freeze_curriculum, shared_globals=shared_globals)
             if self.num_obs != 49 or self.num_privileged_obs not in (None, 104, 182) or self.num_actions != 16:
                 raise Go2SimError("go2sim implements the walk layout (16 actions, 49 / 104 obs; go2_train_walk.py:300-320), the stair layout "
                                   "(49 / 182 obs; go2_train_stair.py:282-300) and the base layout (12 actions, 45 obs; go2_train_crouch.py / "
@@ -302,6 +302,13 @@ class Go2Env:
     def curriculum_state(self):
         """extras["curriculum"] of the reference (go2_env_walk.py:674-690); this call synchronises the stream."""
         return self._sim.env_globals(torch.cuda.current_stream(self.device).cuda_stream).as_dict()
+
+    def sync_globals(self, group=None):
+        """One batch sharded over ranks (``shared_globals=True``): all-reduce of the curriculum counters, the shared state machine, broadcast of
+        rank 0's global DR draws (distributed.sync_env_globals).  Call on every rank once per rollout."""
+        from .distributed import sync_env_globals
+
+        return sync_env_globals(self._sim, group, torch.cuda.current_stream(self.device).cuda_stream)
 
     def check_errno(self):
         """rigid_solver.py:1208-1211: blocking form of the poll (``step`` runs the asynchronous one every ``errno_poll_every`` steps)."""

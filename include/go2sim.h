@@ -206,6 +206,9 @@ enum go2sim_icfg {
   GO2SIM_IC_USE_TERRAIN,       /* terrain-relative rewards, spawn rows, terrain_row + height scan in the privileged obs */
   GO2SIM_IC_DR_SCHEDULE,       /* 1 = two-phase DR level (_get_dr_level :972-988) and t_sample = dr level (:1507) */
   GO2SIM_IC_N_TERRAIN_ROWS, GO2SIM_IC_SCAN_N,
+  GO2SIM_IC_SHARED_GLOBALS,    /* 1 = this handle is one shard of a larger batch (one process per GPU): the curriculum counters are only
+                                  accumulated, and neither the curriculum update nor the "global" DR draws run inside env_step; the host combines the
+                                  shards with go2sim_env_sync_counters / _sync_apply / _set_global_dr (distributed.sync_env_globals) */
   GO2SIM_IC_COUNT
 };
 /* reward terms of go2_env_walk.py:1251-1366 */
@@ -275,6 +278,9 @@ typedef struct go2sim_env_globals {
                                   filled by go2sim_env_globals() from terrain_row_sum / last_reset_count */
   int   terrain_row_sum;
   int   lock_terrain_rows;     /* env._lock_terrain_rows (go2_env_stair.py:399,1513; set by go2_eval_stairs.py:657) */
+  int   sync_calls;            /* GO2SIM_IC_SHARED_GLOBALS: number of go2sim_env_sync_apply calls (keys the global-DR draws) */
+  double shard_counters[5];    /* GO2SIM_IC_SHARED_GLOBALS: this shard's increments since the last go2sim_env_sync_counters:
+                                  episodes, time-outs, tracking sum, tracking n (go2_env_walk.py:460-463, 712-715), resets counted for the friction throttle (:744) */
 } go2sim_env_globals_t;
 
 typedef struct go2sim go2sim_t;
@@ -365,6 +371,22 @@ int go2sim_env_set_episode_length(go2sim_t* h, const int* ep_len_dev, void* stre
 int go2sim_env_set_commands(go2sim_t* h, const float* cmd_dev, void* stream);
 int go2sim_env_globals(go2sim_t* h, go2sim_env_globals_t* out_host, void* stream);
 int go2sim_env_set_level(go2sim_t* h, double level, void* stream);
+/* ---- one batch sharded over several handles / processes (GO2SIM_IC_SHARED_GLOBALS) --------------------------------------
+ * The reference has ONE CurriculumManager and one set of "global" DR scalars for all envs (go2_env_walk.py:458-463, 737-756, 803-848).
+ * A shard accumulates its increments of the four curriculum counters and of the friction-throttle counter on the device;
+ *   go2sim_env_sync_counters   copies them out ([5] doubles, host) and clears them                                        (synchronises)
+ *   -- the caller sums them over the shards (one all-reduce of 5 doubles, RCCL) --
+ *   go2sim_env_sync_apply      adds the summed increments to the handle's totals and runs what Go2Env.reset_idx runs once per call on them:
+ *                              _maybe_update_curriculum_on_reset (:688-729), sample_level (:85-93) and the global DR draws (:737-756, 803-848);
+ *                              the draws of this shard are returned in dr_out[10] = friction, mass_shift, com_shift[3], leg_mass_shift[4], t_sample
+ *   -- the caller broadcasts the draws of shard 0 --
+ *   go2sim_env_set_global_dr   stores the 10 scalars and applies the first nine to every env of the shard (set_friction / set_mass_shift / set_COM_shift of
+ *                              :751-752, 810, 820, 843) followed by the full-batch kinematics refresh.
+ * All shards then hold the same level, the same t_sample and the same global scalars.  Staleness against the single-process env: the reset calls
+ * between two syncs use the level / scalars of the last sync. */
+int go2sim_env_sync_counters(go2sim_t* h, double* counters5_host, void* stream);
+int go2sim_env_sync_apply(go2sim_t* h, const double* summed_counters5_host, double* dr_out10_host, void* stream);
+int go2sim_env_set_global_dr(go2sim_t* h, const double* dr10_host, void* stream);
 /* zero-copy address of the live go2sim_env_globals_t (device memory for the HIP library): lets the host shim expose
  * extras["episode"] / extras["curriculum"] (go2_env_Omni_walk_16output.py:674-690, 1229-1234) as device tensors
  * without a stream synchronisation. */

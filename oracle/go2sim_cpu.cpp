@@ -2179,50 +2179,66 @@ void env_reset_stats(go2sim* h, int b) {
   h->g.n_reset_now += 1;
 }
 
+// the update step of _maybe_update_curriculum_on_reset (go2_env_walk.py:717-729) on the accumulated counters
+void globals_curriculum_check(go2sim* h) {
+  const Cfg& c = h->cfg; go2sim_env_globals_t& g = h->g;
+  if (g.curr_ep_total < c.i[GO2SIM_IC_CURR_UPDATE_EVERY]) return;
+  double timeout_rate = g.curr_timeout_total / std::max(1, g.curr_ep_total);
+  double fall_rate = 1.0 - timeout_rate;
+  double tracking_avg = g.curr_tracking_sum / std::max(1, g.curr_tracking_n);
+  if (curriculum_update(h, timeout_rate, tracking_avg, fall_rate)) apply_curriculum_level(h);
+  g.curr_ep_total = 0; g.curr_timeout_total = 0.0; g.curr_tracking_sum = 0.0; g.curr_tracking_n = 0;
+}
+// t_sample (CurriculumManager.sample_level :85-93) and the "global" DR draws (:737-756, 803-848) of one reset call; `n_throttle` resets are counted
+// for the friction throttle, `key` numbers the call in the Philox stream
+void globals_draws(go2sim* h, int n_throttle, uint32_t key) {
+  const Cfg& c = h->cfg; go2sim_env_globals_t& g = h->g;
+  dm_u4 r0 = rng4(h, RNG_GLOBAL_DR, 0xffffffffu, key, 0);
+  dm_u4 r1 = rng4(h, RNG_GLOBAL_DR, 0xffffffffu, key, 1);
+  dm_u4 r2 = rng4(h, RNG_GLOBAL_DR, 0xffffffffu, key, 2);
+  double t;                                                                             // CurriculumManager.sample_level :85-93
+  if (c.i[GO2SIM_IC_DR_SCHEDULE]) t = dr_level(c, c.i[GO2SIM_IC_CURR_ENABLED] ? g.level : 1.0);   // go2_env_stair.py:1506-1507
+  else if (!c.i[GO2SIM_IC_CURR_ENABLED]) t = 1.0;
+  else if (dm_u01(r0.v[0]) < c.f[GO2SIM_FC_CURR_MIX_PROB_CURRENT]) t = clamp01d(g.level);
+  else {
+    double hi = std::min(g.level, c.d[GO2SIM_FC_CURR_MIX_LEVEL_HIGH]);
+    double lo = std::min(c.d[GO2SIM_FC_CURR_MIX_LEVEL_LOW], hi);
+    t = clamp01d(lo + (hi - lo) * (double)dm_u01(r0.v[1]));
+  }
+  g.t_sample = t;
+  double ts = g.t_sample;
+  if (c.i[GO2SIM_IC_HAS_FRICTION_DR]) {                                                  // _randomize_friction :737-756
+    g.global_dr_reset_counter += n_throttle;
+    if (g.global_dr_reset_counter >= c.i[GO2SIM_IC_GLOBAL_DR_INTERVAL]) {
+      g.global_dr_reset_counter = 0;
+      g.friction = rand_float(lerp_lo(c, GO2SIM_FC_FRICTION_EASY_LO, ts), lerp_hi(c, GO2SIM_FC_FRICTION_EASY_LO, ts), r0.v[2]);
+    }
+  }
+  if (c.i[GO2SIM_IC_HAS_MASS_DR])                                                        // _randomize_mass :803-822
+    g.mass_shift = rand_float(lerp_lo(c, GO2SIM_FC_MASS_EASY_LO, ts), lerp_hi(c, GO2SIM_FC_MASS_EASY_LO, ts), r0.v[3]);
+  if (c.i[GO2SIM_IC_HAS_COM_DR])
+    for (int k = 0; k < 3; ++k) g.com_shift[k] = rand_float(lerp_lo(c, GO2SIM_FC_COM_EASY_LO, ts), lerp_hi(c, GO2SIM_FC_COM_EASY_LO, ts), r1.v[k]);
+  if (c.i[GO2SIM_IC_HAS_LEGM_DR])                                                        // _randomize_leg_mass :834-848
+    for (int k = 0; k < 4; ++k) g.leg_mass_shift[k] = rand_float(lerp_lo(c, GO2SIM_FC_LEGM_EASY_LO, ts), lerp_hi(c, GO2SIM_FC_LEGM_EASY_LO, ts), r2.v[k]);
+}
+
 // single-instance part of reset_idx: curriculum, t_sample, "global" DR  (go2_env_walk.py:688-756,803-848,1160-1171)
 void env_globals_update(go2sim* h, bool count_push) {
   const Cfg& c = h->cfg; go2sim_env_globals_t& g = h->g;
   if (count_push && c.i[GO2SIM_IC_HAS_PUSH] && g.push_enable) g.push_counter += 1;
   int n = g.n_reset_now;
   if (n > 0) {
-    if (c.i[GO2SIM_IC_CURR_ENABLED] && !c.i[GO2SIM_IC_FREEZE_CURRICULUM]) {                // _maybe_update_curriculum_on_reset
-      // `float(tensor.sum().item())` of float32 tensors (:698, :710) added to python floats
-      g.curr_ep_total += n; g.curr_timeout_total += (double)(float)h->acc_timeouts; g.curr_tracking_sum += (double)(float)h->acc_tracking; g.curr_tracking_n += n;
-      if (g.curr_ep_total >= c.i[GO2SIM_IC_CURR_UPDATE_EVERY]) {
-        double timeout_rate = g.curr_timeout_total / std::max(1, g.curr_ep_total);
-        double fall_rate = 1.0 - timeout_rate;
-        double tracking_avg = g.curr_tracking_sum / std::max(1, g.curr_tracking_n);
-        if (curriculum_update(h, timeout_rate, tracking_avg, fall_rate)) apply_curriculum_level(h);
-        g.curr_ep_total = 0; g.curr_timeout_total = 0.0; g.curr_tracking_sum = 0.0; g.curr_tracking_n = 0;
+    // `float(tensor.sum().item())` of float32 tensors (:698, :710) added to python floats
+    const double timeouts = (double)(float)h->acc_timeouts, tracking = (double)(float)h->acc_tracking;
+    if (c.i[GO2SIM_IC_SHARED_GLOBALS]) {              // one shard of a larger batch: the increments are combined by the host (go2sim_env_sync_*)
+      g.shard_counters[0] += n; g.shard_counters[1] += timeouts; g.shard_counters[2] += tracking; g.shard_counters[3] += n; g.shard_counters[4] += n;
+    } else {
+      if (c.i[GO2SIM_IC_CURR_ENABLED] && !c.i[GO2SIM_IC_FREEZE_CURRICULUM]) {                // _maybe_update_curriculum_on_reset
+        g.curr_ep_total += n; g.curr_timeout_total += timeouts; g.curr_tracking_sum += tracking; g.curr_tracking_n += n;
+        globals_curriculum_check(h);
       }
+      globals_draws(h, n, g.reset_calls);
     }
-    dm_u4 r0 = rng4(h, RNG_GLOBAL_DR, 0xffffffffu, g.reset_calls, 0);
-    dm_u4 r1 = rng4(h, RNG_GLOBAL_DR, 0xffffffffu, g.reset_calls, 1);
-    dm_u4 r2 = rng4(h, RNG_GLOBAL_DR, 0xffffffffu, g.reset_calls, 2);
-    double t;                                                                             // CurriculumManager.sample_level :85-93
-    if (c.i[GO2SIM_IC_DR_SCHEDULE]) t = dr_level(c, c.i[GO2SIM_IC_CURR_ENABLED] ? g.level : 1.0);   // go2_env_stair.py:1506-1507
-    else if (!c.i[GO2SIM_IC_CURR_ENABLED]) t = 1.0;
-    else if (dm_u01(r0.v[0]) < c.f[GO2SIM_FC_CURR_MIX_PROB_CURRENT]) t = clamp01d(g.level);
-    else {
-      double hi = std::min(g.level, c.d[GO2SIM_FC_CURR_MIX_LEVEL_HIGH]);
-      double lo = std::min(c.d[GO2SIM_FC_CURR_MIX_LEVEL_LOW], hi);
-      t = clamp01d(lo + (hi - lo) * (double)dm_u01(r0.v[1]));
-    }
-    g.t_sample = t;
-    double ts = g.t_sample;
-    if (c.i[GO2SIM_IC_HAS_FRICTION_DR]) {                                                  // _randomize_friction :737-756
-      g.global_dr_reset_counter += n;
-      if (g.global_dr_reset_counter >= c.i[GO2SIM_IC_GLOBAL_DR_INTERVAL]) {
-        g.global_dr_reset_counter = 0;
-        g.friction = rand_float(lerp_lo(c, GO2SIM_FC_FRICTION_EASY_LO, ts), lerp_hi(c, GO2SIM_FC_FRICTION_EASY_LO, ts), r0.v[2]);
-      }
-    }
-    if (c.i[GO2SIM_IC_HAS_MASS_DR])                                                        // _randomize_mass :803-822
-      g.mass_shift = rand_float(lerp_lo(c, GO2SIM_FC_MASS_EASY_LO, ts), lerp_hi(c, GO2SIM_FC_MASS_EASY_LO, ts), r0.v[3]);
-    if (c.i[GO2SIM_IC_HAS_COM_DR])
-      for (int k = 0; k < 3; ++k) g.com_shift[k] = rand_float(lerp_lo(c, GO2SIM_FC_COM_EASY_LO, ts), lerp_hi(c, GO2SIM_FC_COM_EASY_LO, ts), r1.v[k]);
-    if (c.i[GO2SIM_IC_HAS_LEGM_DR])                                                        // _randomize_leg_mass :834-848
-      for (int k = 0; k < 4; ++k) g.leg_mass_shift[k] = rand_float(lerp_lo(c, GO2SIM_FC_LEGM_EASY_LO, ts), lerp_hi(c, GO2SIM_FC_LEGM_EASY_LO, ts), r2.v[k]);
     g.last_reset_count = n;
     for (int k = 0; k < NREW; ++k)
       g.last_episode_rew[k] = (c.i[GO2SIM_IC_ENV_KIND] == 1) ? (float)((double)(float)(h->acc_ep[k] / (double)n) / c.d[GO2SIM_FC_EPISODE_LENGTH_S]) : (float)(h->acc_ep[k] / (double)n);
@@ -2857,6 +2873,42 @@ int go2sim_cpu_env_set_level(go2sim* h, double level, void*) {
   if (!h || !h->cfg.set) return GO2SIM_E_BADARG;
   h->g.level = level;
   apply_curriculum_level(h);
+  return GO2SIM_E_OK;
+}
+int go2sim_cpu_env_sync_counters(go2sim* h, double* out5, void*) {
+  if (!h || !h->cfg.set || !out5) return GO2SIM_E_BADARG;
+  for (int k = 0; k < 5; ++k) { out5[k] = h->g.shard_counters[k]; h->g.shard_counters[k] = 0.0; }
+  return GO2SIM_E_OK;
+}
+int go2sim_cpu_env_sync_apply(go2sim* h, const double* s5, double* dr_out10, void*) {
+  if (!h || !h->cfg.set || !s5) return GO2SIM_E_BADARG;
+  const Cfg& c = h->cfg; go2sim_env_globals_t& g = h->g;
+  const int n = (int)s5[0];
+  if (n > 0) {
+    if (c.i[GO2SIM_IC_CURR_ENABLED] && !c.i[GO2SIM_IC_FREEZE_CURRICULUM]) {
+      g.curr_ep_total += n; g.curr_timeout_total += s5[1]; g.curr_tracking_sum += s5[2]; g.curr_tracking_n += (int)s5[3];
+      globals_curriculum_check(h);
+    }
+    globals_draws(h, (int)s5[4], (uint32_t)g.sync_calls);
+    g.sync_calls += 1;
+  }
+  if (dr_out10) {
+    dr_out10[0] = g.friction; dr_out10[1] = g.mass_shift;
+    for (int k = 0; k < 3; ++k) dr_out10[2 + k] = g.com_shift[k];
+    for (int k = 0; k < 4; ++k) dr_out10[5 + k] = g.leg_mass_shift[k];
+    dr_out10[9] = g.t_sample;
+  }
+  return GO2SIM_E_OK;
+}
+int go2sim_cpu_env_set_global_dr(go2sim* h, const double* dr10, void*) {
+  if (!h || !h->cfg.set || !dr10) return GO2SIM_E_BADARG;
+  go2sim_env_globals_t& g = h->g;
+  g.friction = (float)dr10[0]; g.mass_shift = (float)dr10[1];
+  for (int k = 0; k < 3; ++k) g.com_shift[k] = (float)dr10[2 + k];
+  for (int k = 0; k < 4; ++k) g.leg_mass_shift[k] = (float)dr10[5 + k];
+  g.t_sample = dr10[9];
+#pragma omp parallel for schedule(static)
+  for (int b = 0; b < h->B; ++b) env_apply_globals_and_fk(h, b);
   return GO2SIM_E_OK;
 }
 int go2sim_cpu_enable_timing(go2sim*, int) { return GO2SIM_E_BADARG; }

@@ -59,3 +59,98 @@ def test_single_process_fallback():
     x = torch.arange(10, dtype=torch.float32)
     mean, std = global_mean_std(x)
     assert float(mean) == pytest.approx(4.5) and float(std) == pytest.approx(float(x.std()), rel=1e-6)
+
+
+# ---- one batch sharded over two ranks keeps ONE curriculum level and ONE set of global DR scalars ----
+def _shard_cfgs():
+    from go2_sim2real_locomotion_rl_amd.configs import get_walk_cfgs
+
+    cfgs = get_walk_cfgs()
+    cfgs[0]["episode_length_s"] = 0.3                                   # 15-step episodes: resets (and time-outs) inside a short run
+    cfgs[0]["curriculum"].update({"update_every_episodes": 20, "global_dr_update_interval": 10, "ready_streak": 1, "cooldown_updates": 0,
+                                  "ready_timeout_rate": 0.0, "ready_tracking": -1.0, "ready_fall_rate": 1.0, "hard_fall_rate": 2.0})   # always "ready": the level rises
+    return cfgs
+
+
+def _shard_worker(rank, world, port, n_local, steps, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from go2_sim2real_locomotion_rl_amd import build
+        from go2_sim2real_locomotion_rl_amd.capi import Go2Sim, load_cpu_oracle_lib
+        from go2_sim2real_locomotion_rl_amd.configs import flatten_walk_cfg
+        from go2_sim2real_locomotion_rl_amd.distributed import sync_env_globals
+        from go2_sim2real_locomotion_rl_amd.model_blob import pack_model
+
+        sim = Go2Sim(load_cpu_oracle_lib(), pack_model(), n_local, 0, shard_seed(5, rank))
+        f, i, _ = flatten_walk_cfg(n_local, *_shard_cfgs(), shared_globals=True)
+        sim.env_configure(f, i)
+        sim.env_reset()
+        obs = np.zeros((n_local, 49), np.float32); priv = np.zeros((n_local, 104), np.float32); rew = np.zeros(n_local, np.float32)
+        rst = np.zeros(n_local, np.uint8); to = np.zeros(n_local, np.float32)
+        rng = np.random.default_rng(100 + rank)
+        log = []
+        for s in range(steps):
+            sim.env_step((0.3 * rng.standard_normal((n_local, 16))).astype(np.float32), obs, priv, rew, rst, to)
+            if (s + 1) % 6 == 0:
+                summed, dr = sync_env_globals(sim)
+                g = sim.env_globals()
+                log.append({"summed": summed.tolist(), "dr": dr.tolist(), "level": g.level, "t_sample": g.t_sample, "friction": g.friction,
+                            "mass_shift": g.mass_shift, "curr_ep_total": g.curr_ep_total, "priv_friction": priv[:, 52].tolist(),
+                            "geom_friction": sim.get_field_np(C_("F_GEOM_FRICTION"))[:, 0].tolist()})
+        torch.save(log, os.path.join(out_dir, f"shard{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def C_(name):
+    from go2_sim2real_locomotion_rl_amd.capi import C
+
+    return C["GO2SIM_" + name]
+
+
+def test_sharded_env_keeps_one_curriculum_and_one_global_dr(tmp_path):
+    from go2_sim2real_locomotion_rl_amd import build
+
+    build.build_oracle(verbose=False)
+    world, n_local, steps = 2, 6, 60
+    mp.spawn(_shard_worker, args=(world, _free_port(), n_local, steps, str(tmp_path)), nprocs=world, join=True)
+    a, b = (torch.load(tmp_path / f"shard{r}.pt") for r in range(world))
+    assert len(a) == len(b) == steps // 6
+    levels = []
+    for x, y in zip(a, b):
+        assert x["summed"] == y["summed"]                                                   # the all-reduced counters
+        assert x["level"] == y["level"] and x["t_sample"] == y["t_sample"] and x["curr_ep_total"] == y["curr_ep_total"]
+        assert x["dr"] == y["dr"] and x["friction"] == y["friction"] and x["mass_shift"] == y["mass_shift"]   # rank 0's draws everywhere
+        assert set(x["geom_friction"]) == set(y["geom_friction"]) == {x["friction"]}        # applied to every env of both shards
+        levels.append(x["level"])
+    assert sum(s["summed"][0] for s in a) >= 2 * n_local * 3                                # every env was reset several times
+    assert levels[-1] > levels[0] >= 0.10                                                   # the shared level moved (summed counters crossed 20 episodes)
+    assert len({s["friction"] for s in a}) > 1                                              # the throttled friction draw happened more than once
+
+
+@pytest.mark.gpu
+def test_shared_globals_hip_matches_oracle(oracle_lib, hip_lib, blob):
+    """GO2SIM_IC_SHARED_GLOBALS on the HIP library: counters, state machine, draws and their application equal the oracle's bit for bit."""
+    from go2_sim2real_locomotion_rl_amd.configs import flatten_walk_cfg
+    from go2_sim2real_locomotion_rl_amd.distributed import sync_env_globals
+    from util import CpuEnv, GpuEnv, bits_equal
+
+    n, steps = 48, 60
+    mut = lambda env_cfg, *_: (env_cfg.update(_shard_cfgs()[0]))
+    cpu = CpuEnv(oracle_lib, blob, n, seed=5, mutate=mut, shared_globals=True); gpu = GpuEnv(hip_lib, blob, n, seed=5, mutate=mut, shared_globals=True)
+    cpu.reset(); gpu.reset()
+    rng = np.random.default_rng(3)
+    for s in range(steps):
+        a = (0.3 * rng.standard_normal((n, 16))).astype(np.float32)
+        oc, pc, rc, dc, tc = cpu.step(a); og, pg, rg, dg, tg = gpu.step(a)
+        assert np.array_equal(dc, dg) and bits_equal(oc, og) and bits_equal(pc, pg) and bits_equal(rc, rg), f"step {s}"
+        if (s + 1) % 6 == 0:
+            sc, drc = sync_env_globals(cpu.sim); sg, drg = sync_env_globals(gpu.sim)
+            assert np.array_equal(sc, sg) and np.array_equal(drc, drg) and sc[0] > 0
+            gc, gg = cpu.sim.env_globals(), gpu.sim.env_globals()
+            assert gc.level == gg.level and gc.t_sample == gg.t_sample and gc.sync_calls == gg.sync_calls and gc.friction == gg.friction
+            assert bits_equal(cpu.field("F_GEOM_FRICTION"), gpu.field("F_GEOM_FRICTION")) and bits_equal(cpu.field("F_MASS_SHIFT"), gpu.field("F_MASS_SHIFT"))
+            assert bits_equal(cpu.field("F_LINK_POS"), gpu.field("F_LINK_POS"))
+    assert gc.level > 0.10
