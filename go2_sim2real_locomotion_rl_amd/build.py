@@ -13,7 +13,8 @@ HIP_HDR_GJK = os.path.join(_HERE, "csrc", "go2sim_gjk_dev.h")
 HIP_LIB = os.path.join(_HERE, "csrc", "libgo2sim.so")
 ORACLE_SRC = os.path.join(REPO_ROOT, "oracle", "go2sim_cpu.cpp")
 ORACLE_SRC_POLICY = os.path.join(REPO_ROOT, "oracle", "policy_cpu.cpp")
-ORACLE_LIB = os.path.join(REPO_ROOT, "oracle", "libgo2sim_cpu.so")
+ORACLE_LIB = os.path.join(REPO_ROOT, "oracle", "libgo2sim_cpu.so")             # strict: the reference's CPU (serial) summation order
+ORACLE_LIB_FAST = os.path.join(REPO_ROOT, "oracle", "libgo2sim_cpu_fast.so")   # -DGO2SIM_FAST_ORDER: mirrors the HIP product's reduction order bit for bit
 
 # -ffp-contract=off on BOTH sides is part of the numeric contract (include/go2sim_detmath.h):
 # identical IEEE binary32 operation sequences => bit-identical CPU/GPU results.
@@ -60,12 +61,15 @@ def build_hip_variant(name, extra_flags, force=False, verbose=True):
 
 
 def build_oracle(force=False, verbose=True):
-    if not force and _newer(ORACLE_LIB, ORACLE_SRC, ORACLE_SRC_POLICY, os.path.join(REPO_ROOT, "oracle", "gjk_epa_cpu.h"), *_headers()):
-        return ORACLE_LIB
-    cmd = ["g++", *CPU_FLAGS, ORACLE_SRC, ORACLE_SRC_POLICY, "-o", ORACLE_LIB]
-    if verbose:
-        print("[build]", " ".join(cmd), file=sys.stderr)
-    subprocess.run(cmd, check=True)
+    """Both oracle builds: the strict one (reference CPU order) and the FAST ORDER mirror of the HIP product (oracle/go2sim_cpu.cpp header)."""
+    deps = [ORACLE_SRC, ORACLE_SRC_POLICY, os.path.join(REPO_ROOT, "oracle", "gjk_epa_cpu.h"), *_headers()]
+    for lib, extra in ((ORACLE_LIB, []), (ORACLE_LIB_FAST, ["-DGO2SIM_FAST_ORDER"])):
+        if not force and _newer(lib, *deps):
+            continue
+        cmd = ["g++", *CPU_FLAGS, *extra, ORACLE_SRC, ORACLE_SRC_POLICY, "-o", lib]
+        if verbose:
+            print("[build]", " ".join(cmd), file=sys.stderr)
+        subprocess.run(cmd, check=True)
     return ORACLE_LIB
 
 

@@ -18,6 +18,7 @@ REPO_ROOT = os.path.dirname(_HERE)
 HEADER = os.path.join(REPO_ROOT, "include", "go2sim.h")
 HIP_LIB = os.path.join(_HERE, "csrc", "libgo2sim.so")
 CPU_LIB = os.path.join(REPO_ROOT, "oracle", "libgo2sim_cpu.so")
+CPU_LIB_FAST = os.path.join(REPO_ROOT, "oracle", "libgo2sim_cpu_fast.so")
 
 
 def _parse_header(path=HEADER):
@@ -304,6 +305,7 @@ def load_hip_lib():
     return Go2SimLib(HIP_LIB, "go2sim_")
 
 
-def load_cpu_oracle_lib():
-    """The CPU oracle.  Test infrastructure only (tests/, smoke(), bench cpu_baseline)."""
-    return Go2SimLib(CPU_LIB, "go2sim_cpu_")
+def load_cpu_oracle_lib(fast=False):
+    """The CPU oracle.  Test infrastructure only (tests/, smoke(), bench cpu_baseline).  fast=False: the strict build (the reference's CPU /
+    serial summation order); fast=True: the -DGO2SIM_FAST_ORDER build that mirrors the HIP product's reduction order bit for bit."""
+    return Go2SimLib(CPU_LIB_FAST if fast else CPU_LIB, "go2sim_cpu_")

@@ -2271,10 +2271,51 @@ DEV void team_serial_sum(const float (&x)[NQ], const float (&base)[NQ], int tl, 
   for (int q = 0; q < NQ; ++q) total[q] = team_bcast_dyn<T>(acc[q], 16 * nseg - 1);
 }
 
+// ---- FAST ORDER (default): lane-parallel reductions and reciprocal forms on the critical path of the Newton solve -----------------------------
+// north_star allows a float32 tolerance on floats.  The strict build (-DGO2SIM_FAST_ORDER=0) keeps every sum in the reference's first-to-last
+// order (team_serial_sum above); the product build replaces the chains that the slowest environment of a launch waits for:
+//   * sums over constraint rows / dofs: every lane adds its own terms (row c on lane c % T), then a butterfly over the lanes -- 4 DPP steps inside a
+//     row of 16 lanes (xor 1, xor 2, mirror in 8, mirror in 16) and one add per pair of rows -- instead of a 16..32-step dependent chain;
+//   * triangular solves: reciprocal diagonal (18 divisions side by side instead of 36 in sequence; the reference's LDL^T path stores D_inv the same
+//     way, forward_dynamics.py:545-687), column-oriented with one lane per row;
+//   * rank-1 Cholesky rotations: 1 / r = r * (1 / tmp) with the division issued beside the square root, c = r * (1 / L_kk), s = v_k * (1 / L_kk) with the
+//     reciprocal diagonal carried from update to update.
+// The FAST ORDER build of the CPU oracle (oracle/go2sim_cpu.cpp with -DGO2SIM_FAST_ORDER) mirrors this arithmetic operation for operation (tolerance 0 in the GPU
+// parity tests); tests/test_fast_order.py bounds fast against strict.
+#ifndef GO2SIM_FAST_ORDER
+#define GO2SIM_FAST_ORDER 1
+#endif
+template <int CTRL>
+DEV float dpp_perm(float x) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, true)); }
+// butterfly sum over the T lanes of a team (every lane ends with the total); `x` = the lane's own partial sum
+template <int T, int NQ>
+DEV void team_tree_sum(const float (&x)[NQ], float (&total)[NQ]) {
+  static_assert(T == 32 || T == 64, "teams of 32 or 64 lanes");
+  float a[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) a[q] = x[q];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) a[q] = a[q] + dpp_perm<0xB1>(a[q]);        // quad_perm [1,0,3,2]: lane ^ 1
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) a[q] = a[q] + dpp_perm<0x4E>(a[q]);        // quad_perm [2,3,0,1]: lane ^ 2
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) a[q] = a[q] + dpp_perm<0x141>(a[q]);       // row_half_mirror: lane ^ 7
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) a[q] = a[q] + dpp_perm<0x140>(a[q]);       // row_mirror: lane ^ 15
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    if constexpr (T == 32) total[q] = team_bcast<T>(a[q], 0) + team_bcast<T>(a[q], 16);
+    else total[q] = (team_bcast<T>(a[q], 0) + team_bcast<T>(a[q], 16)) + (team_bcast<T>(a[q], 32) + team_bcast<T>(a[q], 48));
+  }
+}
+template <int T>
+DEV float team_tree_sum1(float x) { const float xs[1] = {x}; float t[1]; team_tree_sum<T, 1>(xs, t); return t[0]; }
+
 template <int T, class S, class MT>
 DEV void ts_update_constraint(const MT& m, S* s, int tl, int n_con, float& cost, float& prev_cost, float& gauss) {
   prev_cost = cost;
   float row_cost = 0.0f;                                               // 0.5 * Jaref^2 * D * active of the lane's row (rows one per lane)
+  bool first_row = true;                                               // (FAST ORDER: the lane's partial sum over its rows c = tl, tl + T, ...)
   for (int c = tl; c < n_con; c += T) {
     s->prev_active[c] = s->active[c];
     float Ja = s->Jaref[c];
@@ -2284,7 +2325,13 @@ DEV void ts_update_constraint(const MT& m, S* s, int tl, int n_con, float& cost,
     const float DA = D * (float)act;
     s->DA[c] = DA;
     s->efc_force[c] = 0.0f + (-Ja * D * (float)act);
-    row_cost = 0.5f * (Ja * Ja * DA);
+    const float rc = 0.5f * (Ja * Ja * DA);
+#if GO2SIM_FAST_ORDER
+    row_cost = first_row ? rc : row_cost + rc;
+    first_row = false;
+#else
+    row_cost = rc;
+#endif
   }
   team_sync();
   for (int d = tl; d < ND; d += T) {
@@ -2294,7 +2341,18 @@ DEV void ts_update_constraint(const MT& m, S* s, int tl, int n_con, float& cost,
     s->qfrc[d] = q;
   }
   bool done = false;
+#if GO2SIM_FAST_ORDER
   if constexpr (T >= 32) {
+    const int d = tl < ND ? tl : ND - 1;
+    const float v = 0.5f * (s->Ma[d] - s->force[d]) * (s->qacc[d] - s->acc_smooth[d]);
+    const float xs[2] = {tl < ND ? v : 0.0f, row_cost};
+    float tot[2];
+    team_tree_sum<T, 2>(xs, tot);
+    gauss = tot[0]; cost = tot[1] + tot[0];
+    done = true;
+  }
+#endif
+  if constexpr (T >= 32 && !GO2SIM_FAST_ORDER) {
     const int n_wave = __builtin_amdgcn_readfirstlane(imx(__shfl(n_con, 0), __shfl(n_con, T == 64 ? 0 : 32)));
     if (n_wave <= T) {                                                 // serial-order lane scans: the 18 dof terms, then the rows on top of them
       const int d = tl < ND ? tl : ND - 1;
@@ -2380,6 +2438,9 @@ DEV bool ts_cholesky_incremental_reg(const MT& m, S* s, int tl, int n_con) {
   float Lr[ND];
 #pragma unroll
   for (int k = 0; k < ND; ++k) Lr[k] = s->H[row * DS + k];
+#if GO2SIM_FAST_ORDER
+  float invL = 1.0f / s->H[row * DS + row];                            // reciprocal of my diagonal element, carried through the updates
+#endif
   // The rows whose activity flipped are found T at a time (lane c tests row c) and collected in a bit mask per team; the teams of a wavefront
   // then walk their own lists in step: pass f updates every team's f-th flipped row at once.  (A common loop over the row index would run the
   // rank-1 update once per flipped row of EITHER team, with the other team masked off.)
@@ -2404,9 +2465,18 @@ DEV bool ts_cholesky_incremental_reg(const MT& m, S* s, int tl, int n_con) {
           const float tmp = Lkk * Lkk + sign * (vk * vk);
           if (tmp < m.eps) { degenerated = true; break; }
           const float r = dm_sqrt(tmp);
+#if GO2SIM_FAST_ORDER
+          const float invLkk = team_bcast<T>(invL, k);
+          const float rinv = r * (1.0f / tmp);                           // the division does not wait for the square root
+          const float cc = r * invLkk;
+          const float cinv = Lkk * rinv;
+          const float sk = vk * invLkk;
+          if (row == k) invL = rinv;
+#else
           const float cc = r / Lkk;
           const float cinv = 1.0f / cc;
           const float sk = vk / Lkk;
+#endif
           if (row == k) Lr[k] = r;
           else if (row > k) {
             const float hik = (Lr[k] + sk * v * sign) * cinv;
@@ -2441,6 +2511,9 @@ DEV bool ts_cholesky_incremental_pipelined(const MT& m, S* s, int tl, int n_con)
   const bool own = tl < ND;
   const unsigned urow = own ? (unsigned)row : 0u;                       // "column k lies left of my row" is (unsigned)k < urow (never true for spare lanes)
   float Ld = s->H[row * DS + row];                                     // my diagonal element
+#if GO2SIM_FAST_ORDER
+  float invLd = 1.0f / Ld;                                             // ... and its reciprocal, carried through the updates
+#endif
   for (int base = 0; base < n_con && !degenerated; base += T) {
     const int c_me = base + tl;
     const bool flip = c_me < n_con && ((s->active[c_me] != 0) != (s->prev_active[c_me] != 0));
@@ -2475,9 +2548,17 @@ DEV bool ts_cholesky_incremental_pipelined(const MT& m, S* s, int tl, int n_con)
         const float tmp = Ld * Ld + sg_me * (dv * dv);
         const bool deg = rot && tmp < m.eps;
         const float r = dm_sqrt(tmp);
+#if GO2SIM_FAST_ORDER
+        const float rinv = r * (1.0f / tmp);                             // the division does not wait for the square root
+        const float cc = r * invLd;
+        float cinv = Ld * rinv;
+        const float sk = dv * invLd;
+        if (rot) invLd = rinv;
+#else
         const float cc = r / Ld;
         float cinv = 1.0f / cc;
         const float sk = dv / Ld;
+#endif
         cinv = rot ? cinv : 0.0f;                                        // 0 marks "no rotation for this pair" (1 / cc is never 0)
         {
           const unsigned long long dbal = __ballot(deg);
@@ -2585,6 +2666,36 @@ DEV bool ts_cholesky_incremental(const MT& m, S* s, int tl, int n_con) {
 // redundantly by every lane with the running vector in registers; rows (and, through the mirror, columns) arrive as wide reads
 template <int T, class S>
 DEV void ts_update_gradient(S* s, int tl) {
+#if GO2SIM_FAST_ORDER
+  if constexpr (T >= 32) {
+    // FAST ORDER: lane i owns row i of the factor (the mirrored storage gives it column i as well), the running right-hand side element i and the
+    // reciprocal of the diagonal element.  Step j: lane j finishes its unknown with one multiplication, the value travels by v_readlane, the lanes
+    // below (forward) / above (backward) subtract their term.  Per unknown the chain is mul -> readlane -> mul -> sub; the order of the subtractions
+    // per row is ascending j in the forward and descending j in the backward substitution.
+    const int row = tl < ND ? tl : ND - 1;
+    float Hr[ND];
+#pragma unroll
+    for (int k = 0; k < ND; ++k) Hr[k] = s->H[row * DS + k];
+    const float g = s->Ma[row] - s->force[row] - s->qfrc[row];
+    if (tl < ND) s->grad[row] = g;
+    const float linv = 1.0f / s->H[row * DS + row];
+    float cur = g;
+#pragma unroll
+    for (int j = 0; j < ND; ++j) {
+      const float yj = team_bcast<T>(cur * linv, j);
+      cur = (row == j) ? yj : ((row > j) ? cur - Hr[j] * yj : cur);
+    }
+#pragma unroll
+    for (int j_ = 0; j_ < ND; ++j_) {
+      const int j = ND - 1 - j_;
+      const float xj = team_bcast<T>(cur * linv, j);
+      cur = (row == j) ? xj : ((row < j) ? cur - Hr[j] * xj : cur);   // Hr[j] (j > row) mirrors L[j][row]
+    }
+    if (tl < ND) s->Mgrad[row] = cur;
+    team_sync();
+    return;
+  }
+#endif
   for (int d = tl; d < ND; d += T) s->grad[d] = s->Ma[d] - s->force[d] - s->qfrc[d];
   team_sync();
   float y[ND];
@@ -2612,13 +2723,42 @@ DEV void ts_update_gradient(S* s, int tl) {
 
 // the lane's own constraint row during a line search (zeros on lanes without a row): Jaref, J.search and the three quadratic coefficients
 struct LsRow { float Ja, jv, q0, q1, q2; };
+#if GO2SIM_FAST_ORDER
+// FAST ORDER: the lane's partial sums of the three quadratic coefficients over its rows (row c on lane c % T) with the active set of `alpha`;
+// rows that fit one per lane come from registers (rw), otherwise from the row arrays
+template <int T, class S>
+DEV void ts_ls_partials(S* s, int tl, int n_con, const LsRow& rw, float alpha, float (&p)[3]) {
+  if (n_con <= T) {
+    const float act = (float)((rw.Ja + alpha * rw.jv) < 0.0f);
+    p[0] = rw.q0 * act; p[1] = rw.q1 * act; p[2] = rw.q2 * act;
+    return;
+  }
+  p[0] = p[1] = p[2] = 0.0f;
+  bool first = true;
+  for (int c = tl; c < n_con; c += T) {
+    const float act = (float)((s->Jaref[c] + alpha * s->jv[c]) < 0.0f);
+    const float a0 = s->qf0[c] * act, a1 = s->qf1[c] * act, a2 = s->qf2[c] * act;
+    p[0] = first ? a0 : p[0] + a0; p[1] = first ? a1 : p[1] + a1; p[2] = first ? a2 : p[2] + a2;
+    first = false;
+  }
+}
+#endif
 // func_ls_point_fn_opt, solver.py:2009-2077.  `nseg` > 0: every row sits on its own lane and the three sums over the rows are serial-order
 // lane scans (team_serial_sum); nseg == 0: more rows than lanes (global-scratch path), the scalar loops over the LDS / scratch arrays.
 template <int T, class S, class MT>
 DEV LsPoint ts_ls_point(const MT& m, S* s, int tl, int n_con, int nseg, const LsRow& rw, float alpha, float qg0, float qg1, float qg2) {
   float t0 = qg0 + 0.0f, t1 = qg1 + 0.0f, t2 = qg2 + 0.0f;
   bool done = false;
+#if GO2SIM_FAST_ORDER
   if constexpr (T >= 32) {
+    float pp[3], tot[3];
+    ts_ls_partials<T>(s, tl, n_con, rw, alpha, pp);
+    team_tree_sum<T, 3>(pp, tot);
+    t0 = tot[0] + t0; t1 = tot[1] + t1; t2 = tot[2] + t2;
+    done = true;
+  }
+#endif
+  if constexpr (T >= 32 && !GO2SIM_FAST_ORDER) {
     if (nseg > 0) {
       const float x = rw.Ja + alpha * rw.jv;
       const float active = (float)(x < 0.0f);
@@ -2656,7 +2796,22 @@ GO2SIM_LS3_ATTR void ts_ls_point3(const MT& m, S* s, int tl, int n_con, int nseg
   float b0 = qg0 + 0.0f, b1 = qg1 + 0.0f, b2 = qg2 + 0.0f;
   float t[3][3] = {{b0, b1, b2}, {b0, b1, b2}, {b0, b1, b2}};
   bool done = false;
+#if GO2SIM_FAST_ORDER
   if constexpr (T >= 32) {
+    float pp[9], tot[9];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      float p3[3];
+      ts_ls_partials<T>(s, tl, n_con, rw, a[k], p3);
+      pp[3 * k] = p3[0]; pp[3 * k + 1] = p3[1]; pp[3 * k + 2] = p3[2];
+    }
+    team_tree_sum<T, 9>(pp, tot);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { t[k][0] = tot[3 * k] + b0; t[k][1] = tot[3 * k + 1] + b1; t[k][2] = tot[3 * k + 2] + b2; }
+    done = true;
+  }
+#endif
+  if constexpr (T >= 32 && !GO2SIM_FAST_ORDER) {
     if (nseg > 0) {
       float xs[9], bs[9], tot[9];
 #pragma unroll
@@ -2702,10 +2857,14 @@ DEV float ts_linesearch(const MT& m, S* s, int tl, int n_con, float gauss) {
   float snorm = 0.0f;
   if constexpr (T >= 32) {
     const float my = s->search[tl < ND ? tl : ND - 1];
+#if GO2SIM_FAST_ORDER
+    snorm = team_tree_sum1<T>(tl < ND ? my * my : 0.0f);
+#else
     const float xq[1] = {tl < ND ? my * my : 0.0f}, zero[1] = {0.0f};
     float tot[1];
     team_serial_sum<T, 1>(xq, zero, tl, 2, tot);
     snorm = tot[0];
+#endif
   } else {
 #pragma unroll
     for (int jd = 0; jd < ND; ++jd) snorm = snorm + sr[jd] * sr[jd];
@@ -2746,7 +2905,11 @@ DEV float ts_linesearch(const MT& m, S* s, int tl, int n_con, float gauss) {
     const float sd = s->search[d];
     const float xq[2] = {tl < ND ? (sd * s->Ma[d] - sd * s->force[d]) : 0.0f, tl < ND ? 0.5f * sd * s->mv[d] : 0.0f}, zero[2] = {0.0f, 0.0f};
     float tot[2];
+#if GO2SIM_FAST_ORDER
+    team_tree_sum<T, 2>(xq, tot);
+#else
     team_serial_sum<T, 2>(xq, zero, tl, 2, tot);
+#endif
     qg1 = tot[0]; qg2 = tot[1];
   } else {
 #pragma unroll
@@ -2761,7 +2924,28 @@ DEV float ts_linesearch(const MT& m, S* s, int tl, int n_con, float gauss) {
   {
     float t0 = qg0, t1 = qg1, t2 = qg2;
     bool done = false;
+#if GO2SIM_FAST_ORDER
     if constexpr (T >= 32) {
+      float pp[3], tot[3];
+      if (n_con <= T) {
+        const float active = (float)(rw.Ja < 0.0f);
+        pp[0] = rw.q0 * active; pp[1] = rw.q1 * active; pp[2] = rw.q2 * active;
+      } else {
+        pp[0] = pp[1] = pp[2] = 0.0f;
+        bool first = true;
+        for (int c = tl; c < n_con; c += T) {
+          const float active = (float)(s->Jaref[c] < 0.0f);
+          const float a0 = s->qf0[c] * active, a1 = s->qf1[c] * active, a2 = s->qf2[c] * active;
+          pp[0] = first ? a0 : pp[0] + a0; pp[1] = first ? a1 : pp[1] + a1; pp[2] = first ? a2 : pp[2] + a2;
+          first = false;
+        }
+      }
+      team_tree_sum<T, 3>(pp, tot);
+      t0 = tot[0] + t0; t1 = tot[1] + t1; t2 = tot[2] + t2;
+      done = true;
+    }
+#endif
+    if constexpr (T >= 32 && !GO2SIM_FAST_ORDER) {
       if (nseg > 0) {
         const float active = (float)(rw.Ja < 0.0f);
         const float xs[3] = {rw.q0 * active, rw.q1 * active, rw.q2 * active}, bs[3] = {t0, t1, t2};
@@ -2984,10 +3168,14 @@ DEV int ts_solve(const MT& m, const E& e, S* s, int tl, int nc, int n_con, unsig
         float grad_norm = 0.0f;
         if constexpr (T >= 32) {
           const float g = s->grad[tl < ND ? tl : ND - 1];
+#if GO2SIM_FAST_ORDER
+          grad_norm = team_tree_sum1<T>(tl < ND ? g * g : 0.0f);
+#else
           const float xq[1] = {tl < ND ? g * g : 0.0f}, zero[1] = {0.0f};
           float tot[1];
           team_serial_sum<T, 1>(xq, zero, tl, 2, tot);
           grad_norm = tot[0];
+#endif
         } else {
 #pragma unroll
           for (int d = 0; d < ND; ++d) { float g = s->grad[d]; grad_norm = grad_norm + g * g; }

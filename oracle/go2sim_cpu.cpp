@@ -1364,6 +1364,35 @@ void add_joint_limit_constraints(const Model& m, Env& e) {
 }
 
 // func_hessian_direct_batch, solver.py:1285-1343
+// ---------------------------------------------------------------------------------------------
+// GO2SIM_FAST_ORDER: the summation order / reciprocal forms of the HIP solver (csrc/go2sim.hip, "FAST ORDER").  The strict build follows the
+// reference's CPU (serial) variants; north_star allows a float32 tolerance on floats, and the HIP product uses it for the reductions that sit on
+// the critical path of the Newton solve: sums over constraint rows / dofs are lane-parallel butterfly trees instead of first-to-last chains,
+// the triangular solves multiply by a stored reciprocal diagonal (as the reference's own LDL^T path does for the mass matrix,
+// forward_dynamics.py:545-687) and run column-oriented, and the rank-1 Cholesky rotations use reciprocals that are formed off the critical
+// path.  This build mirrors that arithmetic operation for operation, so that HIP == libgo2sim_cpu_fast.so bit for bit;
+// tests/test_fast_order.py bounds fast vs strict.
+// ---------------------------------------------------------------------------------------------
+#ifdef GO2SIM_FAST_ORDER
+inline int fast_team(const Model& m) { return m.terrain_enabled ? 64 : 32; }   // lanes per env of k_constraint_solve_team (flat: 32, heightfield: 64)
+// sum of `n` terms spread over the W lanes of a team: lane l adds its terms l, l + W, ... first to last, then a butterfly over the lanes
+// (xor 1, xor 2, mirror in 8, mirror in 16 inside rows of 16 lanes; the rows are added pairwise)
+template <class F>
+inline real team_tree_sum(int W, int n, F term) {
+  real y[64], z[64];
+  for (int l = 0; l < W; ++l) {
+    real p = 0.0f; bool first = true;
+    for (int c = l; c < n; c += W) { real t = term(c); p = first ? t : p + t; first = false; }
+    y[l] = p;
+  }
+  for (int l = 0; l < W; ++l) z[l] = y[l] + y[l ^ 1];
+  for (int l = 0; l < W; ++l) y[l] = z[l] + z[l ^ 2];
+  for (int l = 0; l < W; ++l) z[l] = y[l] + y[l ^ 7];
+  for (int l = 0; l < W; ++l) y[l] = z[l] + z[l ^ 15];
+  return (W == 32) ? (y[0] + y[16]) : ((y[0] + y[16]) + (y[32] + y[48]));
+}
+#endif
+
 void hessian_direct(const Model& m, Env& e) {
   for (int i = 0; i < ND; ++i) for (int j = 0; j < i + 1; ++j) e.H[i][j] = 0.0f;
   for (int i_d1 = 0; i_d1 < ND; ++i_d1)
@@ -1392,6 +1421,10 @@ void cholesky_factor_direct(const Model& m, Env& e) {
 // func_hessian_and_cholesky_factor_incremental_dense_batch, solver.py:1632-1675
 bool cholesky_incremental(const Model& m, Env& e) {
   bool is_degenerated = false;
+#ifdef GO2SIM_FAST_ORDER
+  real invd[ND];                                                   // reciprocal diagonal of the factor, carried through the updates
+  for (int k = 0; k < ND; ++k) invd[k] = 1.0f / e.H[k][k];
+#endif
   for (int i_c = 0; i_c < e.n_con; ++i_c) {
     bool is_active = e.active[i_c] != 0, is_active_prev = e.prev_active[i_c] != 0;
     if (is_active ^ is_active_prev) {
@@ -1404,9 +1437,17 @@ bool cholesky_incremental(const Model& m, Env& e) {
           real tmp = Lkk * Lkk + sign * (e.nt_vec[k] * e.nt_vec[k]);
           if (tmp < m.eps) { is_degenerated = true; break; }
           real r = dm_sqrt(tmp);
+#ifdef GO2SIM_FAST_ORDER
+          real rinv = r * (1.0f / tmp);                              // 1 / r without a division after the square root
+          real c = r * invd[k];
+          real cinv = Lkk * rinv;
+          real s = e.nt_vec[k] * invd[k];
+          invd[k] = rinv;
+#else
           real c = r / Lkk;
           real cinv = 1.0f / c;
           real s = e.nt_vec[k] / Lkk;
+#endif
           e.H[k][k] = r;
           for (int i = k + 1; i < ND; ++i) e.H[i][k] = (e.H[i][k] + s * e.nt_vec[i] * sign) * cinv;
           for (int i = k + 1; i < ND; ++i) e.nt_vec[i] = e.nt_vec[i] * c - s * e.H[i][k];
@@ -1418,6 +1459,22 @@ bool cholesky_incremental(const Model& m, Env& e) {
 }
 // func_cholesky_solve_batch, solver.py:1747-1765
 void cholesky_solve(Env& e) {
+#ifdef GO2SIM_FAST_ORDER
+  real linv[ND], cur[ND];                                          // column-oriented substitutions with the reciprocal diagonal
+  for (int i = 0; i < ND; ++i) { linv[i] = 1.0f / e.H[i][i]; cur[i] = e.grad[i]; }
+  for (int j = 0; j < ND; ++j) {
+    real yj = cur[j] * linv[j];
+    cur[j] = yj;
+    for (int i = j + 1; i < ND; ++i) cur[i] = cur[i] - e.H[i][j] * yj;
+  }
+  for (int j = ND - 1; j >= 0; --j) {
+    real xj = cur[j] * linv[j];
+    cur[j] = xj;
+    for (int i = 0; i < j; ++i) cur[i] = cur[i] - e.H[j][i] * xj;
+  }
+  for (int i = 0; i < ND; ++i) e.Mgrad[i] = cur[i];
+  return;
+#endif
   for (int i_d = 0; i_d < ND; ++i_d) {
     real cur = e.grad[i_d];
     for (int j_d = 0; j_d < i_d; ++j_d) cur = cur - e.H[i_d][j_d] * e.Mgrad[j_d];
@@ -1447,12 +1504,18 @@ void update_constraint(const Model& m, Env& e) {
     for (int i_c = 0; i_c < e.n_con; ++i_c) q = q + e.jac[i_c][i_d] * e.efc_force[i_c];
     e.qfrc_constraint[i_d] = q;
   }
+#ifdef GO2SIM_FAST_ORDER
+  const int W = fast_team(m);
+  gauss_i = team_tree_sum(W, ND, [&](int i_d) { return 0.5f * (e.Ma[i_d] - e.force[i_d]) * (e.qacc[i_d] - e.acc_smooth[i_d]); });
+  cost_i = team_tree_sum(W, e.n_con, [&](int i_c) { return 0.5f * (e.Jaref[i_c] * e.Jaref[i_c] * (e.efc_D[i_c] * (real)e.active[i_c])); }) + gauss_i;
+#else
   for (int i_d = 0; i_d < ND; ++i_d) {
     real v = 0.5f * (e.Ma[i_d] - e.force[i_d]) * (e.qacc[i_d] - e.acc_smooth[i_d]);
     gauss_i = gauss_i + v;
     cost_i = cost_i + v;
   }
   for (int i_c = 0; i_c < e.n_con; ++i_c) cost_i = cost_i + 0.5f * (e.Jaref[i_c] * e.Jaref[i_c] * e.efc_D[i_c] * (real)e.active[i_c]);
+#endif
   e.gauss = gauss_i;
   e.cost = cost_i;
 }
@@ -1478,6 +1541,23 @@ LsPoint ls_init_and_eval_p0(const Model& m, Env& e) {
     e.jv[i_c] = jv;
   }
   real qg1 = 0.0f, qg2 = 0.0f;
+#ifdef GO2SIM_FAST_ORDER
+  const int W = fast_team(m);
+  qg1 = team_tree_sum(W, ND, [&](int i_d) { return e.search[i_d] * e.Ma[i_d] - e.search[i_d] * e.force[i_d]; });
+  qg2 = team_tree_sum(W, ND, [&](int i_d) { return 0.5f * e.search[i_d] * e.mv[i_d]; });
+  e.quad_gauss[0] = e.gauss; e.quad_gauss[1] = qg1; e.quad_gauss[2] = qg2;
+  real t0, t1, t2;
+  {
+    auto qf = [&](int i_c, int k) {
+      real Ja = e.Jaref[i_c], jv = e.jv[i_c], D = e.efc_D[i_c];
+      real q = (k == 0) ? D * (0.5f * Ja * Ja) : ((k == 1) ? D * (jv * Ja) : D * (0.5f * jv * jv));
+      return q * (real)(Ja < 0.0f);
+    };
+    t0 = team_tree_sum(W, e.n_con, [&](int c) { return qf(c, 0); }) + e.gauss;
+    t1 = team_tree_sum(W, e.n_con, [&](int c) { return qf(c, 1); }) + qg1;
+    t2 = team_tree_sum(W, e.n_con, [&](int c) { return qf(c, 2); }) + qg2;
+  }
+#else
   for (int i_d = 0; i_d < ND; ++i_d) {
     qg1 = qg1 + (e.search[i_d] * e.Ma[i_d] - e.search[i_d] * e.force[i_d]);
     qg2 = qg2 + 0.5f * e.search[i_d] * e.mv[i_d];
@@ -1490,6 +1570,7 @@ LsPoint ls_init_and_eval_p0(const Model& m, Env& e) {
     real active = (real)(Ja < 0.0f);
     t0 = t0 + qf_0 * active; t1 = t1 + qf_1 * active; t2 = t2 + qf_2 * active;
   }
+#endif
   LsPoint p; p.alpha = 0.0f; p.cost = t0; p.grad = t1; p.hess = 2.0f * t2;
   if (p.hess <= 0.0f) p.hess = m.eps;
   e.ls_it = 1;
@@ -1498,6 +1579,19 @@ LsPoint ls_init_and_eval_p0(const Model& m, Env& e) {
 // func_ls_point_fn_opt, solver.py:2009-2077
 LsPoint ls_point_fn(const Model& m, Env& e, real alpha) {
   real t0 = e.quad_gauss[0] + 0.0f, t1 = e.quad_gauss[1] + 0.0f, t2 = e.quad_gauss[2] + 0.0f;  // + eq_sum (zero)
+#ifdef GO2SIM_FAST_ORDER
+  {
+    const int W = fast_team(m);
+    auto qf = [&](int i_c, int k) {
+      real Ja = e.Jaref[i_c], jv = e.jv[i_c], D = e.efc_D[i_c];
+      real q = (k == 0) ? D * (0.5f * Ja * Ja) : ((k == 1) ? D * (jv * Ja) : D * (0.5f * jv * jv));
+      return q * (real)((Ja + alpha * jv) < 0.0f);
+    };
+    t0 = team_tree_sum(W, e.n_con, [&](int c) { return qf(c, 0); }) + t0;
+    t1 = team_tree_sum(W, e.n_con, [&](int c) { return qf(c, 1); }) + t1;
+    t2 = team_tree_sum(W, e.n_con, [&](int c) { return qf(c, 2); }) + t2;
+  }
+#else
   for (int i_c = 0; i_c < e.n_con; ++i_c) {
     real Ja = e.Jaref[i_c], jv = e.jv[i_c], D = e.efc_D[i_c];
     real x = Ja + alpha * jv;
@@ -1505,6 +1599,7 @@ LsPoint ls_point_fn(const Model& m, Env& e, real alpha) {
     real qf_0 = D * (0.5f * Ja * Ja), qf_1 = D * (jv * Ja), qf_2 = D * (0.5f * jv * jv);
     t0 = t0 + qf_0 * active; t1 = t1 + qf_1 * active; t2 = t2 + qf_2 * active;
   }
+#endif
   LsPoint p; p.alpha = alpha;
   p.cost = alpha * alpha * t2 + alpha * t1 + t0;
   p.grad = 2.0f * alpha * t2 + t1;
@@ -1517,6 +1612,18 @@ LsPoint ls_point_fn(const Model& m, Env& e, real alpha) {
 void ls_point_fn_3(const Model& m, Env& e, const real a[3], real costs[3], real grads[3], real hess[3]) {
   real b0 = e.quad_gauss[0] + 0.0f, b1 = e.quad_gauss[1] + 0.0f, b2 = e.quad_gauss[2] + 0.0f;
   real t[3][3] = {{b0, b1, b2}, {b0, b1, b2}, {b0, b1, b2}};
+#ifdef GO2SIM_FAST_ORDER
+  {
+    const int W = fast_team(m);
+    for (int k = 0; k < 3; ++k)
+      for (int q = 0; q < 3; ++q)
+        t[k][q] = team_tree_sum(W, e.n_con, [&](int i_c) {
+          real Ja = e.Jaref[i_c], jv = e.jv[i_c], D = e.efc_D[i_c];
+          real qf = (q == 0) ? D * (0.5f * Ja * Ja) : ((q == 1) ? D * (jv * Ja) : D * (0.5f * jv * jv));
+          return qf * (real)((Ja + a[k] * jv) < 0.0f);
+        }) + t[k][q];
+  }
+#else
   for (int i_c = 0; i_c < e.n_con; ++i_c) {
     real Ja = e.Jaref[i_c], jv = e.jv[i_c], D = e.efc_D[i_c];
     real qf_0 = D * (0.5f * Ja * Ja), qf_1 = D * (jv * Ja), qf_2 = D * (0.5f * jv * jv);
@@ -1526,6 +1633,7 @@ void ls_point_fn_3(const Model& m, Env& e, const real a[3], real costs[3], real 
       t[k][0] = t[k][0] + qf_0 * act; t[k][1] = t[k][1] + qf_1 * act; t[k][2] = t[k][2] + qf_2 * act;
     }
   }
+#endif
   for (int k = 0; k < 3; ++k) {
     costs[k] = a[k] * a[k] * t[k][2] + a[k] * t[k][1] + t[k][0];
     grads[k] = 2.0f * a[k] * t[k][2] + t[k][1];
@@ -1551,7 +1659,11 @@ int update_bracket(LsPoint& p, const real alphas[3], const real costs[3], const 
 // func_linesearch_batch, solver.py:2246-2417
 real linesearch(const Model& m, Env& e) {
   real snorm = 0.0f;
+#ifdef GO2SIM_FAST_ORDER
+  snorm = team_tree_sum(fast_team(m), ND, [&](int jd) { return e.search[jd] * e.search[jd]; });
+#else
   for (int jd = 0; jd < ND; ++jd) snorm = snorm + e.search[jd] * e.search[jd];
+#endif
   snorm = dm_sqrt(snorm);
   real scale = m.meaninertia * (real)std::max(1, ND);
   real gtol = m.tolerance * m.ls_tolerance * snorm * scale;
@@ -1652,7 +1764,11 @@ void solve_iter(const Model& m, Env& e) {
     real tol_scaled = (m.meaninertia * (real)std::max(1, ND)) * m.tolerance;
     real improvement = e.prev_cost - e.cost;
     real grad_norm = 0.0f;
+#ifdef GO2SIM_FAST_ORDER
+    grad_norm = team_tree_sum(fast_team(m), ND, [&](int i_d) { return e.grad[i_d] * e.grad[i_d]; });
+#else
     for (int i_d = 0; i_d < ND; ++i_d) grad_norm = grad_norm + e.grad[i_d] * e.grad[i_d];
+#endif
     grad_norm = dm_sqrt(grad_norm);
     e.improved = (grad_norm > tol_scaled) && (improvement > tol_scaled);
     if (e.improved)

@@ -17,7 +17,7 @@ def libs_built():
     """Both native libraries exist (built in-tree; they travel to the GPU box as .so files)."""
     from go2_sim2real_locomotion_rl_amd import build
 
-    if not os.path.exists(build.ORACLE_LIB) or os.path.exists("/usr/bin/g++"):
+    if not os.path.exists(build.ORACLE_LIB) or not os.path.exists(build.ORACLE_LIB_FAST) or os.path.exists("/usr/bin/g++"):
         build.build_oracle(verbose=False)
     if not os.path.exists(build.HIP_LIB):
         build.build_hip(verbose=False)
@@ -32,10 +32,28 @@ def blob():
 
 
 @pytest.fixture(scope="session")
-def oracle_lib(libs_built):
+def oracle_strict_lib(libs_built):
+    """The strict oracle: the reference's CPU (serial) summation order."""
     from go2_sim2real_locomotion_rl_amd.capi import load_cpu_oracle_lib
 
-    return load_cpu_oracle_lib()
+    return load_cpu_oracle_lib(fast=False)
+
+
+@pytest.fixture(scope="session")
+def oracle_fast_lib(libs_built):
+    """The FAST ORDER oracle: the HIP product's reduction order, operation for operation (the checker of every GPU parity test)."""
+    from go2_sim2real_locomotion_rl_amd.capi import load_cpu_oracle_lib
+
+    return load_cpu_oracle_lib(fast=True)
+
+
+@pytest.fixture
+def oracle_lib(request, oracle_strict_lib, oracle_fast_lib):
+    """CPU tests run the strict oracle; `-m gpu` tests compare the HIP library with the oracle build that mirrors its arithmetic.  With
+    GO2SIM_TEST_HIP_LIB pointing at a -DGO2SIM_FAST_ORDER=0 build of the HIP library, GO2SIM_TEST_STRICT=1 selects the strict oracle for them."""
+    if request.node.get_closest_marker("gpu") is not None and os.environ.get("GO2SIM_TEST_STRICT") != "1":
+        return oracle_fast_lib
+    return oracle_strict_lib
 
 
 @pytest.fixture(scope="session")

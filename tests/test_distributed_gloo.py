@@ -142,15 +142,17 @@ def test_shared_globals_hip_matches_oracle(oracle_lib, hip_lib, blob):
     cpu = CpuEnv(oracle_lib, blob, n, seed=5, mutate=mut, shared_globals=True); gpu = GpuEnv(hip_lib, blob, n, seed=5, mutate=mut, shared_globals=True)
     cpu.reset(); gpu.reset()
     rng = np.random.default_rng(3)
+    n_resets = 0
     for s in range(steps):
         a = (0.3 * rng.standard_normal((n, 16))).astype(np.float32)
         oc, pc, rc, dc, tc = cpu.step(a); og, pg, rg, dg, tg = gpu.step(a)
         assert np.array_equal(dc, dg) and bits_equal(oc, og) and bits_equal(pc, pg) and bits_equal(rc, rg), f"step {s}"
         if (s + 1) % 6 == 0:
             sc, drc = sync_env_globals(cpu.sim); sg, drg = sync_env_globals(gpu.sim)
-            assert np.array_equal(sc, sg) and np.array_equal(drc, drg) and sc[0] > 0
+            assert np.array_equal(sc, sg) and np.array_equal(drc, drg)
+            n_resets += sc[0]
             gc, gg = cpu.sim.env_globals(), gpu.sim.env_globals()
             assert gc.level == gg.level and gc.t_sample == gg.t_sample and gc.sync_calls == gg.sync_calls and gc.friction == gg.friction
             assert bits_equal(cpu.field("F_GEOM_FRICTION"), gpu.field("F_GEOM_FRICTION")) and bits_equal(cpu.field("F_MASS_SHIFT"), gpu.field("F_MASS_SHIFT"))
             assert bits_equal(cpu.field("F_LINK_POS"), gpu.field("F_LINK_POS"))
-    assert gc.level > 0.10
+    assert gc.level > 0.10 and n_resets >= 2 * n

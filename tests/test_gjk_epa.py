@@ -34,7 +34,7 @@ def _make_query(lib, blob, prefix, gjk_which):
 @pytest.fixture(scope="module", params=["oracle", pytest.param("hip_lds", marks=pytest.mark.gpu), pytest.param("hip_global", marks=pytest.mark.gpu)])
 def query(request, blob):
     if request.param == "oracle":
-        return _make_query(request.getfixturevalue("oracle_lib"), blob, "go2sim_cpu_", 1)
+        return _make_query(request.getfixturevalue("oracle_strict_lib"), blob, "go2sim_cpu_", 1)
     return _make_query(request.getfixturevalue("hip_lib"), blob, "go2sim_", 1 if request.param == "hip_lds" else 2)
 
 

@@ -24,8 +24,10 @@ CASES = ["base_jump", "base_crouch", "walk", "walk_delay1", "walk_delay2", "stai
 REF_DIR = "/root/reference/examples/locomotion/final"
 
 
-def load_fixture(case):
-    z = np.load(os.path.join(GOLDEN, f"ref_env_{case}.npz"))
+def load_fixture(case, physics="strict"):
+    """physics: which build of the oracle's rigid-body step ran underneath the reference's env code when the fixture was recorded -- "strict"
+    (the reference's CPU summation order) or "fast" (the FAST ORDER arithmetic of the HIP product, oracle/go2sim_cpu.cpp)."""
+    z = np.load(os.path.join(GOLDEN, f"ref_env_{case}.npz" if physics == "strict" else f"ref_env_{case}_{physics}.npz"))
     return z, json.loads(str(z["cfgs_json"])), json.loads(str(z["meta_json"]))
 
 
@@ -83,8 +85,9 @@ class FusedEnv:
         return self._host(t)
 
 
-def replay_and_compare(lib, blob, case, gpu):
-    z, cfgs, meta = load_fixture(case)
+def replay_and_compare(lib, blob, case, gpu, physics):
+    z, cfgs, meta = load_fixture(case, physics)
+    assert meta["physics"] == physics
     assert meta["n_time_out_resets"] >= 3 and meta["n_fall_resets"] >= 3, "every fixture passes through both kinds of reset"
     env = FusedEnv(lib, blob, case, cfgs, meta, gpu)
     assert env.names == meta["reward_names"]
@@ -112,9 +115,10 @@ def replay_and_compare(lib, blob, case, gpu):
     return z, meta
 
 
+@pytest.mark.parametrize("physics", ["strict", "fast"])
 @pytest.mark.parametrize("case", CASES)
-def test_oracle_env_matches_the_reference_env_files(oracle_lib, blob, case):
-    z, meta = replay_and_compare(oracle_lib, blob, case, gpu=False)
+def test_oracle_env_matches_the_reference_env_files(oracle_strict_lib, oracle_fast_lib, blob, case, physics):
+    z, meta = replay_and_compare(oracle_fast_lib if physics == "fast" else oracle_strict_lib, blob, case, gpu=False, physics=physics)
     if case in ("walk", "stairs"):
         assert len(set(np.round(z["level"], 9))) > 1, "the curriculum level moved inside the tape (update_every_episodes = 6)"
 
@@ -122,7 +126,7 @@ def test_oracle_env_matches_the_reference_env_files(oracle_lib, blob, case):
 @pytest.mark.gpu
 @pytest.mark.parametrize("case", CASES)
 def test_hip_env_matches_the_reference_env_files(hip_lib, blob, case):
-    replay_and_compare(hip_lib, blob, case, gpu=True)
+    replay_and_compare(hip_lib, blob, case, gpu=True, physics="strict" if os.environ.get("GO2SIM_TEST_STRICT") == "1" else "fast")
 
 
 @pytest.mark.skipif(not os.path.isdir(REF_DIR), reason="the reference tree exists in the build container only")
@@ -136,9 +140,9 @@ def test_fixtures_are_what_the_reference_files_produce(oracle_lib, case):
     sys.path.insert(0, os.path.join(os.path.dirname(GOLDEN), "..", "tools"))
     import make_ref_env_fixtures as M
 
-    z, cfgs, meta = load_fixture(case)
+    z, cfgs, meta = load_fixture(case, "fast")
     assert json.loads(json.dumps(M.pinned_cfgs(case))) == cfgs
-    out, _ = M.run_case(case, B=meta["n_envs"], T=meta["steps"], seed=meta["seed"], n_run=30)
+    out, _ = M.run_case(case, B=meta["n_envs"], T=meta["steps"], seed=meta["seed"], n_run=30, physics="fast")
     for key in ("obs", "priv", "rew", "rew_terms", "done", "time_outs", "ctrl_pos", "ctrl_force", "commands", "base_pos", "episode_length"):
         assert np.array_equal(out[key], z[key][:30]), key
     assert np.array_equal(out["actions"], z["actions"][:30])

@@ -30,7 +30,7 @@ def actions():
 
 
 def main():
-    env = CpuEnv(load_cpu_oracle_lib(), pack_model(), B, seed=SEED)
+    env = CpuEnv(load_cpu_oracle_lib(fast=True), pack_model(), B, seed=SEED)
     env.reset()
     acts = actions()
     obs, priv, rew, rst, to, ncon, qpos = [], [], [], [], [], [], []

@@ -108,13 +108,19 @@ def load_reference_env_module(stem):
     return mod
 
 
-def run_case(case, B=8, T=96, seed=11, n_run=None):
+def fixture_path(case, physics):
+    return os.path.join(OUT_DIR, f"ref_env_{case}.npz" if physics == "strict" else f"ref_env_{case}_{physics}.npz")
+
+
+def run_case(case, B=8, T=96, seed=11, n_run=None, physics="strict"):
     """Runs the reference env of `case` over the first `n_run` (default: all) steps of the T-step action tape."""
     import go2_sim2real_locomotion_rl_amd.genesis_shim as gs
     from go2_sim2real_locomotion_rl_amd.capi import load_cpu_oracle_lib
     from util import gs_on_oracle
 
-    gs_on_oracle(gs, load_cpu_oracle_lib(), seed=seed)
+    # physics underneath the reference's env code: the strict oracle (reference CPU summation order) or its FAST ORDER build (the arithmetic of the
+    # HIP product); the env layer that is being pinned is the same reference code either way
+    gs_on_oracle(gs, load_cpu_oracle_lib(fast=(physics == "fast")), seed=seed)
     stem = {"base_jump": "go2_env_base", "base_crouch": "go2_env_base", "walk": "go2_env_walk", "walk_delay1": "go2_env_walk", "walk_delay2": "go2_env_walk", "stairs": "go2_env_stair"}[case]
     cfgs = pinned_cfgs(case)
     cfg_json = json.dumps(cfgs)                                           # before the env multiplies the reward scales by dt in place
@@ -163,7 +169,7 @@ def run_case(case, B=8, T=96, seed=11, n_run=None):
     out = {k: np.stack(v) if k != "level" else np.asarray(v, np.float64) for k, v in rec.items()}
     out["actions"] = acts[:n_run]
     done, to = out["done"].astype(bool), out["time_outs"] > 0
-    meta = {"case": case, "reference_file": f"examples/locomotion/final/{stem}.py", "n_envs": B, "steps": n_run, "seed": seed, "reward_names": names,
+    meta = {"case": case, "reference_file": f"examples/locomotion/final/{stem}.py", "physics": physics, "n_envs": B, "steps": n_run, "seed": seed, "reward_names": names,
             "n_time_out_resets": int((done & to).sum()), "n_fall_resets": int((done & ~to).sum()),
             "terrain_rows": None if rows is None else rows.tolist()}
     out["cfgs_json"] = np.array(cfg_json)
@@ -179,10 +185,11 @@ def main():
     build.build_oracle()
     os.makedirs(OUT_DIR, exist_ok=True)
     for case in sys.argv[1:] or ["base_jump", "base_crouch", "walk", "walk_delay1", "walk_delay2", "stairs"]:
-        out, meta = run_case(case)
-        path = os.path.join(OUT_DIR, f"ref_env_{case}.npz")
-        np.savez_compressed(path, **out)
-        print(f"{path}: {meta['n_time_out_resets']} time-out resets, {meta['n_fall_resets']} fall resets, {os.path.getsize(path) // 1024} KiB")
+        for physics in ("strict", "fast"):
+            out, meta = run_case(case, physics=physics)
+            path = fixture_path(case, physics)
+            np.savez_compressed(path, **out)
+            print(f"{path}: {meta['n_time_out_resets']} time-out resets, {meta['n_fall_resets']} fall resets, {os.path.getsize(path) // 1024} KiB")
 
 
 if __name__ == "__main__":

@@ -13,7 +13,7 @@ task = sys.argv[1] if len(sys.argv) > 1 else "walk"
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 3000
 blob = pack_model()
-cpu, gpu = CpuEnv(load_cpu_oracle_lib(), blob, B, seed=77, task=task), GpuEnv(load_hip_lib(), blob, B, seed=77, task=task)
+cpu, gpu = CpuEnv(load_cpu_oracle_lib(fast=True), blob, B, seed=77, task=task), GpuEnv(load_hip_lib(), blob, B, seed=77, task=task)
 cpu.reset(); gpu.reset()
 rng = np.random.default_rng(1)
 n_act = cpu.n_act

@@ -15,7 +15,7 @@ KIND = sys.argv[4] if len(sys.argv) > 4 else "0.5"
 FIELDS = ["F_MASS_MAT", "F_FORCE", "F_ACC_SMOOTH", "I_N_CONTACTS", "F_CONTACT_POS", "F_CONTACT_PEN", "I_N_CONSTRAINTS", "I_SOLVER_ITERS", "F_EFC_FORCE",
           "F_QFRC_CONSTRAINT", "F_QACC_WS", "F_ACC", "F_CONTACT_FORCE", "F_QPOS", "F_VEL", "F_LINK_POS"]
 blob = pack_model()
-cpu, gpu = CpuEnv(load_cpu_oracle_lib(), blob, B, seed=SEED), GpuEnv(load_hip_lib(), blob, B, seed=SEED)
+cpu, gpu = CpuEnv(load_cpu_oracle_lib(fast=True), blob, B, seed=SEED), GpuEnv(load_hip_lib(), blob, B, seed=SEED)
 cpu.reset(); gpu.reset()
 acts = make_actions(STEPS, B, seed=SEED, kind=KIND)
 for s, a in enumerate(acts):

@@ -17,7 +17,7 @@ if len(sys.argv) > 3:
 if len(sys.argv) > 4:
     _m["solver"]["ls_iterations"] = int(sys.argv[4])
 blob = pack_model(_m)
-cpu = Go2Sim(load_cpu_oracle_lib(), blob, B, 0, 7)
+cpu = Go2Sim(load_cpu_oracle_lib(fast=True), blob, B, 0, 7)
 gpu = Go2Sim(load_hip_lib(), blob, B, 0, 7)
 f, i, names = flatten_walk_cfg(B, *get_walk_cfgs())
 cpu.env_configure(f, i); gpu.env_configure(f, i)
