@@ -6,9 +6,9 @@ tolerance 0).  These tests bound what the change of order does to the results, a
 (serial) variants -- north_star's "within a stated fp32 tolerance, with contact counts and done masks bit-exact":
 
 * one rigid substep from IDENTICAL states (the strict trajectory's state is uploaded into the fast oracle before every step, so no chaotic growth
-  enters): accelerations within 2e-3 relative to the per-env acceleration scale + 2e-3 absolute (the Newton solve stops on `improvement < tol`, so two
-  summation orders may stop one iteration apart: the bound is the solver's own stopping accuracy, not rounding), positions / velocities after the step
-  within 1e-5, contact counts and constraint counts equal;
+  enters): accelerations within 1e-5 of the per-env acceleration scale (+ 1e-6 absolute; measured: <= 1.6e-6 of the scale although 5-8 % of the
+  solves stop one Newton iteration apart -- the solve stops on `improvement < tol`, and the iterates of both orders are then equally converged),
+  positions / velocities after the step within 1e-5 (measured: <= 3.9e-6), contact counts and constraint counts equal;
 * free trajectories over a short horizon: observations within 2e-4, rewards within 2e-5 after 4 env steps, done masks and contact counts equal.
 """
 import numpy as np
@@ -44,7 +44,7 @@ def test_one_substep_from_identical_states(oracle_strict_lib, oracle_fast_lib, b
         assert np.array_equal(strict.field("I_N_CONSTRAINTS"), fast.field("I_N_CONSTRAINTS")), f"step {s}: constraint counts"
         a_s, a_f = strict.field("F_ACC"), fast.field("F_ACC")
         scale = np.abs(a_s).max(axis=0, keepdims=True)
-        err = np.abs(a_s - a_f) / (2e-3 * scale + 2e-3)
+        err = np.abs(a_s - a_f) / (1e-5 * scale + 1e-6)
         worst_acc = max(worst_acc, float(err.max()))
         worst_q = max(worst_q, float(np.abs(strict.field("F_QPOS") - fast.field("F_QPOS")).max()), float(np.abs(strict.field("F_VEL") - fast.field("F_VEL")).max()))
         n_rows += int(strict.field("I_N_CONSTRAINTS").sum())
