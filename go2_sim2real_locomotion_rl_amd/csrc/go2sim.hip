@@ -1708,6 +1708,7 @@ struct CollideData {
   float stage[T][5][7];
   int cnt[T];
   unsigned gjk_slot_mask;                             // bit i set = gjk[i] is taken
+  float gjk_res[T][8];                                // T = 16: answers of the cooperative GJK / EPA queries, indexed by the lane that asked
   unsigned ncv[NCV];                                  // ncache_valid of this env for the duration of the kernel
 };
 struct ContactStage { float* st; int n; };   // per-lane staging of the (<= 5) contacts of one pair
@@ -1718,66 +1719,93 @@ DEV void stage_contact(ContactStage& cs, V3 normal, V3 pos, float pen) {
   cs.n++;
 }
 
-// func_convex_convex_contact (CCD_ALGORITHM_CODE.MPR branch), narrowphase.py:514-961; contacts go to the lane's staging buffer
-DEV void convex_convex_contact_staged(const Model& m, const E& e, int i_ga, int i_gb, ContactStage& cs, GjkStoreLds* gjk_slots, unsigned* gjk_slot_mask, GjkStoreFull* gjk_full, unsigned* ncv) {
+// func_convex_convex_contact (CCD_ALGORITHM_CODE.MPR branch), narrowphase.py:514-961; contacts go to the lane's staging buffer.
+// The function is cut in three so that the GJK / EPA fallback of the unperturbed detection -- the one the landing robots need -- can be answered
+// by the whole team between the pieces (k_collide_team, T = 16):  cc_detect0 = pair set-up + MPR (+ cold retry) + "prefer GJK" decision;
+// [GJK / EPA, by one lane (cc_gjk_lane) or by the team (dgc_contact)];  cc_rest = bookkeeping of detection 0 and the four perturbed detections.
+struct CcState {
+  Pair pr; V3 ga_pos_o, gb_pos_o; Q4 ga_quat_o, gb_quat_o;
+  int i_pair, type_a, type_b; bool multi_contact, want_gjk; float tolerance;
+  bool is_col; float penetration; V3 normal, contact_pos;
+};
+DEV void cc_mpr_with_retry(const Model& m, CcState& c, int i_detection, unsigned* ncv, const Arr3& normal_cache, bool& guess_available) {
   const float EPS = m.eps;
-  int type_a = m.geoms[i_ga].type, type_b = m.geoms[i_gb].type;
-  bool multi_contact = (type_a != GEOM_SPHERE) && (type_b != GEOM_SPHERE);
-  float tolerance = compute_tolerance(m, i_ga, i_gb, m.mc_tolerance);
-  V3 ga_pos_o = e.g_pos()[i_ga], gb_pos_o = e.g_pos()[i_gb]; Q4 ga_quat_o = e.g_quat()[i_ga], gb_quat_o = e.g_quat()[i_gb];
-  Pair pr; pr.i_ga = i_ga; pr.i_gb = i_gb; pr.pos_a = ga_pos_o; pr.quat_a = ga_quat_o; pr.pos_b = gb_pos_o; pr.quat_b = gb_quat_o; pr.prism = nullptr; pr.ga = geom_lite(m, i_ga); pr.gb = geom_lite(m, i_gb);
+  bool is_mpr_updated = false;
+  V3 normal_ws = ((ncv[c.i_pair >> 5] >> (c.i_pair & 31)) & 1u) ? (V3)normal_cache[c.i_pair] : v3(0, 0, 0);
+  guess_available = (dm_abs(normal_ws.x) > EPS) || (dm_abs(normal_ws.y) > EPS) || (dm_abs(normal_ws.z) > EPS);
+  for (int i_mpr = 0; i_mpr < 2; ++i_mpr) {
+    if (i_mpr == 1) {
+      if ((i_detection == 0) && !c.is_col && guess_available) { normal_ws = v3(0, 0, 0); guess_available = false; is_mpr_updated = false; }
+    }
+    if (!is_mpr_updated) {
+      PHD_BEGIN
+#if defined(GO2SIM_REPEAT_PHASE) && GO2SIM_REPEAT_PHASE == 35
+      mpr_contact(m, c.pr, normal_ws, c.is_col, c.normal, c.penetration, c.contact_pos);
+#endif
+      mpr_contact(m, c.pr, normal_ws, c.is_col, c.normal, c.penetration, c.contact_pos);
+      PHD(36)
+      is_mpr_updated = true;
+    }
+  }
+}
+DEV bool cc_prefer_gjk(const Model& m, const CcState& c, bool guess_available) {
+  if (c.penetration > c.tolerance) return !guess_available || (m.mc_tolerance * c.penetration >= m.mpr_to_gjk_ratio * c.tolerance);
+  return false;
+}
+DEV void cc_detect0(const Model& m, const E& e, int i_ga, int i_gb, unsigned* ncv, CcState& c) {
+  c.type_a = m.geoms[i_ga].type; c.type_b = m.geoms[i_gb].type;
+  c.multi_contact = (c.type_a != GEOM_SPHERE) && (c.type_b != GEOM_SPHERE);
+  c.tolerance = compute_tolerance(m, i_ga, i_gb, m.mc_tolerance);
+  c.ga_pos_o = e.g_pos()[i_ga]; c.gb_pos_o = e.g_pos()[i_gb]; c.ga_quat_o = e.g_quat()[i_ga]; c.gb_quat_o = e.g_quat()[i_gb];
+  Pair& pr = c.pr;
+  pr.i_ga = i_ga; pr.i_gb = i_gb; pr.pos_a = c.ga_pos_o; pr.quat_a = c.ga_quat_o; pr.pos_b = c.gb_pos_o; pr.quat_b = c.gb_quat_o; pr.prism = nullptr; pr.ga = geom_lite(m, i_ga); pr.gb = geom_lite(m, i_gb);
   pair_set_rots(pr);
+  c.is_col = false; c.penetration = 0.0f; c.normal = v3(0, 0, 0); c.contact_pos = v3(0, 0, 0);
+  c.i_pair = (i_ga > i_gb) ? m.pair_idx[i_gb][i_ga] : m.pair_idx[i_ga][i_gb];
+  bool guess_available;
+  cc_mpr_with_retry(m, c, 0, ncv, e.normal_cache(), guess_available);
+  c.want_gjk = cc_prefer_gjk(m, c, guess_available);
+}
+// narrowphase.py:734-845: safe GJK + EPA replaces the MPR answer (one lane; LDS polytope slot when `gjk_slots` is given, else the global record)
+DEV void cc_gjk_lane(const Model& m, const E& e, CcState& c, GjkStoreLds* gjk_slots, unsigned* gjk_slot_mask, GjkStoreFull* gjk_full) {
+  atomicAdd(&e.gjk_fallback()[0], 1);
+  const Pair& pr = c.pr;
+  DgPair dp;                                                 // the out-of-line callee takes a reference: this record only exists on the cold
+  dp.m = &m; dp.i_ga = pr.i_ga; dp.i_gb = pr.i_gb; dp.pos_a = pr.pos_a; dp.quat_a = pr.quat_a; dp.pos_b = pr.pos_b; dp.quat_b = pr.quat_b;   // path, `pr` stays in registers
+  dp.ga = pr.ga; dp.gb = pr.gb; dp.ra = pr.ra; dp.rb = pr.rb;
+  dp.discrete = c.type_a == GEOM_BOX && c.type_b == GEOM_BOX;     // func_is_discrete_geoms, collider/utils.py:105-126
+#if defined(GO2SIM_REPEAT_PHASE) && GO2SIM_REPEAT_PHASE == 34
+  { const DgResult g0 = gjk_query(dp, gjk_slots, gjk_slot_mask, gjk_full, m.eps); if (g0.penetration == 12345.0f) c.penetration = 0.0f; }
+#endif
+  PHD_BEGIN
+  const DgResult gr = gjk_query(dp, gjk_slots, gjk_slot_mask, gjk_full, m.eps);
+  PHD(34)
+  c.is_col = gr.is_col;
+  c.penetration = gr.penetration;
+  if (c.is_col) { c.contact_pos = gr.pos; c.normal = gr.normal; }
+}
+DEV void cc_rest(const Model& m, const E& e, CcState& c, ContactStage& cs, GjkStoreLds* gjk_slots, unsigned* gjk_slot_mask, GjkStoreFull* gjk_full, unsigned* ncv) {
+  const float EPS = m.eps;
+  const int i_ga = c.pr.i_ga, i_gb = c.pr.i_gb, i_pair = c.i_pair;
+  const bool multi_contact = c.multi_contact;
+  const float tolerance = c.tolerance;
+  Pair& pr = c.pr;
   bool is_col_0 = false; V3 normal_0 = v3(0, 0, 0), contact_pos_0 = v3(0, 0, 0);
-  bool is_col = false; float penetration = 0.0f; V3 normal = v3(0, 0, 0), contact_pos = v3(0, 0, 0);
+  bool& is_col = c.is_col; float& penetration = c.penetration; V3& normal = c.normal; V3& contact_pos = c.contact_pos;
   V3 axis_0 = v3(0, 0, 0), axis_1 = v3(0, 0, 0); Q4 qrot = q4(0, 0, 0, 0);
-  int i_pair = (i_ga > i_gb) ? m.pair_idx[i_gb][i_ga] : m.pair_idx[i_ga][i_gb];
   auto normal_cache = e.normal_cache();
   PHD_BEGIN
   for (int i_detection = 0; i_detection < 5; ++i_detection) {
     if (i_detection == 1) { PHD(44) }
-    bool prefer_gjk = false;
-    if (multi_contact && is_col_0) {
+    if (i_detection > 0 && multi_contact && is_col_0) {
       V3 axis = (float)(2 * (i_detection % 2) - 1) * axis_0 + (float)(1 - 2 * ((i_detection / 2) % 2)) * axis_1;
       qrot = rotvec_to_quat(m.mc_perturbation * axis, EPS);
-      rotate_frame(ga_pos_o, ga_quat_o, contact_pos_0, qrot, pr.pos_a, pr.quat_a);
-      rotate_frame(gb_pos_o, gb_quat_o, contact_pos_0, inv_quat(qrot), pr.pos_b, pr.quat_b);
+      rotate_frame(c.ga_pos_o, c.ga_quat_o, contact_pos_0, qrot, pr.pos_a, pr.quat_a);
+      rotate_frame(c.gb_pos_o, c.gb_quat_o, contact_pos_0, inv_quat(qrot), pr.pos_b, pr.quat_b);
       pair_set_rots(pr);
-    }
-    if ((multi_contact && is_col_0) || (i_detection == 0)) {
-      bool is_mpr_updated = false;
-      V3 normal_ws = ((ncv[i_pair >> 5] >> (i_pair & 31)) & 1u) ? (V3)normal_cache[i_pair] : v3(0, 0, 0);
-      bool guess_available = (dm_abs(normal_ws.x) > EPS) || (dm_abs(normal_ws.y) > EPS) || (dm_abs(normal_ws.z) > EPS);
-      for (int i_mpr = 0; i_mpr < 2; ++i_mpr) {
-        if (i_mpr == 1) {
-          if ((i_detection == 0) && !is_col && guess_available) { normal_ws = v3(0, 0, 0); guess_available = false; is_mpr_updated = false; }
-        }
-        if (!is_mpr_updated) {
-          PHD_BEGIN
-#if defined(GO2SIM_REPEAT_PHASE) && GO2SIM_REPEAT_PHASE == 35
-          mpr_contact(m, pr, normal_ws, is_col, normal, penetration, contact_pos);
-#endif
-          mpr_contact(m, pr, normal_ws, is_col, normal, penetration, contact_pos);
-          PHD(36)
-          is_mpr_updated = true;
-        }
-      }
-      if (penetration > tolerance) prefer_gjk = !guess_available || (m.mc_tolerance * penetration >= m.mpr_to_gjk_ratio * tolerance);
-      if (prefer_gjk) {                                          // narrowphase.py:734-845: safe GJK + EPA replaces the MPR answer
-        atomicAdd(&e.gjk_fallback()[0], 1);
-        DgPair dp;                                                 // the out-of-line callee takes a reference: this record only exists on the cold
-        dp.m = &m; dp.i_ga = pr.i_ga; dp.i_gb = pr.i_gb; dp.pos_a = pr.pos_a; dp.quat_a = pr.quat_a; dp.pos_b = pr.pos_b; dp.quat_b = pr.quat_b;   // path, `pr` stays in registers
-        dp.ga = pr.ga; dp.gb = pr.gb; dp.ra = pr.ra; dp.rb = pr.rb;
-        dp.discrete = type_a == GEOM_BOX && type_b == GEOM_BOX;     // func_is_discrete_geoms, collider/utils.py:105-126
-#if defined(GO2SIM_REPEAT_PHASE) && GO2SIM_REPEAT_PHASE == 34
-        { const DgResult g0 = gjk_query(dp, gjk_slots, gjk_slot_mask, gjk_full, m.eps); if (g0.penetration == 12345.0f) penetration = 0.0f; }
-#endif
-        PHD_BEGIN
-        const DgResult gr = gjk_query(dp, gjk_slots, gjk_slot_mask, gjk_full, m.eps);
-        PHD(34)
-        is_col = gr.is_col;
-        penetration = gr.penetration;
-        if (is_col) { contact_pos = gr.pos; normal = gr.normal; }
-      }
+      bool guess_available;
+      cc_mpr_with_retry(m, c, i_detection, ncv, normal_cache, guess_available);
+      if (cc_prefer_gjk(m, c, guess_available)) cc_gjk_lane(m, e, c, gjk_slots, gjk_slot_mask, gjk_full);
     }
     if (i_detection == 0) {
       is_col_0 = is_col; normal_0 = normal; contact_pos_0 = contact_pos;
@@ -1810,6 +1838,12 @@ DEV void convex_convex_contact_staged(const Model& m, const E& e, int i_ga, int 
     }
   }
   PHD(46)
+}
+DEV void convex_convex_contact_staged(const Model& m, const E& e, int i_ga, int i_gb, ContactStage& cs, GjkStoreLds* gjk_slots, unsigned* gjk_slot_mask, GjkStoreFull* gjk_full, unsigned* ncv) {
+  CcState c;
+  cc_detect0(m, e, i_ga, i_gb, ncv, c);
+  if (c.want_gjk) cc_gjk_lane(m, e, c, gjk_slots, gjk_slot_mask, gjk_full);
+  cc_rest(m, e, c, cs, gjk_slots, gjk_slot_mask, gjk_full, ncv);
 }
 
 // func_contact_mpr_terrain, narrowphase.py:345-490, split for one-lane-per-prism execution.
@@ -2036,13 +2070,61 @@ __global__ __launch_bounds__(64) void k_collide_team(Pool P, const Model* __rest
     int ip = it * T + tl;
     ContactStage cs; cs.st = &s->stage[tl][0][0]; cs.n = 0;
     int i_ga = 0, i_gb = 0;
+    bool convex_pair = false;
     if (ip < n_broad) {
       int pk = s->pair_sorted[ip];
       i_ga = pk & 0xff; i_gb = pk >> 8;
       if (m.geoms[i_ga].type > m.geoms[i_gb].type) { int t = i_ga; i_ga = i_gb; i_gb = t; }
-      const bool with_terrain = m.geoms[i_gb].type == GEOM_TERRAIN;
-      if (!with_terrain) convex_convex_contact_staged(m, e, i_ga, i_gb, cs, s->gjk, &s->gjk_slot_mask, &gjk_scratch[(size_t)b * T + tl], s->ncv);
+      convex_pair = m.geoms[i_gb].type != GEOM_TERRAIN;
     }
+#ifndef GO2SIM_GJK_SERIAL
+    if constexpr (T == 16) {
+      // MPR of every pair on its own lane; then the pairs whose MPR answer has to be replaced by safe GJK + EPA (narrowphase.py:727-845) are
+      // answered by QUADS: the four quads of the team take four flagged pairs at a time (the four feet of a landing robot), the four lanes of a
+      // quad cooperate on their query (csrc/go2sim_gjk_dev.h, cooperative form, W = 4); then every lane finishes its pair
+      static_assert(GJK_SLOTS >= 4, "one LDS polytope slot per quad");
+      CcState cst;
+      cst.want_gjk = false;
+      if (convex_pair) cc_detect0(m, e, i_ga, i_gb, s->ncv, cst);
+      const bool wants = convex_pair && cst.want_gjk;
+      const unsigned want = dgc_ballot<16>(wants);
+      const int n_want = __popc(want), quad = tl >> 2, ql = tl & 3;
+      for (int r0 = 0; r0 < n_want; r0 += 4) {                          // team-uniform rounds
+        unsigned rest = want;
+        for (int k = 0; k < r0 + quad; ++k) rest &= rest - 1u;           // drop the pairs taken by earlier rounds / lower quads
+        const int L = rest ? __ffs((int)rest) - 1 : -1;                  // the lane whose pair my quad answers in this round
+        const int Ls = L < 0 ? tl : L;
+        DgPair dp;                                                       // (all 16 lanes shuffle: the source lanes have to be active)
+        dp.m = mp; dp.i_ga = __shfl(i_ga, Ls, 16); dp.i_gb = __shfl(i_gb, Ls, 16);
+        dp.pos_a = v3(__shfl(cst.pr.pos_a.x, Ls, 16), __shfl(cst.pr.pos_a.y, Ls, 16), __shfl(cst.pr.pos_a.z, Ls, 16));
+        dp.quat_a = q4(__shfl(cst.pr.quat_a.w, Ls, 16), __shfl(cst.pr.quat_a.x, Ls, 16), __shfl(cst.pr.quat_a.y, Ls, 16), __shfl(cst.pr.quat_a.z, Ls, 16));
+        dp.pos_b = v3(__shfl(cst.pr.pos_b.x, Ls, 16), __shfl(cst.pr.pos_b.y, Ls, 16), __shfl(cst.pr.pos_b.z, Ls, 16));
+        dp.quat_b = q4(__shfl(cst.pr.quat_b.w, Ls, 16), __shfl(cst.pr.quat_b.x, Ls, 16), __shfl(cst.pr.quat_b.y, Ls, 16), __shfl(cst.pr.quat_b.z, Ls, 16));
+        if (L >= 0) {
+          dp.ga = geom_lite(m, dp.i_ga); dp.gb = geom_lite(m, dp.i_gb); dp.ra = make_rot(dp.quat_a); dp.rb = make_rot(dp.quat_b);
+          dp.discrete = dp.ga.type == GEOM_BOX && dp.gb.type == GEOM_BOX;  // func_is_discrete_geoms, collider/utils.py:105-126
+          PHD_BEGIN
+          DgResult gr = dgc_contact<4>(dp, s->gjk[quad], m.eps, ql);
+          if (gr.overflow) gr = dgc_contact<4>(dp, gjk_scratch[(size_t)b * T + L], m.eps, ql);   // outgrew the LDS slot: the same query on the full-capacity record
+          PHD(34)
+          if (ql == 0) {
+            float* o = s->gjk_res[L];
+            o[0] = gr.is_col ? 1.0f : 0.0f; o[1] = gr.penetration; o[2] = gr.normal.x; o[3] = gr.normal.y; o[4] = gr.normal.z; o[5] = gr.pos.x; o[6] = gr.pos.y; o[7] = gr.pos.z;
+          }
+        }
+      }
+      team_sync();
+      if (wants) {
+        atomicAdd(&e.gjk_fallback()[0], 1);
+        const float* o = s->gjk_res[tl];
+        cst.is_col = o[0] != 0.0f;
+        cst.penetration = o[1];
+        if (cst.is_col) { cst.normal = v3(o[2], o[3], o[4]); cst.contact_pos = v3(o[5], o[6], o[7]); }
+      }
+      if (convex_pair) cc_rest(m, e, cst, cs, nullptr, &s->gjk_slot_mask, &gjk_scratch[(size_t)b * T + tl], s->ncv);
+    } else
+#endif
+    if (convex_pair) convex_convex_contact_staged(m, e, i_ga, i_gb, cs, s->gjk, &s->gjk_slot_mask, &gjk_scratch[(size_t)b * T + tl], s->ncv);
     s->cnt[tl] = cs.n;
     team_sync();
     int off = 0, tot = 0;
@@ -3322,16 +3404,37 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 
 // diagnostics (go2sim_debug_narrowphase): one narrow-phase query on explicit poses, by one lane.  which = 0: MPR from a cold start
 // (func_mpr_contact, mpr.py:763-819); 1: safe GJK + EPA the way k_collide_team runs it (LDS polytope slot, global record on overflow);
-// 2: safe GJK + EPA on the full-capacity global record only.  out = {is_col, penetration, normal[3], pos[3]}
+// 2: safe GJK + EPA on the full-capacity global record only; 3 / 4: the cooperative form k_collide_team<16> runs (the 4 lanes of a quad answer the
+// query together) on an LDS slot / on the global record; 5 / 6: the same with 16 lanes per query.  out = {is_col, penetration, normal[3], pos[3]}
 __global__ __launch_bounds__(64) void k_debug_narrowphase(const Model* __restrict__ mp, int which, int i_ga, int i_gb, V3 pa, Q4 qa, V3 pb, Q4 qb,
                                                           GjkStoreFull* __restrict__ full, float* __restrict__ out8) {
   __shared__ GjkStoreLds slots[GJK_SLOTS_MAX];
+  __shared__ GjkStoreTeam team_store;
   __shared__ unsigned mask;
   if (threadIdx.x == 0) mask = 0u;
   __syncthreads();
-  if (threadIdx.x != 0) return;
   const Model& m = *mp;
   bool is_col = false; V3 normal = v3(0, 0, 0), pos = v3(0, 0, 0); float pen = 0.0f;
+  if (which >= 3) {
+    if (threadIdx.x >= 16) return;
+    DgPair dp; dp.m = mp; dp.i_ga = i_ga; dp.i_gb = i_gb; dp.pos_a = pa; dp.quat_a = qa; dp.pos_b = pb; dp.quat_b = qb;
+    dp.ga = geom_lite(m, i_ga); dp.gb = geom_lite(m, i_gb); dp.ra = make_rot(qa); dp.rb = make_rot(qb);
+    dp.discrete = m.geoms[i_ga].type == GEOM_BOX && m.geoms[i_gb].type == GEOM_BOX;
+    DgResult r;
+    if (which <= 4) {                                                   // the form the collision kernel runs: a quad per query, the quad's LDS slot
+      if (threadIdx.x >= 4) return;
+      r = (which == 3) ? dgc_contact<4>(dp, slots[0], m.eps, (int)threadIdx.x) : dgc_contact<4>(dp, *full, m.eps, (int)threadIdx.x);
+      if (r.overflow) r = dgc_contact<4>(dp, *full, m.eps, (int)threadIdx.x);
+    } else {                                                            // 16 lanes (one DPP row) on one query
+      r = (which == 5) ? dgc_contact<16>(dp, team_store, m.eps, (int)threadIdx.x) : dgc_contact<16>(dp, *full, m.eps, (int)threadIdx.x);
+      if (r.overflow) r = dgc_contact<16>(dp, *full, m.eps, (int)threadIdx.x);
+    }
+    if (threadIdx.x != 0) return;
+    is_col = r.is_col; pen = r.penetration; normal = r.normal; pos = r.pos;
+    out8[0] = is_col ? 1.0f : 0.0f; out8[1] = pen; out8[2] = normal.x; out8[3] = normal.y; out8[4] = normal.z; out8[5] = pos.x; out8[6] = pos.y; out8[7] = pos.z;
+    return;
+  }
+  if (threadIdx.x != 0) return;
   if (which == 0) {
     Pair pr; pr.i_ga = i_ga; pr.i_gb = i_gb; pr.pos_a = pa; pr.quat_a = qa; pr.pos_b = pb; pr.quat_b = qb; pr.prism = nullptr; pr.ga = geom_lite(m, i_ga); pr.gb = geom_lite(m, i_gb);
     pair_set_rots(pr);
@@ -5565,7 +5668,7 @@ int go2sim_read_timing(go2sim_t* h, float* ms_out8, int* cnt_out8, int reset) {
 }
 
 int go2sim_debug_narrowphase(go2sim_t* h, int which, int i_ga, int i_gb, const float* pa, const float* qa, const float* pb, const float* qb, float* out8) {
-  if (!h || !out8 || !pa || !qa || !pb || !qb || i_ga < 0 || i_gb < 0 || i_ga >= NG || i_gb >= NG || which < 0 || which > 2) return GO2SIM_E_BADARG;
+  if (!h || !out8 || !pa || !qa || !pb || !qb || i_ga < 0 || i_gb < 0 || i_ga >= NG || i_gb >= NG || which < 0 || which > 6) return GO2SIM_E_BADARG;
   float* dout = nullptr;
   HIPCHK(hipSetDevice(h->device));
   HIPCHK(hipMalloc((void**)&dout, 8 * sizeof(float)));

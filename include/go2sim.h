@@ -394,7 +394,9 @@ int go2sim_env_globals_ptr(go2sim_t* h, void** ptr_out);
 
 /* diagnostics: ONE narrow-phase query on explicit world poses of geoms i_ga, i_gb (host pointers: pos[3], quat[4] wxyz; out8 = {is_col,
  * penetration, normal[3], pos[3]}), evaluated by the library's own narrow-phase code: which = 0 MPR from a cold start (collider/mpr.py:763-819),
- * 1 safe GJK + EPA as the collision kernel runs it (collider/gjk.py:161-437), 2 the same on the full-capacity polytope record.  Synchronous.
+ * 1 safe GJK + EPA by one lane with the LDS polytope slot (collider/gjk.py:161-437), 2 the same on the full-capacity polytope record, 3 / 4 the
+ * cooperative query the collision kernel runs (the 4 lanes of a quad on one query) with an LDS slot / on the full-capacity record, 5 / 6 the same
+ * with 16 lanes per query.  Synchronous.
  * Lets the closed-form checks of tests/test_gjk_epa.py run against the HIP implementation, not only against the oracle. */
 int go2sim_debug_narrowphase(go2sim_t* h, int which, int i_ga, int i_gb, const float* pos_a, const float* quat_a, const float* pos_b,
                              const float* quat_b, float* out8);

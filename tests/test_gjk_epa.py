@@ -30,12 +30,17 @@ def _make_query(lib, blob, prefix, gjk_which):
     return q
 
 
-# backends: the oracle (CPU), the HIP library with the LDS polytope slot (1) and with the full-capacity global record (2)
-@pytest.fixture(scope="module", params=["oracle", pytest.param("hip_lds", marks=pytest.mark.gpu), pytest.param("hip_global", marks=pytest.mark.gpu)])
+# backends: the oracle (CPU); the HIP library's one-lane query with the LDS polytope slot (1) and with the full-capacity global record (2); its
+# cooperative query -- what k_collide_team runs: the 4 lanes of a quad on one query -- with an LDS slot (3) and on the global record (4), and the
+# same code with 16 lanes per query (5, 6)
+HIP_BACKENDS = {"hip_lds": 1, "hip_global": 2, "hip_quad_lds": 3, "hip_quad_global": 4, "hip_row_lds": 5, "hip_row_global": 6}
+
+
+@pytest.fixture(scope="module", params=["oracle"] + [pytest.param(k, marks=pytest.mark.gpu) for k in HIP_BACKENDS])
 def query(request, blob):
     if request.param == "oracle":
         return _make_query(request.getfixturevalue("oracle_strict_lib"), blob, "go2sim_cpu_", 1)
-    return _make_query(request.getfixturevalue("hip_lib"), blob, "go2sim_", 1 if request.param == "hip_lds" else 2)
+    return _make_query(request.getfixturevalue("hip_lib"), blob, "go2sim_", HIP_BACKENDS[request.param])
 
 
 @pytest.fixture(scope="module")
@@ -92,11 +97,12 @@ def test_hip_queries_equal_oracle_bit_for_bit(oracle_lib, hip_lib, blob, geoms):
     cpu = _make_query(oracle_lib, blob, "go2sim_cpu_", 1)
     lds = _make_query(hip_lib, blob, "go2sim_", 1)
     glb = _make_query(hip_lib, blob, "go2sim_", 2)
+    coop = [(name, _make_query(hip_lib, blob, "go2sim_", w)) for name, w in HIP_BACKENDS.items() if w >= 3]   # the cooperative forms
     rng = np.random.default_rng(7)
     g = geoms["all"]
     ids = [geoms["sphere"], geoms["box"], geoms["cyl"]] + [i for i, x in enumerate(g) if x["type"] == 3][1:4]
     n_col = 0
-    for trial in range(120):
+    for trial in range(240):
         a = int(rng.choice(ids))
         quat = rng.standard_normal(4); quat /= np.linalg.norm(quat)
         if trial % 3 == 0:                                                     # geom against the ground slab at a random depth
@@ -115,5 +121,9 @@ def test_hip_queries_equal_oracle_bit_for_bit(oracle_lib, hip_lib, blob, geoms):
             rc, rl, rg = cpu(which, ia, ib, pa, qa, pb, qb), lds(which, ia, ib, pa, qa, pb, qb), glb(which, ia, ib, pa, qa, pb, qb)
             assert np.array_equal(rc["raw"].view(np.int32), rl["raw"].view(np.int32)), (trial, which, ia, ib, rc, rl)
             assert np.array_equal(rc["raw"].view(np.int32), rg["raw"].view(np.int32)), (trial, which, ia, ib, rc, rg)
+            if which == 1:
+                for name, qf in coop:
+                    rt = qf(which, ia, ib, pa, qa, pb, qb)
+                    assert np.array_equal(rc["raw"].view(np.int32), rt["raw"].view(np.int32)), (name, trial, ia, ib, rc, rt)
             n_col += int(rc["is_col"] and which == 1)
-    assert n_col > 40          # the sweep does exercise EPA
+    assert n_col > 80          # the sweep does exercise EPA
