@@ -58,7 +58,7 @@ NACT = {"walk": 16, "stairs": 16, "jump_dr": 12}
 # k_integrate_fk_dynamics + k_integrate_fk; "k_env_pre" is only non-zero with GO2SIM_NO_FUSE=1.
 KERNEL_CLASSES = ["k_dynamics", "k_collide", "k_constraint_solve", "k_integrate_fk", "k_env_pre", "k_env_post(a+globals+b)", "misc", "env_step_total"]
 LAUNCHES_PER_ENV_STEP = 9
-PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
 
 
 def source_hash():

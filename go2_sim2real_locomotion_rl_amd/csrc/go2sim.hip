@@ -2585,6 +2585,91 @@ DEV bool ts_cholesky_incremental_reg(const MT& m, S* s, int tl, int n_con) {
 // divisions of ALL pairs of the step are one instruction stream, lanes side by side -- then every pair's rotation is handed from its lane k to
 // the rows below it.  Each matrix / vector element sees exactly the operations of the serial algorithm in the same order, so the result is
 // bit-identical; the "degenerated" verdict is the same too (any pair degenerating makes the caller rebuild the factor from scratch).
+#if GO2SIM_FAST_ORDER && defined(GO2SIM_PIPELINE_REG)
+// Register form of the pipeline (-DGO2SIM_PIPELINE_REG, FAST ORDER builds; measured equal to the LDS form below: solver 0.223 vs 0.217 ms per step in the
+// landing window, so the smaller LDS form is the default): lane i keeps row i of the factor and its update-vector elements in registers for the whole call,
+// the time loop is unrolled so that the column of every slot is a compile-time index, and the rotation (c, 1/c, s) of column k travels from lane k by
+// v_readlane -- no LDS round trip and no barrier inside a time step (the LDS form below pays two per step).  Same operations per element, same order.
+template <int T, int FMAX, class S, class MT>
+DEV bool ts_cholesky_incremental_pipelined(const MT& m, S* s, int tl, int n_con) {
+  static_assert(T >= ND && (T == 32 || T == 64), "one lane per row of the factor");
+  bool degenerated = false;
+  const int row = tl < ND ? tl : ND - 1;
+  const bool own = tl < ND;
+  const unsigned urow = own ? (unsigned)row : 0u;                       // "column k lies left of my row" is (unsigned)k < urow (never true for spare lanes)
+  float Lr[ND];
+#pragma unroll
+  for (int k = 0; k < ND; ++k) Lr[k] = s->H[row * DS + k];
+  float Ld = s->H[row * DS + row];                                     // my diagonal element ...
+  float invLd = 1.0f / Ld;                                             // ... and its reciprocal, carried through the updates
+  for (int base = 0; base < n_con && !degenerated; base += T) {
+    const int c_me = base + tl;
+    const bool flip = c_me < n_con && ((s->active[c_me] != 0) != (s->prev_active[c_me] != 0));
+    const unsigned long long bal = __ballot(flip);
+    unsigned long long mask = (T == 64) ? bal : ((bal >> ((threadIdx.x / T) * T)) & ((1ull << (T & 63)) - 1ull));
+    while (mask != 0ull && !degenerated) {                              // batches of up to FMAX flipped rows, in row order
+      float W[FMAX], sg[FMAX]; int nb = 0;                              // update vectors (my element), sign of each update (0 = slot unused)
+#pragma unroll
+      for (int f = 0; f < FMAX; ++f) {
+        W[f] = 0.0f; sg[f] = 0.0f;
+        if (mask != 0ull) {
+          const int c = base + __ffsll((long long)mask) - 1;
+          mask &= mask - 1ull;
+          W[f] = s->J[c * DS + row] * dm_sqrt(s->efc_D[c]);
+          sg[f] = (s->active[c] != 0) ? 1.0f : -1.0f;
+          nb = f + 1;
+        }
+      }
+      const int nb_wave = __builtin_amdgcn_readfirstlane(imx(__shfl(nb, 0), __shfl(nb, T == 64 ? 0 : 32)));   // both teams (nb is team-uniform)
+      PHC(52, 1) PHC(53, nb_wave) PHC(54, ND - 1 + nb_wave)
+#pragma unroll
+      for (int t = 0; t < ND - 1 + FMAX; ++t) {
+        if (t >= ND - 1 + nb_wave) break;
+        // ---- my pair of this step: row f_me at my own column ----
+        const int f_me = t - row;
+        float dv = 0.0f, sg_me = 0.0f;
+#pragma unroll
+        for (int f = 0; f < FMAX; ++f) { dv = (f_me == f) ? W[f] : dv; sg_me = (f_me == f) ? sg[f] : sg_me; }
+        const bool rot = own && sg_me != 0.0f && dm_abs(dv) > m.eps;     // (sg_me == 0: no pair at my column in this step)
+        const float tmp = Ld * Ld + sg_me * (dv * dv);
+        const bool deg = rot && tmp < m.eps;
+        const float r = dm_sqrt(tmp);
+        const float rinv = r * (1.0f / tmp);                             // the division does not wait for the square root
+        const float cc = r * invLd;
+        float cinv = Ld * rinv;
+        const float sk = dv * invLd;
+        cinv = rot ? cinv : 0.0f;                                        // 0 marks "no rotation for this pair" (L_kk / r is never 0)
+        {
+          const unsigned long long dbal = __ballot(deg);
+          const unsigned long long mine = (T == 64) ? dbal : ((dbal >> ((threadIdx.x / T) * T)) & ((1ull << (T & 63)) - 1ull));
+          if (mine != 0ull) { degenerated = true; break; }
+        }
+        if (rot) { Ld = r; invLd = rinv; }
+        // ---- every pair's rotation goes from the lane of its column to the rows below it ----
+#pragma unroll
+        for (int f = 0; f < FMAX; ++f) {
+          const int k = t - f;                                           // compile-time after unrolling
+          if (k < 0 || k > ND - 2) continue;
+          const float c_k = team_bcast<T>(cc, k), ci_k = team_bcast<T>(cinv, k), s_k = team_bcast<T>(sk, k);
+          const bool on = (unsigned)k < urow && sg[f] != 0.0f && ci_k != 0.0f;   // left of my row, slot in use, pair rotates
+          const float hik = (Lr[k] + s_k * W[f] * sg[f]) * ci_k;
+          const float wn = W[f] * c_k - s_k * hik;
+          Lr[k] = on ? hik : Lr[k];
+          W[f] = on ? wn : W[f];
+        }
+      }
+    }
+  }
+  if (!degenerated && own) {                                            // a degenerated factor is rebuilt from scratch by the caller
+#pragma unroll
+    for (int k = 0; k < ND; ++k)
+      if (k < row) { s->H[row * DS + k] = Lr[k]; s->H[k * DS + row] = Lr[k]; }   // (the strict upper triangle mirrors the lower one)
+    s->H[row * DS + row] = Ld;
+  }
+  team_sync();
+  return degenerated;
+}
+#else
 template <int T, int FMAX, class S, class MT>
 DEV bool ts_cholesky_incremental_pipelined(const MT& m, S* s, int tl, int n_con) {
   static_assert(T >= ND && (T == 32 || T == 64), "one lane per row of the factor");
@@ -2680,6 +2765,7 @@ DEV bool ts_cholesky_incremental_pipelined(const MT& m, S* s, int tl, int n_con)
   }
   return degenerated;
 }
+#endif
 template <int T, class S, class MT>
 DEV bool ts_cholesky_incremental(const MT& m, S* s, int tl, int n_con) {
   if constexpr (T >= ND) {
@@ -4846,6 +4932,7 @@ struct go2sim {
   int fk_team = 16;                         // lanes per environment in k_integrate_fk_team / k_fk_team
   int collide_team = 16;                    // lanes per environment in k_collide_team
   int solver_team = 32;                     // lanes per environment in k_constraint_solve_team
+  int terrain_solver_team = 64;             // ... on heightfield terrain (96 LDS rows)
   uint32_t step_count = 0; int action_write_idx = 0;
   // timing
   bool timing = false;
@@ -4912,7 +4999,8 @@ static void launch_collide_solve(go2sim* h, hipStream_t s) {
     ScopedTimer t(h, s, T_SOLVE);
     // flat ground: 32 lanes per env and 32 LDS rows; heightfield terrain (many more contacts): one env per wavefront with 96 LDS rows
     if (h->hm.terrain_enabled) {
-      hipLaunchKernelGGL((k_constraint_solve_team<64, RL_TERRAIN>), dim3(h->B), b, 0, s, h->P, h->dm, h->dms, h->solver_ovf);
+      if (h->terrain_solver_team == 32) hipLaunchKernelGGL((k_constraint_solve_team<32, RL_TERRAIN>), dim3((h->B + 1) / 2), b, 0, s, h->P, h->dm, h->dms, h->solver_ovf);
+      else hipLaunchKernelGGL((k_constraint_solve_team<64, RL_TERRAIN>), dim3(h->B), b, 0, s, h->P, h->dm, h->dms, h->solver_ovf);
     } else {
       const int T = h->solver_team;
       dim3 gs((h->B + 64 / T - 1) / (64 / T));
@@ -5024,7 +5112,8 @@ static bool step_graph_build(go2sim* h, const float* actions, float* obs, float*
                    : graph_add_kernel(h, last, k_collide_team<64>, gc, b64, nullptr, nullptr, nullptr, h->P, h->dm, h->gjk_scratch); }
     if (!ok) break;
     if (h->hm.terrain_enabled) {
-      ok = graph_add_kernel(h, last, k_constraint_solve_team<64, RL_TERRAIN>, dim3(h->B), b64, nullptr, nullptr, nullptr, h->P, h->dm, h->dms, h->solver_ovf);
+      if (h->terrain_solver_team == 32) ok = graph_add_kernel(h, last, k_constraint_solve_team<32, RL_TERRAIN>, dim3((h->B + 1) / 2), b64, nullptr, nullptr, nullptr, h->P, h->dm, h->dms, h->solver_ovf);
+      else ok = graph_add_kernel(h, last, k_constraint_solve_team<64, RL_TERRAIN>, dim3(h->B), b64, nullptr, nullptr, nullptr, h->P, h->dm, h->dms, h->solver_ovf);
     } else {
       const int T = h->solver_team; const dim3 gs = team_grid(T);
       ok = T == 16 ? graph_add_kernel(h, last, k_constraint_solve_team<16, RL>, gs, b64, nullptr, nullptr, nullptr, h->P, h->dm, h->dms, h->solver_ovf)
@@ -5116,6 +5205,7 @@ int go2sim_create(const void* blob, size_t nbytes, int n_envs, int device, uint6
     if (const char* t = getenv("GO2SIM_COLLIDE_TEAM")) { int v = atoi(t); if (v == 16 || v == 32 || v == 64) h->collide_team = v; }
     CK(hipMalloc((void**)&h->gjk_scratch, (size_t)n_envs * h->collide_team * sizeof(GjkStoreFull)));   // ~20 KB per narrow-phase lane
     if (const char* t = getenv("GO2SIM_SOLVER_TEAM")) { int v = atoi(t); if (v == 16 || v == 32 || v == 64) h->solver_team = v; }
+    if (const char* t = getenv("GO2SIM_TERRAIN_SOLVER_TEAM")) { int v = atoi(t); if (v == 32 || v == 64) h->terrain_solver_team = v; }
     Glob g0; memset(&g0, 0, sizeof(g0)); g0.friction = 1.0f;
     CK(hipMemcpy(h->dglob, &g0, sizeof(Glob), hipMemcpyHostToDevice));
     CK(hipMemset(h->dacc, 0, sizeof(Acc)));
