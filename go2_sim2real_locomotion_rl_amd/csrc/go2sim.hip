@@ -3016,6 +3016,12 @@ GO2SIM_LS3_ATTR void ts_ls_point3(const MT& m, S* s, int tl, int n_con, int nseg
   }
 }
 
+#ifdef GO2SIM_BRACKET_DEBUG   // investigation build (tools/repro_bracket): every bracket step of the first 4 envs is logged (40 floats per record)
+constexpr int BRLOG_ENVS = 4, BRLOG_CAP = 8192, BRLOG_W = 40;
+__device__ float g_brlog[BRLOG_ENVS * BRLOG_CAP * BRLOG_W];
+__device__ int g_brcnt[BRLOG_ENVS];
+__device__ int g_brenv_of_wg[65536];
+#endif
 // func_linesearch_batch, solver.py:2246-2417
 template <int T, class S, class MT>
 DEV float ts_linesearch(const MT& m, S* s, int tl, int n_con, float gauss) {
@@ -3164,6 +3170,9 @@ DEV float ts_linesearch(const MT& m, S* s, int tl, int n_con, float gauss) {
     for (int i = 0; i < 3; ++i)
       if (dm_abs(grads[i]) < gtol && (!best_found || costs[i] < best_cost)) { best_alpha = al[i]; best_cost = costs[i]; best_found = true; }
     if (best_found) return best_alpha;
+#ifdef GO2SIM_BRACKET_DEBUG
+    const LsPoint p1_in = p1, p2_in = p2;
+#endif
     int b1 = update_bracket(p1, al, costs, grads, hess, p1_next_alpha);
 #ifdef GO2SIM_BRACKET_FENCE   // investigation builds (tools/repro_bracket/README.md): value barriers around the inlined bracket step
     asm volatile("" : "+v"(p1.alpha), "+v"(p1.cost), "+v"(p1.grad), "+v"(p1.hess), "+v"(p1_next_alpha), "+v"(b1));
@@ -3171,6 +3180,29 @@ DEV float ts_linesearch(const MT& m, S* s, int tl, int n_con, float gauss) {
     int b2 = update_bracket(p2, al, costs, grads, hess, p2_next_alpha);
 #ifdef GO2SIM_BRACKET_FENCE
     asm volatile("" : "+v"(p2.alpha), "+v"(p2.cost), "+v"(p2.grad), "+v"(p2.hess), "+v"(p2_next_alpha), "+v"(b2));
+#endif
+#ifdef GO2SIM_BRACKET_DEBUG
+    {
+      const int env = g_brenv_of_wg[blockIdx.x] + (int)(threadIdx.x / T);
+      if (tl == 0 && env < BRLOG_ENVS) {
+        const int k = g_brcnt[env];
+        if (k < BRLOG_CAP) {
+          float* o = &g_brlog[((size_t)env * BRLOG_CAP + k) * BRLOG_W];
+          int q = 0;
+          o[q++] = (float)ls_it; o[q++] = gtol;
+          for (int i = 0; i < 3; ++i) o[q++] = al[i];
+          for (int i = 0; i < 3; ++i) o[q++] = costs[i];
+          for (int i = 0; i < 3; ++i) o[q++] = grads[i];
+          for (int i = 0; i < 3; ++i) o[q++] = hess[i];
+          o[q++] = p1_in.alpha; o[q++] = p1_in.cost; o[q++] = p1_in.grad; o[q++] = p1_in.hess;
+          o[q++] = p2_in.alpha; o[q++] = p2_in.cost; o[q++] = p2_in.grad; o[q++] = p2_in.hess;
+          o[q++] = p1.alpha; o[q++] = p1.cost; o[q++] = p1.grad; o[q++] = p1.hess;
+          o[q++] = p2.alpha; o[q++] = p2.cost; o[q++] = p2.grad; o[q++] = p2.hess;
+          o[q++] = p1_next_alpha; o[q++] = p2_next_alpha; o[q++] = (float)b1; o[q++] = (float)b2;
+          g_brcnt[env] = k + 1;
+        }
+      }
+    }
 #endif
     if (b1 == 0 && b2 == 0) return al[2];
     al[0] = p1_next_alpha; al[1] = p2_next_alpha; al[2] = (p1.alpha + p2.alpha) * 0.5f;
@@ -3460,6 +3492,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   const int tl = threadIdx.x % T, slot = threadIdx.x / T;
   const int b = xcd_block() * EPW + slot;
   const bool env_valid = b < P.B;
+#ifdef GO2SIM_BRACKET_DEBUG
+  if (threadIdx.x == 0) g_brenv_of_wg[blockIdx.x] = xcd_block() * EPW;
+#endif
   E e(P, env_valid ? b : P.B - 1);
   const int nc = e.n_contacts()[0];
   const int ws_flag = e.is_warmstart()[0];
@@ -5771,6 +5806,15 @@ int go2sim_debug_narrowphase(go2sim_t* h, int which, int i_ga, int i_gb, const f
   return GO2SIM_E_OK;
 }
 
+#ifdef GO2SIM_BRACKET_DEBUG
+int go2sim_debug_brlog(go2sim_t* h, float* out, int* cnt) {
+  if (!h || !out || !cnt) return GO2SIM_E_BADARG;
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_brlog), sizeof(float) * BRLOG_ENVS * BRLOG_CAP * BRLOG_W));
+  HIPCHK(hipMemcpyFromSymbol(cnt, HIP_SYMBOL(g_brcnt), sizeof(int) * BRLOG_ENVS));
+  return GO2SIM_E_OK;
+}
+#endif
 /* development/test aid (not declared in include/go2sim.h): device address of ANY pool field by name */
 #ifdef GO2SIM_PHASE_PROFILE
 int go2sim_debug_phases(go2sim_t* h, unsigned long long* out64, int reset) {
