@@ -174,24 +174,30 @@ def protocol_run(B, device, local_rank, seed, workload, kind, warm, steps, strea
     return out
 
 
-def ref_protocol(B, device, local_rank, stream, warm=1000, steps=1000):
-    """The reference's own `go2` benchmark (tests/test_rigid_benchmarks.py:316-374): plane + Go2, dt = 0.01 with ONE substep per scene.step,
-    engine position control (default gains kp 100 / kv 10, genesis/utils/geom.py:2042-2047) holding the standing pose, joint angles initialised
-    uniformly inside their limits, FPS = steps * n_envs / elapsed.  Differences, stated: the ground is the plane.urdf box of the Go2Env scene (the
-    benchmark uses gs.morphs.Plane), and warm-up / record are counted in steps (10 s + 10 s of simulated time) instead of 45 s + 15 s of wall clock."""
-    from go2_sim2real_locomotion_rl_amd.model_blob import load_model_json
+def ref_protocol(B, device, local_rank, stream, warm=1000, steps=1000, robot="go2"):
+    """The reference's own rigid benchmarks (tests/test_rigid_benchmarks.py): plane + robot, dt = 0.01 with ONE substep per scene.step, engine position
+    control, FPS = steps * n_envs / elapsed.
+      go2      (:316-374): default gains kp 100 / kv 10 (genesis/utils/geom.py:2042-2047) holding the standing pose, joint angles initialised uniformly
+               inside their limits;
+      anymal_c (:378-412): anymal_c.urdf at z = 0.8, kp 1000 on the 12 motors, position targets 0 -- the second robot of the benchmark set that the
+               model compiler handles (tools/compile_go2_model.py --robot anymal_c; same kernels, 14 collision geoms padded to the compile-time 28).
+    Differences, stated: the ground is the plane.urdf box of the Go2Env scene (the benchmarks use gs.morphs.Plane), and warm-up / record are counted in
+    steps (10 s + 10 s of simulated time) instead of 45 s + 15 s of wall clock."""
+    from go2_sim2real_locomotion_rl_amd.model_blob import MODEL_JSON, load_model_json
 
-    model = load_model_json()
-    sim = Go2Sim(load_hip_lib(), pack_model(), B, local_rank, 1)
+    model = load_model_json(MODEL_JSON if robot == "go2" else os.path.join(os.path.dirname(MODEL_JSON), f"{robot}_model.json"))
+    sim = Go2Sim(load_hip_lib(), pack_model(model), B, local_rank, 1)
     lim = np.array([[d["limit"][0], d["limit"][1]] for d in model["dofs"]], np.float32)[6:]
     eff = [abs(d["force_range"][1]) for d in model["dofs"]][6:]
+    kp = 100.0 if robot == "go2" else 1000.0
     for k in range(12):
-        sim.set_dof_gains(6 + k, 100.0, 10.0, -eff[k], eff[k])
+        sim.set_dof_gains(6 + k, kp, 10.0, -eff[k], eff[k])
     rng = np.random.default_rng(0)
-    qpos = np.tile(np.array([0, 0, 0.42, 1, 0, 0, 0] + [0.0] * 12, np.float32)[:, None], (1, B))
-    qpos[7:] = lim[:, :1] + (lim[:, 1:] - lim[:, :1]) * rng.random((12, B), dtype=np.float32)
+    qpos = np.tile(np.asarray(model["qpos0"], np.float32)[:, None], (1, B))
     ctrl = np.zeros((18, B), np.float32)
-    ctrl[6:] = np.array([0.0, 0.0, 0.0, 0.0, 0.8, 0.8, 1.0, 1.0, -1.5, -1.5, -1.5, -1.5], np.float32)[:, None]
+    if robot == "go2":
+        qpos[7:] = lim[:, :1] + (lim[:, 1:] - lim[:, :1]) * rng.random((12, B), dtype=np.float32)
+        ctrl[6:] = np.array([0.0, 0.0, 0.0, 0.0, 0.8, 0.8, 1.0, 1.0, -1.5, -1.5, -1.5, -1.5], np.float32)[:, None]
     mode = np.zeros((18, B), np.int32); mode[6:] = 2
     put = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
     sim.set_field(C["GO2SIM_F_QPOS"], put(qpos), stream); sim.set_field(C["GO2SIM_F_CTRL_POS"], put(ctrl), stream)
@@ -207,9 +213,10 @@ def ref_protocol(B, device, local_rank, stream, warm=1000, steps=1000):
     dt = time.perf_counter() - t0
     nc = torch.zeros(1, B, dtype=torch.int32, device=device); sim.get_field(C["GO2SIM_I_N_CONSTRAINTS"], nc, stream)
     torch.cuda.synchronize()
+    where = "316-374 (go2, Newton)" if robot == "go2" else "378-412 (anymal, Newton)"
     out = {"value": round(B * steps / dt, 1), "unit": "FPS = scene steps (dt 0.01, 1 substep) x n_envs / s", "realtime_factor": round(B * steps / dt * 0.01, 1),
            "n_envs": B, "warmup_steps": warm, "steps": steps, "errno": sim.check_errno(), "constraint_rows_mean": round(float(nc.float().mean()), 2),
-           "constraint_rows_max": int(nc.max()), "protocol": "tests/test_rigid_benchmarks.py:316-374 (go2, Newton); ground = plane.urdf box; step-counted warm-up"}
+           "constraint_rows_max": int(nc.max()), "protocol": f"tests/test_rigid_benchmarks.py:{where}; ground = plane.urdf box; step-counted warm-up"}
     del sim
     return out
 
@@ -450,7 +457,7 @@ def main():
         roofline = roofline_of(ms, cnt, K, B, WORKLOAD, value)
         del sim2
 
-    action_sets = curriculum_live = workloads = refp = envcls = None
+    action_sets = curriculum_live = workloads = refp = refp_anymal = envcls = None
     if extras_on:
         del sim
         envcls = go2env_class_run(B, device, local_rank, 1 + rank, W, K)
@@ -461,6 +468,7 @@ def main():
                      "jump_dr": protocol_run(B, device, local_rank, 1, "jump_dr", "C", 100, 300, stream),
                      "note": "BASELINE configs[2] (stair heightfield, level 0.65) and configs[4] (jump env + per-env mass / friction DR), set C, env-steps/s, 100 warm-up + 300 timed steps"}
         refp = ref_protocol(B, device, local_rank, stream)
+        refp_anymal = ref_protocol(B, device, local_rank, stream, robot="anymal_c")
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -486,7 +494,7 @@ def main():
                                 "env step, open-loop actions" + ("; rewards / dones land in the rollout storage, GAE + RCCL all-gather of the advantage moments every 24 steps"
                                                                  if world > 1 else ""))},
             "roofline": roofline, "cpu_baseline": cpu, "steady_state": steady, "action_sets": action_sets, "curriculum_live": curriculum_live,
-            "workloads": workloads, "ref_protocol_fps": refp, "go2env_class": envcls, "ref_logged": ref_logged(),
+            "workloads": workloads, "ref_protocol_fps": refp, "ref_protocol_fps_anymal_c": refp_anymal, "go2env_class": envcls, "ref_logged": ref_logged(),
         }
         print(json.dumps(out), flush=True)
     if dist is not None:

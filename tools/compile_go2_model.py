@@ -201,12 +201,14 @@ def load_urdf(path):
             "origin": T_from(_floats(o.get("xyz", "0 0 0")), _floats(o.get("rpy", "0 0 0"))),
             "axis": _floats(j.find("axis").get("xyz")) if j.find("axis") is not None else [1, 0, 0],
             "limit": None,
+            "damping": float(j.find("dynamics").get("damping", "0")) if j.find("dynamics") is not None else 0.0,      # urdf.py:326-330
+            "frictionloss": float(j.find("dynamics").get("friction", "0")) if j.find("dynamics") is not None else 0.0,
         }
         lim = j.find("limit")
         if lim is not None:
-            J["limit"] = {
-                "lower": float(lim.get("lower", "0")),
-                "upper": float(lim.get("upper", "0")),
+            J["limit"] = {   # absent bounds = unbounded (genesis/utils/urdf.py:269-274: `lower if lower is not None else -inf`)
+                "lower": float(lim.get("lower")) if lim.get("lower") is not None else -1e30,
+                "upper": float(lim.get("upper")) if lim.get("upper") is not None else 1e30,
                 "effort": float(lim.get("effort")) if lim.get("effort") is not None else None,
             }
         joints.append(J)
@@ -552,7 +554,14 @@ def compute_invweight(model):
 # --------------------------------------------------------------------------------------
 # main assembly
 # --------------------------------------------------------------------------------------
-def build_model(assets_dir, base_init_pos=(0.0, 0.0, 0.42), base_init_quat=(1.0, 0.0, 0.0, 0.0), substep_dt=0.01):
+ROBOTS = {   # URDFs of the reference's benchmark set that have the kernels' compile-time shape (13 links, free base + 12 revolute joints, primitives)
+    "go2": dict(urdf="urdf/go2/urdf/go2.urdf", base_init_pos=(0.0, 0.0, 0.42)),
+    "anymal_c": dict(urdf="urdf/anymal_c/urdf/anymal_c.urdf", base_init_pos=(0.0, 0.0, 0.8)),   # tests/test_rigid_benchmarks.py:392-399
+}
+N_GEOMS_KERNEL = 28   # GO2SIM_NG: a model with fewer collision geoms is padded with inert spheres on the ground link (no collision pairs)
+
+
+def build_model(assets_dir, base_init_pos=(0.0, 0.0, 0.42), base_init_quat=(1.0, 0.0, 0.0, 0.0), substep_dt=0.01, robot="go2"):
     sol_timeconst = max(0.01, 2.0 * substep_dt)  # rigid_solver.py:260-261 + _sanitize_sol_params
     sol_params = [sol_timeconst, 1.0, 0.9, 0.95, 0.001, 0.5, 2.0]
 
@@ -575,10 +584,19 @@ def build_model(assets_dir, base_init_pos=(0.0, 0.0, 0.42), base_init_quat=(1.0,
     )
     for g in pl["collisions"]:
         geoms_out.append(dict(g, link=0))
+    # a robot with fewer collision geoms than the kernels' compile-time count is padded with inert spheres (no collision pairs, far away) that
+    # belong to the fixed ground link -- inside its geom range, because geoms are stored link-major
+    robot_links_raw, _ = load_urdf(os.path.join(assets_dir, ROBOTS[robot]["urdf"]))
+    n_pad = N_GEOMS_KERNEL - len(geoms_out) - sum(len(l["collisions"]) for l in robot_links_raw)
+    if n_pad < 0:
+        raise ValueError(f"{robot}: more than {N_GEOMS_KERNEL} collision geoms")
+    for k in range(n_pad):
+        geoms_out.append(dict(type=GEOM_SPHERE, data=[1e-3], origin=T_from([1000.0 + 10.0 * k, 1000.0, -1000.0], [0, 0, 0]), link=0, dummy=True))
+    links_out[0]["geom_end"] = len(geoms_out)
     entities.append(dict(link_start=0, link_end=1, dof_start=0, dof_end=0, geom_start=0, geom_end=len(geoms_out)))
 
     # ---- entity 1: go2 ----------------------------------------------------------------------------
-    links, joints = load_urdf(os.path.join(assets_dir, "urdf/go2/urdf/go2.urdf"))
+    links, joints = load_urdf(os.path.join(assets_dir, ROBOTS[robot]["urdf"]))
     links, joints = merge_fixed_links(links, joints)
     order, parent_of = bfs_order(links, joints)
     by_name = {l["name"]: l for l in links}
@@ -598,7 +616,8 @@ def build_model(assets_dir, base_init_pos=(0.0, 0.0, 0.42), base_init_quat=(1.0,
             parent = -1
         else:
             j = joint_of[name]
-            assert j["type"] == "revolute"
+            if j["type"] != "revolute":
+                raise ValueError(f"joint {j['name']}: only revolute joints below a free base are compiled (type {j['type']})")
             jtype, n_d, n_q = JOINT_REVOLUTE, 1, 1
             lpos, lquat = j["origin"][:3, 3].tolist(), R_to_quat(j["origin"][:3, :3]).tolist()
             parent = link0 + order.index(parent_of[name])
@@ -630,7 +649,7 @@ def build_model(assets_dir, base_init_pos=(0.0, 0.0, 0.42), base_init_quat=(1.0,
                 dict(motion_ang=[float(a) for a in j["axis"]], motion_vel=[0.0, 0.0, 0.0],
                      limit=[j["limit"]["lower"], j["limit"]["upper"]], invweight=0.0,
                      armature=0.1,  # options/morphs.py:1000 default_armature, mjcf.py:188-190
-                     damping=0.0, stiffness=0.0, frictionloss=0.0,
+                     damping=j["damping"], stiffness=0.0, frictionloss=j["frictionloss"],
                      kp=100.0, kv=10.0,  # geom.py default_dofs_kp/kv (overwritten by the env)
                      force_range=[-eff, eff])
             )
@@ -642,6 +661,9 @@ def build_model(assets_dir, base_init_pos=(0.0, 0.0, 0.42), base_init_quat=(1.0,
         n_joints += 1
     entities.append(dict(link_start=link0, link_end=len(links_out), dof_start=0, dof_end=n_dofs,
                          geom_start=entities[0]["geom_end"], geom_end=len(geoms_out)))
+    if len(links_out) != 14 or n_dofs != 18 or len(geoms_out) > N_GEOMS_KERNEL:
+        raise ValueError(f"{robot}: {len(links_out)} links / {n_dofs} dofs / {len(geoms_out)} geoms do not fit the kernels' compile-time shape (14 / 18 / <= {N_GEOMS_KERNEL})")
+    n_real_geoms = len(geoms_out) - n_pad
 
     # ---- geoms ------------------------------------------------------------------------------------
     ring_k = support_theta_table()
@@ -668,7 +690,7 @@ def build_model(assets_dir, base_init_pos=(0.0, 0.0, 0.42), base_init_quat=(1.0,
 
     model = dict(
         format="go2sim-model-v1",
-        source="genesis/assets/urdf/{plane/plane.urdf,go2/urdf/go2.urdf} via tools/compile_go2_model.py",
+        source="genesis/assets/urdf/plane/plane.urdf + " + ROBOTS[robot]["urdf"] + " via tools/compile_go2_model.py", robot=robot, n_real_geoms=n_real_geoms,
         substep_dt=substep_dt, gravity=[0.0, 0.0, -9.81], eps=EPS32,
         solver=dict(iterations=50, tolerance=1e-6, ls_iterations=50, ls_tolerance=1e-2),
         collider=dict(max_collision_pairs=30, n_contacts_per_pair=5, broad_multiplier=8, mc_perturbation=1e-2,
@@ -698,7 +720,7 @@ def build_model(assets_dir, base_init_pos=(0.0, 0.0, 0.42), base_init_quat=(1.0,
         for b in range(a + 1, ng):
             lb = links_out[geoms_json[b]["link"]]
             ia, ib = geoms_json[a]["link"], geoms_json[b]["link"]
-            if ia == ib:
+            if ia == ib or geoms_out[a].get("dummy") or geoms_out[b].get("dummy"):
                 continue
             if la["is_fixed"] and lb["is_fixed"]:
                 continue
@@ -731,9 +753,12 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--assets", default="/root/reference/genesis/assets")
     here = os.path.dirname(os.path.abspath(__file__))
-    ap.add_argument("--out", default=os.path.join(here, "..", "go2_sim2real_locomotion_rl_amd", "model", "go2_model.json"))
+    ap.add_argument("--robot", choices=sorted(ROBOTS), default="go2")
+    ap.add_argument("--out", default=None)
     args = ap.parse_args()
-    model = build_model(args.assets)
+    if args.out is None:
+        args.out = os.path.join(here, "..", "go2_sim2real_locomotion_rl_amd", "model", f"{args.robot}_model.json")
+    model = build_model(args.assets, base_init_pos=ROBOTS[args.robot]["base_init_pos"], robot=args.robot)
     txt = json.dumps(model, indent=1, sort_keys=True)
     with open(args.out, "w") as f:
         f.write(txt + "\n")
