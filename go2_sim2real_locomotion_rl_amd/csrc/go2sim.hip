@@ -1360,6 +1360,12 @@ DEV V3 support_cylinder_local(const Model& m, const Geom& G, V3 d_mesh, int* vid
 }
 // support_driver, collider/mpr.py:146-176
 // _func_support_prism, support_field.py:262-280: the terrain geom is represented by the current 6-vertex prism
+// the lanes of my team that pass p (bit l = lane l of the team)
+template <int T> DEV unsigned long long team_ballot(bool p) {
+  const unsigned long long b = __ballot(p);
+  if constexpr (T == 64) return b;
+  else return (b >> (threadIdx.x & (64 - T))) & ((1ull << T) - 1ull);
+}
 DEV V3 vsel(bool c, V3 a, V3 b) { return v3(c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z); }
 DEV V3 support_prism(const V3* prism, V3 d) {
   // the bottom (0..2) or top (3..5) triangle, then the first vertex with the largest projection; written with value selects and constant
@@ -1694,10 +1700,9 @@ struct CollideData {
     int cand_key[MAXB], cand_pair[MAXB];
   };
   // terrain pass: one slot per (geom, terrain) pair of the broad-phase list
-  struct TPair { int i_ga, r_min, r_max, c_min, c_max, n_items, item_off; float zmin; V3 pos_a; Q4 quat_a; V3 center_a; };
+  struct TPair { int i_ga, r_min, r_max, c_min, c_max, n_items, item_off; float zmin, tol; V3 pos_a; Q4 quat_a; V3 center_a; };
   struct Terrain {
     TPair tp[NG];
-    float acc_pos[5][3];   // contacts already accepted for the current terrain pair (dedupe)
   };
   union alignas(16) {
     Broad bp;
@@ -1885,11 +1890,8 @@ DEV bool terrain_pair_setup(const Model& m, const E& e, int i_ga, int i_gb, TP& 
 }
 // height of the k-th vertex of the strip of row r (vertex order of func_add_prism_vert: (c, i) with i fastest)
 DEV float terrain_strip_z(const Model& m, int r, int c_min, int k) { return m.terrain_hf[(size_t)(r + (k & 1)) * m.terrain_cols + c_min + (k >> 1)]; }
-// (2) the prism that exists after the k-th vertex of row r was pushed (k >= 2) is tested iff one of its top vertices reaches the geom
-template <class TP>
-DEV bool terrain_prism_eligible(const Model& m, const TP& t, int r, int k) {
-  return terrain_strip_z(m, r, t.c_min, k - 2) >= t.zmin || terrain_strip_z(m, r, t.c_min, k - 1) >= t.zmin || terrain_strip_z(m, r, t.c_min, k) >= t.zmin;
-}
+// (2) the prism that exists after the k-th vertex of row r was pushed (k >= 2) is tested iff one of its top vertices reaches the geom: evaluated one
+//     cell per lane in k_collide_team
 // (3) MPR of the geom against that prism; the contact is returned in world coordinates
 template <class TP>
 DEV bool terrain_prism_contact(const Model& m, const E& e, const TP& t, int i_gb, int r, int k, V3& normal, V3& contact_pos, float& penetration) {
@@ -2152,6 +2154,7 @@ __global__ __launch_bounds__(64) void k_collide_team(Pool P, const Model* __rest
   //      prism: the pairs enumerate the prisms their geom can reach, the MPR queries run T at a time, and the accept / dedupe / cap logic of
   //      the serial loop is replayed in prism order, which reproduces the contact list of the reference exactly. ----
   if (m.terrain_enabled) {
+    PH(33)
     int n_tp = 0;                                                       // terrain pairs, in broad-phase order
     for (int ip = 0; ip < n_broad; ++ip) {
       int pk = s->pair_sorted[ip];
@@ -2161,36 +2164,63 @@ __global__ __launch_bounds__(64) void k_collide_team(Pool P, const Model* __rest
       if (n_tp < NG) { if (tl == 0) { s->tr.tp[n_tp].i_ga = i_ga; s->tr.tp[n_tp].n_items = i_gb; } n_tp++; }
     }
     team_sync();
-    for (int p = tl; p < n_tp; p += T) {                                // pair setup + count of reachable prisms
+    for (int p = tl; p < n_tp; p += T) {                                // pair setup: pose in the terrain frame, cell range, dedupe tolerance
       auto& t = s->tr.tp[p];
       int i_gb = t.n_items;
       terrain_pair_setup(m, e, t.i_ga, i_gb, t);
-      int cnt = 0;
-      const int nk = 2 * (t.c_max - t.c_min + 1);
-      for (int r = t.r_min; r < t.r_max; ++r)
-        for (int k = 2; k < nk; ++k) cnt += terrain_prism_eligible(m, t, r, k);
-      t.n_items = cnt; t.item_off = i_gb;                                // item_off temporarily carries the terrain geom index
+      t.n_items = imx(0, t.r_max - t.r_min) * imx(0, 2 * (t.c_max - t.c_min + 1) - 2);   // prisms under the geom's bounding box ("cells")
+      t.tol = compute_tolerance(m, t.i_ga, i_gb, m.mc_tolerance);
+      t.item_off = i_gb;                                                 // item_off temporarily carries the terrain geom index
     }
     team_sync();
+    PH(26)
     int* items = (int*)&gjk_scratch[(size_t)b * T];                     // prism descriptors p | r << 5 | k << 18 (the GJK scratch is idle in this pass)
     const int items_cap = (int)(sizeof(GjkStoreFull) * T / sizeof(int));
-    int i_terrain = 0, n_items = 0;
-    for (int p = 0; p < n_tp; ++p) { int c = s->tr.tp[p].n_items; if (p == 0) i_terrain = s->tr.tp[p].item_off; n_items += c; }
+    int i_terrain = 0, n_cells = 0;
+    for (int p = 0; p < n_tp; ++p) { int c = s->tr.tp[p].n_items; if (p == 0) i_terrain = s->tr.tp[p].item_off; n_cells += c; }
     team_sync();
-    { int off = 0; for (int p = 0; p < n_tp; ++p) { int c = s->tr.tp[p].n_items; if (tl == 0) s->tr.tp[p].item_off = off; off += c; } }
+    { int off = 0; for (int p = 0; p < n_tp; ++p) { int c = s->tr.tp[p].n_items; if (tl == 0) s->tr.tp[p].item_off = off; off += c; } }   // first cell of the pair
     team_sync();
-    for (int p = tl; p < n_tp; p += T) {                                // descriptors in (pair, row, vertex) order
-      const auto& t = s->tr.tp[p];
-      int q = t.item_off;
-      const int nk = 2 * (t.c_max - t.c_min + 1);
-      for (int r = t.r_min; r < t.r_max; ++r)
-        for (int k = 2; k < nk; ++k)
-          if (terrain_prism_eligible(m, t, r, k)) { if (q < items_cap) items[q] = p | (r << 5) | (k << 18); q++; }
+    // One lane per cell, TU cells per lane in flight (the heights come from L2 / HBM: the loads of a batch are issued together).  A cell is a
+    // descriptor iff one of the three top vertices of its prism reaches the geom (narrowphase.py:430-436); the descriptors are compacted in
+    // (pair, row, vertex) order, the order in which the serial loop meets them.
+    int n_items = 0;
+    {
+      constexpr int TU = 4;
+      int p_cur = 0, p_end = n_tp > 0 ? s->tr.tp[0].n_items : 0;        // cells [.., p_end) belong to pairs <= p_cur (per-lane cursor: a lane's cells ascend)
+      for (int base = 0; base < n_cells; base += T * TU) {
+        int desc[TU]; bool el[TU];
+#pragma unroll
+        for (int u = 0; u < TU; ++u) {
+          const int ci = base + u * T + tl;
+          el[u] = false; desc[u] = 0;
+          if (ci < n_cells) {
+            while (ci >= p_end) { ++p_cur; p_end += s->tr.tp[p_cur].n_items; }
+            const auto& t = s->tr.tp[p_cur];
+            const int nkk = 2 * (t.c_max - t.c_min + 1) - 2;
+            const int local = ci - (p_end - t.n_items);
+            const int r = t.r_min + local / nkk, k = 2 + local % nkk;
+            const float z0 = terrain_strip_z(m, r, t.c_min, k - 2), z1 = terrain_strip_z(m, r, t.c_min, k - 1), z2 = terrain_strip_z(m, r, t.c_min, k);
+            el[u] = (z0 >= t.zmin) | (z1 >= t.zmin) | (z2 >= t.zmin);
+            desc[u] = p_cur | (r << 5) | (k << 18);
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < TU; ++u) {
+          const unsigned long long mk = team_ballot<T>(el[u]);
+          if (el[u]) { const int q = n_items + __popcll(mk & ((1ull << tl) - 1ull)); if (q < items_cap) items[q] = desc[u]; }
+          n_items += __popcll(mk);
+        }
+      }
     }
     if (n_items > items_cap) n_items = items_cap;
     team_sync();
+    PH(27)
     int cur_p = -1, n_con = 0;                                          // replay state (identical on every lane)
     float tolerance = 0.0f;
+    V3 acc[5];                                                          // contacts already accepted for the current terrain pair (dedupe); team-uniform
+#pragma unroll
+    for (int j = 0; j < 5; ++j) acc[j] = v3(0, 0, 0);
     for (int base = 0; base < n_items; base += T) {
       const int q = base + tl;
       float* st = &s->stage[tl][0][0];
@@ -2200,45 +2230,53 @@ __global__ __launch_bounds__(64) void k_collide_team(Pool P, const Model* __rest
         const auto& t = s->tr.tp[d & 31];
         V3 normal, cpos; float pen;
         if (terrain_prism_contact(m, e, t, i_terrain, (d >> 5) & 0x1fff, d >> 18, normal, cpos, pen)) {
-          has = 1;
+          has = 1 + (d & 31);
           st[0] = normal.x; st[1] = normal.y; st[2] = normal.z; st[3] = cpos.x; st[4] = cpos.y; st[5] = cpos.z; st[6] = pen;
         }
       }
-      s->cnt[tl] = has;
+      s->cnt[tl] = has;                                                  // 0 = no contact, else 1 + pair slot
       team_sync();
-      const int n_chunk = imn(T, n_items - base);
-      for (int l = 0; l < n_chunk; ++l) {
-        const int p = items[base + l] & 31;
-        if (p != cur_p) { cur_p = p; n_con = 0; tolerance = compute_tolerance(m, s->tr.tp[p].i_ga, i_terrain, m.mc_tolerance); }
-        if (!s->cnt[l] || n_con >= m.n_contacts_per_pair) continue;
+      PH(28)
+      // replay of the serial accept / dedupe / cap logic over the prisms of this round that produced a contact (team-uniform: every lane reads the
+      // same staged values); the j-th accepted contact of the round is then written out by lane j
+      unsigned long long hm = team_ballot<T>(has != 0);
+      int n_acc = 0, my_l = -1, my_ic = 0;
+      while (hm) {
+        const int l = __ffsll((long long)hm) - 1;
+        hm &= hm - 1ull;
+        const int p = s->cnt[l] - 1;
+        if (p != cur_p) { cur_p = p; n_con = 0; tolerance = s->tr.tp[p].tol; }
+        if (n_con >= m.n_contacts_per_pair) continue;
         const float* pc = &s->stage[l][0][0];
-        V3 cpos = v3(pc[3], pc[4], pc[5]);
+        const V3 cpos = v3(pc[3], pc[4], pc[5]);
         bool valid = true;
-        for (int j = 0; j < n_con; ++j) {
-          if (nc_run - j - 1 < m.max_contact_pairs && norm(cpos - v3(s->tr.acc_pos[n_con - j - 1][0], s->tr.acc_pos[n_con - j - 1][1], s->tr.acc_pos[n_con - j - 1][2])) < tolerance) { valid = false; break; }
-        }
+#pragma unroll
+        for (int jj = 0; jj < 5; ++jj)                                  // acc[jj] is contact nc_run - n_con + jj of the list
+          if (jj < n_con && nc_run - n_con + jj < m.max_contact_pairs && norm(cpos - acc[jj]) < tolerance) valid = false;
         if (!valid) continue;
-        const int i_ga = s->tr.tp[p].i_ga, i_c = nc_run;
-        team_sync();
-        if (tl == 0 && n_con < 5) { s->tr.acc_pos[n_con][0] = cpos.x; s->tr.acc_pos[n_con][1] = cpos.y; s->tr.acc_pos[n_con][2] = cpos.z; }
-        if (i_c < m.max_contact_pairs) {
-          if (tl == 0) {                                                 // func_add_contact, contact.py:165-199
-            float friction_a = e.geom_friction()[i_ga] * e.friction_ratio()[i_ga];
-            float friction_b = e.geom_friction()[i_terrain] * e.friction_ratio()[i_terrain];
-            e.c_geom()[i_c] = i_ga; e.c_geom()[MAXC + i_c] = i_terrain;
-            e.c_normal()[i_c] = v3(pc[0], pc[1], pc[2]); e.c_pos()[i_c] = cpos; e.c_pen()[i_c] = pc[6];
-            e.c_friction()[i_c] = fmx(fmx(friction_a, friction_b), 1e-2f);
-            auto sol = e.c_sol()[i_c];
-            for (int qq = 0; qq < 7; ++qq) sol[qq] = 0.5f * (m.geoms[i_ga].sol_params[qq] + m.geoms[i_terrain].sol_params[qq]);
-            e.c_link()[i_c] = m.geoms[i_ga].link; e.c_link()[MAXC + i_c] = m.geoms[i_terrain].link;
-          }
-        } else if (tl == 0) {
+#pragma unroll
+        for (int jj = 0; jj < 5; ++jj) if (jj == n_con) acc[jj] = cpos;
+        if (tl == n_acc) { my_l = l; my_ic = nc_run; }
+        n_acc++; nc_run++; n_con++;
+      }
+      if (my_l >= 0) {
+        if (my_ic < m.max_contact_pairs) {                               // func_add_contact, contact.py:165-199
+          const float* pc = &s->stage[my_l][0][0];
+          const int i_ga = s->tr.tp[s->cnt[my_l] - 1].i_ga, i_c = my_ic;
+          float friction_a = e.geom_friction()[i_ga] * e.friction_ratio()[i_ga];
+          float friction_b = e.geom_friction()[i_terrain] * e.friction_ratio()[i_terrain];
+          e.c_geom()[i_c] = i_ga; e.c_geom()[MAXC + i_c] = i_terrain;
+          e.c_normal()[i_c] = v3(pc[0], pc[1], pc[2]); e.c_pos()[i_c] = v3(pc[3], pc[4], pc[5]); e.c_pen()[i_c] = pc[6];
+          e.c_friction()[i_c] = fmx(fmx(friction_a, friction_b), 1e-2f);
+          auto sol = e.c_sol()[i_c];
+          for (int qq = 0; qq < 7; ++qq) sol[qq] = 0.5f * (m.geoms[i_ga].sol_params[qq] + m.geoms[i_terrain].sol_params[qq]);
+          e.c_link()[i_c] = m.geoms[i_ga].link; e.c_link()[MAXC + i_c] = m.geoms[i_terrain].link;
+        } else {
           atomicOr(&e.err()[0], GO2SIM_ERR_OVERFLOW_COLLISION_PAIRS);
         }
-        nc_run++; n_con++;
-        team_sync();                                                     // the dedupe of later prisms reads this contact back
       }
-      team_sync();
+      team_sync();                                                       // stage / cnt are rewritten by the next round
+      PH(29)
     }
   }
   if (tl == 0) { e.n_broad()[0] = n_broad; e.n_contacts()[0] = imn(nc_run, m.max_contact_pairs); }

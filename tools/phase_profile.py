@@ -6,7 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from bench import make_actions
 from go2_sim2real_locomotion_rl_amd import capi
-from go2_sim2real_locomotion_rl_amd.configs import flatten_walk_cfg, get_walk_cfgs
+from go2_sim2real_locomotion_rl_amd.configs import build_stair_terrain, flatten_walk_cfg, get_stair_cfgs, get_walk_cfgs
 from go2_sim2real_locomotion_rl_amd.model_blob import pack_model
 
 so = os.path.join(ROOT, "tools", "libgo2sim_prof.so")
@@ -16,19 +16,25 @@ lib = capi.Go2SimLib(so, "go2sim_")
 B = 4096
 dev = torch.device("cuda", 0)
 sim = capi.Go2Sim(lib, pack_model(), B, 0, 1)
-f, i, _ = flatten_walk_cfg(B, *get_walk_cfgs(), freeze_curriculum=True)
+WORKLOAD = os.environ.get("GO2SIM_PROFILE_WORKLOAD", "walk")                    # walk | stairs (BASELINE configs[2])
+cfgs = get_stair_cfgs() if WORKLOAD == "stairs" else get_walk_cfgs()
+if WORKLOAD == "stairs":
+    hf, info = build_stair_terrain(cfgs[0]["terrain"])
+    sim.set_terrain(hf, info["horizontal_scale"], info["vertical_scale"], info["terrain_origin"])
+f, i, _ = flatten_walk_cfg(B, *cfgs, freeze_curriculum=True)
 sim.env_configure(f, i); sim.env_reset()
 W = int(sys.argv[1]) if len(sys.argv) > 1 else 50      # warm-up steps from the reset (5 = the landing window of the driver's bench run)
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 100
-act = make_actions(N + W, B, dev)
-obs = torch.zeros(B, 49, device=dev); priv = torch.zeros(B, 104, device=dev); rew = torch.zeros(B, device=dev)
+act = make_actions(N + W, B, dev, workload=WORKLOAD)
+from bench import NOBS, NPRIV
+obs = torch.zeros(B, NOBS[WORKLOAD], device=dev); priv = torch.zeros(B, NPRIV[WORKLOAD], device=dev); rew = torch.zeros(B, device=dev)
 rst = torch.zeros(B, dtype=torch.uint8, device=dev); to = torch.zeros(B, device=dev)
 for s in range(W):
     sim.env_step(act[s], obs, priv, rew, rst, to)
 PH_MAX_WG = 8192
 out = (ctypes.c_ulonglong * (64 * PH_MAX_WG))()
 lib.lib.go2sim_debug_phases(sim.h, out, 1)
-GROUPS_ = {"post_a": [12, 13, 14, 15, 16, 17], "solver": [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 11], "dynamics": list(range(20, 26)), "collide": list(range(30, 34)), "integrate_fk": [40, 41]}
+GROUPS_ = {"post_a": [12, 13, 14, 15, 16, 17], "solver": [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 11], "dynamics": list(range(20, 26)), "collide": list(range(30, 34)) + [26, 27, 28, 29], "integrate_fk": [40, 41]}
 def xcd_block(bid, n):
     """logical block of physical workgroup `bid` in a grid of n (xcd_block() of csrc/go2sim.hip)"""
     q, r, x, i = n >> 3, n & 7, bid & 7, bid >> 3
@@ -92,9 +98,9 @@ for s in range(W, W + N):
 lib.lib.go2sim_debug_phases(sim.h, out, 1)
 a = np.frombuffer(out, dtype=np.uint64).reshape(PH_MAX_WG, 64).astype(np.float64)
 launches = 2 * N                                   # substep kernels: two launches per env step
-GROUPS = {"solver": [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 11], "dynamics": list(range(20, 26)), "collide": list(range(30, 36)), "integrate_fk": [40, 41]}   # (ids 34-39, 42-49: PHD sections, printed above)
+GROUPS = {"solver": [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 11], "dynamics": list(range(20, 26)), "collide": list(range(30, 34)) + [26, 27, 28, 29], "integrate_fk": [40, 41]}   # (ids 34-39, 42-49: PHD sections, printed above)
 NAMES = {0: "stage", 1: "rows", 2: "init Ma/Jaref/update", 3: "Hessian", 4: "Cholesky factor", 5: "gradient solve", 6: "line search", 7: "qacc/constraint update",
-         8: "incremental Cholesky", 9: "prologue", 11: "commit", 30: "AABB + clear", 31: "endpoint sort", 32: "candidate pairs", 33: "narrow phase"}
+         8: "incremental Cholesky", 9: "prologue", 11: "commit", 30: "AABB + clear", 31: "endpoint sort", 32: "candidate pairs", 33: "narrow phase", 26: "terrain pair setup/count", 27: "terrain descriptors", 28: "terrain prism MPR", 29: "terrain replay"}
 # sections inside lane-divergent code (PHD): cycles at id, number of executions at id + 1
 for name, i in (("GJK / EPA query", 34), ("  of which GJK", 38), ("  of which EPA + witness", 42), ("    EPA nearest-face scan", 56), ("    EPA horizon walk", 58), ("    EPA face attachment", 60), ("  support pair evaluations (GJK / EPA)", 48), ("MPR query", 36)):
     cyc, cnt = a[:, i], a[:, i + 1]
