@@ -734,6 +734,49 @@ DEV int xcd_block() {
   return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
 }
 
+// ---- heaviest-first dispatch of the constraint solver ------------------------------------------------------------------------------------
+// A solver launch lasts as long as its last wavefront.  On the heightfield (one env per wavefront, two residency rounds) an expensive env that is
+// dispatched late finishes long after everything else.  k_collide_team therefore files every env under (XCD of its solver workgroup, contact count)
+// with one atomic per env, and solver workgroup w takes the w-th env of its XCD in descending contact count instead of env w: the expensive solves
+// start first (and envs of similar cost share a wavefront at T = 32).  Which workgroup solves an env does not enter its result.
+// Record: cnt[8][LPT_CLS] followed by env[8][LPT_CLS][cap].  Two records alternate between consecutive collide / solve pairs; the solver clears the
+// record of the next pair.  A record whose per-XCD total is not what the solver grid expects (stale, filled twice) is ignored: identity mapping.
+constexpr int LPT_CLS = 32;
+DEV int lpt_solver_xcd(int b, int B, int epw_s) {                          // XCD of the solver workgroup that holds env b under the identity mapping (inverse of xcd_block)
+  const int n = (B + epw_s - 1) / epw_s, q = n >> 3, r = n & 7, L = b / epw_s;
+  if (L < r * (q + 1)) return L / (q + 1);
+  return r + (L - r * (q + 1)) / (q > 0 ? q : 1);
+}
+// (the contact count alone is the better key: weighting it with the Newton iterations of the previous solve measured 2-3 % slower)
+DEV void lpt_file(int* __restrict__ rec, int cap, int b, int B, int epw_s, int nc) {
+  const int x = lpt_solver_xcd(b, B, epw_s), cls = LPT_CLS - 1 - imn(LPT_CLS - 1, nc);
+  const int pos = atomicAdd(&rec[x * LPT_CLS + cls], 1);
+  if (pos < cap) rec[8 * LPT_CLS + (x * LPT_CLS + cls) * cap + pos] = b;
+}
+// env of (workgroup, slot) in the solver grid; B (= no env) past the end of the XCD's list
+DEV int lpt_take(const int* __restrict__ rec, int cap, int B, int epw, int slot) {
+  const int ident = xcd_block() * epw + slot;
+#ifdef GO2SIM_NO_XCD_REMAP
+  return ident;
+#endif
+  if (rec == nullptr) return ident;
+  const int n = (int)gridDim.x, q = n >> 3, r = n & 7, x = (int)blockIdx.x & 7;
+  const int start = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q), nblk = q + (x < r ? 1 : 0);
+  const int lo = start * epw, hi = imn(B, (start + nblk) * epw);
+  const int expected = hi > lo ? hi - lo : 0;
+  const int local = ((int)blockIdx.x >> 3) * epw + slot;
+  int total = 0, cls = -1, off = 0;
+#pragma unroll
+  for (int c = 0; c < LPT_CLS; ++c) {
+    const int k = rec[x * LPT_CLS + c];
+    if (cls < 0 && local < total + k) { cls = c; off = local - total; }
+    total += k;
+  }
+  if (total != expected) return ident;
+  if (cls < 0 || off >= cap) return B;
+  return rec[8 * LPT_CLS + (x * LPT_CLS + cls) * cap + off];
+}
+
 struct KinData {
   float qpos[NQ], vel[ND], qpos_next[NQ], vel_next[ND];
   float l_pos[NL * 3], l_quat[NL * 4], i_pos[NL * 3], i_quat[NL * 4];
@@ -1923,7 +1966,7 @@ DEV bool terrain_prism_contact(const Model& m, const E& e, const TP& t, int i_gb
 }
 
 template <int T>
-__global__ __launch_bounds__(64) void k_collide_team(Pool P, const Model* __restrict__ mp, GjkStoreFull* __restrict__ gjk_scratch) {
+__global__ __launch_bounds__(64) void k_collide_team(Pool P, const Model* __restrict__ mp, GjkStoreFull* __restrict__ gjk_scratch, int* __restrict__ lpt_rec, int lpt_cap, int solver_epw) {
   constexpr int EPW = 64 / T;
   __shared__ CollideData<T> lds[EPW];
   const int tl = threadIdx.x % T, slot = threadIdx.x / T;
@@ -2279,7 +2322,10 @@ __global__ __launch_bounds__(64) void k_collide_team(Pool P, const Model* __rest
       PH(29)
     }
   }
-  if (tl == 0) { e.n_broad()[0] = n_broad; e.n_contacts()[0] = imn(nc_run, m.max_contact_pairs); }
+  if (tl == 0) {
+    e.n_broad()[0] = n_broad; e.n_contacts()[0] = imn(nc_run, m.max_contact_pairs);
+    if (lpt_rec) lpt_file(lpt_rec, lpt_cap, b, P.B, solver_epw, imn(nc_run, m.max_contact_pairs));
+  }
   team_sync();
   for (int i = tl; i < NCV; i += T) e.ncache_valid()[i] = (int)s->ncv[i];
   PH(33)
@@ -2501,7 +2547,60 @@ DEV void ts_update_constraint(const MT& m, S* s, int tl, int n_con, float& cost,
   team_sync();
 }
 
-// func_hessian_direct_batch, solver.py:1285-1343: one lane per lower-triangle entry, rows summed first to last
+// func_hessian_direct_batch, solver.py:1285-1343.
+#if GO2SIM_FAST_ORDER
+// FAST ORDER: one lane per 3 x 3 block of the lower triangle (21 blocks), so that a constraint row costs 6 LDS reads + 1 for 9 multiply-adds instead of
+// 3 reads per multiply-add; the row factor J[c][i] * D[c] * active[c] (0 where the reference skips the row: |J[c][i]| <= eps) is formed once per block
+// row and the sum runs as a fused multiply-add chain over the rows first to last.  Teams of 64 lanes split the rows in three interleaved groups
+// (rows c = g mod 3 on lanes 21 g .. 21 g + 20) and add the partial sums as (p0 + p1) + p2.
+template <int T, class S, class MT>
+DEV void ts_hessian_direct(const MT& m, S* s, int tl, int n_con) {
+  constexpr int NB = 21, G = (T >= 3 * NB) ? 3 : 1;
+  for (int u0 = 0; u0 < NB * G; u0 += T) {
+    const int u = u0 + tl;
+    const bool on = u < NB * G;
+    const int g = on ? u / NB : 0, blk = on ? u - NB * g : 0;
+    const int bi = (blk >= 15) ? 5 : (blk >= 10) ? 4 : (blk >= 6) ? 3 : (blk >= 3) ? 2 : (blk >= 1) ? 1 : 0;
+    const int bj = blk - bi * (bi + 1) / 2;
+    float h[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int q = 0; q < 3; ++q) h[a][q] = 0.0f;
+    const float* Ji = &s->J[3 * bi];
+    const float* Jj = &s->J[3 * bj];
+    const int n_c = on ? n_con : 0;
+#pragma unroll 4
+    for (int c = g; c < n_c; c += G) {
+      const float D = s->DA[c];
+      float jd[3], jj[3];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) { const float j1 = Ji[c * DS + a]; jd[a] = (dm_abs(j1) > m.eps) ? j1 * D : 0.0f; jj[a] = Jj[c * DS + a]; }
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) h[a][q] = __builtin_fmaf(jj[q], jd[a], h[a][q]);
+    }
+    if constexpr (G == 3) {
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) { const float p1 = __shfl(h[a][q], tl + NB, T), p2 = __shfl(h[a][q], tl + 2 * NB, T); h[a][q] = (h[a][q] + p1) + p2; }
+    }
+    if (on && g == 0) {
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+          const int i = 3 * bi + a, j = 3 * bj + q;
+          if (j <= i) s->H[i * DS + j] = h[a][q] + s->M[i * DS + j];
+        }
+    }
+  }
+  team_sync();
+}
+#else
+// one lane per lower-triangle entry, rows summed first to last
 template <int T, class S, class MT>
 DEV void ts_hessian_direct(const MT& m, S* s, int tl, int n_con) {
   for (int idx = tl; idx < ND * (ND + 1) / 2; idx += T) {
@@ -2519,6 +2618,7 @@ DEV void ts_hessian_direct(const MT& m, S* s, int tl, int n_con) {
   }
   team_sync();
 }
+#endif
 
 // func_cholesky_factor_direct_batch, solver.py:1467-1494 (column by column; statically unrolled so that the pivot-row prefix is
 // fetched with wide LDS reads that are all in flight at once)
@@ -3515,7 +3615,8 @@ DEVN void ts_solve_overflow(float* Pf, int* Pi, int PB, float* Pfa, int* Pia, in
 }
 
 template <int T, int RLN>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_constraint_solve_team(Pool P, const Model* __restrict__ gm, const ModelS* __restrict__ mp, SolverData<MAXR>* __restrict__ overflow) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_constraint_solve_team(Pool P, const Model* __restrict__ gm, const ModelS* __restrict__ mp, SolverData<MAXR>* __restrict__ overflow,
+                                                                                                         const int* __restrict__ lpt_rec, int* __restrict__ lpt_next, int lpt_cap) {
   constexpr int EPW = 64 / T;
   __shared__ SolverData<RLN> lds[EPW];
   __shared__ alignas(16) char blk_raw[lds_dma_bytes(SOLVER_BLOCK_BYTES)];
@@ -3528,10 +3629,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   PH_BEGIN
   wg_dma_to_lds<SOLVER_BLOCK_BYTES>(blk_raw, mp->links);
   const int tl = threadIdx.x % T, slot = threadIdx.x / T;
-  const int b = xcd_block() * EPW + slot;
+  const int b = lpt_take(lpt_rec, lpt_cap, P.B, EPW, slot);
+  if (lpt_next && blockIdx.x == 0) for (int i = threadIdx.x; i < 8 * LPT_CLS; i += 64) lpt_next[i] = 0;   // the record of the next collide / solve pair
   const bool env_valid = b < P.B;
 #ifdef GO2SIM_BRACKET_DEBUG
-  if (threadIdx.x == 0) g_brenv_of_wg[blockIdx.x] = xcd_block() * EPW;
+  if (threadIdx.x == 0) g_brenv_of_wg[blockIdx.x] = b - slot;
 #endif
   E e(P, env_valid ? b : P.B - 1);
   const int nc = e.n_contacts()[0];
@@ -4984,6 +5086,7 @@ struct go2sim {
   GjkStoreFull* gjk_scratch = nullptr;      // full-capacity polytope records of the GJK / EPA fallback (queries that outgrow their LDS slot) and
                                             // prism descriptors of the terrain pass: one block per (env, narrow-phase lane)
   SolverData<MAXR>* solver_ovf = nullptr;   // per-env global scratch for solves that do not fit in LDS (> RL rows)
+  int* lpt = nullptr; int lpt_cap = 0; int lpt_parity = 0; bool use_lpt = true;   // heaviest-first dispatch records of the solver (two, alternating)
   // One env step = 11 dependent kernel launches (12 with terrain).  Issued one by one they cost the host ~20 us each -- close to the GPU time of
   // the step -- so the sequence is kept as an instantiated hipGraph: per step the three step-dependent kernel nodes get their new arguments
   // (actions pointer, step counter, ring index) and the graph is launched with one call.  GO2SIM_NO_GRAPH=1 (or timing mode) uses plain launches.
@@ -5058,28 +5161,36 @@ static void launch_dynamics(go2sim* h, hipStream_t s, const float* actions = nul
   else if (T == 32) hipLaunchKernelGGL(k_dynamics_team<32>, gd, b, 0, s, h->P, h->dms);
   else hipLaunchKernelGGL(k_dynamics_team<64>, gd, b, 0, s, h->P, h->dms);
 }
+static int solver_epw(const go2sim* h) { return 64 / (h->hm.terrain_enabled ? h->terrain_solver_team : h->solver_team); }
+static size_t lpt_record_ints(const go2sim* h) { return (size_t)8 * LPT_CLS * (1 + h->lpt_cap); }
 static void launch_collide_solve(go2sim* h, hipStream_t s) {
   dim3 b(WG);
+  const bool lpt_on = h->use_lpt && solver_epw(h) == 1;             // one env per wavefront (heightfield): two residency rounds.  (Two envs per wavefront on flat
+  //                                                                   ground: one round, and unsorted neighbours share the lines of the [feature][env] rows -- measured slower.)
+  int* lpt_cur = lpt_on ? h->lpt + h->lpt_parity * lpt_record_ints(h) : nullptr;
+  int* lpt_next = lpt_on ? h->lpt + (1 - h->lpt_parity) * lpt_record_ints(h) : nullptr;
+  h->lpt_parity ^= 1;
+  const int epw_s = solver_epw(h);
   {
     ScopedTimer t(h, s, T_COLLIDE);
     const int T = h->collide_team;
     dim3 gc((h->B + 64 / T - 1) / (64 / T));
-    if (T == 16) hipLaunchKernelGGL(k_collide_team<16>, gc, b, 0, s, h->P, h->dm, h->gjk_scratch);
-    else if (T == 32) hipLaunchKernelGGL(k_collide_team<32>, gc, b, 0, s, h->P, h->dm, h->gjk_scratch);
-    else hipLaunchKernelGGL(k_collide_team<64>, gc, b, 0, s, h->P, h->dm, h->gjk_scratch);
+    if (T == 16) hipLaunchKernelGGL(k_collide_team<16>, gc, b, 0, s, h->P, h->dm, h->gjk_scratch, lpt_cur, h->lpt_cap, epw_s);
+    else if (T == 32) hipLaunchKernelGGL(k_collide_team<32>, gc, b, 0, s, h->P, h->dm, h->gjk_scratch, lpt_cur, h->lpt_cap, epw_s);
+    else hipLaunchKernelGGL(k_collide_team<64>, gc, b, 0, s, h->P, h->dm, h->gjk_scratch, lpt_cur, h->lpt_cap, epw_s);
   }
   {
     ScopedTimer t(h, s, T_SOLVE);
     // flat ground: 32 lanes per env and 32 LDS rows; heightfield terrain (many more contacts): one env per wavefront with 96 LDS rows
     if (h->hm.terrain_enabled) {
-      if (h->terrain_solver_team == 32) hipLaunchKernelGGL((k_constraint_solve_team<32, RL_TERRAIN>), dim3((h->B + 1) / 2), b, 0, s, h->P, h->dm, h->dms, h->solver_ovf);
-      else hipLaunchKernelGGL((k_constraint_solve_team<64, RL_TERRAIN>), dim3(h->B), b, 0, s, h->P, h->dm, h->dms, h->solver_ovf);
+      if (h->terrain_solver_team == 32) hipLaunchKernelGGL((k_constraint_solve_team<32, RL_TERRAIN>), dim3((h->B + 1) / 2), b, 0, s, h->P, h->dm, h->dms, h->solver_ovf, (const int*)lpt_cur, lpt_next, h->lpt_cap);
+      else hipLaunchKernelGGL((k_constraint_solve_team<64, RL_TERRAIN>), dim3(h->B), b, 0, s, h->P, h->dm, h->dms, h->solver_ovf, (const int*)lpt_cur, lpt_next, h->lpt_cap);
     } else {
       const int T = h->solver_team;
       dim3 gs((h->B + 64 / T - 1) / (64 / T));
-      if (T == 16) hipLaunchKernelGGL((k_constraint_solve_team<16, RL>), gs, b, 0, s, h->P, h->dm, h->dms, h->solver_ovf);
-      else if (T == 32) hipLaunchKernelGGL((k_constraint_solve_team<32, RL>), gs, b, 0, s, h->P, h->dm, h->dms, h->solver_ovf);
-      else hipLaunchKernelGGL((k_constraint_solve_team<64, RL>), gs, b, 0, s, h->P, h->dm, h->dms, h->solver_ovf);
+      if (T == 16) hipLaunchKernelGGL((k_constraint_solve_team<16, RL>), gs, b, 0, s, h->P, h->dm, h->dms, h->solver_ovf, (const int*)lpt_cur, lpt_next, h->lpt_cap);
+      else if (T == 32) hipLaunchKernelGGL((k_constraint_solve_team<32, RL>), gs, b, 0, s, h->P, h->dm, h->dms, h->solver_ovf, (const int*)lpt_cur, lpt_next, h->lpt_cap);
+      else hipLaunchKernelGGL((k_constraint_solve_team<64, RL>), gs, b, 0, s, h->P, h->dm, h->dms, h->solver_ovf, (const int*)lpt_cur, lpt_next, h->lpt_cap);
     }
   }
 }
@@ -5179,19 +5290,24 @@ static bool step_graph_build(go2sim* h, const float* actions, float* obs, float*
   };
   if (!fuse_pre(h)) ok = add_dynamics();
   for (int i = 0; i < substeps && ok; ++i) {                               // same order as launch_substeps
+    // heaviest-first records: substep i uses record i & 1 and clears the other one (an odd substep count would leave record 0 uncleared: no records then)
+    const bool lpt_on = h->use_lpt && (substeps % 2 == 0) && solver_epw(h) == 1;
+    int* lpt_cur = lpt_on ? h->lpt + (i & 1) * lpt_record_ints(h) : nullptr;
+    int* lpt_next = lpt_on ? h->lpt + (1 - (i & 1)) * lpt_record_ints(h) : nullptr;
+    const int epw_s = solver_epw(h);
     { const int T = h->collide_team; const dim3 gc = team_grid(T);
-      ok = T == 16 ? graph_add_kernel(h, last, k_collide_team<16>, gc, b64, nullptr, nullptr, nullptr, h->P, h->dm, h->gjk_scratch)
-         : T == 32 ? graph_add_kernel(h, last, k_collide_team<32>, gc, b64, nullptr, nullptr, nullptr, h->P, h->dm, h->gjk_scratch)
-                   : graph_add_kernel(h, last, k_collide_team<64>, gc, b64, nullptr, nullptr, nullptr, h->P, h->dm, h->gjk_scratch); }
+      ok = T == 16 ? graph_add_kernel(h, last, k_collide_team<16>, gc, b64, nullptr, nullptr, nullptr, h->P, h->dm, h->gjk_scratch, lpt_cur, h->lpt_cap, epw_s)
+         : T == 32 ? graph_add_kernel(h, last, k_collide_team<32>, gc, b64, nullptr, nullptr, nullptr, h->P, h->dm, h->gjk_scratch, lpt_cur, h->lpt_cap, epw_s)
+                   : graph_add_kernel(h, last, k_collide_team<64>, gc, b64, nullptr, nullptr, nullptr, h->P, h->dm, h->gjk_scratch, lpt_cur, h->lpt_cap, epw_s); }
     if (!ok) break;
     if (h->hm.terrain_enabled) {
-      if (h->terrain_solver_team == 32) ok = graph_add_kernel(h, last, k_constraint_solve_team<32, RL_TERRAIN>, dim3((h->B + 1) / 2), b64, nullptr, nullptr, nullptr, h->P, h->dm, h->dms, h->solver_ovf);
-      else ok = graph_add_kernel(h, last, k_constraint_solve_team<64, RL_TERRAIN>, dim3(h->B), b64, nullptr, nullptr, nullptr, h->P, h->dm, h->dms, h->solver_ovf);
+      if (h->terrain_solver_team == 32) ok = graph_add_kernel(h, last, k_constraint_solve_team<32, RL_TERRAIN>, dim3((h->B + 1) / 2), b64, nullptr, nullptr, nullptr, h->P, h->dm, h->dms, h->solver_ovf, (const int*)lpt_cur, lpt_next, h->lpt_cap);
+      else ok = graph_add_kernel(h, last, k_constraint_solve_team<64, RL_TERRAIN>, dim3(h->B), b64, nullptr, nullptr, nullptr, h->P, h->dm, h->dms, h->solver_ovf, (const int*)lpt_cur, lpt_next, h->lpt_cap);
     } else {
       const int T = h->solver_team; const dim3 gs = team_grid(T);
-      ok = T == 16 ? graph_add_kernel(h, last, k_constraint_solve_team<16, RL>, gs, b64, nullptr, nullptr, nullptr, h->P, h->dm, h->dms, h->solver_ovf)
-         : T == 32 ? graph_add_kernel(h, last, k_constraint_solve_team<32, RL>, gs, b64, nullptr, nullptr, nullptr, h->P, h->dm, h->dms, h->solver_ovf)
-                   : graph_add_kernel(h, last, k_constraint_solve_team<64, RL>, gs, b64, nullptr, nullptr, nullptr, h->P, h->dm, h->dms, h->solver_ovf);
+      ok = T == 16 ? graph_add_kernel(h, last, k_constraint_solve_team<16, RL>, gs, b64, nullptr, nullptr, nullptr, h->P, h->dm, h->dms, h->solver_ovf, (const int*)lpt_cur, lpt_next, h->lpt_cap)
+         : T == 32 ? graph_add_kernel(h, last, k_constraint_solve_team<32, RL>, gs, b64, nullptr, nullptr, nullptr, h->P, h->dm, h->dms, h->solver_ovf, (const int*)lpt_cur, lpt_next, h->lpt_cap)
+                   : graph_add_kernel(h, last, k_constraint_solve_team<64, RL>, gs, b64, nullptr, nullptr, nullptr, h->P, h->dm, h->dms, h->solver_ovf, (const int*)lpt_cur, lpt_next, h->lpt_cap);
     }
     if (!ok) break;
     if (i + 1 < substeps && h->fuse_fk_dyn) ok = add_integrate_dynamics();
@@ -5222,7 +5338,7 @@ static void handle_release(go2sim* h) {
   step_graph_destroy(h);
   if (h->ev_created) for (int i = 0; i < TIMING_RING; ++i) { (void)hipEventDestroy(h->ev0[i]); (void)hipEventDestroy(h->ev1[i]); }
   (void)hipFree(h->P.f); (void)hipFree(h->P.i); (void)hipFree(h->P.fa); (void)hipFree(h->P.ia); (void)hipFree(h->dm); (void)hipFree(h->dcfg);
-  (void)hipFree(h->dglob); (void)hipFree(h->dacc); (void)hipFree(h->derr); (void)hipFree(h->solver_ovf); (void)hipFree(h->gjk_scratch);
+  (void)hipFree(h->dglob); (void)hipFree(h->dacc); (void)hipFree(h->derr); (void)hipFree(h->solver_ovf); (void)hipFree(h->gjk_scratch); (void)hipFree(h->lpt);
   (void)hipFree(h->terrain_hf); (void)hipFree(h->dms); (void)hipFree(h->didx);
   if (h->herr_pinned) (void)hipHostFree(h->herr_pinned);
   if (h->ev_errno) (void)hipEventDestroy(h->ev_errno);
@@ -5279,6 +5395,10 @@ int go2sim_create(const void* blob, size_t nbytes, int n_envs, int device, uint6
     CK(hipMalloc((void**)&h->gjk_scratch, (size_t)n_envs * h->collide_team * sizeof(GjkStoreFull)));   // ~20 KB per narrow-phase lane
     if (const char* t = getenv("GO2SIM_SOLVER_TEAM")) { int v = atoi(t); if (v == 16 || v == 32 || v == 64) h->solver_team = v; }
     if (const char* t = getenv("GO2SIM_TERRAIN_SOLVER_TEAM")) { int v = atoi(t); if (v == 32 || v == 64) h->terrain_solver_team = v; }
+    if (const char* t = getenv("GO2SIM_NO_LPT")) { if (atoi(t) != 0) h->use_lpt = false; }
+    h->lpt_cap = n_envs / 8 + 72;
+    CK(hipMalloc((void**)&h->lpt, 2 * lpt_record_ints(h) * sizeof(int)));
+    CK(hipMemset(h->lpt, 0, 2 * lpt_record_ints(h) * sizeof(int)));
     Glob g0; memset(&g0, 0, sizeof(g0)); g0.friction = 1.0f;
     CK(hipMemcpy(h->dglob, &g0, sizeof(Glob), hipMemcpyHostToDevice));
     CK(hipMemset(h->dacc, 0, sizeof(Acc)));
@@ -5564,6 +5684,7 @@ int go2sim_env_step(go2sim_t* h, const float* actions, float* obs, float* priv, 
       if (launched) {
         h->action_write_idx = (h->action_write_idx + 1) % (h->hcfg.i[GO2SIM_IC_MAX_DELAY] + 1);
         h->step_count += 1;
+        h->lpt_parity = 0;                // (the graph leaves record 0 cleared)
         return GO2SIM_E_OK;
       }
       (void)hipGetLastError();            // nothing of this step was enqueued: drop the graph and continue with plain launches

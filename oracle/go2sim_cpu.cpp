@@ -1394,6 +1394,26 @@ inline real team_tree_sum(int W, int n, F term) {
 #endif
 
 void hessian_direct(const Model& m, Env& e) {
+#ifdef GO2SIM_FAST_ORDER
+  // ts_hessian_direct of csrc/go2sim.hip: row factor J[c][i] * (D[c] * active[c]) (0 where the reference skips the row), fused multiply-add chain over
+  // the rows; teams of 64 lanes (heightfield) sum the rows c = g mod 3 separately and add the partial sums as (p0 + p1) + p2
+  const int G = fast_team(m) == 64 ? 3 : 1;
+  for (int i = 0; i < ND; ++i)
+    for (int j = 0; j < i + 1; ++j) {
+      real part[3] = {0.0f, 0.0f, 0.0f};
+      for (int g = 0; g < G; ++g) {
+        real h = 0.0f;
+        for (int c = g; c < e.n_con; c += G) {
+          const real j1 = e.jac[c][i];
+          const real jd = (dm_abs(j1) > m.eps) ? j1 * (e.efc_D[c] * (real)e.active[c]) : 0.0f;
+          h = std::fma(e.jac[c][j], jd, h);
+        }
+        part[g] = h;
+      }
+      e.H[i][j] = ((G == 1) ? part[0] : (part[0] + part[1]) + part[2]) + e.mass_mat[i][j];
+    }
+  return;
+#endif
   for (int i = 0; i < ND; ++i) for (int j = 0; j < i + 1; ++j) e.H[i][j] = 0.0f;
   for (int i_d1 = 0; i_d1 < ND; ++i_d1)
     for (int i_c = 0; i_c < e.n_con; ++i_c)
