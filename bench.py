@@ -59,6 +59,7 @@ NACT = {"walk": 16, "stairs": 16, "jump_dr": 12}
 KERNEL_CLASSES = ["k_dynamics", "k_collide", "k_constraint_solve", "k_integrate_fk", "k_env_pre", "k_env_post(a+globals+b)", "misc", "env_step_total"]
 LAUNCHES_PER_ENV_STEP = 9
 PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
+PMC_TRAFFIC_FILES = {"walk": PMC_TRAFFIC_FILE, "stairs": os.path.join(ROOT, "profiles", "r03_stairs_pmc_traffic.json")}   # per workload (tools/profile_round.sh)
 
 
 def source_hash():
@@ -94,15 +95,18 @@ def make_actions(n_steps, n_envs, device, dt=0.02, workload="walk", kind="C", se
     return act.contiguous()
 
 
-def pmc_traffic_bytes(kernel, n_envs):
+def pmc_traffic_bytes(kernel, n_envs, workload="walk"):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (PMC counters cannot be collected from inside the timed
     process).  FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, both in KB; only valid for 4096 envs AND for the sources the file was
     measured on: a file whose source hash or kernel list does not match this build is refused (returns None, with the reason)."""
     if n_envs != ENVS_PER_GPU:
         return None, "traffic file is for 4096 envs"
-    if not os.path.exists(PMC_TRAFFIC_FILE):
+    path = PMC_TRAFFIC_FILES.get(workload)
+    if path is None:
+        return None, f"counters are not collected for the {workload} workload"
+    if not os.path.exists(path):
         return None, "no traffic file for this round"
-    doc = json.load(open(PMC_TRAFFIC_FILE))
+    doc = json.load(open(path))
     if doc.get("source_sha256") != source_hash():
         return None, "traffic file was measured on different sources (stale): refused"
     rec = doc.get("kernels", {}).get(kernel)
@@ -286,7 +290,7 @@ def roofline_of(ms, cnt, K, B, workload, value):
     units = B * (0.5 if dom < 4 else 1.0)
     algo = ALGO_BYTES[workload]
     achieved = algo * units / (per_launch[dom] * 1e-3) / 1e9 if per_launch[dom] > 0 else 0.0
-    traffic, note = pmc_traffic_bytes(KERNEL_CLASSES[dom], B) if workload == "walk" else (None, "counters are collected for the walk workload only")
+    traffic, note = pmc_traffic_bytes(KERNEL_CLASSES[dom], B, workload)
     r = {"bound": "hbm", "kernel": KERNEL_CLASSES[dom], "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "avg_launch_ms": round(per_launch[dom], 4), "launches_timed": cnt[dom],
          "algo_bytes_per_env_step": algo, "units_per_launch_env_steps": units,

@@ -807,6 +807,8 @@ DEV void tk_stage_links(const E& e, KinData* s, int tl) {
 //  func_forward_velocity_entity :871-994 of forward_kinematics.py)
 // `dk` (optional): the working set of the forward dynamics that follow in the same kernel (k_integrate_fk_dynamics_team): everything the dynamics would
 // otherwise read back from HBM is also left there
+// (with `dk`, i.e. between the substeps of an env step, the outputs that only the forward dynamics reads -- cinr_*, cdofd_*, cd_vel / cd_ang, i_pos --
+//  are not written to HBM at all: the dynamics half of the same kernel takes them from LDS, and the FK that closes the step writes them all)
 template <int T, class MT>
 DEV void tk_kinematics(const MT& m, const E& e, KinData* s, int tl, bool force_update_fixed, DynData* dk = nullptr) {
   // s->l_pos / s->l_quat hold the current link poses (tk_stage_links, issued with the kernel's other staging loads)
@@ -878,11 +880,12 @@ DEV void tk_kinematics(const MT& m, const E& e, KinData* s, int tl, bool force_u
     e.root_com()[i_l] = r;
     V3 ip = ld3(s->i_pos, i_l) - r;
     Q4 iq = ld4(s->i_quat, i_l);
-    e.i_pos()[i_l] = ip; e.i_quat()[i_l] = iq;
+    if (!dk) e.i_pos()[i_l] = ip;
+    e.i_quat()[i_l] = iq;
     float i_mass = s->mass[i_l];
     M3 oI; V3 op;
     transform_inertia_by_trans_quat(L.inertial_i, i_mass, ip, iq, m.eps, oI, op);
-    e.cinr_inertial()[i_l] = oI; e.cinr_pos()[i_l] = op; e.cinr_mass()[i_l] = i_mass;
+    if (!dk) { e.cinr_inertial()[i_l] = oI; e.cinr_pos()[i_l] = op; e.cinr_mass()[i_l] = i_mass; }
     if (dk) { st9(dk->cinr_I, i_l, oI); st9(dk->crb_I, i_l, oI); st3(dk->cinr_pos, i_l, op); st3(dk->crb_pos, i_l, op); dk->cinr_mass[i_l] = i_mass; dk->crb_mass[i_l] = i_mass; }
   }
   for (int i_j = tl; i_j < NJ; i_j += T) {
@@ -944,11 +947,11 @@ DEV void tk_kinematics(const MT& m, const E& e, KinData* s, int tl, bool force_u
             cvel_ang = cvel_ang + ld3(s->cdof_ang, ds + i) * v;
           }
           for (int i = 0; i < 3; ++i) {
-            e.cdofd_ang()[ds + i] = v3(0, 0, 0); e.cdofd_vel()[ds + i] = v3(0, 0, 0);
+            if (!dk) { e.cdofd_ang()[ds + i] = v3(0, 0, 0); e.cdofd_vel()[ds + i] = v3(0, 0, 0); }
             if (dk) { st3(dk->cdofd_ang, ds + i, v3(0, 0, 0)); st3(dk->cdofd_vel, ds + i, v3(0, 0, 0)); }
             V3 oa, ov;
             motion_cross_motion(cvel_ang, cvel_vel, ld3(s->cdof_ang, ds + i + 3), ld3(s->cdof_vel, ds + i + 3), oa, ov);
-            e.cdofd_ang()[ds + i + 3] = oa; e.cdofd_vel()[ds + i + 3] = ov;
+            if (!dk) { e.cdofd_ang()[ds + i + 3] = oa; e.cdofd_vel()[ds + i + 3] = ov; }
             if (dk) { st3(dk->cdofd_ang, ds + i + 3, oa); st3(dk->cdofd_vel, ds + i + 3, ov); }
           }
           for (int i = 0; i < 3; ++i) {
@@ -960,7 +963,7 @@ DEV void tk_kinematics(const MT& m, const E& e, KinData* s, int tl, bool force_u
           for (int i_d = ds; i_d < J.dof_end; ++i_d) {
             V3 oa, ov;
             motion_cross_motion(cvel_ang, cvel_vel, ld3(s->cdof_ang, i_d), ld3(s->cdof_vel, i_d), oa, ov);
-            e.cdofd_ang()[i_d] = oa; e.cdofd_vel()[i_d] = ov;
+            if (!dk) { e.cdofd_ang()[i_d] = oa; e.cdofd_vel()[i_d] = ov; }
             if (dk) { st3(dk->cdofd_ang, i_d, oa); st3(dk->cdofd_vel, i_d, ov); }
           }
           for (int i_d = ds; i_d < J.dof_end; ++i_d) {
@@ -971,7 +974,7 @@ DEV void tk_kinematics(const MT& m, const E& e, KinData* s, int tl, bool force_u
         }
       }
       st3(s->cd_vel, i_l, cvel_vel); st3(s->cd_ang, i_l, cvel_ang);
-      e.cd_vel()[i_l] = cvel_vel; e.cd_ang()[i_l] = cvel_ang;
+      if (!dk) { e.cd_vel()[i_l] = cvel_vel; e.cd_ang()[i_l] = cvel_ang; }
       if (dk) { st3(dk->cd_vel, i_l, cvel_vel); st3(dk->cd_ang, i_l, cvel_ang); }
     }
     team_sync();
@@ -1384,17 +1387,22 @@ DEV V3 support_cylinder_local(const Model& m, const Geom& G, V3 d_mesh, int* vid
   const float support_res = 180.0f;
   float ii = (theta + PI) / PI / 2.0f * support_res;
   float jj = phi / PI * support_res;
+  // the four neighbours of the grid cell are (floor | ceil of ii) x (floor | ceil of jj): two azimuth cells -> two ring vertices, whose table
+  // entries are fetched side by side (two dependent round trips to the model instead of eight); candidates in the order of the reference's loop
+  const int i_lo = wrap180(dm_floor(ii)), i_hi = wrap180(dm_ceil(ii));
+  int j_lo = clampidx(dm_floor(jj)); if (j_lo == 0) j_lo = 1;
+  int j_hi = clampidx(dm_ceil(jj)); if (j_hi == 179) j_hi = 178;
+  const int k_lo = m.theta_to_ring[i_lo], k_hi = m.theta_to_ring[i_hi];
+  const float rx_lo = G.rim[k_lo][0], ry_lo = G.rim[k_lo][1], rx_hi = G.rim[k_hi][0], ry_hi = G.rim[k_hi][1];
+  const float half = 0.5f * G.data[1];
   float dot_max = -1e20f;
   V3 v = v3(0, 0, 0);
   int vid = 0;
-  float half = 0.5f * G.data[1];
+#pragma unroll
   for (int i4 = 0; i4 < 4; ++i4) {
-    int i, j;
-    if (i4 % 2) i = wrap180(dm_ceil(ii)); else i = wrap180(dm_floor(ii));
-    if (i4 / 2 > 0) { j = clampidx(dm_ceil(jj)); if (j == 179) j = 178; }
-    else { j = clampidx(dm_floor(jj)); if (j == 0) j = 1; }
-    int k = m.theta_to_ring[i];
-    V3 pos = v3(G.rim[k][0], G.rim[k][1], (j <= 90) ? half : -half);
+    const bool hi_i = (i4 % 2) != 0, hi_j = (i4 / 2) > 0;
+    const int j = hi_j ? j_hi : j_lo, k = hi_i ? k_hi : k_lo;
+    V3 pos = v3(hi_i ? rx_hi : rx_lo, hi_i ? ry_hi : ry_lo, (j <= 90) ? half : -half);
     float d = dot(pos, d_mesh);
     if (d > dot_max) { v = pos; dot_max = d; vid = k + ((j <= 90) ? 0 : 32); }
   }
@@ -1521,6 +1529,17 @@ DEV void mpr_expand_portal(Simplex& s, V3 v, V3 v1, V3 v2) {
   if (d > 0) { d = dot(s.v[2], v4v0); i_s = (d > 0) ? 1 : 3; }
   else { d = dot(s.v[3], v4v0); i_s = (d > 0) ? 2 : 1; }
   simplex_set(s, i_s, v, v1, v2);
+}
+// The first step of mpr_discover_portal on its own (same expressions): true when the query ends there without a contact (the support point along
+// the line of centres does not pass the origin).  The heightfield pass uses it to drop such prisms before the full queries are distributed.
+DEV bool mpr_first_support_separates(const Model& m, const Pair& pr, V3 center_a, V3 center_b) {
+  const float EPSC = m.ccd_eps;
+  V3 v0 = center_a - center_b;
+  if (dm_abs(v0.x) < EPSC && dm_abs(v0.y) < EPSC && dm_abs(v0.z) < EPSC) v0.x += 10.0f * EPSC;
+  const V3 direction = -normalized(v0);
+  V3 v, v1, v2;
+  compute_support(m, direction, pr, v, v1, v2);
+  return dot(v, direction) < EPSC;
 }
 // mpr_discover_portal, mpr.py:445-598
 DEV int mpr_discover_portal(const Model& m, Simplex& s, const Pair& pr, V3 center_a, V3 center_b) {
@@ -1937,10 +1956,9 @@ DEV float terrain_strip_z(const Model& m, int r, int c_min, int k) { return m.te
 //     cell per lane in k_collide_team
 // (3) MPR of the geom against that prism; the contact is returned in world coordinates
 template <class TP>
-DEV bool terrain_prism_contact(const Model& m, const E& e, const TP& t, int i_gb, int r, int k, V3& normal, V3& contact_pos, float& penetration) {
+DEV void terrain_prism_pair(const Model& m, const TP& t, int i_gb, int r, int k, V3 (&prism)[6], Pair& pr, V3& center_b) {
   const float* tmm = m.terrain_xyz_maxmin;
   const float sh = m.terrain_hs;
-  V3 prism[6];
 #pragma unroll
   for (int j = 0; j < 3; ++j) {
     int kk = k - 2 + j;
@@ -1948,12 +1966,23 @@ DEV bool terrain_prism_contact(const Model& m, const E& e, const TP& t, int i_gb
     prism[j] = v3(x, y, tmm[5]);
     prism[3 + j] = v3(x, y, terrain_strip_z(m, r, t.c_min, kk) + 0.0f);
   }
-  Pair pr; pr.i_ga = t.i_ga; pr.i_gb = i_gb; pr.prism = prism; pr.pos_a = t.pos_a; pr.quat_a = t.quat_a; pr.pos_b = v3(0, 0, 0); pr.quat_b = qident();
+  pr.i_ga = t.i_ga; pr.i_gb = i_gb; pr.prism = prism; pr.pos_a = t.pos_a; pr.quat_a = t.quat_a; pr.pos_b = v3(0, 0, 0); pr.quat_b = qident();
   pr.ga = geom_lite(m, t.i_ga); pr.gb = geom_lite(m, i_gb);
   pair_set_rots(pr);
-  V3 center_b = v3(0, 0, 0);
+  center_b = v3(0, 0, 0);
   for (int i_p = 0; i_p < 6; ++i_p) center_b = center_b + prism[i_p];
   center_b = center_b / 6.0f;
+}
+template <class TP>
+DEV bool terrain_prism_separated_at_once(const Model& m, const TP& t, int i_gb, int r, int k) {
+  V3 prism[6]; Pair pr; V3 center_b;
+  terrain_prism_pair(m, t, i_gb, r, k, prism, pr, center_b);
+  return mpr_first_support_separates(m, pr, t.center_a, center_b);
+}
+template <class TP>
+DEV bool terrain_prism_contact(const Model& m, const E& e, const TP& t, int i_gb, int r, int k, V3& normal, V3& contact_pos, float& penetration) {
+  V3 prism[6]; Pair pr; V3 center_b;
+  terrain_prism_pair(m, t, i_gb, r, k, prism, pr, center_b);
   bool is_col;
   mpr_contact_from_centers(m, pr, t.center_a, center_b, is_col, normal, penetration, contact_pos);
   if (is_col) {
@@ -2258,6 +2287,25 @@ __global__ __launch_bounds__(64) void k_collide_team(Pool P, const Model* __rest
     }
     if (n_items > items_cap) n_items = items_cap;
     team_sync();
+    // About half of the queries end at the first support point of the portal search (the prism lies beside the geom).  That step is evaluated for
+    // every descriptor here, and only the survivors are distributed for the full query (compacted in place, in order: the write position never
+    // passes the read position).  A dropped descriptor is one whose query returns "no contact", so the contact list does not change.
+    {
+      int n_keep = 0;
+      for (int base = 0; base < n_items; base += T) {
+        const int q = base + tl;
+        int d = 0; bool keep = false;
+        if (q < n_items) {
+          d = items[q];
+          keep = !terrain_prism_separated_at_once(m, s->tr.tp[d & 31], i_terrain, (d >> 5) & 0x1fff, d >> 18);
+        }
+        const unsigned long long mk = team_ballot<T>(keep);
+        if (keep) items[n_keep + __popcll(mk & ((1ull << tl) - 1ull))] = d;
+        n_keep += __popcll(mk);
+        team_sync();
+      }
+      n_items = n_keep;
+    }
     PH(27)
     int cur_p = -1, n_con = 0;                                          // replay state (identical on every lane)
     float tolerance = 0.0f;
@@ -2451,6 +2499,9 @@ DEV void team_serial_sum(const float (&x)[NQ], const float (&base)[NQ], int tl, 
 #ifndef GO2SIM_FAST_ORDER
 #define GO2SIM_FAST_ORDER 1
 #endif
+#ifndef REBUILD_FLIPS
+#define REBUILD_FLIPS 1
+#endif
 template <int CTRL>
 DEV float dpp_perm(float x) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, true)); }
 // butterfly sum over the T lanes of a team (every lane ends with the total); `x` = the lane's own partial sum
@@ -2620,10 +2671,10 @@ DEV void ts_hessian_direct(const MT& m, S* s, int tl, int n_con) {
 }
 #endif
 
-// func_cholesky_factor_direct_batch, solver.py:1467-1494 (column by column; statically unrolled so that the pivot-row prefix is
-// fetched with wide LDS reads that are all in flight at once)
+// func_cholesky_factor_direct_batch, solver.py:1467-1494.
+// column by column; statically unrolled so that the pivot-row prefix is fetched with wide LDS reads that are all in flight at once
 template <int T, class S, class MT>
-DEV void ts_cholesky_factor(const MT& m, S* s, int tl) {
+DEV void ts_cholesky_factor_columns(const MT& m, S* s, int tl) {
 #pragma unroll
   for (int i_d = 0; i_d < ND; ++i_d) {
     float pr[ND];
@@ -2644,6 +2695,45 @@ DEV void ts_cholesky_factor(const MT& m, S* s, int tl) {
     }
     team_sync();
   }
+}
+// FAST ORDER, teams of at least ND lanes: right-looking form with one lane per row, the row in registers.  Column k: the diagonal of lane k gives
+// d = sqrt(max(a_kk, eps)) and 1 / d; every row below scales its element (L_jk = a_jk / d as a multiplication) and stores it at its MIRROR position
+// H[k][j] -- so row k of the upper triangle is column k of the factor, the layout the triangular solves read -- and after one LDS round trip every
+// row subtracts L_jk * L_ik from its remaining elements with fused multiply-adds.  (Elements right of a lane's diagonal take part in the
+// arithmetic but are never read.)  36 + (17 - k) instructions per column instead of ~ 33 + 4.5 k.
+template <int T, class S, class MT>
+DEV void ts_cholesky_factor_rows(const MT& m, S* s, int tl) {
+  static_assert(T >= ND, "one lane per row");
+  const int row = tl < ND ? tl : ND - 1;
+  const bool own = tl < ND;
+  float r[ND];
+#pragma unroll
+  for (int k = 0; k < ND; ++k) r[k] = s->H[row * DS + k];
+#pragma unroll
+  for (int k = 0; k < ND; ++k) {
+    const float akk = team_bcast<T>(r[k], k);
+    const float d = dm_sqrt(fmx(akk, m.eps));
+    const float inv = 1.0f / d;
+    const float l = r[k] * inv;
+    if (own && row >= k) s->H[row * DS + k] = (row == k) ? d : l;
+    if (k < ND - 1) {
+      if (own && row > k) s->H[k * DS + row] = l;
+      team_sync();
+      float col[ND];
+#pragma unroll
+      for (int i = k + 1; i < ND; ++i) col[i] = s->H[k * DS + i];
+#pragma unroll
+      for (int i = k + 1; i < ND; ++i) r[i] = __builtin_fmaf(-l, col[i], r[i]);
+    }
+  }
+  team_sync();
+}
+template <int T, class S, class MT>
+DEV void ts_cholesky_factor(const MT& m, S* s, int tl) {
+#if GO2SIM_FAST_ORDER
+  if constexpr (T >= ND) { ts_cholesky_factor_rows<T>(m, s, tl); return; }
+#endif
+  ts_cholesky_factor_columns<T>(m, s, tl);
 }
 
 // func_hessian_and_cholesky_factor_incremental_dense_batch, solver.py:1632-1675; returns true when the factor degenerated.
@@ -2907,7 +2997,27 @@ DEV bool ts_cholesky_incremental_pipelined(const MT& m, S* s, int tl, int n_con)
 template <int T, class S, class MT>
 DEV bool ts_cholesky_incremental(const MT& m, S* s, int tl, int n_con) {
   if constexpr (T >= ND) {
-#ifndef GO2SIM_NO_PIPELINED_RANK1
+#if GO2SIM_FAST_ORDER
+    // FAST ORDER: an env with REBUILD_FLIPS (default 1: any) or more flipped rows has its Hessian summed and factorised afresh -- the caller's rebuild
+    // path, which the reference takes for a degenerated factor -- instead of one rank-1 pass of the factor per flipped row.  With the block-form
+    // Hessian and the row-form factorisation above the rebuild is the cheaper instruction stream even for a single flipped row (measured, driver
+    // window / default run / stairs, M env-steps/s: never 8.67 / 14.07 / 6.04, >= 4 rows 8.85 / 14.08 / 6.43, >= 2 rows 9.21 / 14.12 / 6.63, always
+    // 9.49 / 14.51 / 6.67), it depends on the env alone, and it does not accumulate the rounding of the rank-1 passes.  (First: the teams that stay
+    // are then alone in the wave-level votes below.)
+    {
+      int n_exact = 0;
+      for (int base = 0; base < n_con; base += T) {
+        const int c = base + tl;
+        n_exact += __popcll(team_ballot<T>(c < n_con && ((s->active[c] != 0) != (s->prev_active[c] != 0))));
+      }
+      if (n_exact >= REBUILD_FLIPS) return true;
+      if (n_exact == 0) return false;                                   // nothing flipped: the factor stands
+    }
+#if REBUILD_FLIPS <= 1
+    return false;                                                       // (not reached: every change of the active set is a rebuild)
+#endif
+#endif
+#if !defined(GO2SIM_NO_PIPELINED_RANK1) && !(GO2SIM_FAST_ORDER && REBUILD_FLIPS <= 2)   // (REBUILD_FLIPS <= 2: an env that stays has at most one flipped row)
     // how many rows flipped (the larger count of the teams in this wavefront): one -> the register-resident serial form is the cheaper
     // instruction stream; several -> the pipelined form is 17 + n steps long instead of 18 n
     int n_flip = 0;

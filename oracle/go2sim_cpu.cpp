@@ -1374,6 +1374,9 @@ void add_joint_limit_constraints(const Model& m, Env& e) {
 // tests/test_fast_order.py bounds fast vs strict.
 // ---------------------------------------------------------------------------------------------
 #ifdef GO2SIM_FAST_ORDER
+#ifndef GO2SIM_REBUILD_FLIPS
+#define GO2SIM_REBUILD_FLIPS 1
+#endif
 inline int fast_team(const Model& m) { return m.terrain_enabled ? 64 : 32; }   // lanes per env of k_constraint_solve_team (flat: 32, heightfield: 64)
 // sum of `n` terms spread over the W lanes of a team: lane l adds its terms l, l + W, ... first to last, then a butterfly over the lanes
 // (xor 1, xor 2, mirror in 8, mirror in 16 inside rows of 16 lanes; the rows are added pairwise)
@@ -1426,6 +1429,18 @@ void hessian_direct(const Model& m, Env& e) {
 }
 // func_cholesky_factor_direct_batch, solver.py:1467-1494
 void cholesky_factor_direct(const Model& m, Env& e) {
+#ifdef GO2SIM_FAST_ORDER
+  // ts_cholesky_factor of csrc/go2sim.hip: right-looking, the column scaled by the reciprocal diagonal, fused multiply-add updates of the rows below
+  for (int k = 0; k < ND; ++k) {
+    const real d = dm_sqrt(std::max(e.H[k][k], m.eps));
+    const real inv = 1.0f / d;
+    e.H[k][k] = d;
+    for (int j = k + 1; j < ND; ++j) e.H[j][k] = e.H[j][k] * inv;
+    for (int j = k + 1; j < ND; ++j)
+      for (int i = k + 1; i <= j; ++i) e.H[j][i] = std::fma(-e.H[j][k], e.H[i][k], e.H[j][i]);
+  }
+  return;
+#endif
   for (int i_d = 0; i_d < ND; ++i_d) {
     real tmp = e.H[i_d][i_d];
     for (int j_d = 0; j_d < i_d; ++j_d) tmp = tmp - e.H[i_d][j_d] * e.H[i_d][j_d];
@@ -1442,6 +1457,11 @@ void cholesky_factor_direct(const Model& m, Env& e) {
 bool cholesky_incremental(const Model& m, Env& e) {
   bool is_degenerated = false;
 #ifdef GO2SIM_FAST_ORDER
+  {                                                                // ts_cholesky_incremental: REBUILD_FLIPS or more flipped rows -> the caller's rebuild path
+    int n_flip = 0;
+    for (int i_c = 0; i_c < e.n_con; ++i_c) n_flip += ((e.active[i_c] != 0) != (e.prev_active[i_c] != 0)) ? 1 : 0;
+    if (n_flip >= GO2SIM_REBUILD_FLIPS) return true;
+  }
   real invd[ND];                                                   // reciprocal diagonal of the factor, carried through the updates
   for (int k = 0; k < ND; ++k) invd[k] = 1.0f / e.H[k][k];
 #endif

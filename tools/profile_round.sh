@@ -5,7 +5,8 @@
 #        -> <out>/pmc_traffic.json stamped with the source hash (copy to profiles/rNN_pmc_traffic.json: bench.py reads it, and refuses a stale one)
 #   3. one SQ pass (instruction mix / wave cycles)
 #   4. the same three for the steady state (400 steps after 300)
-#   5. kernel stats of the policy kernels (tools/policy_bench.py)
+#   5. kernel stats + FETCH / WRITE passes of the stairs workload (-> stairs_pmc_traffic.json)
+#   6. kernel stats of the policy kernels (tools/policy_bench.py)
 # Everything lands in gpurun_out/prof_<tag>/; counters are never combined with any trace but --kernel-trace.
 set -e
 TAG=${1:-run}; W=${2:-5}; K=${3:-20}
@@ -36,6 +37,13 @@ run_pass steady_pmc_fetch_size $SF "$SS" --pmc FETCH_SIZE
 run_pass steady_pmc_write_size $SF "$SS" --pmc WRITE_SIZE
 python3 $R/tools/make_pmc_traffic.py $OUT/steady_pmc_fetch_size.json $OUT/steady_pmc_write_size.json $OUT/steady_pmc_traffic.json \
   "rocprofv3 --kernel-trace --pmc <FETCH_SIZE|WRITE_SIZE> -- python3 bench.py --no-extras --no-cpu-baseline --no-profile-pass $SS (last 400 steps)" > /dev/null
+# stairs (BASELINE configs[2]): bench.py --workload stairs, default window (100 warm-up + 300 timed steps)
+ST="--workload stairs --warmup 100 --steps 300"; STF=$(python3 -c "print(300 / 400)")
+run_pass stairs_kernel_window $STF "$ST" --stats
+run_pass stairs_pmc_fetch_size $STF "$ST" --pmc FETCH_SIZE
+run_pass stairs_pmc_write_size $STF "$ST" --pmc WRITE_SIZE
+python3 $R/tools/make_pmc_traffic.py $OUT/stairs_pmc_fetch_size.json $OUT/stairs_pmc_write_size.json $OUT/stairs_pmc_traffic.json \
+  "rocprofv3 --kernel-trace --pmc <FETCH_SIZE|WRITE_SIZE> -- python3 bench.py --no-extras --no-cpu-baseline --no-profile-pass $ST (last 300 steps)" > /dev/null
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/pol -o pol -- python3 $R/tools/policy_bench.py 4096 > $OUT/policy_bench.log 2>&1
 cp $(ls $OUT/pol/*/pol_kernel_stats.csv $OUT/pol/pol_kernel_stats.csv 2>/dev/null | head -1) $OUT/policy_kernel_stats.csv
 rm -rf $OUT/pol
