@@ -100,7 +100,7 @@ a = np.frombuffer(out, dtype=np.uint64).reshape(PH_MAX_WG, 64).astype(np.float64
 launches = 2 * N                                   # substep kernels: two launches per env step
 GROUPS = {"solver": [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 11], "dynamics": list(range(20, 26)), "collide": list(range(30, 34)) + [26, 27, 28, 29], "integrate_fk": [40, 41]}   # (ids 34-39, 42-49: PHD sections, printed above)
 NAMES = {0: "stage", 1: "rows", 2: "init Ma/Jaref/update", 3: "Hessian", 4: "Cholesky factor", 5: "gradient solve", 6: "line search", 7: "qacc/constraint update",
-         8: "incremental Cholesky", 9: "prologue", 11: "commit", 30: "AABB + clear", 31: "endpoint sort", 32: "candidate pairs", 33: "narrow phase", 26: "terrain pair setup/count", 27: "terrain descriptors", 28: "terrain prism MPR", 29: "terrain replay"}
+         8: "active-set change test (FAST ORDER) / incremental Cholesky", 9: "prologue", 11: "commit", 30: "AABB + clear", 31: "endpoint sort", 32: "candidate pairs", 33: "narrow phase", 26: "terrain pair setup/count", 27: "terrain descriptors", 28: "terrain prism MPR", 29: "terrain replay"}
 # sections inside lane-divergent code (PHD): cycles at id, number of executions at id + 1
 for name, i in (("GJK / EPA query", 34), ("  of which GJK", 38), ("  of which EPA + witness", 42), ("    EPA nearest-face scan", 56), ("    EPA horizon walk", 58), ("    EPA face attachment", 60), ("  support pair evaluations (GJK / EPA)", 48), ("MPR query", 36)):
     cyc, cnt = a[:, i], a[:, i + 1]
