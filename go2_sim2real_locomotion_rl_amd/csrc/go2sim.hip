@@ -38,6 +38,7 @@ constexpr int NL = GO2SIM_NL, ND = GO2SIM_ND, NQ = GO2SIM_NQ, NG = GO2SIM_NG, NJ
 constexpr int NPAIR = GO2SIM_NPAIR_MAX, MAXC = GO2SIM_MAX_CONTACTS, MAXB = GO2SIM_MAX_BROAD, MAXR = GO2SIM_MAX_ROWS;
 constexpr int JOINT_FIXED = 0, JOINT_REVOLUTE = 1, JOINT_FREE = 4;
 constexpr int GEOM_SPHERE = 1, GEOM_CYLINDER = 3, GEOM_BOX = 5, GEOM_TERRAIN = 7;
+constexpr int TERRAIN_CB = 4;   // vertices per side of a block of the coarse maximum map of the heightfield
 constexpr int CTRL_FORCE = 0, CTRL_VELOCITY = 1, CTRL_POSITION = 2;
 constexpr int NA = 16, NM = 12, NOBS_MAX = 64, NPRIV_MAX = 192, NREW = 32;
 constexpr int WG = 64;  // one wavefront per workgroup
@@ -269,6 +270,8 @@ struct Model {
   int pair_list[NPAIR];   // derived: valid pair p -> geom_a | geom_b << 8 (a < b)
   // heightfield terrain replacing the ground slab (go2sim_set_terrain; collider.py:374-394); hf is a device pointer
   int terrain_enabled, terrain_rows, terrain_cols; float terrain_hs; float terrain_xyz_maxmin[6]; const float* terrain_hf;
+  // derived: maximum height over blocks of TERRAIN_CB x TERRAIN_CB vertices (vertex (r, c) lies in block (r / CB, c / CB)); device pointer
+  const float* terrain_cmax; int terrain_crows, terrain_ccols;
   // derived tree tables: links grouped by depth, children of every link in DESCENDING index order (the order in which the
   // reference's leaf->root loops add them to the parent), link of every dof
   int n_levels, level_start[NL + 1], level_links[NL], child_start[NL + 1], child_list[NL], dof_link[ND];
@@ -276,6 +279,7 @@ struct Model {
 
 bool parse_model(const void* blob, size_t nbytes, Model& m) {
   m.terrain_enabled = 0; m.terrain_rows = m.terrain_cols = 0; m.terrain_hs = 0.0f; m.terrain_hf = nullptr;
+  m.terrain_cmax = nullptr; m.terrain_crows = m.terrain_ccols = 0;
   if (nbytes < 128) return false;
   const int32_t* H = (const int32_t*)blob;
   if (H[0] != GO2SIM_MODEL_MAGIC || H[1] != GO2SIM_MODEL_VERSION) return false;
@@ -1913,6 +1917,33 @@ DEV void convex_convex_contact_staged(const Model& m, const E& e, int i_ga, int 
   cc_rest(m, e, c, cs, gjk_slots, gjk_slot_mask, gjk_full, ncv);
 }
 
+// Conservative reach test of a (geom, heightfield) pair before any support point is computed: every point of the geom lies within R (+ 1 mm for the
+// rounding of the pose arithmetic) of its origin, so its support-point bounding box lies inside the cube of half-side R around the origin; if the
+// highest vertex of the heightfield under that cube (from the coarse maximum map, 3 x 3 blocks fetched side by side) stays below origin.z - R, no prism
+// top can reach the geom's lowest point: the pair would enumerate its cells and find none eligible (narrowphase.py:430-436), and is dropped here.
+// False (= the exact path decides) whenever the test does not apply.
+DEV bool terrain_pair_out_of_reach(const Model& m, const GeomLite& gl, V3 pos) {
+  float R;
+  if (gl.type == GEOM_SPHERE) R = gl.d0;
+  else if (gl.type == GEOM_BOX) R = 0.5f * dm_sqrt(gl.d0 * gl.d0 + gl.d1 * gl.d1 + gl.d2 * gl.d2);
+  else if (gl.type == GEOM_CYLINDER) R = dm_sqrt(gl.d0 * gl.d0 + 0.25f * (gl.d1 * gl.d1));
+  else return false;
+  R = R * 1.001f + 1e-3f;
+  const float* tmm = m.terrain_xyz_maxmin;
+  const float sh = m.terrain_hs;
+  int r_lo = (int)dm_floor((pos.x - R - tmm[3]) / sh) - 1, r_hi = (int)dm_ceil((pos.x + R - tmm[3]) / sh) + 1;
+  int c_lo = (int)dm_floor((pos.y - R - tmm[4]) / sh) - 1, c_hi = (int)dm_ceil((pos.y + R - tmm[4]) / sh) + 1;
+  r_lo = imx(0, r_lo); c_lo = imx(0, c_lo); r_hi = imn(m.terrain_rows - 1, r_hi); c_hi = imn(m.terrain_cols - 1, c_hi);
+  if (!(r_lo <= r_hi && c_lo <= c_hi)) return false;
+  const int I0 = r_lo / TERRAIN_CB, J0 = c_lo / TERRAIN_CB;
+  if (r_hi / TERRAIN_CB > I0 + 2 || c_hi / TERRAIN_CB > J0 + 2) return false;
+  float mx = -1e30f;
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int q = 0; q < 3; ++q) mx = fmx(mx, m.terrain_cmax[(size_t)imn(I0 + a, m.terrain_crows - 1) * m.terrain_ccols + imn(J0 + q, m.terrain_ccols - 1)]);
+  return mx < pos.z - R;
+}
 // func_contact_mpr_terrain, narrowphase.py:345-490, split for one-lane-per-prism execution.
 // (1) per pair: geom pose in the terrain frame, its bounding box from six support points, the cell range under it.
 template <class TP>
@@ -2227,29 +2258,45 @@ __global__ __launch_bounds__(64) void k_collide_team(Pool P, const Model* __rest
   //      the serial loop is replayed in prism order, which reproduces the contact list of the reference exactly. ----
   if (m.terrain_enabled) {
     PH(33)
-    int n_tp = 0;                                                       // terrain pairs, in broad-phase order
+    int n_list = 0, i_terrain = 0;                                      // terrain pairs, in broad-phase order
     for (int ip = 0; ip < n_broad; ++ip) {
       int pk = s->pair_sorted[ip];
       int i_ga = pk & 0xff, i_gb = pk >> 8;
       if (m.geoms[i_ga].type == GEOM_TERRAIN) { int t = i_ga; i_ga = i_gb; i_gb = t; }
       if (m.geoms[i_gb].type != GEOM_TERRAIN) continue;
-      if (n_tp < NG) { if (tl == 0) { s->tr.tp[n_tp].i_ga = i_ga; s->tr.tp[n_tp].n_items = i_gb; } n_tp++; }
+      if (n_list < NG) { if (tl == 0) s->tr.tp[n_list].i_ga = i_ga; i_terrain = i_gb; n_list++; }
     }
     team_sync();
+    // pairs whose geom is out of reach of the heightfield are dropped before their bounding boxes are computed (they have no eligible cell); the
+    // list is compacted in place, in order (a round reads its entries before any lane of the round writes)
+    int n_tp = 0;
+    for (int base = 0; base < n_list; base += T) {
+      const int p = base + tl;
+      int i_ga = 0; bool keep = false;
+      if (p < n_list) {
+        i_ga = s->tr.tp[p].i_ga;
+        V3 pos_t; Q4 quat_t;
+        transform_pos_quat_by_trans_quat((V3)e.g_pos()[i_ga] - (V3)e.g_pos()[i_terrain], e.g_quat()[i_ga], v3(0, 0, 0), inv_quat(e.g_quat()[i_terrain]), pos_t, quat_t);
+        keep = m.terrain_cmax == nullptr || !terrain_pair_out_of_reach(m, geom_lite(m, i_ga), pos_t);
+      }
+      const unsigned long long mk = team_ballot<T>(keep);
+      team_sync();
+      if (keep) s->tr.tp[n_tp + __popcll(mk & ((1ull << tl) - 1ull))].i_ga = i_ga;
+      n_tp += __popcll(mk);
+      team_sync();
+    }
     for (int p = tl; p < n_tp; p += T) {                                // pair setup: pose in the terrain frame, cell range, dedupe tolerance
       auto& t = s->tr.tp[p];
-      int i_gb = t.n_items;
-      terrain_pair_setup(m, e, t.i_ga, i_gb, t);
+      terrain_pair_setup(m, e, t.i_ga, i_terrain, t);
       t.n_items = imx(0, t.r_max - t.r_min) * imx(0, 2 * (t.c_max - t.c_min + 1) - 2);   // prisms under the geom's bounding box ("cells")
-      t.tol = compute_tolerance(m, t.i_ga, i_gb, m.mc_tolerance);
-      t.item_off = i_gb;                                                 // item_off temporarily carries the terrain geom index
+      t.tol = compute_tolerance(m, t.i_ga, i_terrain, m.mc_tolerance);
     }
     team_sync();
     PH(26)
     int* items = (int*)&gjk_scratch[(size_t)b * T];                     // prism descriptors p | r << 5 | k << 18 (the GJK scratch is idle in this pass)
     const int items_cap = (int)(sizeof(GjkStoreFull) * T / sizeof(int));
-    int i_terrain = 0, n_cells = 0;
-    for (int p = 0; p < n_tp; ++p) { int c = s->tr.tp[p].n_items; if (p == 0) i_terrain = s->tr.tp[p].item_off; n_cells += c; }
+    int n_cells = 0;
+    for (int p = 0; p < n_tp; ++p) n_cells += s->tr.tp[p].n_items;
     team_sync();
     { int off = 0; for (int p = 0; p < n_tp; ++p) { int c = s->tr.tp[p].n_items; if (tl == 0) s->tr.tp[p].item_off = off; off += c; } }   // first cell of the pair
     team_sync();
@@ -5193,6 +5240,7 @@ struct go2sim {
   int* herr_pinned = nullptr; hipEvent_t ev_errno = nullptr; bool errno_poll_pending = false;   // go2sim_errno_poll_*
   int* didx = nullptr; int didx_cap = 0;    // scratch for index lists (go2sim_env_reset_idx)
   float* terrain_hf = nullptr;              // device copy of the heightfield in metres (go2sim_set_terrain)
+  float* terrain_cmax = nullptr;            // ... and its coarse maximum map
   GjkStoreFull* gjk_scratch = nullptr;      // full-capacity polytope records of the GJK / EPA fallback (queries that outgrow their LDS slot) and
                                             // prism descriptors of the terrain pass: one block per (env, narrow-phase lane)
   SolverData<MAXR>* solver_ovf = nullptr;   // per-env global scratch for solves that do not fit in LDS (> RL rows)
@@ -5449,7 +5497,7 @@ static void handle_release(go2sim* h) {
   if (h->ev_created) for (int i = 0; i < TIMING_RING; ++i) { (void)hipEventDestroy(h->ev0[i]); (void)hipEventDestroy(h->ev1[i]); }
   (void)hipFree(h->P.f); (void)hipFree(h->P.i); (void)hipFree(h->P.fa); (void)hipFree(h->P.ia); (void)hipFree(h->dm); (void)hipFree(h->dcfg);
   (void)hipFree(h->dglob); (void)hipFree(h->dacc); (void)hipFree(h->derr); (void)hipFree(h->solver_ovf); (void)hipFree(h->gjk_scratch); (void)hipFree(h->lpt);
-  (void)hipFree(h->terrain_hf); (void)hipFree(h->dms); (void)hipFree(h->didx);
+  (void)hipFree(h->terrain_hf); (void)hipFree(h->terrain_cmax); (void)hipFree(h->dms); (void)hipFree(h->didx);
   if (h->herr_pinned) (void)hipHostFree(h->herr_pinned);
   if (h->ev_errno) (void)hipEventDestroy(h->ev_errno);
   delete h;
@@ -5695,6 +5743,16 @@ int go2sim_set_terrain(go2sim_t* h, const int16_t* hf, int rows, int cols, float
   if (h->terrain_hf) (void)hipFree(h->terrain_hf);
   HIPCHK(hipMalloc((void**)&h->terrain_hf, hfm.size() * sizeof(float)));
   HIPCHK(hipMemcpy(h->terrain_hf, hfm.data(), hfm.size() * sizeof(float), hipMemcpyHostToDevice));
+  {                                                                     // coarse maximum map (terrain_pair_out_of_reach)
+    const int cr = (rows + TERRAIN_CB - 1) / TERRAIN_CB, cc = (cols + TERRAIN_CB - 1) / TERRAIN_CB;
+    std::vector<float> cm((size_t)cr * cc, -1e30f);
+    for (int r = 0; r < rows; ++r)
+      for (int c = 0; c < cols; ++c) { float& d = cm[(size_t)(r / TERRAIN_CB) * cc + c / TERRAIN_CB]; const float v = hfm[(size_t)r * cols + c]; d = d < v ? v : d; }
+    if (h->terrain_cmax) (void)hipFree(h->terrain_cmax);
+    HIPCHK(hipMalloc((void**)&h->terrain_cmax, cm.size() * sizeof(float)));
+    HIPCHK(hipMemcpy(h->terrain_cmax, cm.data(), cm.size() * sizeof(float), hipMemcpyHostToDevice));
+    m.terrain_cmax = h->terrain_cmax; m.terrain_crows = cr; m.terrain_ccols = cc;
+  }
   m.terrain_enabled = 1; m.terrain_rows = rows; m.terrain_cols = cols; m.terrain_hs = horizontal_scale; m.terrain_hf = h->terrain_hf;
   m.terrain_xyz_maxmin[0] = (float)rows * horizontal_scale; m.terrain_xyz_maxmin[1] = (float)cols * horizontal_scale; m.terrain_xyz_maxmin[2] = hmax;
   m.terrain_xyz_maxmin[3] = 0.0f; m.terrain_xyz_maxmin[4] = 0.0f; m.terrain_xyz_maxmin[5] = hmin - 1.0f;
