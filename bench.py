@@ -495,7 +495,7 @@ def main():
                        "window": f"steps {W}..{W + K} after the reset" + (" (landing / contact-onset transient)" if W + K < 100 else ""),
                        "step_graph": bool(using_graph), "graph_fallbacks": graph_fallbacks,
                        "loop": ("closed rollout loop: ActorCritic.act + env step + RolloutStorage (information only)" if args.rollout else
-                                "env step, open-loop actions" + ("; rewards / dones land in the rollout storage, GAE + RCCL all-gather of the advantage moments every 24 steps"
+                                "env step, open-loop actions" + ("; rewards / dones land in the rollout storage; every 24 steps: GAE + RCCL all-gather of the advantage moments, all-reduce of the curriculum counters and broadcast of rank 0's global DR scalars (one curriculum level, one set of global draws over all shards)"
                                                                  if world > 1 else ""))},
             "roofline": roofline, "cpu_baseline": cpu, "steady_state": steady, "action_sets": action_sets, "curriculum_live": curriculum_live,
             "workloads": workloads, "ref_protocol_fps": refp, "ref_protocol_fps_anymal_c": refp_anymal, "go2env_class": envcls, "ref_logged": ref_logged(),
