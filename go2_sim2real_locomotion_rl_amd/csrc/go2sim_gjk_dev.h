@@ -747,12 +747,15 @@ template <int W, class S>
 DEV DgResult dgc_contact(const DgPair& pr, S& st, float eps, int tl) {
   GjkCtl c; c.nv = c.nf = c.nmap = c.hz_n = c.ns = 0; c.last_searched = 0; c.overflow = false;
   DgResult r; r.is_col = false; r.overflow = false; r.penetration = 0.0f; r.normal = v3(0, 0, 0); r.pos = v3(0, 0, 0);
+  PHD_BEGIN
   const bool hit = dgc_gjk<W>(pr, st, c, eps, tl);
   team_sync();
+  PHD(38)
   if (!hit) return r;
   V3 w1 = v3(0, 0, 0), w2 = v3(0, 0, 0); bool has_w = false;
   const float dist = dgc_epa<W>(pr, st, c, eps, w1, w2, has_w, tl);
   team_sync();
+  PHD(42)
   if (c.overflow) { r.overflow = true; return r; }
   if (!(dist < 0.0f) || !has_w) return r;
   const V3 nrm = w2 - w1;

@@ -103,3 +103,56 @@ def test_stair_env_bit_exact(oracle_lib, hip_lib, blob, n_envs, steps, kind, see
     _compare_globals(cpu, gpu)
     if kind == "mixed":
         assert n_resets > 0
+
+
+@pytest.mark.gpu
+def test_stair_env_bit_exact_across_launch_paths(oracle_lib, hip_lib, blob):
+    """The heaviest-first dispatch records of the heightfield solver alternate between the collide / solve pairs of the step graph; plain-launch
+    calls in between (scene_step, substep: an odd number of pairs, records left stale or half-used) must neither disturb the results nor the
+    steps that follow.  Which workgroup solves an env never enters its result, so HIP == oracle at tolerance 0 throughout."""
+    from test_parity_gpu import _compare_fields
+
+    n_envs = 130                                                           # not a multiple of the per-XCD grid split: the records must still partition the envs
+    cpu, gpu = CpuEnv(oracle_lib, blob, n_envs, seed=8, task="stairs"), GpuEnv(hip_lib, blob, n_envs, seed=8, task="stairs")
+    cpu.reset(); gpu.reset()
+    acts = make_actions(40, n_envs, seed=8, kind="mixed")
+    for s, a in enumerate(acts):
+        oc, pc, rc, dc, tc = cpu.step(a)
+        og, pg, rg, dg, tg = gpu.step(a)
+        assert np.array_equal(dc, dg) and bits_equal(oc, og) and bits_equal(rc, rg), f"step {s}"
+        if s % 7 == 3:
+            cpu.sim.substep(); gpu.sim.substep()                           # one pair on the plain-launch path
+        if s % 11 == 5:
+            cpu.sim.scene_step(3); gpu.sim.scene_step(3)                   # three pairs
+        if s % 7 == 3 or s % 11 == 5:
+            _compare_fields(cpu, gpu, f"after the extra substeps of step {s}")
+    _compare_fields(cpu, gpu, "final")
+
+
+@pytest.mark.gpu
+def test_fallen_robots_on_the_heightfield(oracle_lib, hip_lib, blob, terrain):
+    """Robots thrown onto the stairs on their side: bodies, thighs and hips touch the heightfield, so the reach test of the terrain pairs keeps
+    them, many prisms are eligible per pair and the five-contact cap is reached (the case the coarse maximum map must not cut)."""
+    from test_parity_gpu import _compare_fields
+    from util import F
+
+    n_envs = 64
+    cpu, gpu = CpuEnv(oracle_lib, blob, n_envs, seed=12, task="stairs"), GpuEnv(hip_lib, blob, n_envs, seed=12, task="stairs")
+    cpu.reset(); gpu.reset()
+    q = cpu.field("F_QPOS").copy()                                         # [19, B]
+    rng = np.random.default_rng(3)
+    roll = rng.uniform(0.9, 2.2, n_envs).astype(np.float32) * rng.choice([-1.0, 1.0], n_envs).astype(np.float32)
+    q[0] += rng.uniform(1.5, 6.0, n_envs).astype(np.float32)               # onto the first flight of stairs
+    q[2] = _height(terrain[0], q[0], q[1]) + np.float32(0.30)               # a body length above the local step
+    q[3], q[4], q[5], q[6] = np.cos(roll / 2), np.sin(roll / 2), 0.0, 0.0
+    for env in (cpu, gpu):
+        env.sim.set_field_np(F("F_QPOS"), q) if env is cpu else env.set_field("F_QPOS", q)
+        env.sim.forward_kinematics()
+    most = 0
+    for s in range(25):
+        cpu.sim.scene_step(2); gpu.sim.scene_step(2)
+        nc, ng = cpu.field("I_N_CONTACTS"), gpu.field("I_N_CONTACTS")
+        assert np.array_equal(nc, ng), f"contact counts differ at scene step {s}"
+        most = max(most, int(nc.max()))
+        _compare_fields(cpu, gpu, f"scene step {s}")
+    assert most >= 15, "the fallen robots rest on several geoms"
