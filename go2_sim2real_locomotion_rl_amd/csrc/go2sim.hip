@@ -2468,12 +2468,17 @@ struct alignas(16) SolverData {
   float H[ND * DS];   // lower triangle: Hessian, then its Cholesky factor; the strict upper triangle mirrors it so that columns read as rows
   float M[ND * DS];
   float qacc[DS], Ma[DS], grad[DS], Mgrad[DS], search[DS], mv[DS], force[DS], acc_smooth[DS], qfrc[DS], ntv[DS], vel[DS];
-  float cdof_ang[ND * 3], cdof_vel[ND * 3], root_com[NL * 3];
+  // cdof / root_com are read while the rows are built and are dead afterwards; `rot` belongs to the rank-1 pipeline (strict build only).  FAST ORDER
+  // keeps the unfactored Hessian of the Newton solve there, one 3 x 3 block per lane of ts_hessian_direct (Ablk[blk][a][q]): no LDS beyond the 8-per-CU budget
+  union {
+    struct { float cdof_ang[ND * 3], cdof_vel[ND * 3], root_com[NL * 3]; alignas(16) float rot[ND][4]; };
+    float Ablk[21 * 9];
+  };
   alignas(16) float aref[R];   // the row-indexed arrays are 16-byte aligned: the redundant passes over the rows use 128-bit LDS reads
   alignas(16) float efc_D[R]; alignas(16) float Jaref[R]; alignas(16) float jv[R]; alignas(16) float efc_force[R];
   alignas(16) float qf0[R]; alignas(16) float qf1[R]; alignas(16) float qf2[R]; alignas(16) float DA[R];
   alignas(16) int active[R]; alignas(16) int prev_active[R];
-  alignas(16) float rot[ND][4];   // pipelined rank-1 updates: rotation (c, 1/c, s) computed by the lane that owns a column, read by the rows below it
+  // (rot[ND][4] of the union above: pipelined rank-1 updates: rotation (c, 1/c, s) computed by the lane that owns a column, read by the rows below it)
 };
 
 // value of lane k of the caller's team (k is a compile-time constant after unrolling): v_readlane through an SGPR instead of a
@@ -2691,9 +2696,56 @@ DEV void ts_hessian_direct(const MT& m, S* s, int tl, int n_con) {
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
           const int i = 3 * bi + a, j = 3 * bj + q;
-          if (j <= i) s->H[i * DS + j] = h[a][q] + s->M[i * DS + j];
+          const float v = h[a][q] + s->M[i * DS + j];
+          if constexpr (T >= NB) s->Ablk[blk * 9 + 3 * a + q] = v;       // the unfactored Hessian stays with its block lane (ts_hessian_update)
+          if (j <= i) s->H[i * DS + j] = v;
         }
     }
+  }
+  team_sync();
+}
+// The Hessian after a change of the active set: the block lanes add / subtract the rows that flipped (first to last, fused multiply-adds on the stored
+// blocks) instead of summing all rows again, and hand the result to the factorisation.  Cost proportional to the flipped rows.
+template <int T, class S, class MT>
+DEV void ts_hessian_update(const MT& m, S* s, int tl, int n_con) {
+  constexpr int NB = 21;
+  static_assert(T >= NB, "one lane per block");
+  const bool on = tl < NB;
+  const int blk = on ? tl : 0;
+  const int bi = (blk >= 15) ? 5 : (blk >= 10) ? 4 : (blk >= 6) ? 3 : (blk >= 3) ? 2 : (blk >= 1) ? 1 : 0;
+  const int bj = blk - bi * (bi + 1) / 2;
+  float h[3][3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int q = 0; q < 3; ++q) h[a][q] = s->Ablk[blk * 9 + 3 * a + q];
+  const float* Ji = &s->J[3 * bi];
+  const float* Jj = &s->J[3 * bj];
+  for (int base = 0; base < n_con; base += T) {
+    const int c_me = base + tl;
+    unsigned long long mask = team_ballot<T>(c_me < n_con && ((s->active[c_me] != 0) != (s->prev_active[c_me] != 0)));
+    while (mask != 0ull) {
+      const int c = base + __ffsll((long long)mask) - 1;
+      mask &= mask - 1ull;
+      const float D = s->efc_D[c], sg = (s->active[c] != 0) ? 1.0f : -1.0f;
+      float jd[3], jj[3];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) { const float j1 = Ji[c * DS + a]; jd[a] = (dm_abs(j1) > m.eps) ? sg * (j1 * D) : 0.0f; jj[a] = Jj[c * DS + a]; }
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) h[a][q] = __builtin_fmaf(jj[q], jd[a], h[a][q]);
+    }
+  }
+  if (on) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        const int i = 3 * bi + a, j = 3 * bj + q;
+        s->Ablk[blk * 9 + 3 * a + q] = h[a][q];
+        if (j <= i) s->H[i * DS + j] = h[a][q];
+      }
   }
   team_sync();
 }
@@ -3648,7 +3700,12 @@ DEV int ts_solve(const MT& m, const E& e, S* s, int tl, int nc, int n_con, unsig
 #if defined(GO2SIM_REPEAT_PHASE) && GO2SIM_REPEAT_PHASE == 4
         ts_hessian_direct<T>(m, s, tl, n_con);
 #endif
+#if GO2SIM_FAST_ORDER
+        if constexpr (T >= 21) { if (it == 0) ts_hessian_direct<T>(m, s, tl, n_con); else ts_hessian_update<T>(m, s, tl, n_con); }
+        else ts_hessian_direct<T>(m, s, tl, n_con);
+#else
         ts_hessian_direct<T>(m, s, tl, n_con);
+#endif
         PH(3)
         ts_cholesky_factor<T>(m, s, tl);
         PH(4)

@@ -347,6 +347,7 @@ struct Env {
   int active[MAXR], prev_active[MAXR];
   real qacc[ND], Ma[ND], grad[ND], Mgrad[ND], search[ND], mv[ND], qfrc_constraint[ND], nt_vec[ND];
   real H[ND][ND];
+  real Hunf[ND][ND];   // FAST ORDER: the unfactored Hessian of the running Newton solve (lower triangle), updated by the rows that flip
   real cost, prev_cost, gauss, quad_gauss[3], gtol; int ls_it, ls_result, improved, solver_iters;
   V3 contact_force[NL];
   real vel_next[ND], qpos_next[NQ];
@@ -1414,6 +1415,7 @@ void hessian_direct(const Model& m, Env& e) {
         part[g] = h;
       }
       e.H[i][j] = ((G == 1) ? part[0] : (part[0] + part[1]) + part[2]) + e.mass_mat[i][j];
+      e.Hunf[i][j] = e.H[i][j];
     }
   return;
 #endif
@@ -1427,6 +1429,22 @@ void hessian_direct(const Model& m, Env& e) {
     for (int i_d1 = m.entities[i_e].dof_start; i_d1 < m.entities[i_e].dof_end; ++i_d1)
       for (int i_d2 = m.entities[i_e].dof_start; i_d2 < i_d1 + 1; ++i_d2) e.H[i_d1][i_d2] = e.H[i_d1][i_d2] + e.mass_mat[i_d1][i_d2];
 }
+#ifdef GO2SIM_FAST_ORDER
+// ts_hessian_update of csrc/go2sim.hip: after a change of the active set the rows that flipped are added to / subtracted from the stored Hessian
+// (first to last, fused multiply-adds) instead of summing all rows again
+void hessian_update(const Model& m, Env& e) {
+  for (int c = 0; c < e.n_con; ++c) {
+    if ((e.active[c] != 0) == (e.prev_active[c] != 0)) continue;
+    const real sg = e.active[c] ? 1.0f : -1.0f;
+    for (int i = 0; i < ND; ++i) {
+      const real j1 = e.jac[c][i];
+      const real jd = (dm_abs(j1) > m.eps) ? sg * (j1 * e.efc_D[c]) : 0.0f;
+      for (int j = 0; j < i + 1; ++j) e.Hunf[i][j] = std::fma(e.jac[c][j], jd, e.Hunf[i][j]);
+    }
+  }
+  for (int i = 0; i < ND; ++i) for (int j = 0; j < i + 1; ++j) e.H[i][j] = e.Hunf[i][j];
+}
+#endif
 // func_cholesky_factor_direct_batch, solver.py:1467-1494
 void cholesky_factor_direct(const Model& m, Env& e) {
 #ifdef GO2SIM_FAST_ORDER
@@ -1798,7 +1816,11 @@ void solve_iter(const Model& m, Env& e) {
     }
     for (int i_c = 0; i_c < e.n_con; ++i_c) e.Jaref[i_c] = e.Jaref[i_c] + e.jv[i_c] * alpha;
     update_constraint(m, e);
+#ifdef GO2SIM_FAST_ORDER
+    if (cholesky_incremental(m, e)) { hessian_update(m, e); cholesky_factor_direct(m, e); }
+#else
     if (cholesky_incremental(m, e)) { hessian_direct(m, e); cholesky_factor_direct(m, e); }
+#endif
     update_gradient(e);
     // func_terminate_or_update_descent_batch, :2645-2688
     real tol_scaled = (m.meaninertia * (real)std::max(1, ND)) * m.tolerance;
