@@ -86,7 +86,7 @@ if len(sys.argv) > 3 and sys.argv[3] == "each":
             rows[g].append((srt.mean(), srt[int(0.99 * len(srt))], srt[int(0.999 * len(srt))], srt[-1]))
             i = int(np.argmax(tot))
             if worst[g] is None or tot[i] > worst[g][0]:
-                worst[g] = (tot[i], {k: a[i, k] / (1 if g == "post_a" else 2) for k in ids}, {k: a[i, k] for k in (range(50, 55) if g == "solver" else list(range(34, 50)) + list(range(56, 62)))})
+                worst[g] = (tot[i], {k: a[i, k] / (1 if g == "post_a" else 2) for k in ids}, {k: a[i, k] for k in (range(50, 55) if g == "solver" else list(range(34, 50)) + list(range(56, 64)))})
     for g, r in rows.items():
         if not r: continue
         r = np.array(r)
@@ -102,7 +102,7 @@ GROUPS = {"solver": [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 11], "dynamics": list(range(2
 NAMES = {0: "stage", 1: "rows", 2: "init Ma/Jaref/update", 3: "Hessian", 4: "Cholesky factor", 5: "gradient solve", 6: "line search", 7: "qacc/constraint update",
          8: "active-set change test (FAST ORDER) / incremental Cholesky", 9: "prologue", 11: "commit", 30: "AABB + clear", 31: "endpoint sort", 32: "candidate pairs", 33: "narrow phase", 26: "terrain pair setup/count", 27: "terrain descriptors", 28: "terrain prism MPR", 29: "terrain replay"}
 # sections inside lane-divergent code (PHD): cycles at id, number of executions at id + 1
-for name, i in (("GJK / EPA query", 34), ("  of which GJK", 38), ("  of which EPA + witness", 42), ("    EPA nearest-face scan", 56), ("    EPA horizon walk", 58), ("    EPA face attachment", 60), ("  support pair evaluations (GJK / EPA)", 48), ("MPR query", 36)):
+for name, i in (("GJK / EPA query, cooperative (quad)", 34), ("GJK / EPA query, one lane (perturbed detections)", 62), ("  of which GJK", 38), ("  of which EPA + witness", 42), ("    EPA nearest-face scan", 56), ("    EPA horizon walk", 58), ("    EPA face attachment", 60), ("  support pair evaluations (GJK / EPA)", 48), ("MPR query", 36)):
     cyc, cnt = a[:, i], a[:, i + 1]
     if cnt.sum() > 0:
         print(f"-- {name}: {cnt.sum() / launches:8.1f} executions per launch (wave level), {cyc.sum() / cnt.sum():9.0f} cycles each; per WG-launch mean {cyc.mean() * PH_MAX_WG / max(1, (cyc > 0).sum()) / launches:9.0f}, slowest 1% {np.sort(cyc)[-max(1, int((cyc > 0).sum()) // 100):].mean() / launches:9.0f}")
