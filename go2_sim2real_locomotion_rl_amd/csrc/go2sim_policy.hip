@@ -1,10 +1,15 @@
 // go2sim_policy.hip -- policy inference next to the env step (include/go2sim_policy.h).  gfx950 only.
 //
-// One kernel evaluates a whole MLP: a workgroup (4 wavefronts) owns 16 rows of the batch and keeps their activations in LDS across all
-// layers; a layer is a [16 x K] x [K x N] product on the fp32 matrix cores (v_mfma_f32_16x16x4_f32, exact fp32: a k-ordered fma chain), the
-// four wavefronts take the 16-column output tiles round-robin, bias and ELU are applied on the accumulator and the result goes to the other
-// LDS buffer.  Weights stream from L2 (0.8 MB actor / 0.9 MB critic, shared by all 256 workgroups of a 4096-row batch).
-// At 4096 rows this is 256 workgroups = one per CU, 3.3 GFLOP for actor + critic.
+// One kernel evaluates a whole MLP: a workgroup (4 wavefronts) owns RT x 16 rows of the batch and keeps their activations in LDS across all
+// layers; a layer is a [16 x K] x [K x N] product per row tile on the fp32 matrix cores (v_mfma_f32_16x16x4_f32, exact fp32: a k-ordered fma chain),
+// the four wavefronts take the 16-column output tiles round-robin, bias and ELU are applied on the accumulator and the result goes to the other
+// LDS buffer.  Weights stream from L2 (0.8 MB actor / 0.9 MB critic); every weight fragment a wavefront loads is used for RT row tiles (RT = 2: 32 rows
+// per workgroup, 132 KB of LDS, one workgroup per CU, 2 x 128 workgroups at 4096 rows; the accumulation chain of every output element is the one of
+// RT = 1).  Counters at 4096 rows (tools/policy_pmc.sh): 65 us per launch, the matrix pipe busy 38 % of the time (1.69 M matrix instructions = the
+// 3.3 GFLOP), 23 % in the 6.5 M other vector instructions (mostly the deterministic exp of the ELU epilogue, which a wavefront runs between its
+// matrix loops), the rest waiting (LDS / L2 round trips and the barriers between layers).  Measured without effect on that split: the row tile
+// (RT = 1 at two workgroups per CU / RT = 2), K steps fetched 1 / 2 / 4 / 8 ahead (MLP_KU), a hand-issued double buffer.
+// At 4096 rows: 3.3 GFLOP for actor + critic.
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -19,9 +24,19 @@
 
 namespace {
 
-constexpr int MAXL = GO2SIM_MLP_MAX_LAYERS, MAXW = GO2SIM_MLP_MAX_WIDTH, TM = 16, NWAVE = 4, LDW = MAXW + 4;
+#ifndef MLP_KU
+#define MLP_KU 1
+#endif
+#ifndef MLP_RT
+#define MLP_RT 2
+#endif
+// weights and biases are reached through pointers stored in the MlpDev record: without the address space the compiler issues FLAT loads, whose
+// counters do not retire in order, and then waits for every outstanding load before each use
+constexpr int MAXL = GO2SIM_MLP_MAX_LAYERS, MAXW = GO2SIM_MLP_MAX_WIDTH, RT = MLP_RT, TM = 16 * RT, NWAVE = 4, LDW = MAXW + 4;
 constexpr uint32_t RNG_POLICY_NOISE = 11;   // purposes 1..10 belong to the environment (csrc/go2sim.hip)
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(1))) float* gcfp;
+typedef const __attribute__((address_space(1))) f32x4* gcf4p;
 
 struct MlpDev {
   int n_layers;
@@ -38,37 +53,55 @@ struct MlpDev {
 
 __device__ __forceinline__ float elu1(float v) { return v > 0.0f ? v : dm_exp(v) - 1.0f; }   // nn.ELU(alpha=1)
 
-// One layer for the 16 rows of the workgroup.  A wavefront works on TG output tiles (16 columns each) at a time: TG independent accumulators
-// share one A fragment per K step and keep TG weight loads in flight (the loop is bound by the latency of the weight stream from L2).
+// One layer for the RT x 16 rows of the workgroup.  A wavefront works on TG output tiles (16 columns each) at a time: RT x TG independent accumulators
+// share one weight fragment per (tile, K step) over the row tiles and one A fragment per (row tile, K step) over the output tiles.
 template <int TG>
 __device__ __forceinline__ void mlp_layer(const MlpDev& M, int l, const float (*in)[LDW], float (*out)[LDW], float* __restrict__ y, int row0, int B, int wave, int lane) {
   const int K = M.kpad[l], N = M.npad[l], dout = M.dout[l], ntiles = N / 16;
-  const float* __restrict__ W = M.W[l];
-  const float* __restrict__ bias = M.b[l];
+  const gcfp W = (gcfp)M.W[l];
+  const gcfp bias = (gcfp)M.b[l];
   const bool last = l == M.n_layers - 1;
   const int arow = lane & 15, kq = lane >> 4;
   const float* ap = &in[arow][4 * kq];
   for (int g0 = wave * TG; g0 < ntiles; g0 += NWAVE * TG) {
-    f32x4 acc[TG];
-    const float* wrow[TG];
+    f32x4 acc[RT][TG];
+    gcfp wrow[TG];
 #pragma unroll
     for (int t = 0; t < TG; ++t) {
-      acc[t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) acc[rt][t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
       const int nt = (g0 + t < ntiles) ? g0 + t : ntiles - 1;          // a short last group recomputes the last tile (not stored)
       wrow[t] = W + (size_t)(nt * 16 + arow) * K + 4 * kq;
     }
-#pragma unroll 2
-    for (int j = 0; j < K; j += 16) {
-      const float4 av = *(const float4*)(ap + j);
-      float4 wv[TG];
+    // K steps in groups of KU: the weight fragments of a whole group are requested first, then the matrix instructions of its steps are issued in
+    // order, each step waiting only for its own fragments (the counter retires in order), so the L2 latency of the weight stream is paid once per
+    // group instead of once per step -- one wavefront per SIMD has nothing else to hide it.  (A hand-issued double buffer across the loop back edge
+    // was tried: the register copies the compiler places on that edge read the buffer before its loads have landed.)
+    constexpr int KU = MLP_KU;
+    for (int j0 = 0; j0 < K; j0 += 16 * KU) {
+      f32x4 wv[KU][TG];
 #pragma unroll
-      for (int t = 0; t < TG; ++t) wv[t] = *(const float4*)(wrow[t] + j);
+      for (int u = 0; u < KU; ++u) {
+        const int j = (j0 + 16 * u < K) ? j0 + 16 * u : K - 16;         // (a short last group re-reads the last step: no branch around the loads)
 #pragma unroll
-      for (int t = 0; t < TG; ++t) {
-        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, wv[t].x, acc[t], 0, 0, 0);   // k = j + 4 q + 0, q = 0..3
-        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, wv[t].y, acc[t], 0, 0, 0);   // k = j + 4 q + 1
-        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, wv[t].z, acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, wv[t].w, acc[t], 0, 0, 0);
+        for (int t = 0; t < TG; ++t) wv[u][t] = *(gcf4p)(wrow[t] + j);
+      }
+#pragma unroll
+      for (int u = 0; u < KU; ++u) {
+        if (j0 + 16 * u < K) {
+          float4 av[RT];
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt) av[rt] = *(const float4*)(ap + (size_t)rt * 16 * LDW + j0 + 16 * u);
+#pragma unroll
+          for (int t = 0; t < TG; ++t)
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+              acc[rt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt].x, wv[u][t][0], acc[rt][t], 0, 0, 0);   // k = j + 4 q + 0, q = 0..3
+              acc[rt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt].y, wv[u][t][1], acc[rt][t], 0, 0, 0);   // k = j + 4 q + 1
+              acc[rt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt].z, wv[u][t][2], acc[rt][t], 0, 0, 0);
+              acc[rt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt].w, wv[u][t][3], acc[rt][t], 0, 0, 0);
+            }
+        }
       }
     }
 #pragma unroll
@@ -77,21 +110,23 @@ __device__ __forceinline__ void mlp_layer(const MlpDev& M, int l, const float (*
       const int n = (g0 + t) * 16 + arow;                              // accumulator element i of this lane: row 4 * (lane >> 4) + i, column lane & 15
       const float bv = bias[n];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int r = 4 * kq + i;
-        const float v = acc[t][i] + bv;
-        if (last) {
-          const int gr = row0 + r;
-          if (gr < B && n < dout) y[(size_t)gr * dout + n] = v;
-        } else {
-          out[r][n] = elu1(v);
+      for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int r = 16 * rt + 4 * kq + i;
+          const float v = acc[rt][t][i] + bv;
+          if (last) {
+            const int gr = row0 + r;
+            if (gr < B && n < dout) y[(size_t)gr * dout + n] = v;
+          } else {
+            out[r][n] = elu1(v);
+          }
         }
-      }
     }
   }
 }
 
-// blockIdx.y selects the network: actor and critic of one policy step share a launch (2 x 256 workgroups at 4096 rows, two per CU)
+// blockIdx.y selects the network: actor and critic of one policy step share a launch (2 x 128 workgroups of 32 rows at 4096 rows, one per CU)
 __global__ __launch_bounds__(64 * NWAVE) void k_mlp_forward(MlpDev M0, const float* __restrict__ x0, float* __restrict__ y0,
                                                             MlpDev M1, const float* __restrict__ x1, float* __restrict__ y1, int B) {
   __shared__ alignas(16) float act[2][TM][LDW];
