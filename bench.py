@@ -401,6 +401,18 @@ def main():
             return
         sim.env_step(actions[s], obs, priv, rew, rst, to, stream)
 
+    if dist is not None:
+        # The three collectives of a rollout end (all-gather of the advantage moments, all-reduce of the curriculum counters, broadcast of the global DR
+        # scalars) are issued once on dummy tensors before anything is timed: RCCL sets up channels lazily per collective type, and with the driver's
+        # window (20 steps from step 5) the first rollout end falls inside the timed region.
+        _w3 = torch.zeros(3, device=coll_device, dtype=torch.float64)
+        _wg = torch.empty(3 * world, device=coll_device, dtype=torch.float64)
+        dist.all_gather_into_tensor(_wg, _w3)
+        _w5 = torch.zeros(5, device=coll_device, dtype=torch.float64)
+        dist.all_reduce(_w5, op=dist.ReduceOp.SUM)
+        _w10 = torch.zeros(10, device=coll_device, dtype=torch.float64)
+        dist.broadcast(_w10, src=0)
+        torch.cuda.synchronize()
     for s in range(W):
         step(s)
     torch.cuda.synchronize()
