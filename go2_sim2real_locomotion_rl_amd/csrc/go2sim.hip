@@ -506,7 +506,7 @@ constexpr int MODELS_LDS_BYTES = lds_dma_bytes((int)sizeof(ModelS));
   X(last_foot_contact, 4) X(terrain_row, 1) X(terrain_key, 1)
 
 #define GO2SIM_AOS_FLOAT_FIELDS(X)                                                                                   \
-  X(acc, ND) X(qacc_ws, ND) X(force, ND) X(qf_smooth, ND) X(acc_smooth, ND) X(qfrc_constraint, ND) X(mass_mat, ND * ND)  \
+  X(acc, ND) X(qacc_ws, ND) X(force, ND) X(qf_smooth, ND) X(acc_smooth, ND) X(qfrc_constraint, ND) X(mass_mat, NTRI)  \
   X(cdof_ang, ND * 3) X(cdof_vel, ND * 3) X(cdofd_ang, ND * 3) X(cdofd_vel, ND * 3) X(cinr_inertial, NL * 9)            \
   X(cinr_pos, NL * 3) X(cinr_mass, NL) X(i_pos, NL * 3) X(i_quat, NL * 4) X(g_pos, NG * 3) X(g_quat, NG * 4)              \
   X(sort_value, 2 * NG) X(c_pos, MAXC * 3) X(c_normal, MAXC * 3) X(c_pen, MAXC) X(c_friction, MAXC) X(c_sol, MAXC * 7)    \
@@ -612,7 +612,7 @@ struct E {
   FA(episode_sums) FA(rew_terms) FA(rew) FA(obs) FA(priv)
   IA(n_contacts) IA(n_con) IA(err) IA(is_warmstart) IA(first_time) IA(n_broad) IA(solver_iters) IA(ctrl_mode)
   IA(gjk_fallback) IA(delay_steps) IA(episode_length) IA(reset_buf) IA(push_remaining) IA(foot_contact) IA(last_foot_contact) IA(terrain_row) IA(terrain_key)
-  AA(acc) AA(qacc_ws) AA(force) AA(qf_smooth) AA(acc_smooth) AA(qfrc_constraint) AA2(mass_mat, ND) AA3(cdof_ang) AA3(cdof_vel) AA3(cdofd_ang)
+  AA(acc) AA(qacc_ws) AA(force) AA(qf_smooth) AA(acc_smooth) AA(qfrc_constraint) AA3(cdof_ang) AA3(cdof_vel) AA3(cdofd_ang)
   AA3(cdofd_vel) AA9(cinr_inertial) AA3(cinr_pos) AA(cinr_mass) AA3(i_pos) AA4(i_quat) AA3(g_pos) AA4(g_quat) AA(sort_value) AA3(c_pos) AA3(c_normal)
   AA(c_pen) AA(c_friction) AA2(c_sol, 7) AA3(c_force) AA(efc_force) AA3(normal_cache)
   AIA(sort_ig) AIA(broad) AIA(c_geom) AIA(c_link) AIA(ncache_valid)
@@ -1276,7 +1276,9 @@ DEV void tk_dynamics(const MT& m, const E& e, DynData* s, int tl, bool env_valid
   }
   team_sync();
   if (env_valid) for (int i_d = tl; i_d < ND; i_d += T) { float a = s->out[i_d]; astore(e, AO(acc_smooth), i_d, a); astore(e, AO(acc), i_d, a); }
-  if (env_valid) for (int k = tl; k < ND * ND; k += T) astore(e, AO(mass_mat), k, s->M[k]);
+  // the mass matrix is symmetric: its lower triangle goes to the record packed (entry (i, j), j <= i, at i (i + 1) / 2 + j: 684 instead of 1296 bytes per env
+  // written here and read by the solver)
+  if (env_valid) for (int idx = tl; idx < NTRI; idx += T) { int i, j; tri_index(m, idx, i, j); astore(e, AO(mass_mat), idx, s->M[i * ND + j]); }
   PH(25)
 }
 
@@ -3569,7 +3571,7 @@ DEV int ts_solve(const MT& m, const E& e, S* s, int tl, int nc, int n_con, unsig
 #endif
   // ---- stage inputs (branch-free: all loads of the stage are in flight together) ----
   const bool ws = (n_con > 0) && ws_flag;
-  team_stage<ND * ND, T>(tl, [&](int k) { return aload(e, AO(mass_mat), k); }, [&](int k, float v) { s->M[(k / ND) * DS + (k % ND)] = v; });
+  team_stage<NTRI, T>(tl, [&](int k) { return aload(e, AO(mass_mat), k); }, [&](int k, float v) { int i, j; tri_index(m, k, i, j); s->M[i * DS + j] = v; s->M[j * DS + i] = v; });   // packed lower triangle
   team_stage<ND * 3, T>(tl, [&](int k) { return aload(e, AO(cdof_ang), k); }, [&](int k, float v) { s->cdof_ang[k] = v; });
   team_stage<ND * 3, T>(tl, [&](int k) { return aload(e, AO(cdof_vel), k); }, [&](int k, float v) { s->cdof_vel[k] = v; });
   team_stage<NL * 3, T>(tl, [&](int k) { return gload(e, FO(root_com), k); }, [&](int k, float v) { s->root_com[k] = v; });
@@ -5234,6 +5236,22 @@ __global__ void k_errno_reduce(Pool P, int* out) {
 }
 // [n_envs][k] row-major copy of an env buffer
 // field API <-> AoS records (32-bit words): rows[j][b] = rec[b][off + j]
+// GO2SIM_F_MASS_MAT presents the reference's full [n_dofs, n_dofs] matrix; the record holds its lower triangle packed
+__global__ void k_mass_mat_to_rows(const float* __restrict__ rec, int stride, int off, int B, float* __restrict__ rows) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= ND * ND * B) return;
+  const int idx = t / B, b = t - idx * B, i = idx / ND, j = idx - i * ND, a = i > j ? i : j, c = i > j ? j : i;
+  rows[t] = rec[(size_t)b * stride + off + a * (a + 1) / 2 + c];
+}
+__global__ void k_rows_to_mass_mat(const float* __restrict__ rows, float* __restrict__ rec, int stride, int off, int B) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= NTRI * B) return;
+  const int p = t / B, b = t - p * B;
+  int i = 0;
+  while ((i + 1) * (i + 2) / 2 <= p) ++i;
+  const int j = p - i * (i + 1) / 2;
+  rec[(size_t)b * stride + off + p] = rows[(size_t)(i * ND + j) * B + b];
+}
 __global__ void k_aos_to_rows(const int* __restrict__ rec, int stride, int off, int k, int B, int* __restrict__ rows) {
   int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= k * B) return;
@@ -5739,7 +5757,8 @@ int go2sim_get_field(go2sim_t* h, int field, void* dst, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   if (aa) {
     const int* rec = ii ? h->P.ia : (const int*)h->P.fa;
-    hipLaunchKernelGGL(k_aos_to_rows, dim3((k * h->B + 255) / 256), dim3(256), 0, s, rec, ii ? AISTRIDE : ASTRIDE, off, k, h->B, (int*)dst);
+    if (field == GO2SIM_F_MASS_MAT) hipLaunchKernelGGL(k_mass_mat_to_rows, dim3((k * h->B + 255) / 256), dim3(256), 0, s, (const float*)h->P.fa, ASTRIDE, off, h->B, (float*)dst);
+    else hipLaunchKernelGGL(k_aos_to_rows, dim3((k * h->B + 255) / 256), dim3(256), 0, s, rec, ii ? AISTRIDE : ASTRIDE, off, k, h->B, (int*)dst);
     if (field == GO2SIM_F_NORMAL_CACHE) hipLaunchKernelGGL(k_ncache_mask_rows, dim3((NPAIR * h->B + 255) / 256), dim3(256), 0, s, h->P, (float*)dst);
     HIPCHK(hipGetLastError());
   } else {
@@ -5754,7 +5773,8 @@ int go2sim_set_field(go2sim_t* h, int field, const void* src, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   if (aa) {
     int* rec = ii ? h->P.ia : (int*)h->P.fa;
-    hipLaunchKernelGGL(k_rows_to_aos, dim3((k * h->B + 255) / 256), dim3(256), 0, s, (const int*)src, rec, ii ? AISTRIDE : ASTRIDE, off, k, h->B);
+    if (field == GO2SIM_F_MASS_MAT) hipLaunchKernelGGL(k_rows_to_mass_mat, dim3((NTRI * h->B + 255) / 256), dim3(256), 0, s, (const float*)src, h->P.fa, ASTRIDE, off, h->B);
+    else hipLaunchKernelGGL(k_rows_to_aos, dim3((k * h->B + 255) / 256), dim3(256), 0, s, (const int*)src, rec, ii ? AISTRIDE : ASTRIDE, off, k, h->B);
     if (field == GO2SIM_F_NORMAL_CACHE) hipLaunchKernelGGL(k_ncache_set_valid, dim3((NCV * h->B + 255) / 256), dim3(256), 0, s, h->P);
     HIPCHK(hipGetLastError());
   } else {
