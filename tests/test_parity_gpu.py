@@ -387,3 +387,24 @@ def test_normal_cache_field_semantics(oracle_lib, hip_lib, blob):
         assert bits_equal(cpu.field("F_CONTACT_PEN"), gpu.field("F_CONTACT_PEN")), s
     gpu.sim.reset_caches(None, 0); cpu.sim.reset_caches(None, 0)
     assert not gpu.field("F_NORMAL_CACHE").any() and not cpu.field("F_NORMAL_CACHE").any()
+
+
+@pytest.mark.gpu
+def test_mass_matrix_field_semantics(oracle_lib, hip_lib, blob):
+    """The device record holds the mass matrix as a packed lower triangle (what k_dynamics hands to the solver); GO2SIM_F_MASS_MAT presents the
+    reference's full symmetric [n_dofs, n_dofs] matrix (`rigid_solver.mass_mat`): equal to the oracle's, symmetric, and an uploaded matrix reads
+    back unchanged."""
+    n = 24
+    cpu, gpu = CpuEnv(oracle_lib, blob, n, seed=3), GpuEnv(hip_lib, blob, n, seed=3)
+    cpu.reset(); gpu.reset()
+    for a in make_actions(5, n, seed=3, kind="0.5"):
+        cpu.step(a); gpu.step(a)
+    Mc, Mg = cpu.field("F_MASS_MAT"), gpu.field("F_MASS_MAT")
+    assert Mg.shape == (18 * 18, n) and bits_equal(Mc, Mg)
+    full = Mg.reshape(18, 18, n)
+    assert np.array_equal(full, full.transpose(1, 0, 2)) and (np.abs(full[np.arange(18), np.arange(18)]) > 0).all()
+    rng = np.random.default_rng(1)
+    low = np.tril(rng.standard_normal((18, 18))).astype(np.float32)
+    sym = (low + np.tril(low, -1).T)[:, :, None] * np.linspace(1.0, 2.0, n, dtype=np.float32)[None, None, :]
+    gpu.set_field("F_MASS_MAT", sym.reshape(18 * 18, n).astype(np.float32))
+    assert bits_equal(gpu.field("F_MASS_MAT"), sym.reshape(18 * 18, n).astype(np.float32))
