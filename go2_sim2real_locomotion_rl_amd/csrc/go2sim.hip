@@ -752,10 +752,11 @@ DEV int lpt_solver_xcd(int b, int B, int epw_s) {                          // XC
   return r + (L - r * (q + 1)) / (q > 0 ? q : 1);
 }
 // (the contact count alone is the better key: weighting it with the Newton iterations of the previous solve measured 2-3 % slower)
-DEV void lpt_file(int* __restrict__ rec, int cap, int b, int B, int epw_s, int nc) {
-  const int x = lpt_solver_xcd(b, B, epw_s), cls = LPT_CLS - 1 - imn(LPT_CLS - 1, nc);
+// files solver block L (= its epw_s consecutive envs) under the largest contact count of its envs
+DEV void lpt_file(int* __restrict__ rec, int cap, int L, int B, int epw_s, int nc) {
+  const int x = lpt_solver_xcd(L * epw_s, B, epw_s), cls = LPT_CLS - 1 - imn(LPT_CLS - 1, nc);
   const int pos = atomicAdd(&rec[x * LPT_CLS + cls], 1);
-  if (pos < cap) rec[8 * LPT_CLS + (x * LPT_CLS + cls) * cap + pos] = b;
+  if (pos < cap) rec[8 * LPT_CLS + (x * LPT_CLS + cls) * cap + pos] = L;
 }
 // env of (workgroup, slot) in the solver grid; B (= no env) past the end of the XCD's list
 DEV int lpt_take(const int* __restrict__ rec, int cap, int B, int epw, int slot) {
@@ -766,9 +767,9 @@ DEV int lpt_take(const int* __restrict__ rec, int cap, int B, int epw, int slot)
   if (rec == nullptr) return ident;
   const int n = (int)gridDim.x, q = n >> 3, r = n & 7, x = (int)blockIdx.x & 7;
   const int start = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q), nblk = q + (x < r ? 1 : 0);
-  const int lo = start * epw, hi = imn(B, (start + nblk) * epw);
-  const int expected = hi > lo ? hi - lo : 0;
-  const int local = ((int)blockIdx.x >> 3) * epw + slot;
+  (void)start;
+  const int expected = nblk;                                             // blocks of this XCD
+  const int local = (int)blockIdx.x >> 3;
   int total = 0, cls = -1, off = 0;
 #pragma unroll
   for (int c = 0; c < LPT_CLS; ++c) {
@@ -778,7 +779,7 @@ DEV int lpt_take(const int* __restrict__ rec, int cap, int B, int epw, int slot)
   }
   if (total != expected) return ident;
   if (cls < 0 || off >= cap) return B;
-  return rec[8 * LPT_CLS + (x * LPT_CLS + cls) * cap + off];
+  return rec[8 * LPT_CLS + (x * LPT_CLS + cls) * cap + off] * epw + slot;
 }
 
 struct KinData {
@@ -2421,9 +2422,14 @@ __global__ __launch_bounds__(64) void k_collide_team(Pool P, const Model* __rest
   }
   if (tl == 0) {
     e.n_broad()[0] = n_broad; e.n_contacts()[0] = imn(nc_run, m.max_contact_pairs);
-    if (lpt_rec) lpt_file(lpt_rec, lpt_cap, b, P.B, solver_epw, imn(nc_run, m.max_contact_pairs));
+    s->cnt[0] = imn(nc_run, m.max_contact_pairs);
   }
   team_sync();
+  if (lpt_rec && tl == 0 && b % solver_epw == 0) {                       // the first env of a solver block files it (the block's envs sit in this wavefront)
+    int key = s->cnt[0];
+    for (int k = 1; k < solver_epw; ++k) if (b + k < P.B && slot + k < EPW) key = imx(key, lds[slot + k].cnt[0]);
+    lpt_file(lpt_rec, lpt_cap, b / solver_epw, P.B, solver_epw, key);
+  }
   for (int i = tl; i < NCV; i += T) e.ncache_valid()[i] = (int)s->ncv[i];
   PH(33)
 }
@@ -5319,7 +5325,7 @@ struct go2sim {
   GjkStoreFull* gjk_scratch = nullptr;      // full-capacity polytope records of the GJK / EPA fallback (queries that outgrow their LDS slot) and
                                             // prism descriptors of the terrain pass: one block per (env, narrow-phase lane)
   SolverData<MAXR>* solver_ovf = nullptr;   // per-env global scratch for solves that do not fit in LDS (> RL rows)
-  int* lpt = nullptr; int lpt_cap = 0; int lpt_parity = 0; bool use_lpt = true;   // heaviest-first dispatch records of the solver (two, alternating)
+  int* lpt = nullptr; int lpt_cap = 0; int lpt_parity = 0; bool use_lpt = true, lpt_flat = false;   // heaviest-first dispatch records of the solver (two, alternating)
   // One env step = 11 dependent kernel launches (12 with terrain).  Issued one by one they cost the host ~20 us each -- close to the GPU time of
   // the step -- so the sequence is kept as an instantiated hipGraph: per step the three step-dependent kernel nodes get their new arguments
   // (actions pointer, step counter, ring index) and the graph is launched with one call.  GO2SIM_NO_GRAPH=1 (or timing mode) uses plain launches.
@@ -5395,11 +5401,18 @@ static void launch_dynamics(go2sim* h, hipStream_t s, const float* actions = nul
   else hipLaunchKernelGGL(k_dynamics_team<64>, gd, b, 0, s, h->P, h->dms);
 }
 static int solver_epw(const go2sim* h) { return 64 / (h->hm.terrain_enabled ? h->terrain_solver_team : h->solver_team); }
+// the envs of a solver block must sit in one collision wavefront (their contact counts meet there).  On flat ground (two envs per solver wavefront, one
+// residency round) the sorted order measured 1-3 % SLOWER than the identity order, with single envs as well as with adjacent pairs as the sorted unit
+// (the record lookup delays every workgroup's first loads; there is no second round to win it back): off unless GO2SIM_LPT_FLAT=1
+static bool lpt_enabled(const go2sim* h) {
+  const int epw_c = 64 / h->collide_team, epw_s = solver_epw(h);
+  if (!h->use_lpt || epw_s > epw_c || epw_c % epw_s != 0) return false;
+  return epw_s == 1 || h->lpt_flat;
+}
 static size_t lpt_record_ints(const go2sim* h) { return (size_t)8 * LPT_CLS * (1 + h->lpt_cap); }
 static void launch_collide_solve(go2sim* h, hipStream_t s) {
   dim3 b(WG);
-  const bool lpt_on = h->use_lpt && solver_epw(h) == 1;             // one env per wavefront (heightfield): two residency rounds.  (Two envs per wavefront on flat
-  //                                                                   ground: one round, and unsorted neighbours share the lines of the [feature][env] rows -- measured slower.)
+  const bool lpt_on = lpt_enabled(h);
   int* lpt_cur = lpt_on ? h->lpt + h->lpt_parity * lpt_record_ints(h) : nullptr;
   int* lpt_next = lpt_on ? h->lpt + (1 - h->lpt_parity) * lpt_record_ints(h) : nullptr;
   h->lpt_parity ^= 1;
@@ -5524,7 +5537,7 @@ static bool step_graph_build(go2sim* h, const float* actions, float* obs, float*
   if (!fuse_pre(h)) ok = add_dynamics();
   for (int i = 0; i < substeps && ok; ++i) {                               // same order as launch_substeps
     // heaviest-first records: substep i uses record i & 1 and clears the other one (an odd substep count would leave record 0 uncleared: no records then)
-    const bool lpt_on = h->use_lpt && (substeps % 2 == 0) && solver_epw(h) == 1;
+    const bool lpt_on = lpt_enabled(h) && (substeps % 2 == 0);
     int* lpt_cur = lpt_on ? h->lpt + (i & 1) * lpt_record_ints(h) : nullptr;
     int* lpt_next = lpt_on ? h->lpt + (1 - (i & 1)) * lpt_record_ints(h) : nullptr;
     const int epw_s = solver_epw(h);
@@ -5629,6 +5642,7 @@ int go2sim_create(const void* blob, size_t nbytes, int n_envs, int device, uint6
     if (const char* t = getenv("GO2SIM_SOLVER_TEAM")) { int v = atoi(t); if (v == 16 || v == 32 || v == 64) h->solver_team = v; }
     if (const char* t = getenv("GO2SIM_TERRAIN_SOLVER_TEAM")) { int v = atoi(t); if (v == 32 || v == 64) h->terrain_solver_team = v; }
     if (const char* t = getenv("GO2SIM_NO_LPT")) { if (atoi(t) != 0) h->use_lpt = false; }
+    if (const char* t = getenv("GO2SIM_LPT_FLAT")) { h->lpt_flat = atoi(t) != 0; }
     h->lpt_cap = n_envs / 8 + 72;
     CK(hipMalloc((void**)&h->lpt, 2 * lpt_record_ints(h) * sizeof(int)));
     CK(hipMemset(h->lpt, 0, 2 * lpt_record_ints(h) * sizeof(int)));
