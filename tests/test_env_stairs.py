@@ -156,3 +156,39 @@ def test_fallen_robots_on_the_heightfield(oracle_lib, hip_lib, blob, terrain):
         most = max(most, int(nc.max()))
         _compare_fields(cpu, gpu, f"scene step {s}")
     assert most >= 15, "the fallen robots rest on several geoms"
+
+
+@pytest.mark.gpu
+def test_robots_at_the_border_of_the_heightfield(oracle_lib, hip_lib, blob, terrain):
+    """Robots dropped on the rim of the heightfield and just outside it: the cell ranges of the terrain pairs are clamped (or empty), and the reach
+    test of the pairs works on clamped block ranges of the coarse maximum map.  HIP == oracle through the landing (or the fall past the edge)."""
+    from test_parity_gpu import _compare_fields
+    from util import F
+
+    hfm, info = terrain
+    x_max, y_half = np.float32(info["total_x_m"]), np.float32(info["total_y_m"] / 2.0)
+    n_envs = 48
+    cpu, gpu = CpuEnv(oracle_lib, blob, n_envs, seed=14, task="stairs"), GpuEnv(hip_lib, blob, n_envs, seed=14, task="stairs")
+    cpu.reset(); gpu.reset()
+    q = cpu.field("F_QPOS").copy()
+    rng = np.random.default_rng(5)
+    edge = rng.integers(0, 4, n_envs)                                      # which rim: x = 0, x = x_max, y = -y_half, y = +y_half
+    off = rng.uniform(-0.35, 0.35, n_envs).astype(np.float32)              # inside / astride / outside the rim
+    along_x = rng.uniform(0.5, float(x_max) - 0.5, n_envs).astype(np.float32)
+    along_y = rng.uniform(-float(y_half) + 0.5, float(y_half) - 0.5, n_envs).astype(np.float32)
+    q[0] = np.where(edge == 0, off, np.where(edge == 1, x_max + off, along_x))
+    q[1] = np.where(edge == 2, -y_half + off, np.where(edge == 3, y_half + off, along_y))
+    inside_x = np.clip(q[0], 0.0, x_max - np.float32(0.06)); inside_y = np.clip(q[1], -y_half, y_half - np.float32(0.06))
+    q[2] = _height(hfm, inside_x, inside_y) + np.float32(0.45)
+    yaw = rng.uniform(-np.pi, np.pi, n_envs).astype(np.float32)
+    q[3], q[4], q[5], q[6] = np.cos(yaw / 2), 0.0, 0.0, np.sin(yaw / 2)
+    cpu.sim.set_field_np(F("F_QPOS"), q); gpu.set_field("F_QPOS", q)
+    cpu.sim.forward_kinematics(); gpu.sim.forward_kinematics()
+    touched = 0
+    for s in range(30):
+        cpu.sim.scene_step(2); gpu.sim.scene_step(2)
+        nc, ng = cpu.field("I_N_CONTACTS"), gpu.field("I_N_CONTACTS")
+        assert np.array_equal(nc, ng), f"contact counts differ at scene step {s}"
+        touched = max(touched, int((nc > 0).sum()))
+        _compare_fields(cpu, gpu, f"scene step {s}")
+    assert touched >= n_envs // 3, "a good part of the robots landed on the rim"
