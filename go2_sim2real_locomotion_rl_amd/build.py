@@ -73,6 +73,43 @@ def build_oracle(force=False, verbose=True):
     return ORACLE_LIB
 
 
+def build_oracle_variant(name, extra_flags, force=False, verbose=True):
+    """A diagnostic BUILD of the CPU oracle (oracle/libgo2sim_cpu_<name>.so), e.g. ("rng_const_fast", ["-DGO2SIM_RNG_CONST", "-DGO2SIM_FAST_ORDER"]):
+    the generator replaced by the constant schedule of include/go2sim_detmath.h, the counterpart of the reference env files run with
+    torch.rand / randn_like / randint / randperm replaced by the same schedule (tools/make_ref_env_fixtures.py)."""
+    out = os.path.join(REPO_ROOT, "oracle", f"libgo2sim_cpu_{name}.so")
+    deps = [ORACLE_SRC, ORACLE_SRC_POLICY, os.path.join(REPO_ROOT, "oracle", "gjk_epa_cpu.h"), *_headers()]
+    if not force and _newer(out, *deps):
+        return out
+    cmd = ["g++", *CPU_FLAGS, *extra_flags, ORACLE_SRC, ORACLE_SRC_POLICY, "-o", out]
+    if verbose:
+        print("[build]", " ".join(cmd), file=sys.stderr)
+    subprocess.run(cmd, check=True)
+    return out
+
+
+# diagnostic builds the tests use (name -> extra flags); `python -m go2_sim2real_locomotion_rl_amd.build --variants` builds them all so that they
+# travel to the GPU box with the snapshot instead of being compiled there
+HIP_VARIANTS = {
+    "bracket_inline": ["-DGO2SIM_BRACKET_INLINE"],          # tests/test_bracket_inline.py (expected failure)
+    "rng_const": ["-DGO2SIM_RNG_CONST"],                     # tests/test_ref_env_rng_fixtures.py
+    "strict": ["-DGO2SIM_FAST_ORDER=0"],                     # tests/test_strict_order_gpu.py: the reference's summation order
+}
+ORACLE_VARIANTS = {
+    "rng_const": ["-DGO2SIM_RNG_CONST"],
+    "rng_const_fast": ["-DGO2SIM_RNG_CONST", "-DGO2SIM_FAST_ORDER"],
+}
+
+
+def build_variants(force=False, verbose=True):
+    for name, flags in ORACLE_VARIANTS.items():
+        build_oracle_variant(name, flags, force=force, verbose=verbose)
+    for name, flags in HIP_VARIANTS.items():
+        build_hip_variant(name, flags, force=force, verbose=verbose)
+
+
 if __name__ == "__main__":
     build_hip(force="--force" in sys.argv)
     build_oracle(force="--force" in sys.argv)
+    if "--variants" in sys.argv:
+        build_variants(force="--force" in sys.argv)

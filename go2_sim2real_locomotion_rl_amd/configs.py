@@ -147,8 +147,6 @@ def flatten_walk_cfg(num_envs, env_cfg, obs_cfg, reward_cfg, command_cfg, *, mod
     f[F("CMD_START_FRAC")] = command_cfg.get("cmd_curriculum_start_frac", 0.1)
     i[I("CMD_CURRICULUM")] = int(bool(command_cfg.get("cmd_curriculum", False)))
     i[I("COMPOUND_COMMANDS")] = int(bool(command_cfg.get("compound_commands", True)))
-    if not i[I("COMPOUND_COMMANDS")]:
-        raise NotImplementedError("compound_commands=False is not used by the reference configs")
     i[I("N_STANDING")] = int(float(command_cfg.get("rel_standing_envs", 0.0)) * num_envs)
 
     kp_nom, kd_nom = float(env_cfg.get("kp", 60.0)), float(env_cfg.get("kd", 2.0))

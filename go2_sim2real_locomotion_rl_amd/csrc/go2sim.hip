@@ -3952,17 +3952,38 @@ typedef go2sim_env_globals_t Glob;
 
 enum { RNG_ACTION_NOISE = 1, RNG_PUSH = 2, RNG_CMD = 3, RNG_OBS_NOISE = 4, RNG_RESET_DR = 5, RNG_GLOBAL_DR = 6, RNG_RESET_CMD = 7, RNG_RESET_POSE = 8, RNG_TERRAIN_ROW = 9, RNG_TERRAIN_PERM = 10 };
 __host__ __device__ inline dm_u4 rng4(uint64_t seed, uint32_t purpose, uint32_t env, uint32_t step, uint32_t idx) {
+#ifdef GO2SIM_RNG_CONST   // diagnostic build (include/go2sim_detmath.h): every word of a draw is its stream key
+  dm_u4 o; o.v[0] = o.v[1] = o.v[2] = o.v[3] = step; (void)purpose; (void)env; (void)idx; (void)seed; return o;
+#else
   return dm_philox(env, step, purpose, idx, (uint32_t)seed, (uint32_t)(seed >> 32));
+#endif
 }
 // gs_rand_float, go2_env_walk.py:7-8: `(upper - lower) * torch.rand(...) + lower` with python-float bounds: the difference is formed in float64 and
 // both scalars are rounded to float32 where they meet the float32 tensor
 __host__ __device__ inline float rand_float(double lower, double upper, uint32_t r) { return (float)(upper - lower) * dm_u01(r) + (float)lower; }
+#ifdef GO2SIM_RNG_CONST
+DEV int rand_int(int lower, int upper, uint32_t r) { return lower + (int)(dm_rng_const_u(r) * (float)(upper - lower + 1)); }
+#else
 DEV int rand_int(int lower, int upper, uint32_t r) { return lower + (int)(r % (uint32_t)(upper - lower + 1)); }   // gs_rand_int, :11-13
+#endif
 __host__ __device__ inline double clamp01d(double x) { return x < 0.0 ? 0.0 : (x > 1.0 ? 1.0 : x); }
 __host__ __device__ inline double lerpd(double a, double b, double t) { t = clamp01d(t); return a + (b - a) * t; }
 // _lerp_range(easy, hard, t_sample), go2_env_walk.py:37-39: python floats
 __host__ __device__ inline double lerp_lo(const DCfg& c, int easy_lo, double t) { return lerpd(c.d[easy_lo], c.d[easy_lo + 2], t); }
 __host__ __device__ inline double lerp_hi(const DCfg& c, int easy_lo, double t) { return lerpd(c.d[easy_lo + 1], c.d[easy_lo + 3], t); }
+// Go2Env._resample_commands, go2_env_walk.py:927-963: all three components (compound commands), or ONE component chosen by `randint(0, 3)` with the
+// other two at zero; the first `rel_standing_envs * num_envs` envs always stand (:367-368, :960-963).  Words 0..2 of the block are the
+// components' uniforms, word 3 the choice.
+DEV void sample_commands(const DCfg& c, const Glob& g, const dm_u4& r, int b, float& cx, float& cy, float& cz) {
+  cx = rand_float(g.cmd_x_lo, g.cmd_x_hi, r.v[0]); cy = rand_float(g.cmd_y_lo, g.cmd_y_hi, r.v[1]); cz = rand_float(g.cmd_yaw_lo, g.cmd_yaw_hi, r.v[2]);
+  if (!c.i[GO2SIM_IC_COMPOUND_COMMANDS]) {
+    const int choice = rand_int(0, 2, r.v[3]);
+    if (choice != 0) cx = 0.0f;
+    if (choice != 1) cy = 0.0f;
+    if (choice != 2) cz = 0.0f;
+  }
+  if (b < c.i[GO2SIM_IC_N_STANDING]) { cx = 0.0f; cy = 0.0f; cz = 0.0f; }
+}
 
 // torch-side helpers of genesis/utils/geom.py used by Go2Env (evaluation order of the torch code)
 DEV Q4 tc_quat_mul(Q4 u, Q4 v) {                                   // geom.py:989-1007
@@ -4609,8 +4630,8 @@ __global__ __launch_bounds__(WG) void k_env_post_a(Pool P, const Model* __restri
   if (ep_len % c.i[GO2SIM_IC_RESAMPLE_STEPS] == 0) {
     auto cmd = e.commands();
     dm_u4 r = rng4(seed, RNG_CMD, b, step_count, 0);
-    float cx = rand_float(g.cmd_x_lo, g.cmd_x_hi, r.v[0]), cy = rand_float(g.cmd_y_lo, g.cmd_y_hi, r.v[1]), cz = rand_float(g.cmd_yaw_lo, g.cmd_yaw_hi, r.v[2]);
-    if (b < c.i[GO2SIM_IC_N_STANDING]) { cx = 0.0f; cy = 0.0f; cz = 0.0f; }
+    float cx, cy, cz;
+    sample_commands(c, g, r, b, cx, cy, cz);
     cmd[0] = cx; cmd[1] = cy; cmd[2] = cz;
     rs.cmd[0] = cx; rs.cmd[1] = cy; rs.cmd[2] = cz;
   }
@@ -4927,8 +4948,8 @@ DEV void env_reset_one(const Model& m, const DCfg& c, const Glob& g, const E& e,
   { auto es = e.episode_sums(); for (int k = 0; k < NREW; ++k) es[k] = 0.0f; }
   e.episode_length()[0] = 0; e.reset_buf()[0] = 1;
   dm_u4 r = rng4(seed, RNG_RESET_CMD, b, rc, 0);
-  float cx = rand_float(g.cmd_x_lo, g.cmd_x_hi, r.v[0]), cy = rand_float(g.cmd_y_lo, g.cmd_y_hi, r.v[1]), cz = rand_float(g.cmd_yaw_lo, g.cmd_yaw_hi, r.v[2]);
-  if (b < c.i[GO2SIM_IC_N_STANDING]) { cx = 0.0f; cy = 0.0f; cz = 0.0f; }
+  float cx, cy, cz;
+  sample_commands(c, g, r, b, cx, cy, cz);
   auto cmd = e.commands();
   cmd[0] = cx; cmd[1] = cy; cmd[2] = cz;
 }

@@ -120,6 +120,14 @@ def _F(name):
     return C["GO2SIM_" + name]
 
 
+def _cross(a, b):
+    """a x b along the last axis as separate multiplies and subtractions (torch.cross may contract them into fused multiply-adds on the CPU; the
+    C ABI and the reference's kernels round every product)."""
+    ax, ay, az = a.unbind(-1)
+    bx, by, bz = b.unbind(-1)
+    return torch.stack([ay * bz - az * by, az * bx - ax * bz, ax * by - ay * bx], dim=-1)
+
+
 def _broadcast(values, shape):
     """What the reference's setters do to their value argument before the accessor kernel runs (rigid_solver.py:1835-1871 ->
     genesis/utils/misc.py `broadcast_tensor`): a value with fewer dimensions than (n_envs(sel), n_idx(, k)) is matched right-aligned when
@@ -233,7 +241,7 @@ class RigidEntity:
     def get_links_vel(self, links_idx_local=None, envs_idx=None):
         """Linear velocity of the link origins (kernel_get_links_vel, ref = link_origin)."""
         pos, cdv, cda = self._link_vec("F_LINK_POS", 3), self._link_vec("F_LINK_CDVEL", 3), self._link_vec("F_LINK_CDANG", 3)
-        vel = cdv + torch.cross(cda, pos - self._root_com()[:, None, :], dim=-1)
+        vel = cdv + _cross(cda, pos - self._root_com()[:, None, :])
         return vel[self._envs(envs_idx)][:, self._links(links_idx_local)].clone()
 
     def get_vel(self, envs_idx=None):
@@ -369,7 +377,7 @@ class _RigidSolver:
         f = _broadcast(force, (len(e), len(l), 3))
         ext = robot._get("F_EXT_FORCE").reshape(-1, 6, scene._sim.n_envs)                  # [link, (ang3, vel3), B]
         pos = robot._link_vec("F_LINK_POS", 3)[e][:, l]
-        torque = torch.cross(pos - robot._root_com()[e][:, None, :], f, dim=-1)
+        torque = _cross(pos - robot._root_com()[e][:, None, :], f)
         ext[l[:, None], 3:6, e[None, :]] -= f.permute(1, 0, 2)
         ext[l[:, None], 0:3, e[None, :]] -= torque.permute(1, 0, 2)
         robot._set("F_EXT_FORCE", ext.reshape(-1, scene._sim.n_envs))

@@ -151,8 +151,23 @@ DM_FN dm_u4 dm_philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32
   }
   dm_u4 o; o.v[0] = c0; o.v[1] = c1; o.v[2] = c2; o.v[3] = c3; return o;
 }
+#ifdef GO2SIM_RNG_CONST
+/* DIAGNOSTIC BUILD ONLY (tools/make_ref_env_fixtures.py "rng" cases, tests/test_ref_env_rng_fixtures.py; never the product): the generator is
+   replaced by a four-entry schedule of constants so that the reference's env files -- run with torch.rand / randn_like / randint / randperm
+   replaced by the same schedule -- and this library draw identical numbers.  A "random word" is then the stream key (env step for the
+   per-step draws, reset-call number for the reset draws); every uniform of that key is DM_RNG_CONST_U[key & 3], every normal
+   DM_RNG_CONST_Z[key & 3], an integer in [lo, hi] is lo + (int)(u * (hi - lo + 1)) and a permutation is the identity.  All table entries are
+   dyadic, so every product with them is the same in float32, float64 and torch. */
+DM_FN float dm_rng_const_u(uint32_t key) { return (key & 3u) == 0u ? 0.25f : (key & 3u) == 1u ? 0.75f : (key & 3u) == 2u ? 0.0625f : 0.5f; }
+DM_FN float dm_rng_const_z(uint32_t key) { return (key & 3u) == 0u ? 0.5f : (key & 3u) == 1u ? -1.0f : (key & 3u) == 2u ? 0.25f : -0.5f; }
+DM_FN float dm_u01(uint32_t r) { return dm_rng_const_u(r); }
+DM_FN void dm_normal2(uint32_t r0, uint32_t r1, float* n0, float* n1) { (void)r1; *n0 = dm_rng_const_z(r0); *n1 = dm_rng_const_z(r0); }
+#define DM_NORMAL2_DEFINED 1
+#else
 /* uniform in [0,1) with 24 random bits (same granularity as torch.rand for float32) */
 DM_FN float dm_u01(uint32_t r) { return (float)(r >> 8) * 5.9604644775390625e-8f; }
+#endif
+#ifndef DM_NORMAL2_DEFINED
 /* two standard normals from two words (Box-Muller on (0,1] x [0,1)) */
 DM_FN void dm_normal2(uint32_t r0, uint32_t r1, float* n0, float* n1) {
   float u = 1.0f - dm_u01(r0);
@@ -162,5 +177,6 @@ DM_FN void dm_normal2(uint32_t r0, uint32_t r1, float* n0, float* n1) {
   dm_sincos(6.283185307179586f * v, &s, &c);
   *n0 = rad * c; *n1 = rad * s;
 }
+#endif
 
 #endif /* GO2SIM_DETMATH_H */

@@ -1999,13 +1999,21 @@ struct go2sim {
 namespace {
 
 inline dm_u4 rng4(const go2sim* h, uint32_t purpose, uint32_t env, uint32_t step, uint32_t idx) {
+#ifdef GO2SIM_RNG_CONST   // diagnostic build (include/go2sim_detmath.h): every word of a draw is its stream key
+  dm_u4 o; o.v[0] = o.v[1] = o.v[2] = o.v[3] = step; (void)purpose; (void)env; (void)idx; (void)h; return o;
+#else
   return dm_philox(env, step, purpose, idx, (uint32_t)h->seed, (uint32_t)(h->seed >> 32));
+#endif
 }
 enum { RNG_ACTION_NOISE = 1, RNG_PUSH = 2, RNG_CMD = 3, RNG_OBS_NOISE = 4, RNG_RESET_DR = 5, RNG_GLOBAL_DR = 6, RNG_RESET_CMD = 7, RNG_RESET_POSE = 8, RNG_TERRAIN_ROW = 9, RNG_TERRAIN_PERM = 10 };
 // gs_rand_float, go2_env_walk.py:7-8: `(upper - lower) * torch.rand(...) + lower` with python-float bounds: the difference is formed in float64 and
 // both scalars are rounded to float32 where they meet the float32 tensor
 inline real rand_float(double lower, double upper, uint32_t r) { return (real)(upper - lower) * dm_u01(r) + (real)lower; }
+#ifdef GO2SIM_RNG_CONST
+inline int rand_int(int lower, int upper, uint32_t r) { return lower + (int)(dm_rng_const_u(r) * (float)(upper - lower + 1)); }
+#else
 inline int rand_int(int lower, int upper, uint32_t r) { return lower + (int)(r % (uint32_t)(upper - lower + 1)); }   // gs_rand_int, :11-13
+#endif
 
 // Go2Env._apply_curriculum_level, go2_env_walk.py:628-686 (python float64 arithmetic)
 // _get_dr_level, go2_env_stair.py:972-988 (two-phase DR schedule coupled to the terrain level)
@@ -2090,6 +2098,16 @@ bool curriculum_update(go2sim* h, double timeout_rate, double tracking_per_sec, 
 // _lerp_range(easy, hard, t_sample), go2_env_walk.py:37-39: python floats
 inline double lerp_lo(const Cfg& c, int easy_lo, double t) { return lerpd(c.d[easy_lo], c.d[easy_lo + 2], t); }
 inline double lerp_hi(const Cfg& c, int easy_lo, double t) { return lerpd(c.d[easy_lo + 1], c.d[easy_lo + 3], t); }
+// Go2Env._resample_commands, go2_env_walk.py:927-963: all three components (compound commands), or ONE component chosen by `randint(0, 3)` with the
+// other two left at zero (:948-958); the first `rel_standing_envs * num_envs` envs always stand (:367-368, :960-963)
+inline void sample_commands(const Cfg& c, const go2sim_env_globals_t& g, const dm_u4& r, int b, real* cmd) {
+  cmd[0] = rand_float(g.cmd_x_lo, g.cmd_x_hi, r.v[0]); cmd[1] = rand_float(g.cmd_y_lo, g.cmd_y_hi, r.v[1]); cmd[2] = rand_float(g.cmd_yaw_lo, g.cmd_yaw_hi, r.v[2]);
+  if (!c.i[GO2SIM_IC_COMPOUND_COMMANDS]) {
+    const int choice = rand_int(0, 2, r.v[3]);
+    for (int k = 0; k < 3; ++k) if (k != choice) cmd[k] = 0.0f;
+  }
+  if (b < c.i[GO2SIM_IC_N_STANDING]) cmd[0] = cmd[1] = cmd[2] = 0.0f;
+}
 
 // Go2Env.step, pre-physics part: go2_env_walk.py:985-1023 (+ _apply_push :872-906)
 void env_pre(go2sim* h, int b, const real* actions) {
@@ -2317,10 +2335,7 @@ void env_post_a(go2sim* h, int b) {
   }
   if (x.episode_length % c.i[GO2SIM_IC_RESAMPLE_STEPS] == 0) {                          // _resample_commands :927-963
     dm_u4 r = rng4(h, RNG_CMD, b, g.step_count, 0);
-    x.commands[0] = rand_float(g.cmd_x_lo, g.cmd_x_hi, r.v[0]);
-    x.commands[1] = rand_float(g.cmd_y_lo, g.cmd_y_hi, r.v[1]);
-    x.commands[2] = rand_float(g.cmd_yaw_lo, g.cmd_yaw_hi, r.v[2]);
-    if (b < c.i[GO2SIM_IC_N_STANDING]) x.commands[0] = x.commands[1] = x.commands[2] = 0.0f;
+    sample_commands(c, g, r, b, x.commands);
   }
   int maxlen = c.i[GO2SIM_IC_MAX_EPISODE_LENGTH];
   int rst = x.episode_length > maxlen;                                                   // :1062-1070
@@ -2496,10 +2511,7 @@ void env_reset_one(go2sim* h, int b) {
   for (int k = 0; k < NREW; ++k) x.episode_sums[k] = 0.0f;
   x.episode_length = 0; x.reset_buf = 1;
   dm_u4 r = rng4(h, RNG_RESET_CMD, b, rc, 0);                                              // _resample_commands(envs_idx) :1240
-  x.commands[0] = rand_float(g.cmd_x_lo, g.cmd_x_hi, r.v[0]);
-  x.commands[1] = rand_float(g.cmd_y_lo, g.cmd_y_hi, r.v[1]);
-  x.commands[2] = rand_float(g.cmd_yaw_lo, g.cmd_yaw_hi, r.v[2]);
-  if (b < c.i[GO2SIM_IC_N_STANDING]) x.commands[0] = x.commands[1] = x.commands[2] = 0.0f;
+  sample_commands(c, g, r, b, x.commands);
 }
 
 // broadcast of the "global" DR scalars to one env + full-batch FK refresh done by the reference's

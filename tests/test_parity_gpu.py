@@ -238,7 +238,7 @@ def test_go2env_class_matches_c_abi(hip_lib, blob):
 
 
 @pytest.mark.parametrize("task,n_envs,steps,kind,seed", [("crouch", 70, 120, "0.5", 3), ("jump", 33, 160, "mixed", 8), ("jump_dr", 40, 140, "0.5", 9), ("crouch_dr", 48, 100, "mixed", 10),
-                                                           ("jump_dr", 4096, 10, "0.5", 12)])
+                                                           ("jump_dr", 4096, 10, "0.5", 12), ("crouch_dr", 4096, 10, "0.5", 13)])
 def test_base_env_bit_exact(oracle_lib, hip_lib, blob, task, n_envs, steps, kind, seed):
     """go2_env_base.py (crouch / jump): engine PD, reset before reward, 45 observations -- GPU vs oracle, tolerance 0."""
     cpu, gpu = CpuEnv(oracle_lib, blob, n_envs, seed=seed, task=task), GpuEnv(hip_lib, blob, n_envs, seed=seed, task=task)

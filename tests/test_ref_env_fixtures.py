@@ -40,11 +40,11 @@ class FusedEnv:
         base = case.startswith("base")
         f, i, self.names = (flatten_base_cfg if base else flatten_walk_cfg)(B, *cfgs)
         self.motors = [int(i[C["GO2SIM_IC_MOTOR_DOF0"] + k]) for k in range(12)]
-        if case == "stairs":
+        if case.startswith("stairs"):
             hf, info = build_stair_terrain(cfgs[0]["terrain"])
             self.sim.set_terrain(hf, info["horizontal_scale"], info["vertical_scale"], info["terrain_origin"])
         self.sim.env_configure(f, i)
-        if case == "stairs":                                                            # env._env_terrain_row[:] = rows; env._lock_terrain_rows = True
+        if case.startswith("stairs") and meta["terrain_rows"] is not None:              # env._env_terrain_row[:] = rows; env._lock_terrain_rows = True
             rows = np.asarray(meta["terrain_rows"], np.int32)
             self.sim.env_set_terrain_rows(self._dev(rows)); self.sim.env_lock_terrain_rows(True)
         self.sim.env_reset()
@@ -112,6 +112,8 @@ def replay_and_compare(lib, blob, case, gpu, physics):
         assert close(env.env_buf("BASE_POS", 3), z["base_pos"][s]), f"{where}: base position"
         if not case.startswith("base"):
             assert abs(env.sim.env_globals().level - float(z["level"][s])) <= 1e-12, f"{where}: curriculum level"
+        if case.startswith("stairs") and "terrain_row" in z:
+            assert np.array_equal(env.env_buf("TERRAIN_ROW", 1, np.int32)[:, 0], z["terrain_row"][s]), f"{where}: terrain rows"
     return z, meta
 
 

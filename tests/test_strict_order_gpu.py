@@ -1,0 +1,44 @@
+"""The reference-order kernel under the driver's eyes.
+
+The product build sums the solver's reductions in FAST ORDER and every other `-m gpu` parity test compares it with the oracle
+build that mirrors that order.  This file loads the -DGO2SIM_FAST_ORDER=0 build of the SAME HIP source (tools/lib_strict.so, built lazily like
+the other diagnostic variants; every chained sum in the reference's first-to-last CPU order, rank-1 factor updates) and compares it with the
+STRICT oracle -- the restatement of the reference's own summation order -- at tolerance 0: walk, stairs and jump, >= 64 envs x 100 steps."""
+import os
+
+import numpy as np
+import pytest
+
+from util import CpuEnv, GpuEnv, bits_equal, make_actions
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip_strict_lib():
+    from go2_sim2real_locomotion_rl_amd import build
+    from go2_sim2real_locomotion_rl_amd.capi import Go2SimLib
+
+    return Go2SimLib(os.path.abspath(build.build_hip_variant("strict", build.HIP_VARIANTS["strict"], verbose=False)), "go2sim_")
+
+
+@pytest.mark.parametrize("task,n_envs,steps,kind,seed", [("walk", 64, 120, "mixed", 7), ("stairs", 64, 100, "0.5", 5), ("jump", 64, 100, "mixed", 8), ("walk", 130, 40, "2.0", 11)])
+def test_strict_hip_build_equals_strict_oracle(oracle_strict_lib, hip_strict_lib, blob, task, n_envs, steps, kind, seed):
+    cpu, gpu = CpuEnv(oracle_strict_lib, blob, n_envs, seed=seed, task=task), GpuEnv(hip_strict_lib, blob, n_envs, seed=seed, task=task)
+    if task == "stairs":
+        for e in (cpu, gpu):
+            e.sim.env_set_level(0.65)
+    cpu.reset(); gpu.reset()
+    n_resets = 0
+    for s, a in enumerate(make_actions(steps, n_envs, seed=seed, kind=kind, n_act=cpu.n_act)):
+        oc, pc, rc, dc, tc = cpu.step(a)
+        og, pg, rg, dg, tg = gpu.step(a)
+        assert np.array_equal(dc, dg), f"{task}: done mask differs at step {s}"
+        assert np.array_equal(cpu.field("I_N_CONTACTS"), gpu.field("I_N_CONTACTS")), f"{task}: contact counts differ at step {s}"
+        assert bits_equal(oc, og) and bits_equal(pc, pg) and bits_equal(rc, rg) and bits_equal(tc, tg), f"{task}: observations / rewards differ at step {s}"
+        assert bits_equal(cpu.env_buf("REW_TERMS", 32), gpu.env_buf("REW_TERMS", 32)), f"{task}: per-term rewards differ at step {s}"
+        n_resets += int(dc.sum())
+    for fn in ("F_QPOS", "F_VEL", "F_ACC", "F_QACC_WS", "F_EFC_FORCE", "F_CONTACT_FORCE", "I_N_CONSTRAINTS", "I_SOLVER_ITERS", "F_CONTACT_POS", "F_CONTACT_NORMAL"):
+        assert bits_equal(cpu.field(fn), gpu.field(fn)), f"{task}: field {fn} differs"
+    assert gpu.sim.check_errno() == cpu.sim.check_errno() == 0
+    assert n_resets > 0

@@ -15,6 +15,13 @@ whose random ranges are degenerate ([v, v]) -- the draw is v whatever the genera
 curriculum interpolation (`_lerp_range(easy, hard, level)`) is still exercised.  Episodes are made short (0.6-1.0 s) and the action tapes harsh so
 that every case passes through time-out resets and fall resets; the stairs case locks the terrain rows on both sides
 (`_lock_terrain_rows`, go2_env_stair.py:399,1513) because the reference assigns them with torch.randperm.
+
+The `*_rng` cases pin the lines that DO draw numbers (gs_rand_float / gs_rand_int with lower != upper, sample_level's mix branch, _apply_push,
+observation / action noise, the per-env delay, init height / tilt, the single-axis command branch, _assign_terrain_rows): the loaded module's
+global `torch` is replaced by `ScheduledTorch`, which forwards everything except rand / randn_like / randint / randperm; those return the
+four-entry constant schedule of include/go2sim_detmath.h (GO2SIM_RNG_CONST), keyed like the C ABI's Philox stream (the env step for per-step
+draws, the reset-call number inside reset_idx).  The counterpart on the C-ABI side is the diagnostic -DGO2SIM_RNG_CONST build of the oracle and
+of the HIP library (build.ORACLE_VARIANTS / HIP_VARIANTS); the product build is untouched.  These cases keep the reference's shipped ranges.
 """
 import copy
 import importlib.util
@@ -69,6 +76,67 @@ def pinned_cfgs(case):
     return env_cfg, obs_cfg, reward_cfg, command_cfg
 
 
+RNG_U = (0.25, 0.75, 0.0625, 0.5)      # dm_rng_const_u / dm_rng_const_z, include/go2sim_detmath.h
+RNG_Z = (0.5, -1.0, 0.25, -0.5)
+
+
+class ScheduledTorch:
+    """Stands in for the global `torch` of a loaded reference env module: rand / randn_like / randint / randperm return the constant schedule,
+    every other attribute is torch's."""
+
+    def __init__(self):
+        self.mode, self.step_key, self.reset_key, self.calls = "step", 0, 0, {"rand": 0, "randn_like": 0, "randint": 0, "randperm": 0}
+
+    def __getattr__(self, name):
+        return getattr(torch, name)
+
+    def _key(self):
+        return (self.reset_key if self.mode == "reset" else self.step_key) & 3
+
+    def rand(self, *size, **kw):
+        self.calls["rand"] += 1
+        size = kw.get("size", size[0] if len(size) == 1 and isinstance(size[0], (tuple, list, torch.Size)) else size)
+        return torch.full(tuple(size), RNG_U[self._key()], dtype=torch.float32)
+
+    def randn_like(self, t):
+        self.calls["randn_like"] += 1
+        return torch.full_like(t, RNG_Z[self._key()])
+
+    def randint(self, low, high, size, device=None):
+        self.calls["randint"] += 1
+        return torch.full(tuple(size), low + int(RNG_U[self._key()] * (high - low)), dtype=torch.int64)
+
+    def randperm(self, n, device=None):
+        self.calls["randperm"] += 1
+        return torch.arange(n)
+
+
+def rng_cfgs(case):
+    """The reference's configuration of the task with its SHIPPED random ranges; only time scales are shortened so that a 96-step tape passes through
+    every kind of draw (resets, command resampling, pushes, curriculum updates, friction re-draws)."""
+    from go2_sim2real_locomotion_rl_amd.configs import get_crouch_cfgs, get_jump_cfgs, get_stair_cfgs, get_walk_cfgs
+
+    if case in ("base_jump_rng", "base_crouch_rng"):
+        env_cfg, obs_cfg, reward_cfg, command_cfg = pinned_cfgs(case[:-4])
+        command_cfg.update({"lin_vel_x_range": [-0.4, 0.8], "lin_vel_y_range": [-0.3, 0.1], "ang_vel_range": [-0.5, 0.25]})   # the shipped ranges are [0, 0]
+        env_cfg["resampling_time_s"] = 0.3
+        return env_cfg, obs_cfg, reward_cfg, command_cfg
+    env_cfg, obs_cfg, reward_cfg, command_cfg = copy.deepcopy(get_stair_cfgs() if case.startswith("stairs") else get_walk_cfgs())
+    cur = env_cfg["curriculum"]
+    env_cfg.update({"episode_length_s": 0.9, "resampling_time_s": 0.3, "termination_if_roll_greater_than": 25, "termination_if_pitch_greater_than": 25,
+                    "push_interval_s": 0.5, "min_delay_steps": 0, "max_delay_steps": 2})
+    cur.update({"update_every_episodes": 6, "global_dr_update_interval": 4, "push_interval_easy_s": 0.6, "mix_prob_current": 0.6, "level_init": 0.30,
+                "delay_easy_max_steps": 1})
+    if case == "walk_rng_axis":                                                 # `choice = torch.randint(0, 3, (n,))`, go2_env_walk.py:948-958
+        command_cfg["compound_commands"] = False
+    if case == "stairs_rng":
+        cur["level_init"] = 0.65                                                # as shipped: max_row = int(0.65 * 12) = 7, DR level 0.405 >= push_start
+    return env_cfg, obs_cfg, reward_cfg, command_cfg
+
+
+RNG_CASES = ["walk_rng", "walk_rng_axis", "stairs_rng", "base_jump_rng"]
+
+
 def action_tape(T, B, n_act, seed):
     """Per-env action styles: standing, gentle / rough noise, a constant tipping bias, an open-loop trot."""
     rng = np.random.default_rng(seed)
@@ -120,15 +188,41 @@ def run_case(case, B=8, T=96, seed=11, n_run=None, physics="strict"):
 
     # physics underneath the reference's env code: the strict oracle (reference CPU summation order) or its FAST ORDER build (the arithmetic of the
     # HIP product); the env layer that is being pinned is the same reference code either way
-    gs_on_oracle(gs, load_cpu_oracle_lib(fast=(physics == "fast")), seed=seed)
-    stem = {"base_jump": "go2_env_base", "base_crouch": "go2_env_base", "walk": "go2_env_walk", "walk_delay1": "go2_env_walk", "walk_delay2": "go2_env_walk", "stairs": "go2_env_stair"}[case]
-    cfgs = pinned_cfgs(case)
+    rng_case = case.endswith("_rng") or "_rng_" in case
+    if rng_case:
+        from go2_sim2real_locomotion_rl_amd import build
+        from go2_sim2real_locomotion_rl_amd.capi import Go2SimLib
+
+        name = "rng_const_fast" if physics == "fast" else "rng_const"
+        lib = Go2SimLib(build.build_oracle_variant(name, build.ORACLE_VARIANTS[name], verbose=False), "go2sim_cpu_")
+    else:
+        lib = load_cpu_oracle_lib(fast=(physics == "fast"))
+    gs_on_oracle(gs, lib, seed=seed)
+    stem = "go2_env_base" if case.startswith("base") else "go2_env_stair" if case.startswith("stairs") else "go2_env_walk"
+    cfgs = rng_cfgs(case) if rng_case else pinned_cfgs(case)
     cfg_json = json.dumps(cfgs)                                           # before the env multiplies the reward scales by dt in place
     mod = load_reference_env_module(stem)
+    sched = None
+    if rng_case:
+        sched = mod.torch = ScheduledTorch()
     torch.manual_seed(seed)
     log = io.StringIO()
     with redirect_stdout(log):
         env = mod.Go2Env(B, *copy.deepcopy(cfgs))
+    if rng_case:
+        inner = env.reset_idx
+
+        def reset_idx(envs_idx):                                          # the reset-call number keys the draws of one reset_idx call (n > 0)
+            if len(envs_idx) == 0:
+                return inner(envs_idx)
+            sched.mode = "reset"
+            try:
+                return inner(envs_idx)
+            finally:
+                sched.mode = "step"
+                sched.reset_key += 1
+
+        env.reset_idx = reset_idx
     rows = None
     if case == "stairs":
         rows = np.array([(3 * b + 1) % 13 for b in range(B)], np.int64)
@@ -151,10 +245,13 @@ def run_case(case, B=8, T=96, seed=11, n_run=None, physics="strict"):
         env.reset()
     acts = action_tape(T, B, n_act, seed)
     motors = torch.as_tensor(env.motors_dof_idx)
-    rec = {k: [] for k in ("obs", "priv", "rew", "rew_terms", "done", "time_outs", "ctrl_pos", "ctrl_force", "base_pos", "commands", "episode_length", "level")}
+    rec = {k: [] for k in ("obs", "priv", "rew", "rew_terms", "done", "time_outs", "ctrl_pos", "ctrl_force", "base_pos", "commands", "episode_length", "level",
+                           "delay_steps", "push_force", "terrain_row")}
     has_priv = getattr(env, "num_privileged_obs", None) is not None
     n_run = T if n_run is None else n_run
     for s in range(n_run):
+        if sched is not None:
+            sched.step_key = s
         with redirect_stdout(log):
             obs, rew, done, extras = env.step(torch.from_numpy(acts[s]))
         rec["obs"].append(obs.numpy().copy()); rec["rew"].append(rew.numpy().copy()); rec["done"].append(done.numpy().astype(np.uint8))
@@ -166,12 +263,16 @@ def run_case(case, B=8, T=96, seed=11, n_run=None, physics="strict"):
         rec["base_pos"].append(env.base_pos.numpy().copy()); rec["commands"].append(env.commands.numpy().copy())
         rec["episode_length"].append(env.episode_length_buf.numpy().astype(np.int32).copy())
         rec["level"].append(float(env.curriculum.level) if hasattr(env, "curriculum") else 0.0)
+        rec["delay_steps"].append(env._delay_steps.numpy().astype(np.int32).copy() if hasattr(env, "_delay_steps") else np.zeros(B, np.int32))
+        rec["push_force"].append(env._current_push_force.numpy().copy() if hasattr(env, "_current_push_force") else np.zeros((B, 3), np.float32))
+        rec["terrain_row"].append(env._env_terrain_row.numpy().astype(np.int32).copy() if hasattr(env, "_env_terrain_row") else np.zeros(B, np.int32))
     out = {k: np.stack(v) if k != "level" else np.asarray(v, np.float64) for k, v in rec.items()}
     out["actions"] = acts[:n_run]
     done, to = out["done"].astype(bool), out["time_outs"] > 0
     meta = {"case": case, "reference_file": f"examples/locomotion/final/{stem}.py", "physics": physics, "n_envs": B, "steps": n_run, "seed": seed, "reward_names": names,
             "n_time_out_resets": int((done & to).sum()), "n_fall_resets": int((done & ~to).sum()),
-            "terrain_rows": None if rows is None else rows.tolist()}
+            "terrain_rows": None if rows is None else rows.tolist(), "rng_calls": None if sched is None else dict(sched.calls),
+            "reset_calls": None if sched is None else sched.reset_key}
     out["cfgs_json"] = np.array(cfg_json)
     out["meta_json"] = np.array(json.dumps(meta))
     return out, meta
@@ -184,12 +285,13 @@ def main():
 
     build.build_oracle()
     os.makedirs(OUT_DIR, exist_ok=True)
-    for case in sys.argv[1:] or ["base_jump", "base_crouch", "walk", "walk_delay1", "walk_delay2", "stairs"]:
+    for case in sys.argv[1:] or ["base_jump", "base_crouch", "walk", "walk_delay1", "walk_delay2", "stairs"] + RNG_CASES:
         for physics in ("strict", "fast"):
-            out, meta = run_case(case, physics=physics)
+            out, meta = run_case(case, B=16 if case in RNG_CASES else 8, physics=physics)
             path = fixture_path(case, physics)
             np.savez_compressed(path, **out)
-            print(f"{path}: {meta['n_time_out_resets']} time-out resets, {meta['n_fall_resets']} fall resets, {os.path.getsize(path) // 1024} KiB")
+            print(f"{path}: {meta['n_time_out_resets']} time-out resets, {meta['n_fall_resets']} fall resets, {os.path.getsize(path) // 1024} KiB"
+                  + (f", generator calls {meta['rng_calls']}, {meta['reset_calls']} reset calls" if meta.get("rng_calls") else ""))
 
 
 if __name__ == "__main__":
