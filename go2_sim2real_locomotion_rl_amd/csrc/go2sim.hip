@@ -701,6 +701,34 @@ __device__ unsigned long long g_phase_cycles[PH_MAX_WG * 64];
 #define PHC(i, n)
 #endif
 
+// ---- optional wall-clock stamps per workgroup (build with -DGO2SIM_STAMP; tools/launch_overhead.py): every workgroup of the step kernels records
+// s_memrealtime (the 100 MHz constant clock shared by all CUs) at entry and after its last memory operation has retired.  From one step's stamps the
+// host gets, per launch, the span between the earliest workgroup start and the latest workgroup end, and between launches the time in which NO
+// workgroup runs (end-of-kernel write-back + dispatch of the next launch): the fixed cost of a launch that rocprof's kernel durations hide. ----
+#ifdef GO2SIM_STAMP
+constexpr int ST_KINDS = 8, ST_MAX_WG = 4096, ST_DEPTH = 4;
+__device__ unsigned long long g_stamp[ST_KINDS * ST_MAX_WG * ST_DEPTH * 2];
+__device__ unsigned g_stamp_cnt[ST_KINDS * ST_MAX_WG];
+struct StampScope {
+  int kind; unsigned long long t0;
+  DEV StampScope(int k) : kind(k) { t0 = __builtin_amdgcn_s_memrealtime(); }
+  DEV ~StampScope() {
+    __builtin_amdgcn_s_waitcnt(0);
+    const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0 && blockIdx.x < ST_MAX_WG) {
+      const int w = kind * ST_MAX_WG + (int)blockIdx.x;
+      const unsigned c = g_stamp_cnt[w];                               // only this workgroup id of this kind touches the slot: no atomics
+      g_stamp[(w * ST_DEPTH + (int)(c % ST_DEPTH)) * 2] = t0; g_stamp[(w * ST_DEPTH + (int)(c % ST_DEPTH)) * 2 + 1] = t1;
+      g_stamp_cnt[w] = c + 1;
+    }
+  }
+};
+#define STAMP(kind) StampScope stamp_scope_(kind);
+#else
+#define STAMP(kind)
+#endif
+enum { STK_PRE_DYN = 0, STK_COLLIDE, STK_SOLVE, STK_INT_FK_DYN, STK_INT_FK, STK_POST_A, STK_POST_B, STK_OTHER };
+
 // -DGO2SIM_REPEAT_PHASE=k (profiling builds, tools/repeat_probe.py): phase k runs twice; every such phase is idempotent, so the results
 // are unchanged and the time difference prices the phase.  Solver: 0 stage, 1 rows (13 contact rows, 14 joint-limit rows), 3 Hessian +
 // factorisation, 4 Hessian, 5 gradient, 6 line search, 11 commit.  Collision: 30 AABBs, 31 endpoint sort, 32 candidate pairs, 34 GJK / EPA
@@ -1027,6 +1055,7 @@ DEV void tk_integrate(const MT& m, const E& e, KinData* s, int tl) {
 // (abd/diff.py:25-54) + FK / forward velocity of the new state
 template <int T>
 __global__ __launch_bounds__(64) void k_integrate_fk_team(Pool P, const ModelS* __restrict__ mp) {
+  STAMP(STK_INT_FK)
   constexpr int EPW = 64 / T;
   __shared__ KinData lds[EPW];
   __shared__ alignas(16) char ms_raw[MODELS_LDS_BYTES];
@@ -1333,6 +1362,7 @@ __global__ __launch_bounds__(64) void k_dynamics_team(Pool P, const ModelS* __re
 // the top of the kernel.
 template <int T>
 __global__ __launch_bounds__(64) void k_integrate_fk_dynamics_team(Pool P, const ModelS* __restrict__ mp) {
+  STAMP(STK_INT_FK_DYN)
   constexpr int EPW = 64 / T;
   __shared__ DynData lds_d[EPW];
   __shared__ alignas(16) char ms_raw[MODELS_LDS_BYTES];
@@ -2030,6 +2060,7 @@ DEV bool terrain_prism_contact(const Model& m, const E& e, const TP& t, int i_gb
 
 template <int T>
 __global__ __launch_bounds__(64) void k_collide_team(Pool P, const Model* __restrict__ mp, GjkStoreFull* __restrict__ gjk_scratch, int* __restrict__ lpt_rec, int lpt_cap, int solver_epw) {
+  STAMP(STK_COLLIDE)
   constexpr int EPW = 64 / T;
   __shared__ CollideData<T> lds[EPW];
   const int tl = threadIdx.x % T, slot = threadIdx.x / T;
@@ -2454,6 +2485,26 @@ GO2SIM_BRACKET_ATTR int update_bracket(LsPoint& p, const float alphas[3], const 
   p_next_alpha = p.alpha;
   if (flag > 0) p_next_alpha = p.alpha - p.grad / p.hess;
   return flag;
+}
+
+// The out-of-line form of the product: everything travels BY VALUE (arguments and the result in vector registers under the AMDGPU calling convention),
+// so keeping the bracket step out of line no longer costs a round trip through private memory per call (round 3: LsPoint& and four array pointers,
+// 35 memory instructions for 53 vector ones).  -DGO2SIM_BRACKET_BYREF restores the by-reference form for A / B runs.
+struct BrOut { float alpha, cost, grad, hess, next_alpha; int flag; };
+DEVN BrOut update_bracket_v(float pa, float pc, float pg, float ph, float a0, float a1, float a2, float c0, float c1, float c2, float g0, float g1, float g2,
+                            float h0, float h1, float h2) {
+  LsPoint p = {pa, pc, pg, ph};
+  const float alphas[3] = {a0, a1, a2}, costs[3] = {c0, c1, c2}, grads[3] = {g0, g1, g2}, hess[3] = {h0, h1, h2};
+  int flag = 0;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    if (p.grad < 0 && grads[i] < 0 && p.grad < grads[i]) { p.alpha = alphas[i]; p.cost = costs[i]; p.grad = grads[i]; p.hess = hess[i]; flag = 1; }
+    else if (p.grad > 0 && grads[i] > 0 && p.grad > grads[i]) { p.alpha = alphas[i]; p.cost = costs[i]; p.grad = grads[i]; p.hess = hess[i]; flag = 2; }
+  }
+  float next_alpha = p.alpha;
+  if (flag > 0) next_alpha = p.alpha - p.grad / p.hess;
+  BrOut o = {p.alpha, p.cost, p.grad, p.hess, next_alpha, flag};
+  return o;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -3380,6 +3431,12 @@ __device__ int g_brenv_of_wg[65536];
 // func_linesearch_batch, solver.py:2246-2417
 template <int T, class S, class MT>
 DEV float ts_linesearch(const MT& m, S* s, int tl, int n_con, float gauss) {
+#if defined(GO2SIM_PHASE_PROFILE) && GO2SIM_FAST_ORDER   // where a line search spends its cycles: 50 set-up (mv, jv, coefficients, p0), 51 the 1-D Newton steps (52: their number),
+  unsigned long long ls_t0 = __builtin_readcyclecounter();   // 53 the bracket refinement (54: its rounds of three points)
+#define LS_MARK(id) { const unsigned long long ls_n = __builtin_readcyclecounter(); PHC(id, ls_n - ls_t0) ls_t0 = ls_n; }
+#else
+#define LS_MARK(id)
+#endif
   float sr[ND];
 #pragma unroll
   for (int d = 0; d < ND; ++d) sr[d] = s->search[d];
@@ -3494,13 +3551,14 @@ DEV float ts_linesearch(const MT& m, S* s, int tl, int n_con, float gauss) {
     p0.alpha = 0.0f; p0.cost = t0; p0.grad = t1; p0.hess = 2.0f * t2;
     if (p0.hess <= 0.0f) p0.hess = m.eps;
   }
+  LS_MARK(50)
   int ls_it = 1;
   float res_alpha = 0.0f;
   bool done = false;
   LsPoint p1 = ts_ls_point<T>(m, s, tl, n_con, nseg, rw, p0.alpha - p0.grad / p0.hess, qg0, qg1, qg2);
   ls_it += 1;
   if (p0.cost < p1.cost) p1 = p0;
-  if (dm_abs(p1.grad) < gtol) return p1.alpha;
+  if (dm_abs(p1.grad) < gtol) { LS_MARK(51) PHC(52, 1) return p1.alpha; }
   int direction = (p1.grad < 0) * 2 - 1;
   int p2update = 0;
   LsPoint p2 = p1;
@@ -3510,6 +3568,7 @@ DEV float ts_linesearch(const MT& m, S* s, int tl, int n_con, float gauss) {
     ls_it += 1;
     if (dm_abs(p1.grad) < gtol) { res_alpha = p1.alpha; done = true; break; }
   }
+  LS_MARK(51) PHC(52, ls_it - 1)
   if (done) return res_alpha;
   if (ls_it >= m.ls_iterations) return p1.alpha;
   if (!p2update) return p1.alpha;
@@ -3524,10 +3583,19 @@ DEV float ts_linesearch(const MT& m, S* s, int tl, int n_con, float gauss) {
 #pragma unroll
     for (int i = 0; i < 3; ++i)
       if (dm_abs(grads[i]) < gtol && (!best_found || costs[i] < best_cost)) { best_alpha = al[i]; best_cost = costs[i]; best_found = true; }
-    if (best_found) return best_alpha;
+    PHC(54, 1)
+    if (best_found) { LS_MARK(53) return best_alpha; }
 #ifdef GO2SIM_BRACKET_DEBUG
     const LsPoint p1_in = p1, p2_in = p2;
 #endif
+#if !defined(GO2SIM_BRACKET_INLINE) && !defined(GO2SIM_BRACKET_BYREF)
+    const BrOut o1 = update_bracket_v(p1.alpha, p1.cost, p1.grad, p1.hess, al[0], al[1], al[2], costs[0], costs[1], costs[2], grads[0], grads[1], grads[2], hess[0], hess[1], hess[2]);
+    p1.alpha = o1.alpha; p1.cost = o1.cost; p1.grad = o1.grad; p1.hess = o1.hess; p1_next_alpha = o1.next_alpha;
+    const int b1 = o1.flag;
+    const BrOut o2 = update_bracket_v(p2.alpha, p2.cost, p2.grad, p2.hess, al[0], al[1], al[2], costs[0], costs[1], costs[2], grads[0], grads[1], grads[2], hess[0], hess[1], hess[2]);
+    p2.alpha = o2.alpha; p2.cost = o2.cost; p2.grad = o2.grad; p2.hess = o2.hess; p2_next_alpha = o2.next_alpha;
+    const int b2 = o2.flag;
+#else
     int b1 = update_bracket(p1, al, costs, grads, hess, p1_next_alpha);
 #ifdef GO2SIM_BRACKET_FENCE   // investigation builds (tools/repro_bracket/README.md): value barriers around the inlined bracket step
     asm volatile("" : "+v"(p1.alpha), "+v"(p1.cost), "+v"(p1.grad), "+v"(p1.hess), "+v"(p1_next_alpha), "+v"(b1));
@@ -3535,6 +3603,7 @@ DEV float ts_linesearch(const MT& m, S* s, int tl, int n_con, float gauss) {
     int b2 = update_bracket(p2, al, costs, grads, hess, p2_next_alpha);
 #ifdef GO2SIM_BRACKET_FENCE
     asm volatile("" : "+v"(p2.alpha), "+v"(p2.cost), "+v"(p2.grad), "+v"(p2.hess), "+v"(p2_next_alpha), "+v"(b2));
+#endif
 #endif
 #ifdef GO2SIM_BRACKET_DEBUG
     {
@@ -3559,14 +3628,16 @@ DEV float ts_linesearch(const MT& m, S* s, int tl, int n_con, float gauss) {
       }
     }
 #endif
-    if (b1 == 0 && b2 == 0) return al[2];
+    if (b1 == 0 && b2 == 0) { LS_MARK(53) return al[2]; }
     al[0] = p1_next_alpha; al[1] = p2_next_alpha; al[2] = (p1.alpha + p2.alpha) * 0.5f;
   }
+  LS_MARK(53)
   if (p1.cost <= p2.cost && p1.cost < p0.cost) return p1.alpha;
   if (p2.cost <= p1.cost && p2.cost < p0.cost) return p2.alpha;
   return 0.0f;
 }
 
+#undef LS_MARK
 // rows + resolve for one environment (add_collision_constraints solver.py:498-595, add_joint_limit_constraints :1088-1143,
 // func_solve_init :2739-2859, func_solve_body :2941-2966, func_solve_iter :2862-2938)
 template <int T, class S, class MT>
@@ -3839,6 +3910,7 @@ DEVN void ts_solve_overflow(float* Pf, int* Pi, int PB, float* Pfa, int* Pia, in
 template <int T, int RLN>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_constraint_solve_team(Pool P, const Model* __restrict__ gm, const ModelS* __restrict__ mp, SolverData<MAXR>* __restrict__ overflow,
                                                                                                          const int* __restrict__ lpt_rec, int* __restrict__ lpt_next, int lpt_cap) {
+  STAMP(STK_SOLVE)
   constexpr int EPW = 64 / T;
   __shared__ SolverData<RLN> lds[EPW];
   __shared__ alignas(16) char blk_raw[lds_dma_bytes(SOLVER_BLOCK_BYTES)];
@@ -4227,6 +4299,7 @@ __global__ __launch_bounds__(WG) void k_env_pre(Pool P, const Model* __restrict_
 template <int T>
 __global__ __launch_bounds__(64) void k_pre_dynamics_team(Pool P, const ModelS* __restrict__ mp, const DCfg cv, const Glob* __restrict__ gp,
                                                           const float* __restrict__ actions_in, uint64_t seed, uint32_t step_count, int write_idx) {
+  STAMP(STK_PRE_DYN)
   static_assert(T >= NA, "one lane per action");
   constexpr int EPW = 64 / T;
   __shared__ DynData lds[EPW];
@@ -4550,6 +4623,7 @@ DEV float reward_term(const Model& m, const DCfg& c, RewState& rs, int id, const
 DEV void env_globals_body(const DCfg& c, Glob& g, Acc* acc, uint64_t seed, int count_push);
 __global__ __launch_bounds__(WG) void k_env_post_a(Pool P, const Model* __restrict__ mp, const DCfg cv, Glob* gp,
                                                    Acc* acc, uint64_t seed, uint32_t step_count) {
+  STAMP(STK_POST_A)
   __shared__ float s_es[NREW][WG], s_r[NREW][WG];
   int b = blockIdx.x * WG + threadIdx.x;
   if (b >= P.B) return;
@@ -5038,6 +5112,7 @@ __global__ __launch_bounds__(64) void k_env_post_b_team(Pool P, const Model* __r
                                                         const Glob* __restrict__ gp, uint64_t seed, uint32_t step_count, float* __restrict__ obs_out,
                                                         float* __restrict__ priv_out, float* __restrict__ rew_out, uint8_t* __restrict__ reset_out,
                                                         float* __restrict__ timeout_out) {
+  STAMP(STK_POST_B)
   constexpr int EPW = 64 / T;
   // FK refresh after a reset call (the reference's set_dofs_position / set_pos / set_quat re-run the full-batch FK, and the "global" mass /
   // COM randomisation touches every env): done here, at the end of the kernel, instead of in a launch of its own.  The model tables are
@@ -6255,6 +6330,15 @@ int go2sim_debug_brlog(go2sim_t* h, float* out, int* cnt) {
 }
 #endif
 /* development/test aid (not declared in include/go2sim.h): device address of ANY pool field by name */
+#ifdef GO2SIM_STAMP
+int go2sim_debug_stamps(go2sim_t* h, unsigned long long* stamps, unsigned* counts) {   // [ST_KINDS][ST_MAX_WG][ST_DEPTH][2], [ST_KINDS][ST_MAX_WG]
+  if (!h || !stamps || !counts) return GO2SIM_E_BADARG;
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpyFromSymbol(stamps, HIP_SYMBOL(g_stamp), sizeof(unsigned long long) * ST_KINDS * ST_MAX_WG * ST_DEPTH * 2));
+  HIPCHK(hipMemcpyFromSymbol(counts, HIP_SYMBOL(g_stamp_cnt), sizeof(unsigned) * ST_KINDS * ST_MAX_WG));
+  return GO2SIM_E_OK;
+}
+#endif
 #ifdef GO2SIM_PHASE_PROFILE
 int go2sim_debug_phases(go2sim_t* h, unsigned long long* out64, int reset) {
   if (!h || !out64) return GO2SIM_E_BADARG;

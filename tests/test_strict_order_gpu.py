@@ -22,7 +22,7 @@ def hip_strict_lib():
     return Go2SimLib(os.path.abspath(build.build_hip_variant("strict", build.HIP_VARIANTS["strict"], verbose=False)), "go2sim_")
 
 
-@pytest.mark.parametrize("task,n_envs,steps,kind,seed", [("walk", 64, 120, "mixed", 7), ("stairs", 64, 100, "0.5", 5), ("jump", 64, 100, "mixed", 8), ("walk", 130, 40, "2.0", 11)])
+@pytest.mark.parametrize("task,n_envs,steps,kind,seed", [("walk", 64, 120, "mixed", 7), ("stairs", 64, 120, "mixed", 5), ("jump", 64, 100, "mixed", 8), ("walk", 130, 40, "2.0", 11)])
 def test_strict_hip_build_equals_strict_oracle(oracle_strict_lib, hip_strict_lib, blob, task, n_envs, steps, kind, seed):
     cpu, gpu = CpuEnv(oracle_strict_lib, blob, n_envs, seed=seed, task=task), GpuEnv(hip_strict_lib, blob, n_envs, seed=seed, task=task)
     if task == "stairs":
@@ -41,4 +41,4 @@ def test_strict_hip_build_equals_strict_oracle(oracle_strict_lib, hip_strict_lib
     for fn in ("F_QPOS", "F_VEL", "F_ACC", "F_QACC_WS", "F_EFC_FORCE", "F_CONTACT_FORCE", "I_N_CONSTRAINTS", "I_SOLVER_ITERS", "F_CONTACT_POS", "F_CONTACT_NORMAL"):
         assert bits_equal(cpu.field(fn), gpu.field(fn)), f"{task}: field {fn} differs"
     assert gpu.sim.check_errno() == cpu.sim.check_errno() == 0
-    assert n_resets > 0
+    assert n_resets > 0, "the action set was meant to provoke falls / resets"

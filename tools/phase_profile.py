@@ -9,9 +9,8 @@ from go2_sim2real_locomotion_rl_amd import capi
 from go2_sim2real_locomotion_rl_amd.configs import build_stair_terrain, flatten_walk_cfg, get_stair_cfgs, get_walk_cfgs
 from go2_sim2real_locomotion_rl_amd.model_blob import pack_model
 
-so = os.path.join(ROOT, "tools", "libgo2sim_prof.so")
-if not os.path.exists(so):
-    raise SystemExit("build first: hipcc ... -DGO2SIM_PHASE_PROFILE -o tools/libgo2sim_prof.so")
+from go2_sim2real_locomotion_rl_amd import build
+so = build.build_hip_variant("prof", ["-DGO2SIM_PHASE_PROFILE"], verbose=False)     # tools/lib_prof.so, rebuilt when the sources are newer
 lib = capi.Go2SimLib(so, "go2sim_")
 B = 4096
 dev = torch.device("cuda", 0)
