@@ -14,7 +14,10 @@ open-loop sine gait 0.3*sin(2*pi*1.5Hz*t + phase_leg) (+0 stiffness actions), in
 steps from the reset, then exactly K timed steps.  With a short W the timed window is the landing / contact-onset transient.
 
 Rank 0 prints ONE JSON line.  Besides the contract keys it carries (N=1 only, all measured in this process):
-  roofline      : dominant kernel of the timed window, HIP-event timed in a replay of the same workload
+  roofline      : dominant kernel of the timed window, HIP-event timed in a replay of the same workload (the north-star HBM roofline)
+  roofline_issue: the roofline that fits the path: vector issue-slot utilisation, lane occupancy and waves per SIMD of the same kernel (stamped SQ
+                  counter file under profiles/), and the single-env latency floor (step time at 256 envs, measured live)
+  rollouts      : closed collection loops (policy + env + storage): stairs = the counterpart of the reference's logged collection time
   steady_state  : the SAME handle continued: settle phase, then >= 1000 timed steps (+ per-kernel ms from 200 event-timed steps)
   action_sets   : SURVEY 8d sets A (zeros), B (0.5*N(0,1): falls / resets) and C (sine gait), each 200 warm-up + 1000 timed steps
   curriculum_live : set C with the metric-gated curriculum running (not frozen)
@@ -58,8 +61,11 @@ NACT = {"walk": 16, "stairs": 16, "jump_dr": 12}
 # k_integrate_fk_dynamics + k_integrate_fk; "k_env_pre" is only non-zero with GO2SIM_NO_FUSE=1.
 KERNEL_CLASSES = ["k_dynamics", "k_collide", "k_constraint_solve", "k_integrate_fk", "k_env_pre", "k_env_post(a+globals+b)", "misc", "env_step_total"]
 LAUNCHES_PER_ENV_STEP = 9
-PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
-PMC_TRAFFIC_FILES = {"walk": PMC_TRAFFIC_FILE, "stairs": os.path.join(ROOT, "profiles", "r03_stairs_pmc_traffic.json")}   # per workload (tools/profile_round.sh)
+PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")
+PMC_TRAFFIC_FILES = {"walk": PMC_TRAFFIC_FILE, "stairs": os.path.join(ROOT, "profiles", "r04_stairs_pmc_traffic.json")}   # per workload (tools/profile_round.sh)
+PMC_SQ_FILES = {5: os.path.join(ROOT, "profiles", "r04_pmc_sq.json"), 300: os.path.join(ROOT, "profiles", "r04_steady_pmc_sq.json")}   # by warm-up: landing window / steady gait
+KERNEL_OF_CLASS = {"k_dynamics": "k_pre_dynamics", "k_collide": "k_collide", "k_constraint_solve": "k_constraint_solve", "k_integrate_fk": "k_integrate_fk_dynamics",
+                   "k_env_post(a+globals+b)": "k_env_post_a"}
 
 
 def source_hash():
@@ -115,6 +121,81 @@ def pmc_traffic_bytes(kernel, n_envs, workload="walk"):
     return int((2 * rec["fetch_size_kb"] + rec["write_size_kb"]) * 1024), None
 
 
+def roofline_issue_of(kernel_class, n_envs, warmup, workload, latency_floor):
+    """The roofline that FITS this path: the kernels move 0.3 TB/s of 8 and run no matrix instructions -- what a launch costs is the
+    instruction stream of its slowest wavefront.  Reported for the dominant kernel from the committed, source-stamped SQ counter pass
+    (tools/profile_round.sh -> tools/make_pmc_sq.py): the share of the chip's vector issue slots the launch uses over its duration, the same while the
+    mean wave is alive, lanes active per vector instruction, waves per SIMD; plus, measured live, the single-environment latency floor (the step time
+    at 256 envs: what one env's chain through the nine launches costs when the chip is almost empty)."""
+    out = {"bound": "valu-issue / slowest-wave latency", "kernel": KERNEL_OF_CLASS.get(kernel_class, kernel_class), "peak": 1.0, "unit": "fraction of vector issue slots (4 cycles per wave64 instruction, 1024 SIMDs)",
+           "latency_floor": latency_floor}
+    path = PMC_SQ_FILES.get(5 if warmup < 100 else 300)
+    note = None
+    if workload != "walk" or n_envs != ENVS_PER_GPU:
+        note = "SQ counters are collected for the walk workload at 4096 envs"
+    elif not os.path.exists(path):
+        note = "no SQ counter file for this round"
+    else:
+        doc = json.load(open(path))
+        rec = doc.get("kernels", {}).get(out["kernel"])
+        if doc.get("source_sha256") != source_hash():
+            note = "SQ counter file was measured on different sources (stale): refused"
+        elif rec is None:
+            note = f"kernel {out['kernel']} not in the SQ counter file"
+        else:
+            out.update({"achieved": rec.get("valu_issue_util"), "frac": rec.get("valu_issue_util"), "valu_busy_while_mean_wave_alive": rec.get("valu_busy_while_alive"),
+                        "lane_occupancy": rec.get("lane_occupancy"), "waves_per_simd": rec.get("waves_per_simd"), "avg_us_under_pmc": rec.get("avg_us_under_pmc"),
+                        "source": os.path.relpath(path, ROOT), "window": "landing window (steps 5..25)" if warmup < 100 else "steady gait (steps 300..700)"})
+    if note:
+        out.update({"achieved": None, "frac": None, "note": note})
+    return out
+
+
+def latency_floor(device, local_rank, stream, W, K, n_envs=256):
+    """Step time of the same workload and window at 256 envs: every kernel then holds at most one wave on a quarter of the SIMDs, so the step time
+    is the length of one environment's chain through the launches."""
+    sim = make_sim(load_hip_lib(), n_envs, local_rank, 1, "walk")
+    act = make_actions(W + K, n_envs, device)
+    buf = Buffers(n_envs, "walk", device)
+    for s in range(W):
+        sim.env_step(act[s], buf.obs, buf.priv, buf.rew, buf.rst, buf.to, stream)
+    dt = timed_run(sim, act, W, K, buf, stream)
+    del sim
+    return {"n_envs": n_envs, "ms_per_step": round(dt / K * 1e3, 4), "window": f"steps {W}..{W + K} after the reset"}
+
+
+def rollout_run(B, device, local_rank, workload, n_warm_rollouts, n_rollouts, stream):
+    """`--workload <w> --rollout` semantics as one number: policy inference (ActorCritic.act, random-init weights) + env step + RolloutStorage every step,
+    GAE + advantage statistics every 24 steps -- what rsl_rl's collection phase does; the counterpart of the reference's logged collection time."""
+    from go2_sim2real_locomotion_rl_amd import ActorCritic, RolloutStorage
+
+    sim = make_sim(load_hip_lib(), B, local_rank, 1, workload)
+    buf = Buffers(B, workload, device)
+    storage = RolloutStorage(ROLLOUT_LEN, B, device=device)
+    policy = ActorCritic(NOBS[workload], NPRIV[workload], NACT[workload], [512, 256, 128], [512, 256, 128], activation="elu", init_noise_std=0.3, device=device, seed=1)
+
+    def rollout():
+        for t in range(ROLLOUT_LEN):
+            a = policy.act(buf.obs, buf.priv)
+            sim.env_step(a, buf.obs, buf.priv, buf.rew, buf.rst, buf.to, stream)
+            storage.add_transitions(t, buf.rew, buf.rst, policy.values, buf.to, gamma=0.99)
+        storage.compute_returns(policy.evaluate(buf.priv), 0.99, 0.95)
+
+    for _ in range(n_warm_rollouts):
+        rollout()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n_rollouts):
+        rollout()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    out = {"value": round(B * ROLLOUT_LEN * n_rollouts / dt, 1), "unit": "env-steps/s", "collection_time_s_per_rollout": round(dt / n_rollouts, 6), "n_envs": B,
+           "rollouts_timed": n_rollouts, "rollouts_warmup": n_warm_rollouts, "errno": sim.check_errno(),
+           "loop": "ActorCritic.act (fused MLP + sampling) -> go2sim_env_step -> RolloutStorage.add_transitions, x 24; then evaluate + compute_returns (GAE, advantage normalisation)"}
+    del sim
+    return out
+
+
 def make_sim(lib, n_envs, device_index, seed, workload, freeze_curriculum=True, shared_globals=False):
     """Configured handle: walk (flat plane) or stairs (go2_train_stair.py terrain + cfg), curriculum frozen at its initial level."""
     sim = Go2Sim(lib, pack_model(), n_envs, device_index, seed)
@@ -129,6 +210,10 @@ def make_sim(lib, n_envs, device_index, seed, workload, freeze_curriculum=True, 
         sim.set_terrain(hf, info["horizontal_scale"], info["vertical_scale"], info["terrain_origin"])
     f, i, _ = flatten_walk_cfg(n_envs, *cfgs, freeze_curriculum=freeze_curriculum, shared_globals=shared_globals)
     sim.env_configure(f, i)
+    if shared_globals:       # first sync of a sharded batch before the constructor's reset: every shard starts at rank 0's t_sample / global draws
+        from go2_sim2real_locomotion_rl_amd.distributed import sync_env_globals
+
+        sync_env_globals(sim, None, None, initial=True)
     sim.env_reset()
     return sim
 
@@ -260,7 +345,7 @@ def ref_logged():
     rows = d.get("per_iteration", [])
     return {"source": "logs/test1/events.out.tfevents.* (go2_train_stair.py run, 4096 envs x 24 steps per iteration, policy inference included, hardware unstated)",
             "collection_env_steps_per_s": [round(r["collection_env_steps_per_s"], 1) for r in rows],
-            "total_fps": [r["total_fps"] for r in rows], "compare_with": "workloads.stairs (env step only) and `--workload stairs --rollout` (policy + storage included)"}
+            "total_fps": [r["total_fps"] for r in rows], "compare_with": "rollouts.stairs (policy + env + storage, the like-for-like loop) and workloads.stairs (env step only)"}
 
 
 def cpu_baseline(n_envs, steps, warmup, threads=None):
@@ -457,7 +542,7 @@ def main():
 
     # ---- HIP-event pass of the headline window: the SAME workload replayed on a fresh handle (same seed => identical trajectories), with HIP
     # events recorded around every kernel launch on the launch stream.  Kept out of the timed region so `value` carries no event overhead.
-    roofline = None
+    roofline = roofline_issue = None
     if not args.no_profile_pass and world == 1:
         sim2 = make_sim(load_hip_lib(), B, local_rank, 1 + rank, WORKLOAD)
         sim2.enable_timing(True)
@@ -472,8 +557,9 @@ def main():
         sim2.enable_timing(False)
         roofline = roofline_of(ms, cnt, K, B, WORKLOAD, value)
         del sim2
+        roofline_issue = roofline_issue_of(roofline["kernel"], B, W, WORKLOAD, latency_floor(device, local_rank, stream, W, K) if WORKLOAD == "walk" else None)
 
-    action_sets = curriculum_live = workloads = refp = refp_anymal = envcls = None
+    action_sets = curriculum_live = workloads = refp = refp_anymal = envcls = rollouts = None
     if extras_on:
         del sim
         envcls = go2env_class_run(B, device, local_rank, 1 + rank, W, K)
@@ -483,6 +569,9 @@ def main():
         workloads = {"stairs": protocol_run(B, device, local_rank, 1, "stairs", "C", 100, 300, stream),
                      "jump_dr": protocol_run(B, device, local_rank, 1, "jump_dr", "C", 100, 300, stream),
                      "note": "BASELINE configs[2] (stair heightfield, level 0.65) and configs[4] (jump env + per-env mass / friction DR), set C, env-steps/s, 100 warm-up + 300 timed steps"}
+        rollouts = {"stairs": rollout_run(B, device, local_rank, "stairs", 5, 20, stream), "walk": rollout_run(B, device, local_rank, "walk", 5, 20, stream),
+                    "note": "closed collection loop (policy inference + env step + rollout storage, 24-step rollouts, 4096 envs): `stairs` is the like-for-like counterpart of "
+                            "ref_logged.collection_env_steps_per_s (137.6 k / 93.5 k env-steps/s in the reference's logs/test1, hardware unstated); vs_baseline stays null"}
         refp = ref_protocol(B, device, local_rank, stream)
         refp_anymal = ref_protocol(B, device, local_rank, stream, robot="anymal_c")
 
@@ -509,7 +598,7 @@ def main():
                        "loop": ("closed rollout loop: ActorCritic.act + env step + RolloutStorage (information only)" if args.rollout else
                                 "env step, open-loop actions" + ("; rewards / dones land in the rollout storage; every 24 steps: GAE + RCCL all-gather of the advantage moments, all-reduce of the curriculum counters and broadcast of rank 0's global DR scalars (one curriculum level, one set of global draws over all shards)"
                                                                  if world > 1 else ""))},
-            "roofline": roofline, "cpu_baseline": cpu, "steady_state": steady, "action_sets": action_sets, "curriculum_live": curriculum_live,
+            "roofline": roofline, "roofline_issue": roofline_issue, "cpu_baseline": cpu, "steady_state": steady, "rollouts": rollouts, "action_sets": action_sets, "curriculum_live": curriculum_live,
             "workloads": workloads, "ref_protocol_fps": refp, "ref_protocol_fps_anymal_c": refp_anymal, "go2env_class": envcls, "ref_logged": ref_logged(),
         }
         print(json.dumps(out), flush=True)

@@ -273,6 +273,16 @@ class Go2Sim:
     def env_set_global_dr(self, dr10, stream=None):
         self._call("env_set_global_dr", (ctypes.c_double * 10)(*[float(v) for v in dr10]), _ptr(stream))
 
+    def env_sync_counters_dev(self, counters5, stream=None):
+        """float64[5] tensor / array in the library's memory space (device for the HIP library); stream-ordered, no synchronisation"""
+        self._call("env_sync_counters_dev", _ptr(counters5), _ptr(stream))
+
+    def env_sync_apply_dev(self, summed5, dr_out10, stream=None):
+        self._call("env_sync_apply_dev", _ptr(summed5), _ptr(dr_out10), _ptr(stream))
+
+    def env_set_global_dr_dev(self, dr10, stream=None):
+        self._call("env_set_global_dr_dev", _ptr(dr10), _ptr(stream))
+
     def env_set_level(self, level, stream=None):
         self._call("env_set_level", ctypes.c_double(level), _ptr(stream))
 

@@ -4913,6 +4913,36 @@ __host__ __device__ inline void globals_draws(const DCfg& c, Glob& g, uint64_t s
 }
 
 // single-instance part of reset_idx: curriculum, t_sample, "global" DR (go2_env_walk.py:688-756,803-848,1160-1171)
+// go2sim_env_sync_apply on one Glob (host copy or device): the summed shard counters enter the curriculum state machine, then the draws of one reset
+// call.  The first apply of a handle draws even without a counted reset (and draws the friction regardless of the throttle): a sync issued between
+// configure and the constructor's reset puts the shard where the single-process env starts (include/go2sim.h); the caller passes the env count of
+// the batch as the throttle increment of that sync, as the constructor's reset_idx would count it.
+__host__ __device__ inline void sync_apply_body(const DCfg& c, Glob& g, uint64_t seed, const double* s5, double* dr_out10) {
+  const int n = (int)s5[0];
+  const bool first = g.sync_calls == 0;
+  if (n > 0 || first) {
+    if (n > 0 && c.i[GO2SIM_IC_CURR_ENABLED] && !c.i[GO2SIM_IC_FREEZE_CURRICULUM]) {
+      g.curr_ep_total += n; g.curr_timeout_total += s5[1]; g.curr_tracking_sum += s5[2]; g.curr_tracking_n += (int)s5[3];
+      globals_curriculum_check(c, g);
+    }
+    globals_draws(c, g, seed, (int)s5[4], (uint32_t)g.sync_calls);
+    g.sync_calls += 1;
+  }
+  dr_out10[0] = g.friction; dr_out10[1] = g.mass_shift;
+  for (int k = 0; k < 3; ++k) dr_out10[2 + k] = g.com_shift[k];
+  for (int k = 0; k < 4; ++k) dr_out10[5 + k] = g.leg_mass_shift[k];
+  dr_out10[9] = g.t_sample;
+}
+__host__ __device__ inline void set_global_dr_body(Glob& g, const double* dr10) {
+  g.friction = (float)dr10[0]; g.mass_shift = (float)dr10[1];
+  for (int k = 0; k < 3; ++k) g.com_shift[k] = (float)dr10[2 + k];
+  for (int k = 0; k < 4; ++k) g.leg_mass_shift[k] = (float)dr10[5 + k];
+  g.t_sample = dr10[9];
+}
+__global__ void k_env_sync_counters(Glob* gp, double* out5) { for (int k = 0; k < 5; ++k) { out5[k] = gp->shard_counters[k]; gp->shard_counters[k] = 0.0; } }
+__global__ void k_env_sync_apply(const DCfg* __restrict__ cp, Glob* gp, uint64_t seed, const double* __restrict__ s5, double* dr_out10) { sync_apply_body(*cp, *gp, seed, s5, dr_out10); }
+__global__ void k_env_set_global_dr(Glob* gp, const double* __restrict__ dr10) { set_global_dr_body(*gp, dr10); }
+
 DEV void env_globals_body(const DCfg& c, Glob& g, Acc* acc, uint64_t seed, int count_push) {
   if (count_push && c.i[GO2SIM_IC_HAS_PUSH] && g.push_enable) g.push_counter += 1;
   int n = acc->n_reset_now;
@@ -4921,7 +4951,8 @@ DEV void env_globals_body(const DCfg& c, Glob& g, Acc* acc, uint64_t seed, int c
     // `float(tensor.sum().item())` of float32 tensors (:698, :710) added to python floats
     const double timeouts = (double)(float)acc->timeouts, tracking = (double)(float)acc->tracking;
     if (c.i[GO2SIM_IC_SHARED_GLOBALS]) {              // one shard of a larger batch: the increments are combined by the host (go2sim_env_sync_*)
-      g.shard_counters[0] += n; g.shard_counters[1] += timeouts; g.shard_counters[2] += tracking; g.shard_counters[3] += n; g.shard_counters[4] += n;
+      g.shard_counters[0] += n; g.shard_counters[1] += timeouts; g.shard_counters[2] += tracking; g.shard_counters[3] += n;
+      if (!(g.sync_calls > 0 && g.reset_calls == 0)) g.shard_counters[4] += n;   // (the constructor's reset after an initial sync: that sync already counted these envs for the friction throttle)
     } else {
       if (c.i[GO2SIM_IC_CURR_ENABLED] && !c.i[GO2SIM_IC_FREEZE_CURRICULUM]) {
         g.curr_ep_total += n; g.curr_timeout_total += timeouts; g.curr_tracking_sum += tracking; g.curr_tracking_n += n;
@@ -6255,34 +6286,40 @@ int go2sim_env_sync_counters(go2sim_t* h, double* out5, void* stream) {
 int go2sim_env_sync_apply(go2sim_t* h, const double* s5, double* dr_out10, void* stream) {
   if (!h || !h->cfg_set || !s5) return GO2SIM_E_BADARG;
   hipStream_t s = (hipStream_t)stream;
-  const DCfg& c = h->hcfg;
   Glob g; int rc = glob_download(h, g, s); if (rc) return rc;
-  const int n = (int)s5[0];
-  if (n > 0) {
-    if (c.i[GO2SIM_IC_CURR_ENABLED] && !c.i[GO2SIM_IC_FREEZE_CURRICULUM]) {
-      g.curr_ep_total += n; g.curr_timeout_total += s5[1]; g.curr_tracking_sum += s5[2]; g.curr_tracking_n += (int)s5[3];
-      globals_curriculum_check(c, g);
-    }
-    globals_draws(c, g, h->seed, (int)s5[4], (uint32_t)g.sync_calls);
-    g.sync_calls += 1;
-  }
-  if (dr_out10) {
-    dr_out10[0] = g.friction; dr_out10[1] = g.mass_shift;
-    for (int k = 0; k < 3; ++k) dr_out10[2 + k] = g.com_shift[k];
-    for (int k = 0; k < 4; ++k) dr_out10[5 + k] = g.leg_mass_shift[k];
-    dr_out10[9] = g.t_sample;
-  }
+  double dr[10];
+  sync_apply_body(h->hcfg, g, h->seed, s5, dr);
+  if (dr_out10) for (int k = 0; k < 10; ++k) dr_out10[k] = dr[k];
   return glob_upload(h, g, s);
 }
 int go2sim_env_set_global_dr(go2sim_t* h, const double* dr10, void* stream) {
   if (!h || !h->cfg_set || !dr10) return GO2SIM_E_BADARG;
   hipStream_t s = (hipStream_t)stream;
   Glob g; int rc = glob_download(h, g, s); if (rc) return rc;
-  g.friction = (float)dr10[0]; g.mass_shift = (float)dr10[1];
-  for (int k = 0; k < 3; ++k) g.com_shift[k] = (float)dr10[2 + k];
-  for (int k = 0; k < 4; ++k) g.leg_mass_shift[k] = (float)dr10[5 + k];
-  g.t_sample = dr10[9];
+  set_global_dr_body(g, dr10);
   rc = glob_upload(h, g, s); if (rc) return rc;
+  hipLaunchKernelGGL(k_env_apply_global_dr, grid_for(h->B), dim3(WG), 0, s, h->P, h->dcfg, h->dglob);
+  launch_fk_team(h, s, 1, nullptr);
+  HIPCHK(hipGetLastError());
+  return GO2SIM_E_OK;
+}
+// the same three steps on device arrays: three single-thread kernels on the caller's stream, no host round trip (the RCCL path of distributed.sync_env_globals)
+int go2sim_env_sync_counters_dev(go2sim_t* h, double* out5_dev, void* stream) {
+  if (!h || !h->cfg_set || !out5_dev) return GO2SIM_E_BADARG;
+  hipLaunchKernelGGL(k_env_sync_counters, dim3(1), dim3(1), 0, (hipStream_t)stream, h->dglob, out5_dev);
+  HIPCHK(hipGetLastError());
+  return GO2SIM_E_OK;
+}
+int go2sim_env_sync_apply_dev(go2sim_t* h, const double* s5_dev, double* dr_out10_dev, void* stream) {
+  if (!h || !h->cfg_set || !s5_dev || !dr_out10_dev) return GO2SIM_E_BADARG;
+  hipLaunchKernelGGL(k_env_sync_apply, dim3(1), dim3(1), 0, (hipStream_t)stream, h->dcfg, h->dglob, h->seed, s5_dev, dr_out10_dev);
+  HIPCHK(hipGetLastError());
+  return GO2SIM_E_OK;
+}
+int go2sim_env_set_global_dr_dev(go2sim_t* h, const double* dr10_dev, void* stream) {
+  if (!h || !h->cfg_set || !dr10_dev) return GO2SIM_E_BADARG;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_env_set_global_dr, dim3(1), dim3(1), 0, s, h->dglob, dr10_dev);
   hipLaunchKernelGGL(k_env_apply_global_dr, grid_for(h->B), dim3(WG), 0, s, h->P, h->dcfg, h->dglob);
   launch_fk_team(h, s, 1, nullptr);
   HIPCHK(hipGetLastError());

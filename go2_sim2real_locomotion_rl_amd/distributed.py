@@ -64,7 +64,7 @@ def allgather_moments(moments3: torch.Tensor, group=None) -> torch.Tensor:
     return moments3
 
 
-def sync_env_globals(sim, group=None, stream=None):
+def sync_env_globals(sim, group=None, stream=None, initial=False):
     """One batch sharded over ranks, one curriculum / one set of global DR scalars.  `sim` is a capi.Go2Sim configured with
     ``shared_globals=True`` (GO2SIM_IC_SHARED_GLOBALS).  Call it on every rank at the same cadence (once per rollout):
       1. this shard's increments of [episodes, time-outs, tracking sum, tracking n, throttle resets] (go2_env_walk.py:460-463, 712-715, 744)
@@ -72,16 +72,36 @@ def sync_env_globals(sim, group=None, stream=None):
       3. every rank runs _maybe_update_curriculum_on_reset / sample_level / the global DR draws on the SAME summed counters
       4. broadcast of rank 0's draws (friction, mass shift, COM shift, leg-mass shifts and the sampled DR level t_sample: 10 float64), applied
          to all envs of every shard.
-    Returns (summed counters, the 10 scalars now in force).  Without a process group it degenerates to the single-shard case."""
-    dev = torch.device("cuda", torch.cuda.current_device()) if (dist.is_available() and dist.is_initialized() and dist.get_backend(group) == "nccl") else torch.device("cpu")
-    counters = torch.from_numpy(sim.env_sync_counters(stream)).to(dev)
+    Returns (summed counters, the 10 scalars now in force; device tensors under nccl).  Without a process group it degenerates to the single-shard case.
+    Call it ONCE with ``initial=True`` between env_configure and the constructor's env_reset as well (Go2Env and bench.make_sim do): that first apply draws
+    t_sample at level_init and the global scalars on rank 0 -- with the batch's env count as the friction-throttle increment, as the constructor's reset_idx
+    counts it -- and every shard starts where the single-process env starts."""
     multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    src = (dist.get_global_rank(group, 0) if group is not None else 0) if multi else 0
+    if multi and dist.get_backend(group) == "nccl":
+        # RCCL: counters and scalars stay on the device from the shard's Glob to the collective and back (three single-thread kernels of the library
+        # around two collectives, all ordered on torch's current stream); nothing is copied to the host and nothing synchronises
+        dev = torch.device("cuda", torch.cuda.current_device())
+        stream = torch.cuda.current_stream().cuda_stream if stream is None else stream
+        counters = torch.empty(5, dtype=torch.float64, device=dev)
+        dr = torch.empty(10, dtype=torch.float64, device=dev)
+        sim.env_sync_counters_dev(counters, stream)
+        if initial:
+            counters[4] += float(sim.n_envs)
+        dist.all_reduce(counters, op=dist.ReduceOp.SUM, group=group)
+        sim.env_sync_apply_dev(counters, dr, stream)
+        dist.broadcast(dr, src=src, group=group)
+        sim.env_set_global_dr_dev(dr, stream)
+        return counters, dr
+    counters = torch.from_numpy(sim.env_sync_counters(stream))       # gloo (CPU tests, rehearsal) and the single-shard case: host arrays
+    if initial:
+        counters[4] += float(sim.n_envs)
     if multi:
         dist.all_reduce(counters, op=dist.ReduceOp.SUM, group=group)
-    summed = counters.cpu().numpy()
-    dr = torch.from_numpy(sim.env_sync_apply(summed, stream)).to(dev)
+    summed = counters.numpy()
+    dr = torch.from_numpy(sim.env_sync_apply(summed, stream))
     if multi:
-        dist.broadcast(dr, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
-    dr = dr.cpu().numpy()
+        dist.broadcast(dr, src=src, group=group)
+    dr = dr.numpy()
     sim.env_set_global_dr(dr, stream)
     return summed, dr

@@ -125,6 +125,11 @@ class Go2Env:
         self.errno_poll_every = int(errno_poll_every)  # env steps between errno polls (simulator.py:267: every 10 substeps)
         self._steps_since_poll = 0
         self._views = {}
+        self._shared_globals = bool(shared_globals) and not self.is_base_env
+        if self._shared_globals:
+            # one batch sharded over ranks: the first sync (before the constructor's reset) puts every shard at the single-process starting point -- rank 0's
+            # t_sample at level_init and first global draws; without it the shard's first episodes would sample the easy end of every DR range
+            self.sync_globals(initial=True)
         self.reset()
 
     # ---- reference API -------------------------------------------------------------------------
@@ -303,12 +308,12 @@ class Go2Env:
         """extras["curriculum"] of the reference (go2_env_walk.py:674-690); this call synchronises the stream."""
         return self._sim.env_globals(torch.cuda.current_stream(self.device).cuda_stream).as_dict()
 
-    def sync_globals(self, group=None):
+    def sync_globals(self, group=None, initial=False):
         """One batch sharded over ranks (``shared_globals=True``): all-reduce of the curriculum counters, the shared state machine, broadcast of
         rank 0's global DR draws (distributed.sync_env_globals).  Call on every rank once per rollout."""
         from .distributed import sync_env_globals
 
-        return sync_env_globals(self._sim, group, torch.cuda.current_stream(self.device).cuda_stream)
+        return sync_env_globals(self._sim, group, torch.cuda.current_stream(self.device).cuda_stream, initial=initial)
 
     def check_errno(self):
         """rigid_solver.py:1208-1211: blocking form of the poll (``step`` runs the asynchronous one every ``errno_poll_every`` steps)."""

@@ -387,6 +387,16 @@ int go2sim_env_set_level(go2sim_t* h, double level, void* stream);
 int go2sim_env_sync_counters(go2sim_t* h, double* counters5_host, void* stream);
 int go2sim_env_sync_apply(go2sim_t* h, const double* summed_counters5_host, double* dr_out10_host, void* stream);
 int go2sim_env_set_global_dr(go2sim_t* h, const double* dr10_host, void* stream);
+/* The same three steps with DEVICE arrays (caller-owned, float64), stream-ordered and without any host synchronisation: the form the RCCL path uses
+ * (distributed.sync_env_globals under backend "nccl": counters and scalars never leave the device; the host forms above serve gloo and tests).
+ * The very first go2sim_env_sync_apply[_dev] of a handle draws the scalars even when no reset has been counted yet, so that a sync issued between
+ * go2sim_env_configure and go2sim_env_reset puts every shard where the single-process env starts: t_sample at level_init and the first global
+ * draws of the constructor's reset_idx (go2_env_walk.py:1243-1245).  For that initial sync the caller adds its env count to counters[4] (the
+ * friction-throttle increment the constructor's reset would make: distributed.sync_env_globals(initial=True)); the reset that follows does not
+ * count its envs for the throttle again. */
+int go2sim_env_sync_counters_dev(go2sim_t* h, double* counters5_dev, void* stream);
+int go2sim_env_sync_apply_dev(go2sim_t* h, const double* summed_counters5_dev, double* dr_out10_dev, void* stream);
+int go2sim_env_set_global_dr_dev(go2sim_t* h, const double* dr10_dev, void* stream);
 /* zero-copy address of the live go2sim_env_globals_t (device memory for the HIP library): lets the host shim expose
  * extras["episode"] / extras["curriculum"] (go2_env_Omni_walk_16output.py:674-690, 1229-1234) as device tensors
  * without a stream synchronisation. */

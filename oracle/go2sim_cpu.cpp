@@ -2424,7 +2424,8 @@ void env_globals_update(go2sim* h, bool count_push) {
     // `float(tensor.sum().item())` of float32 tensors (:698, :710) added to python floats
     const double timeouts = (double)(float)h->acc_timeouts, tracking = (double)(float)h->acc_tracking;
     if (c.i[GO2SIM_IC_SHARED_GLOBALS]) {              // one shard of a larger batch: the increments are combined by the host (go2sim_env_sync_*)
-      g.shard_counters[0] += n; g.shard_counters[1] += timeouts; g.shard_counters[2] += tracking; g.shard_counters[3] += n; g.shard_counters[4] += n;
+      g.shard_counters[0] += n; g.shard_counters[1] += timeouts; g.shard_counters[2] += tracking; g.shard_counters[3] += n;
+      if (!(g.sync_calls > 0 && g.reset_calls == 0)) g.shard_counters[4] += n;   // (the constructor's reset after an initial sync: that sync already counted these envs for the friction throttle)
     } else {
       if (c.i[GO2SIM_IC_CURR_ENABLED] && !c.i[GO2SIM_IC_FREEZE_CURRICULUM]) {                // _maybe_update_curriculum_on_reset
         g.curr_ep_total += n; g.curr_timeout_total += timeouts; g.curr_tracking_sum += tracking; g.curr_tracking_n += n;
@@ -3074,8 +3075,9 @@ int go2sim_cpu_env_sync_apply(go2sim* h, const double* s5, double* dr_out10, voi
   if (!h || !h->cfg.set || !s5) return GO2SIM_E_BADARG;
   const Cfg& c = h->cfg; go2sim_env_globals_t& g = h->g;
   const int n = (int)s5[0];
-  if (n > 0) {
-    if (c.i[GO2SIM_IC_CURR_ENABLED] && !c.i[GO2SIM_IC_FREEZE_CURRICULUM]) {
+  const bool first = g.sync_calls == 0;            // the first apply draws even without a counted reset (include/go2sim.h)
+  if (n > 0 || first) {
+    if (n > 0 && c.i[GO2SIM_IC_CURR_ENABLED] && !c.i[GO2SIM_IC_FREEZE_CURRICULUM]) {
       g.curr_ep_total += n; g.curr_timeout_total += s5[1]; g.curr_tracking_sum += s5[2]; g.curr_tracking_n += (int)s5[3];
       globals_curriculum_check(h);
     }
@@ -3101,6 +3103,10 @@ int go2sim_cpu_env_set_global_dr(go2sim* h, const double* dr10, void*) {
   for (int b = 0; b < h->B; ++b) env_apply_globals_and_fk(h, b);
   return GO2SIM_E_OK;
 }
+// the "device array" forms of the HIP library: host arrays here
+int go2sim_cpu_env_sync_counters_dev(go2sim* h, double* out5, void* s) { return go2sim_cpu_env_sync_counters(h, out5, s); }
+int go2sim_cpu_env_sync_apply_dev(go2sim* h, const double* s5, double* dr_out10, void* s) { return (dr_out10 == nullptr) ? GO2SIM_E_BADARG : go2sim_cpu_env_sync_apply(h, s5, dr_out10, s); }
+int go2sim_cpu_env_set_global_dr_dev(go2sim* h, const double* dr10, void* s) { return go2sim_cpu_env_set_global_dr(h, dr10, s); }
 int go2sim_cpu_enable_timing(go2sim*, int) { return GO2SIM_E_BADARG; }
 int go2sim_cpu_read_timing(go2sim*, float*, int*, int) { return GO2SIM_E_BADARG; }
 
