@@ -101,7 +101,30 @@ ORACLE_VARIANTS = {
 }
 
 
+# SHAPE VARIANTS: the same sources compiled for another link / dof / qpos / geom / joint count (include/go2sim.h GO2SIM_NL ...), in the reference's
+# summation order (-DGO2SIM_FAST_ORDER=0: the FAST ORDER block forms are laid out for 18 dofs).  Test infrastructure for the reference's analytic known
+# answers (tests/test_analytic_shapes.py; models: tools/compile_go2_model.py --robot pendulum | double_pendulum | box).
+SHAPES = {
+    "pendulum": dict(NL=3, ND=1, NQ=1, NG=2, NJ=1),           # plane | fixed base, arm + point mass (1 continuous joint)
+    "double_pendulum": dict(NL=4, ND=2, NQ=2, NG=3, NJ=2),
+    "box": dict(NL=2, ND=6, NQ=7, NG=2, NJ=1),                 # plane | free cube
+}
+
+
+def _shape_flags(name):
+    return [f"-DGO2SIM_{k}={v}" for k, v in SHAPES[name].items()]
+
+
+def build_shape_variant(name, hip=True, force=False, verbose=True):
+    """(oracle/libgo2sim_cpu_shape_<name>.so, tools/lib_shape_<name>.so or None)"""
+    cpu = build_oracle_variant("shape_" + name, _shape_flags(name), force=force, verbose=verbose)
+    gpu = build_hip_variant("shape_" + name, ["-DGO2SIM_FAST_ORDER=0", *_shape_flags(name)], force=force, verbose=verbose) if hip else None
+    return cpu, gpu
+
+
 def build_variants(force=False, verbose=True):
+    for name in SHAPES:
+        build_shape_variant(name, hip=shutil.which("hipcc") is not None or os.path.exists("/opt/rocm/bin/hipcc"), force=force, verbose=verbose)
     for name, flags in ORACLE_VARIANTS.items():
         build_oracle_variant(name, flags, force=force, verbose=verbose)
     for name, flags in HIP_VARIANTS.items():

@@ -1355,6 +1355,9 @@ __global__ __launch_bounds__(64) void k_dynamics_team(Pool P, const ModelS* __re
 }
 
 
+// the kinematics working set of k_integrate_fk_dynamics_team: laid over the M | L words of the dynamics record where it fits (the Go2 shape), else on its own
+template <bool OVERLAY, int EPW> struct KinSeparate { KinData k[EPW]; DEV KinData* at(int slot, void*) { return &k[slot]; } };
+template <int EPW> struct KinSeparate<true, EPW> { DEV KinData* at(int, void* overlay) { return (KinData*)overlay; } };
 // kernel_step_2 of substep i followed by kernel_step_1 of substep i + 1 (rigid_solver.py:3072-3180, 3008-3069) in one launch: integrate, commit, FK,
 // COM / cinr / cdof, geoms, forward velocity -- and straight on to the forward dynamics of the new state, whose inputs stay in LDS instead of making
 // an HBM round trip between two kernels (the FK outputs are still written out: the collision kernel, the solver and the env kernels read them).
@@ -1375,8 +1378,10 @@ __global__ __launch_bounds__(64) void k_integrate_fk_dynamics_team(Pool P, const
   DynData* d = &lds_d[slot];
   // the kinematics working set lives in the M | L words of the dynamics record, which the dynamics only start writing (mass matrix, then its factor)
   // after the kinematics are done: same LDS footprint, hence the same 8 workgroups per CU, as k_dynamics_team alone
-  static_assert(offsetof(DynData, L) == offsetof(DynData, M) + sizeof(float) * ND * ND && sizeof(KinData) <= 2 * sizeof(float) * ND * ND, "KinData overlay");
-  KinData* s = (KinData*)d->M;
+  static_assert(offsetof(DynData, L) == offsetof(DynData, M) + sizeof(float) * ND * ND, "KinData overlay");
+  constexpr bool KIN_OVERLAY = sizeof(KinData) <= 2 * sizeof(float) * ND * ND;       // (shape variants with few dofs: the kinematics set gets its own LDS block)
+  __shared__ KinSeparate<KIN_OVERLAY, EPW> lds_k;
+  KinData* s = lds_k.at(slot, d->M);
   PH_BEGIN
   team_stage<ND, T>(tl, [&](int i) { return gload(e, FO(vel), i); }, [&](int i, float v) { s->vel[i] = v; });
   team_stage<ND, T>(tl, [&](int i) { return aload(e, AO(acc), i); }, [&](int i, float a) { s->vel_next[i] = a; });
@@ -3154,7 +3159,7 @@ DEV bool ts_cholesky_incremental_pipelined(const MT& m, S* s, int tl, int n_con)
 #endif
 template <int T, class S, class MT>
 DEV bool ts_cholesky_incremental(const MT& m, S* s, int tl, int n_con) {
-  if constexpr (T >= ND) {
+  if constexpr (T >= ND && (T == 32 || T == 64)) {   // (the register / pipelined forms shuffle across teams of 32 or 64 lanes)
 #if GO2SIM_FAST_ORDER
     // FAST ORDER: an env with REBUILD_FLIPS (default 1: any) or more flipped rows has its Hessian summed and factorised afresh -- the caller's rebuild
     // path, which the reference takes for a degenerated factor -- instead of one rank-1 pass of the factor per flipped row.  With the block-form

@@ -63,12 +63,18 @@ extern "C" {
 #define GO2SIM_MODEL_VERSION 1
 
 /* compile-time shape of the Go2+plane model the kernels are specialised for */
+/* (a SHAPE VARIANT of the two libraries is the same sources compiled with other counts, e.g. -DGO2SIM_NL=3 -DGO2SIM_ND=1 ... for a fixed-base
+ *  pendulum: build.SHAPES / build.build_shape_variant; test infrastructure for the reference's analytic known answers, tests/test_analytic_shapes.py) */
+#ifndef GO2SIM_NL
 #define GO2SIM_NL 14   /* links   (plane + 13)            */
 #define GO2SIM_ND 18   /* dofs    (6 free + 12 revolute)  */
 #define GO2SIM_NQ 19   /* qpos                            */
 #define GO2SIM_NG 28   /* geoms   (ground box + 27)       */
 #define GO2SIM_NJ 13   /* joints                          */
+#endif
+#ifndef GO2SIM_NPAIR_MAX
 #define GO2SIM_NPAIR_MAX 320
+#endif
 #define GO2SIM_MAX_CONTACTS 150
 #define GO2SIM_MAX_BROAD 240
 #define GO2SIM_NMOTOR 12

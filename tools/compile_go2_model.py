@@ -157,7 +157,7 @@ def _floats(s):
 
 
 def load_urdf(path):
-    root = ET.parse(path).getroot()
+    root = ET.fromstring(path) if path.lstrip().startswith("<") else ET.parse(path).getroot()       # a file, or URDF text (the synthetic shape models)
     links, joints = [], []
     for l in root.findall("link"):
         L = {"name": l.get("name"), "inertial": None, "collisions": []}
@@ -561,7 +561,53 @@ ROBOTS = {   # URDFs of the reference's benchmark set that have the kernels' com
 N_GEOMS_KERNEL = 28   # GO2SIM_NG: a model with fewer collision geoms is padded with inert spheres on the ground link (no collision pairs)
 
 
+def synth_multi_pendulum(n):
+    """URDF text of the n-segment pendulum of the reference's analytic tests (tests/test_rigid_physics.py:225-277 `_build_multi_pendulum`, re-expressed: a
+    fixed base, per segment a continuous joint about x and a massless 1 m arm carrying a 1 kg point mass, inertia 1e-12).  The reference's links
+    are visual-only; a small collision sphere is added to every mass so that the collision pipeline has geoms to carry (they never touch anything:
+    spheres of adjacent links are filtered, the pivot stands 5 m above the ground)."""
+    x = ['<robot name="multi_pendulum">', '<link name="base"/>']
+    parent = "base"
+    for i in range(n):
+        x.append(f'<joint name="PendulumJoint_{i}" type="continuous"><origin xyz="0 0 0" rpy="0 0 0"/><axis xyz="1 0 0"/><parent link="{parent}"/>'
+                 f'<child link="PendulumArm_{i}"/><limit effort="{100.0 * (n - i)}" velocity="30.0"/><dynamics damping="0.0" friction="0.0"/></joint>')
+        x.append(f'<link name="PendulumArm_{i}"><inertial><origin xyz="0 0 0" rpy="0 0 0"/><mass value="0.0"/>'
+                 '<inertia ixx="0" ixy="0" ixz="0" iyy="0" iyz="0" izz="0"/></inertial></link>')
+        x.append(f'<joint name="PendulumMassJoint_{i}" type="fixed"><origin xyz="0 0 1.0" rpy="0 0 0"/><parent link="PendulumArm_{i}"/><child link="PendulumMass_{i}"/></joint>')
+        x.append(f'<link name="PendulumMass_{i}"><inertial><origin xyz="0 0 0" rpy="0 0 0"/><mass value="1.0"/>'
+                 '<inertia ixx="1e-12" ixy="0" ixz="0" iyy="1e-12" iyz="0" izz="1e-12"/></inertial>'
+                 '<collision><origin xyz="0 0 0" rpy="0 0 0"/><geometry><sphere radius="0.06"/></geometry></collision></link>')
+        parent = f"PendulumMass_{i}"
+    x.append("</robot>")
+    return "".join(x)
+
+
+def synth_box(size=0.04, density=200.0):
+    """A free cube (gs.morphs.Box(size=(0.04, 0.04, 0.04)) of tests/test_rigid_physics.py:1750-1800, default material density 200 kg / m^3): mass rho s^3,
+    inertia m s^2 / 6."""
+    m = density * size ** 3
+    i = m * size * size / 6.0
+    return (f'<robot name="box"><link name="box"><inertial><origin xyz="0 0 0" rpy="0 0 0"/><mass value="{m!r}"/>'
+            f'<inertia ixx="{i!r}" ixy="0" ixz="0" iyy="{i!r}" iyz="0" izz="{i!r}"/></inertial>'
+            f'<collision><origin xyz="0 0 0" rpy="0 0 0"/><geometry><box size="{size} {size} {size}"/></geometry></collision></link></robot>')
+
+
+# Shape variants (test infrastructure: the same library sources compiled for another link / dof / geom count, build.SHAPES): synthetic URDF text, whether
+# the root is fixed, where it stands, the substep, and the armature (the reference's tests build these with default_armature=None, tests/utils.py:595)
+SHAPE_ROBOTS = {
+    "pendulum": dict(urdf=synth_multi_pendulum(1), fixed=True, base_init_pos=(0.0, 0.0, 5.0), substep_dt=0.002, armature=0.0),
+    "double_pendulum": dict(urdf=synth_multi_pendulum(2), fixed=True, base_init_pos=(0.0, 0.0, 5.0), substep_dt=0.002, armature=0.0),
+    "box": dict(urdf=synth_box(), fixed=False, base_init_pos=(0.65, 0.0, 0.02), substep_dt=0.01, armature=0.0),
+}
+
+
 def build_model(assets_dir, base_init_pos=(0.0, 0.0, 0.42), base_init_quat=(1.0, 0.0, 0.0, 0.0), substep_dt=0.01, robot="go2"):
+    shape = SHAPE_ROBOTS.get(robot)                                   # a shape variant: no padding to the Go2 geom count, no Go2 shape check
+    robot_urdf = shape["urdf"] if shape else os.path.join(assets_dir, ROBOTS[robot]["urdf"])
+    fixed_base = bool(shape and shape["fixed"])
+    armature = shape["armature"] if shape else 0.1                    # options/morphs.py:1000 default_armature, mjcf.py:188-190
+    if shape:
+        base_init_pos, substep_dt = shape["base_init_pos"], shape["substep_dt"]
     sol_timeconst = max(0.01, 2.0 * substep_dt)  # rigid_solver.py:260-261 + _sanitize_sol_params
     sol_params = [sol_timeconst, 1.0, 0.9, 0.95, 0.001, 0.5, 2.0]
 
@@ -586,8 +632,8 @@ def build_model(assets_dir, base_init_pos=(0.0, 0.0, 0.42), base_init_quat=(1.0,
         geoms_out.append(dict(g, link=0))
     # a robot with fewer collision geoms than the kernels' compile-time count is padded with inert spheres (no collision pairs, far away) that
     # belong to the fixed ground link -- inside its geom range, because geoms are stored link-major
-    robot_links_raw, _ = load_urdf(os.path.join(assets_dir, ROBOTS[robot]["urdf"]))
-    n_pad = N_GEOMS_KERNEL - len(geoms_out) - sum(len(l["collisions"]) for l in robot_links_raw)
+    robot_links_raw, _ = load_urdf(robot_urdf)
+    n_pad = 0 if shape else N_GEOMS_KERNEL - len(geoms_out) - sum(len(l["collisions"]) for l in robot_links_raw)
     if n_pad < 0:
         raise ValueError(f"{robot}: more than {N_GEOMS_KERNEL} collision geoms")
     for k in range(n_pad):
@@ -596,7 +642,10 @@ def build_model(assets_dir, base_init_pos=(0.0, 0.0, 0.42), base_init_quat=(1.0,
     entities.append(dict(link_start=0, link_end=1, dof_start=0, dof_end=0, geom_start=0, geom_end=len(geoms_out)))
 
     # ---- entity 1: go2 ----------------------------------------------------------------------------
-    links, joints = load_urdf(os.path.join(assets_dir, ROBOTS[robot]["urdf"]))
+    links, joints = load_urdf(robot_urdf)
+    for l in links:                                                   # a link without <inertial> (the pendulum's base): massless
+        if l["inertial"] is None:
+            l["inertial"] = {"origin": np.eye(4), "mass": 0.0, "inertia": np.zeros((3, 3))}
     links, joints = merge_fixed_links(links, joints)
     order, parent_of = bfs_order(links, joints)
     by_name = {l["name"]: l for l in links}
@@ -611,29 +660,33 @@ def build_model(assets_dir, base_init_pos=(0.0, 0.0, 0.42), base_init_quat=(1.0,
         Rin = ine["origin"][:3, :3]
         ev, eq = mju_eig3(Rin @ ine["inertia"] @ Rin.T)
         if name not in parent_of:
-            jtype, n_d, n_q = JOINT_FREE, 6, 7
+            jtype, n_d, n_q = (JOINT_FIXED, 0, 0) if fixed_base else (JOINT_FREE, 6, 7)      # gs.morphs.URDF(fixed=True): the root carries no joint
             lpos, lquat = list(base_init_pos), list(base_init_quat)
             parent = -1
         else:
             j = joint_of[name]
-            if j["type"] != "revolute":
-                raise ValueError(f"joint {j['name']}: only revolute joints below a free base are compiled (type {j['type']})")
+            if j["type"] not in ("revolute", "continuous"):
+                raise ValueError(f"joint {j['name']}: only revolute / continuous joints below the root are compiled (type {j['type']})")
+            if j["type"] == "continuous":
+                j["limit"] = dict(j["limit"] or {}, lower=-1e30, upper=1e30, effort=(j["limit"] or {}).get("effort"))
             jtype, n_d, n_q = JOINT_REVOLUTE, 1, 1
             lpos, lquat = j["origin"][:3, 3].tolist(), R_to_quat(j["origin"][:3, :3]).tolist()
             parent = link0 + order.index(parent_of[name])
+        has_joint = jtype != JOINT_FIXED
         rec = dict(
-            name=name, parent=parent, root=link0, entity=1, is_fixed=0,
-            joint_start=n_joints, joint_end=n_joints + 1, dof_start=n_dofs, dof_end=n_dofs + n_d,
+            name=name, parent=parent, root=link0, entity=1, is_fixed=int(not has_joint),
+            joint_start=n_joints, joint_end=n_joints + int(has_joint), dof_start=n_dofs, dof_end=n_dofs + n_d,
             q_start=n_qs, q_end=n_qs + n_q, n_dofs=n_d, geom_start=len(geoms_out),
             geom_end=len(geoms_out) + len(l["collisions"]), pos=lpos, quat=lquat,
             inertial_pos=ine["origin"][:3, 3].tolist(), inertial_quat=eq.tolist(),
             inertial_i=np.diag(ev).tolist(), inertial_mass=ine["mass"], invweight=[0.0, 0.0],
         )
         links_out.append(rec)
-        joints_out.append(
-            dict(name="root_joint" if jtype == JOINT_FREE else joint_of[name]["name"], type=jtype, link=gi,
-                 q_start=n_qs, dof_start=n_dofs, dof_end=n_dofs + n_d, pos=[0.0, 0.0, 0.0], sol_params=sol_params)
-        )
+        if has_joint:
+            joints_out.append(
+                dict(name="root_joint" if jtype == JOINT_FREE else joint_of[name]["name"], type=jtype, link=gi,
+                     q_start=n_qs, dof_start=n_dofs, dof_end=n_dofs + n_d, pos=[0.0, 0.0, 0.0], sol_params=sol_params)
+            )
         if jtype == JOINT_FREE:
             for k in range(6):
                 dofs_out.append(
@@ -642,26 +695,26 @@ def build_model(assets_dir, base_init_pos=(0.0, 0.0, 0.42), base_init_quat=(1.0,
                          frictionloss=0.0, kp=0.0, kv=0.0, force_range=[-1e30, 1e30])
                 )
             qpos0.extend(list(base_init_pos) + list(base_init_quat))
-        else:
+        elif has_joint:
             j = joint_of[name]
             eff = j["limit"]["effort"]
             dofs_out.append(
                 dict(motion_ang=[float(a) for a in j["axis"]], motion_vel=[0.0, 0.0, 0.0],
                      limit=[j["limit"]["lower"], j["limit"]["upper"]], invweight=0.0,
-                     armature=0.1,  # options/morphs.py:1000 default_armature, mjcf.py:188-190
+                     armature=armature,
                      damping=j["damping"], stiffness=0.0, frictionloss=j["frictionloss"],
                      kp=100.0, kv=10.0,  # geom.py default_dofs_kp/kv (overwritten by the env)
-                     force_range=[-eff, eff])
+                     force_range=[-eff, eff] if eff is not None else [-1e30, 1e30])
             )
             qpos0.append(0.0)
         for g in l["collisions"]:
             geoms_out.append(dict(g, link=gi))
         n_dofs += n_d
         n_qs += n_q
-        n_joints += 1
+        n_joints += int(has_joint)
     entities.append(dict(link_start=link0, link_end=len(links_out), dof_start=0, dof_end=n_dofs,
                          geom_start=entities[0]["geom_end"], geom_end=len(geoms_out)))
-    if len(links_out) != 14 or n_dofs != 18 or len(geoms_out) > N_GEOMS_KERNEL:
+    if not shape and (len(links_out) != 14 or n_dofs != 18 or len(geoms_out) > N_GEOMS_KERNEL):
         raise ValueError(f"{robot}: {len(links_out)} links / {n_dofs} dofs / {len(geoms_out)} geoms do not fit the kernels' compile-time shape (14 / 18 / <= {N_GEOMS_KERNEL})")
     n_real_geoms = len(geoms_out) - n_pad
 
@@ -690,7 +743,9 @@ def build_model(assets_dir, base_init_pos=(0.0, 0.0, 0.42), base_init_quat=(1.0,
 
     model = dict(
         format="go2sim-model-v1",
-        source="genesis/assets/urdf/plane/plane.urdf + " + ROBOTS[robot]["urdf"] + " via tools/compile_go2_model.py", robot=robot, n_real_geoms=n_real_geoms,
+        source="genesis/assets/urdf/plane/plane.urdf + " + (f"synthetic URDF text ({robot}: tools/compile_go2_model.py SHAPE_ROBOTS)" if shape else ROBOTS[robot]["urdf"]) +
+               " via tools/compile_go2_model.py", robot=robot, n_real_geoms=n_real_geoms,
+        shape=dict(NL=len(links_out), ND=n_dofs, NQ=n_qs, NG=len(geoms_out), NJ=n_joints),
         substep_dt=substep_dt, gravity=[0.0, 0.0, -9.81], eps=EPS32,
         solver=dict(iterations=50, tolerance=1e-6, ls_iterations=50, ls_tolerance=1e-2),
         collider=dict(max_collision_pairs=30, n_contacts_per_pair=5, broad_multiplier=8, mc_perturbation=1e-2,
@@ -753,12 +808,12 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--assets", default="/root/reference/genesis/assets")
     here = os.path.dirname(os.path.abspath(__file__))
-    ap.add_argument("--robot", choices=sorted(ROBOTS), default="go2")
+    ap.add_argument("--robot", choices=sorted(ROBOTS) + sorted(SHAPE_ROBOTS), default="go2")
     ap.add_argument("--out", default=None)
     args = ap.parse_args()
     if args.out is None:
         args.out = os.path.join(here, "..", "go2_sim2real_locomotion_rl_amd", "model", f"{args.robot}_model.json")
-    model = build_model(args.assets, base_init_pos=ROBOTS[args.robot]["base_init_pos"], robot=args.robot)
+    model = build_model(args.assets, base_init_pos=ROBOTS.get(args.robot, {}).get("base_init_pos", (0.0, 0.0, 0.42)), robot=args.robot)
     txt = json.dumps(model, indent=1, sort_keys=True)
     with open(args.out, "w") as f:
         f.write(txt + "\n")
