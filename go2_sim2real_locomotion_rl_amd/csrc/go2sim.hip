@@ -4637,13 +4637,20 @@ DEV float reward_term(const Model& m, const DCfg& c, RewState& rs, int id, const
 // One lane per env; the kernel is a single wave per 64 envs, so its duration is its dependency chain: every input is loaded before the
 // first store (one memory round trip instead of one per reward term) and the per-term episode sums sit in LDS for the dynamic term loop.
 DEV void env_globals_body(const DCfg& c, Glob& g, Acc* acc, uint64_t seed, int count_push);
-__global__ __launch_bounds__(WG) void k_env_post_a(Pool P, const Model* __restrict__ mp, const DCfg cv, Glob* gp,
+// Lane per env; the workgroup is POST_A_WAVES wavefronts over the SAME 64 envs.  Every wave loads the state and forms the shared quantities (base frame
+// velocities, Euler angles, foot contacts, command gates) redundantly; the reward TERMS -- the long serial part: 19 independent functions of that state --
+// are dealt to the waves (term k runs on one wave, its value goes to LDS), and wave 0 then adds them in the reference's order and makes every store.
+// The three terms that touch env state beyond their own value (feet_air_time writes and feet_stance reads _feet_air_time, go2_env_walk.py:1303-1314;
+// forward_progress moves _last_base_pos_x) stay together on wave 0, in order.  Same operations per value and the same sum order: results unchanged.
+constexpr int POST_A_WAVES = 4;
+__global__ __launch_bounds__(WG * POST_A_WAVES) void k_env_post_a(Pool P, const Model* __restrict__ mp, const DCfg cv, Glob* gp,
                                                    Acc* acc, uint64_t seed, uint32_t step_count) {
   STAMP(STK_POST_A)
   __shared__ float s_es[NREW][WG], s_r[NREW][WG];
-  int b = blockIdx.x * WG + threadIdx.x;
+  const int ln = threadIdx.x % WG, wv = threadIdx.x / WG;
+  const bool w0 = wv == 0;                                          // the wave that owns the env's stores
+  int b = blockIdx.x * WG + ln;
   if (b >= P.B) return;
-  const int ln = threadIdx.x;
   const Model& m = *mp; const DCfg& c = cv;  const Glob& g = *gp;
   E e(P, b);
   const int nrew = c.i[GO2SIM_IC_N_REWARDS];
@@ -4678,41 +4685,49 @@ __global__ __launch_bounds__(WG) void k_env_post_a(Pool P, const Model* __restri
     float es_[NREW];
 #pragma unroll
     for (int k = 0; k < NREW; ++k) es_[k] = episode_sums[k];           // all NREW rows exist; unconditional loads stay in flight together
+    if (w0) {
 #pragma unroll
-    for (int k = 0; k < NREW; ++k) s_es[k][ln] = es_[k];
+      for (int k = 0; k < NREW; ++k) s_es[k][ln] = es_[k];
+    }
   }
   PH(12)
-  // ---- stores start here ----
-  { auto ext = e.ext(); for (int i = 0; i < NL * 6; ++i) ext[i] = 0.0f; }
-  e.episode_length()[0] = ep_len;
-  auto base_pos = e.base_pos(); auto base_quat = e.base_quat();
-  base_pos[0] = bp.x; base_pos[1] = bp.y; base_pos[2] = bp.z;
-  base_quat[0] = bq.w; base_quat[1] = bq.x; base_quat[2] = bq.y; base_quat[3] = bq.z;
+  // ---- stores start here (wave 0 only) ----
+  if (w0) {
+    { auto ext = e.ext(); for (int i = 0; i < NL * 6; ++i) ext[i] = 0.0f; }
+    e.episode_length()[0] = ep_len;
+    auto base_pos = e.base_pos(); auto base_quat = e.base_quat();
+    base_pos[0] = bp.x; base_pos[1] = bp.y; base_pos[2] = bp.z;
+    base_quat[0] = bq.w; base_quat[1] = bq.x; base_quat[2] = bq.y; base_quat[3] = bq.z;
+  }
   Q4 inv_init = inv_quat(q4(c.f[GO2SIM_FC_BASE_INIT_QUAT0], c.f[GO2SIM_FC_BASE_INIT_QUAT0 + 1], c.f[GO2SIM_FC_BASE_INIT_QUAT0 + 2], c.f[GO2SIM_FC_BASE_INIT_QUAT0 + 3]));
   V3 eul = tc_quat_to_xyz_rpy_deg(tc_quat_mul(bq, inv_init), m.eps);
-  auto base_euler = e.base_euler();
-  base_euler[0] = eul.x; base_euler[1] = eul.y; base_euler[2] = eul.z;
   Q4 inv_bq = inv_quat(bq);
   V3 velw = cdv + cross(cda, bp - rcom);
-  { auto bvw = e.base_vel_world(); bvw[0] = velw.x; bvw[1] = velw.y; bvw[2] = velw.z; }
   V3 blv = tc_transform_by_quat(velw, inv_bq), bav = tc_transform_by_quat(cda, inv_bq);
   V3 pg = tc_transform_by_quat(v3(0.0f, 0.0f, -1.0f), inv_bq);
-  auto o_blv = e.base_lin_vel(); auto o_bav = e.base_ang_vel(); auto o_pg = e.projected_gravity();
-  o_blv[0] = blv.x; o_blv[1] = blv.y; o_blv[2] = blv.z;
-  o_bav[0] = bav.x; o_bav[1] = bav.y; o_bav[2] = bav.z;
-  o_pg[0] = pg.x; o_pg[1] = pg.y; o_pg[2] = pg.z;
+  if (w0) {
+    auto base_euler = e.base_euler();
+    base_euler[0] = eul.x; base_euler[1] = eul.y; base_euler[2] = eul.z;
+    { auto bvw = e.base_vel_world(); bvw[0] = velw.x; bvw[1] = velw.y; bvw[2] = velw.z; }
+    auto o_blv = e.base_lin_vel(); auto o_bav = e.base_ang_vel(); auto o_pg = e.projected_gravity();
+    o_blv[0] = blv.x; o_blv[1] = blv.y; o_blv[2] = blv.z;
+    o_bav[0] = bav.x; o_bav[1] = bav.y; o_bav[2] = bav.z;
+    o_pg[0] = pg.x; o_pg[1] = pg.y; o_pg[2] = pg.z;
+  }
   rs.blv[0] = blv.x; rs.blv[1] = blv.y; rs.blv[2] = blv.z; rs.bav[0] = bav.x; rs.bav[1] = bav.y; rs.bav[2] = bav.z;
   rs.pg[0] = pg.x; rs.pg[1] = pg.y; rs.pg[2] = pg.z; rs.base_pos[0] = bp.x; rs.base_pos[1] = bp.y; rs.base_pos[2] = bp.z;
-  auto dof_pos = e.e_dof_pos(); auto dof_vel = e.e_dof_vel();
+  if (w0) {
+    auto dof_pos = e.e_dof_pos(); auto dof_vel = e.e_dof_vel();
 #pragma unroll
-  for (int i = 0; i < NM; ++i) { dof_pos[i] = rs.dof_pos[i]; dof_vel[i] = rs.dof_vel[i]; }
+    for (int i = 0; i < NM; ++i) { dof_pos[i] = rs.dof_pos[i]; dof_vel[i] = rs.dof_vel[i]; }
+  }
   RewCtx rc; rc.was_reset = 0; rc.vel_world[0] = velw.x; rc.vel_world[1] = velw.y; rc.vel_world[2] = velw.z;
   auto fc = e.foot_contact(); auto lfc = e.last_foot_contact();
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    lfc[i] = fc_old[i];
     int ct = dm_abs(f_cf[i].z) > c.f[GO2SIM_FC_FOOT_CONTACT_THRESHOLD];
-    fc[i] = ct; rs.fc[i] = ct;
+    if (w0) { lfc[i] = fc_old[i]; fc[i] = ct; }
+    rs.fc[i] = ct;
     V3 lp = f_lp[i];
     V3 lv = f_cdv[i] + cross(f_cda[i], lp - rcom);
     rc.link_vel_xy[2 * i] = lv.x; rc.link_vel_xy[2 * i + 1] = lv.y; rc.foot_z[i] = lp.z; rc.foot_xy[2 * i] = lp.x; rc.foot_xy[2 * i + 1] = lp.y;
@@ -4722,7 +4737,7 @@ __global__ __launch_bounds__(WG) void k_env_post_a(Pool P, const Model* __restri
     dm_u4 r = rng4(seed, RNG_CMD, b, step_count, 0);
     float cx, cy, cz;
     sample_commands(c, g, r, b, cx, cy, cz);
-    cmd[0] = cx; cmd[1] = cy; cmd[2] = cz;
+    if (w0) { cmd[0] = cx; cmd[1] = cy; cmd[2] = cz; }
     rs.cmd[0] = cx; rs.cmd[1] = cy; rs.cmd[2] = cz;
   }
   int maxlen = c.i[GO2SIM_IC_MAX_EPISODE_LENGTH];
@@ -4731,30 +4746,40 @@ __global__ __launch_bounds__(WG) void k_env_post_a(Pool P, const Model* __restri
   rst |= dm_abs(eul.x) > c.f[GO2SIM_FC_TERM_ROLL_DEG];
   rst |= dm_abs(blv.z) > c.f[GO2SIM_FC_TERM_ZVEL];
   rst |= dm_abs(blv.y) > c.f[GO2SIM_FC_TERM_YVEL];
-  e.reset_buf()[0] = rst;
   float time_out = (ep_len > maxlen) ? 1.0f : 0.0f;
-  e.time_out()[0] = time_out;
+  if (w0) { e.reset_buf()[0] = rst; e.time_out()[0] = time_out; }
   float rew = 0.0f;
   float tracking_int = 0.0f;
   PH(13)
   const float fat0[4] = {rs.fat[0], rs.fat[1], rs.fat[2], rs.fat[3]};
   const float last_x0 = rs.last_x;
   const RewGates gates = reward_gates(rs);
-  int id_next = c.i[GO2SIM_IC_REWARD_ID0]; float scale_next = c.f[GO2SIM_FC_REWARD_SCALE0];
+  if (!base_env) {                                                   // the terms, dealt to the waves: stateful ones on wave 0, the others round-robin
+    int id_next = c.i[GO2SIM_IC_REWARD_ID0]; float scale_next = c.f[GO2SIM_FC_REWARD_SCALE0];
+    int j = 0;
+    for (int k = 0; k < nrew; ++k) {
+      const int id = id_next; const float scale = scale_next;
+      { const int kn = (k + 1 < NREW) ? k + 1 : k; id_next = c.i[GO2SIM_IC_REWARD_ID0 + kn]; scale_next = c.f[GO2SIM_FC_REWARD_SCALE0 + kn]; }   // the table reads of the next term overlap this one
+      const bool stateful = id == GO2SIM_R_FEET_AIR_TIME || id == GO2SIM_R_FEET_STANCE || id == GO2SIM_R_FORWARD_PROGRESS;
+      const int owner = stateful ? 0 : (1 + j) % POST_A_WAVES;
+      j += stateful ? 0 : 1;
+      if (wv == owner) s_r[k][ln] = reward_term(m, c, rs, id, rc, gates) * scale;
+    }
+  }
+  __syncthreads();
+  PH(14)
+  if (!w0) return;                                                   // the rest is wave 0's: the sum in the reference's order, the statistics, the stores
   for (int k = 0; k < nrew; ++k) {
-    const int id = id_next; const float scale = scale_next;
-    { const int kn = (k + 1 < NREW) ? k + 1 : k; id_next = c.i[GO2SIM_IC_REWARD_ID0 + kn]; scale_next = c.f[GO2SIM_FC_REWARD_SCALE0 + kn]; }   // the table reads of the next term overlap this one
+    const int id = c.i[GO2SIM_IC_REWARD_ID0 + k];
     float es = s_es[k][ln];
     if (!base_env) {
-      float r = reward_term(m, c, rs, id, rc, gates) * scale;
-      s_r[k][ln] = r;
+      const float r = s_r[k][ln];
       rew = rew + r;
       es = es + r;
       s_es[k][ln] = es;
     }
     if (id == GO2SIM_R_TRACKING_LIN_VEL || id == GO2SIM_R_TRACKING_ANG_VEL) tracking_int = tracking_int + es;
   }
-  PH(14)
   if (rst) {
     float ep_steps = fmx((float)ep_len, 1.0f);
     float ep_seconds = ep_steps * c.f[GO2SIM_FC_DT];
@@ -4767,7 +4792,7 @@ __global__ __launch_bounds__(WG) void k_env_post_a(Pool P, const Model* __restri
   // runs in whichever workgroup finishes last, instead of in a kernel of its own.
   PH(15)
   __threadfence();
-  __syncthreads();
+  __builtin_amdgcn_wave_barrier();                                   // (only wave 0 is left: its lanes are the workgroup's 64 envs)
   PH(16)
   if (threadIdx.x == 0) {
     const int ticket = atomicAdd(&acc->done, 1);
@@ -5475,6 +5500,7 @@ struct go2sim {
   struct StepGraph {
     hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
     hipGraphNode_t n_pre = nullptr, n_post_a = nullptr, n_post_b = nullptr;
+    hipGraphNode_t extra_dep = nullptr;             // graph_add_kernel: second parent of the next node (consumed by that call)
     hipKernelNodeParams p_pre{}, p_post_a{}, p_post_b{};
     std::vector<void*> owned;                       // argument storage of all nodes (malloc'ed)
     const float** a_actions = nullptr; uint32_t* a_pre_step = nullptr; int* a_pre_widx = nullptr; uint32_t* a_pa_step = nullptr; uint32_t* a_pb_step = nullptr;
@@ -5486,6 +5512,9 @@ struct go2sim {
   bool use_graph = true;
   int graph_fallbacks = 0;                  // times the graph path was abandoned for plain launches (go2sim_graph_status)
   bool fuse_fk_dyn = true;                  // k_integrate_fk_dynamics_team between the substeps of a scene step (GO2SIM_NO_FUSE=1: separate launches)
+  bool par_pre = false;                     // step graph: the first collision pass as a second root beside the pre-physics / dynamics launch (GO2SIM_PAR_PRE=1).
+                                            // Measured slower than the chain (window 10.26 vs 10.40 M, default run 14.84 vs 15.24 M, stairs 7.51 vs 7.61 M env-steps/s):
+                                            // the dynamics wavefronts take SIMDs from the collision pass instead of waiting for its early finishers
   int dyn_team = 32;                        // lanes per environment in k_dynamics_team
   int fk_team = 16;                         // lanes per environment in k_integrate_fk_team / k_fk_team
   int collide_team = 16;                    // lanes per environment in k_collide_team
@@ -5635,7 +5664,10 @@ static bool graph_add_kernel(go2sim* h, hipGraphNode_t& last, void (*kernel)(P..
   hipKernelNodeParams kp{};
   kp.func = (void*)kernel; kp.gridDim = grid; kp.blockDim = block; kp.sharedMemBytes = 0; kp.kernelParams = ptrs; kp.extra = nullptr;
   hipGraphNode_t node = nullptr;
-  if (hipGraphAddKernelNode(&node, g.graph, last ? &last : nullptr, last ? 1 : 0, &kp) != hipSuccess) return false;
+  hipGraphNode_t deps[2] = {last, g.extra_dep};                       // (extra_dep: the second parent of a join node, set by the caller for one call)
+  const int n_deps = (last ? 1 : 0) + ((last && g.extra_dep) ? 1 : 0);
+  g.extra_dep = nullptr;
+  if (hipGraphAddKernelNode(&node, g.graph, n_deps ? deps : nullptr, n_deps, &kp) != hipSuccess) return false;
   last = node;
   if (node_out) *node_out = node;
   if (params_out) *params_out = kp;
@@ -5684,11 +5716,18 @@ static bool step_graph_build(go2sim* h, const float* actions, float* obs, float*
     int* lpt_cur = lpt_on ? h->lpt + (i & 1) * lpt_record_ints(h) : nullptr;
     int* lpt_next = lpt_on ? h->lpt + (1 - (i & 1)) * lpt_record_ints(h) : nullptr;
     const int epw_s = solver_epw(h);
+    // The first collision pass reads nothing the pre-physics / dynamics launch writes (geom poses, sort buffers and the normal cache come from the end of the
+    // previous step): it is a second ROOT of the graph, and the first solve joins the two.  The collision launch is as long as its slowest workgroup
+    // (landing window: mean 42 us, span 66 us, one wave per SIMD with the whole register file); the dynamics wavefronts take the SIMDs its early finishers
+    // leave.  Tried and measured slower: off unless GO2SIM_PAR_PRE=1 (go2sim::par_pre).
+    hipGraphNode_t pre_node = nullptr;
+    if (i == 0 && fuse_pre(h) && h->par_pre) { pre_node = last; last = nullptr; }
     { const int T = h->collide_team; const dim3 gc = team_grid(T);
       ok = T == 16 ? graph_add_kernel(h, last, k_collide_team<16>, gc, b64, nullptr, nullptr, nullptr, h->P, h->dm, h->gjk_scratch, lpt_cur, h->lpt_cap, epw_s)
          : T == 32 ? graph_add_kernel(h, last, k_collide_team<32>, gc, b64, nullptr, nullptr, nullptr, h->P, h->dm, h->gjk_scratch, lpt_cur, h->lpt_cap, epw_s)
                    : graph_add_kernel(h, last, k_collide_team<64>, gc, b64, nullptr, nullptr, nullptr, h->P, h->dm, h->gjk_scratch, lpt_cur, h->lpt_cap, epw_s); }
     if (!ok) break;
+    g.extra_dep = pre_node;                                            // the solve waits for the collision pass AND (first substep) for the dynamics
     if (h->hm.terrain_enabled) {
       if (h->terrain_solver_team == 32) ok = graph_add_kernel(h, last, k_constraint_solve_team<32, RL_TERRAIN>, dim3((h->B + 1) / 2), b64, nullptr, nullptr, nullptr, h->P, h->dm, h->dms, h->solver_ovf, (const int*)lpt_cur, lpt_next, h->lpt_cap);
       else ok = graph_add_kernel(h, last, k_constraint_solve_team<64, RL_TERRAIN>, dim3(h->B), b64, nullptr, nullptr, nullptr, h->P, h->dm, h->dms, h->solver_ovf, (const int*)lpt_cur, lpt_next, h->lpt_cap);
@@ -5703,7 +5742,7 @@ static bool step_graph_build(go2sim* h, const float* actions, float* obs, float*
     else { ok = add_integrate(); if (ok && i + 1 < substeps) ok = add_dynamics(); }
   }
   if (!ok) return false;
-  ok = graph_add_kernel(h, last, k_env_post_a, ge, be, &g.n_post_a, &g.p_post_a, &sl, h->P, h->dm, h->hcfg, h->dglob, h->dacc, h->seed, h->step_count);
+  ok = graph_add_kernel(h, last, k_env_post_a, ge, dim3(WG * POST_A_WAVES), &g.n_post_a, &g.p_post_a, &sl, h->P, h->dm, h->hcfg, h->dglob, h->dacc, h->seed, h->step_count);
   if (!ok) return false;
   g.a_pa_step = (uint32_t*)sl[6];
   if (h->hcfg.i[GO2SIM_IC_USE_TERRAIN]) {
@@ -5779,6 +5818,7 @@ int go2sim_create(const void* blob, size_t nbytes, int n_envs, int device, uint6
     if (const char* t = getenv("GO2SIM_DYN_TEAM")) { int v = atoi(t); if (v == 16 || v == 32 || v == 64) h->dyn_team = v; }
     if (const char* t = getenv("GO2SIM_NO_GRAPH")) { if (atoi(t) != 0) h->use_graph = false; }
     if (const char* t = getenv("GO2SIM_NO_FUSE")) { if (atoi(t) != 0) h->fuse_fk_dyn = false; }
+    if (const char* t = getenv("GO2SIM_PAR_PRE")) { if (atoi(t) != 0) h->par_pre = true; }
     if (const char* t = getenv("GO2SIM_FK_TEAM")) { int v = atoi(t); if (v == 16 || v == 32 || v == 64) h->fk_team = v; }
     if (const char* t = getenv("GO2SIM_COLLIDE_TEAM")) { int v = atoi(t); if (v == 16 || v == 32 || v == 64) h->collide_team = v; }
     CK(hipMalloc((void**)&h->gjk_scratch, (size_t)n_envs * h->collide_team * sizeof(GjkStoreFull)));   // ~20 KB per narrow-phase lane
@@ -6100,7 +6140,7 @@ int go2sim_env_step(go2sim_t* h, const float* actions, float* obs, float* priv, 
   launch_substeps(h, s, h->hcfg.i[GO2SIM_IC_SUBSTEPS], fuse_pre(h) ? actions : nullptr);
   {
     ScopedTimer t(h, s, T_ENV_POST);
-    hipLaunchKernelGGL(k_env_post_a, g, b, 0, s, h->P, h->dm, h->hcfg, h->dglob, h->dacc, h->seed, h->step_count);
+    hipLaunchKernelGGL(k_env_post_a, g, dim3(WG * POST_A_WAVES), 0, s, h->P, h->dm, h->hcfg, h->dglob, h->dacc, h->seed, h->step_count);
     if (h->hcfg.i[GO2SIM_IC_USE_TERRAIN]) hipLaunchKernelGGL(k_env_terrain_rows, dim3((h->B + 255) / 256), dim3(256), 0, s, h->P, h->dcfg, h->dglob, h->seed);
     hipLaunchKernelGGL(k_env_post_b_team<16>, dim3((h->B + 3) / 4), dim3(64), 0, s, h->P, h->dm, h->dms, h->dcfg, h->dglob, h->seed, h->step_count, obs, priv, rew, reset, timeout);
   }
