@@ -122,13 +122,21 @@ def build_shape_variant(name, hip=True, force=False, verbose=True):
     return cpu, gpu
 
 
-def build_variants(force=False, verbose=True):
-    for name in SHAPES:
-        build_shape_variant(name, hip=shutil.which("hipcc") is not None or os.path.exists("/opt/rocm/bin/hipcc"), force=force, verbose=verbose)
-    for name, flags in ORACLE_VARIANTS.items():
-        build_oracle_variant(name, flags, force=force, verbose=verbose)
-    for name, flags in HIP_VARIANTS.items():
-        build_hip_variant(name, flags, force=force, verbose=verbose)
+def build_variants(force=False, verbose=True, jobs=4):
+    """Every diagnostic / shape-variant library the tests load, `jobs` compilers at a time (each build is one hipcc or g++ process; a fresh tree needs nine
+    HIP builds of about a minute each)."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    have_hip = shutil.which("hipcc") is not None or os.path.exists("/opt/rocm/bin/hipcc")
+    tasks = [(build_oracle_variant, ("shape_" + n, _shape_flags(n))) for n in SHAPES]
+    tasks += [(build_oracle_variant, (n, f)) for n, f in ORACLE_VARIANTS.items()]
+    if have_hip:
+        tasks += [(build_hip_variant, ("shape_" + n, ["-DGO2SIM_FAST_ORDER=0", *_shape_flags(n)])) for n in SHAPES]
+        tasks += [(build_hip_variant, (n, f)) for n, f in HIP_VARIANTS.items()]
+    with ThreadPoolExecutor(max_workers=max(1, int(jobs))) as pool:
+        futs = [pool.submit(fn, *args, force=force, verbose=verbose) for fn, args in tasks]
+        for f in futs:
+            f.result()
 
 
 if __name__ == "__main__":
