@@ -208,6 +208,10 @@ def test_graft_entry_smoke():
     __graft_entry__.smoke()
 
 
+_STRICT_RUN = pytest.mark.skipif(__import__("os").environ.get("GO2SIM_TEST_STRICT") == "1", reason="loads the product library itself: not part of a GO2SIM_TEST_HIP_LIB / GO2SIM_TEST_STRICT run")
+
+
+@_STRICT_RUN
 def test_go2env_class_matches_c_abi(hip_lib, blob):
     """The reference-shaped Go2Env class (go2_env.py) is a zero-arithmetic wrapper: same numbers as the raw C-ABI run."""
     import torch
@@ -271,6 +275,7 @@ def test_go2env_class_base_family(hip_lib, blob):
     assert set(extras["episode"]) == {"rew_" + n for n in env.reward_scales}
 
 
+@_STRICT_RUN
 def test_gs_surface_on_hip_backend(oracle_lib):
     """The gs shim drives the HIP library by default; its accessor results equal the oracle-backed shim on the same script."""
     import torch
