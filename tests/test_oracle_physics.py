@@ -156,3 +156,72 @@ def test_warm_start_and_cache_reset(oracle_lib, blob):
     sim.reset_caches()
     assert sim.get_field_np(F("I_IS_WARMSTART"))[0, 0] == 0
     assert np.abs(sim.get_field_np(F("F_NORMAL_CACHE"))).max() == 0 and np.abs(sim.get_field_np(F("F_QACC_WS"))).max() == 0
+
+
+def _normalized_quat_case(sim_cls, lib, blob, **kw):
+    """tests/test_rigid_physics.py:1413-1463 on the Go2 model itself: the state after a step does not depend on whether the root quaternion handed to
+    the solver was normalised; links and geoms carry unit quaternions."""
+    rng = np.random.default_rng(11)
+    n = 6
+    quat = rng.standard_normal((4, n)).astype(np.float32)                       # torch.randn((4,)) per env
+    unit = (quat / np.linalg.norm(quat, axis=0, keepdims=True)).astype(np.float32)
+    posts = []
+    for qroot in (unit, quat):
+        env = sim_cls(lib, blob, n, seed=2, **kw)
+        q = env.field("F_QPOS").copy()
+        q[2] = 1.0                                                               # clear of the ground for any orientation (the reference scene has no plane)
+        q[3:7] = qroot
+        if hasattr(env, "set_field"):
+            env.set_field("F_QPOS", q)
+        else:
+            env.sim.set_field_np(F("F_QPOS"), q)
+        env.sim.reset_caches(None, 0); env.sim.forward_kinematics()
+        lq, gq = env.field("F_LINK_QUAT").reshape(-1, 4, n), None
+        assert np.allclose(np.linalg.norm(lq, axis=1), 1.0, atol=5e-5), "link quaternions are normalised by the kinematics (func_update_cartesian_space)"
+        env.sim.scene_step(1)
+        post = env.field("F_QPOS").copy()
+        assert np.allclose(np.linalg.norm(post[3:7], axis=0), 1.0, atol=5e-5)
+        posts.append(post)
+    assert np.abs(posts[0] - posts[1]).max() <= 5e-5, "qpos after the step: normalised vs raw root quaternion (TOL_SINGLE)"
+    return posts
+
+
+def test_state_is_insensitive_to_root_quaternion_normalisation(oracle_lib, blob):
+    _normalized_quat_case(CpuEnv, oracle_lib, blob)
+
+
+@pytest.mark.gpu
+def test_state_is_insensitive_to_root_quaternion_normalisation_hip(oracle_lib, hip_lib, blob):
+    from util import GpuEnv, bits_equal
+
+    a = _normalized_quat_case(GpuEnv, hip_lib, blob)
+    b = _normalized_quat_case(CpuEnv, oracle_lib, blob)
+    assert all(bits_equal(x, y) for x, y in zip(a, b))
+
+
+def _mass_matrix_factor_case(sim_cls, lib, blob, **kw):
+    """test_mass_mat analogue (tests/test_rigid_physics.py:1912-1947: L^T diag(1 / D_inv) L == M).  The factor itself is not exported; its use is: the
+    smooth acceleration is L^-T D^-1 L^-1 f, so M a_smooth must give back the smooth force f."""
+    n = 8
+    env = sim_cls(lib, blob, n, seed=3, **kw)
+    env.reset()
+    for a in make_actions(15, n, seed=5, kind="0.5"):
+        env.step(a)
+    M = env.field("F_MASS_MAT").reshape(18, 18, n).astype(np.float64)
+    a_s, f = env.field("F_ACC_SMOOTH").astype(np.float64), env.field("F_FORCE").astype(np.float64)
+    assert np.allclose(M, np.transpose(M, (1, 0, 2))), "symmetric"
+    back = np.einsum("ijb,jb->ib", M, a_s)
+    assert np.abs(back - f).max() <= 5e-5 * max(1.0, np.abs(f).max()), f"M a_smooth vs f: {np.abs(back - f).max()}"
+    assert np.all(np.linalg.eigvalsh(np.transpose(M, (2, 0, 1))) > 0.0), "positive definite"
+    return env.field("F_MASS_MAT"), env.field("F_ACC_SMOOTH")
+
+
+def test_mass_matrix_factorisation_is_consistent(oracle_lib, blob):
+    _mass_matrix_factor_case(CpuEnv, oracle_lib, blob)
+
+
+@pytest.mark.gpu
+def test_mass_matrix_factorisation_is_consistent_hip(hip_lib, blob):
+    from util import GpuEnv
+
+    _mass_matrix_factor_case(GpuEnv, hip_lib, blob)
