@@ -55,16 +55,17 @@ ROLLOUT_LEN = 24  # num_steps_per_env, go2_train_walk.py:60
 NPRIV = {"walk": 104, "stairs": 182, "jump_dr": 45}
 NOBS = {"walk": 49, "stairs": 49, "jump_dr": 45}
 NACT = {"walk": 16, "stairs": 16, "jump_dr": 12}
-# timing classes of go2sim_enable_timing.  One env step = 9 launches: k_pre_dynamics (pre-physics part + dynamics of substep 1), collide, solve,
-# k_integrate_fk_dynamics (integrate + FK of substep 1 and dynamics of substep 2), collide, solve, k_integrate_fk, k_env_post_a, k_env_post_b.
-# The fused launches are accounted with the class of their second half's neighbour: "k_dynamics" = k_pre_dynamics, "k_integrate_fk" =
-# k_integrate_fk_dynamics + k_integrate_fk; "k_env_pre" is only non-zero with GO2SIM_NO_FUSE=1.
+# timing classes of go2sim_enable_timing.  One env step on flat ground = 7 launches: k_pre_dynamics (pre-physics part + dynamics of substep 1), collide,
+# k_solve_integrate<true> (solve + integrate + FK of substep 1 + dynamics of substep 2), collide, k_solve_integrate<false> (solve + integrate + FK), k_env_post_a,
+# k_env_post_b.  On the heightfield (one env per solver wavefront) the solve, k_integrate_fk_dynamics and k_integrate_fk stay separate launches: 9.
+# The fused launches are accounted with the class of their first half: "k_dynamics" = k_pre_dynamics, "k_constraint_solve" = the two k_solve_integrate launches on flat
+# ground ("k_integrate_fk" is then empty); "k_env_pre" is only non-zero with GO2SIM_NO_FUSE=1.
 KERNEL_CLASSES = ["k_dynamics", "k_collide", "k_constraint_solve", "k_integrate_fk", "k_env_pre", "k_env_post(a+globals+b)", "misc", "env_step_total"]
-LAUNCHES_PER_ENV_STEP = 9
+LAUNCHES_PER_ENV_STEP = {"walk": 7, "jump_dr": 7, "stairs": 9}
 PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")
 PMC_TRAFFIC_FILES = {"walk": PMC_TRAFFIC_FILE, "stairs": os.path.join(ROOT, "profiles", "r04_stairs_pmc_traffic.json")}   # per workload (tools/profile_round.sh)
 PMC_SQ_FILES = {5: os.path.join(ROOT, "profiles", "r04_pmc_sq.json"), 300: os.path.join(ROOT, "profiles", "r04_steady_pmc_sq.json")}   # by warm-up: landing window / steady gait
-KERNEL_OF_CLASS = {"k_dynamics": "k_pre_dynamics", "k_collide": "k_collide", "k_constraint_solve": "k_constraint_solve", "k_integrate_fk": "k_integrate_fk_dynamics",
+KERNEL_OF_CLASS = {"k_dynamics": "k_pre_dynamics", "k_collide": "k_collide", "k_constraint_solve": "k_constraint_solve", "k_integrate_fk": "k_integrate_fk_dynamics",   # (flat ground: the stamped files map k_constraint_solve to k_solve_integrate_team)
                    "k_env_post(a+globals+b)": "k_env_post_a"}
 
 
@@ -379,7 +380,7 @@ def roofline_of(ms, cnt, K, B, workload, value):
     r = {"bound": "hbm", "kernel": KERNEL_CLASSES[dom], "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "avg_launch_ms": round(per_launch[dom], 4), "launches_timed": cnt[dom],
          "algo_bytes_per_env_step": algo, "units_per_launch_env_steps": units,
-         "ms_per_step_by_kernel": {KERNEL_CLASSES[k]: round(per_step[k], 4) for k in range(8)}, "launches_per_env_step": LAUNCHES_PER_ENV_STEP,
+         "ms_per_step_by_kernel": {KERNEL_CLASSES[k]: round(per_step[k], 4) for k in range(8)}, "launches_per_env_step": LAUNCHES_PER_ENV_STEP[workload],
          "whole_step_achieved_GBs": round(value * algo / 1e9, 3)}
     if note:
         r["traffic_note"] = note

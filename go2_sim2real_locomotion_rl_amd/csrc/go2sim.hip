@@ -1053,22 +1053,22 @@ DEV void tk_integrate(const MT& m, const E& e, KinData* s, int tl) {
 
 // kernel_step_2 (rigid_solver.py:3072-3180): func_integrate (forward_dynamics.py:1558-1699) + func_copy_next_to_curr
 // (abd/diff.py:25-54) + FK / forward velocity of the new state
+// `pre` (k_solve_integrate_team): lane d < ND of the team already holds velocity and acceleration of dof d (taken from the solver's LDS block before the
+// overlay), so neither is fetched from HBM again
 template <int T>
-__global__ __launch_bounds__(64) void k_integrate_fk_team(Pool P, const ModelS* __restrict__ mp) {
-  STAMP(STK_INT_FK)
-  constexpr int EPW = 64 / T;
-  __shared__ KinData lds[EPW];
-  __shared__ alignas(16) char ms_raw[MODELS_LDS_BYTES];
+DEV void integrate_fk_body(const Pool& P, const ModelS* __restrict__ mp, int b, KinData* lds, char* ms_raw, bool pre, float pre_vel, float pre_acc) {
   const ModelS& ms = *(const ModelS*)ms_raw;
   wg_dma_to_lds<(int)sizeof(ModelS)>(ms_raw, mp);
   const int tl = threadIdx.x % T, slot = threadIdx.x / T;
-  const int b = xcd_block() * EPW + slot;
   const ModelView m(&ms, mp);
   E e(P, b < P.B ? b : P.B - 1);
   KinData* s = &lds[slot];
   PH_BEGIN
-  team_stage<ND, T>(tl, [&](int d) { return gload(e, FO(vel), d); }, [&](int d, float v) { s->vel[d] = v; });
-  team_stage<ND, T>(tl, [&](int d) { return aload(e, AO(acc), d); }, [&](int d, float a) { s->vel_next[d] = a; });
+  if (pre) { if (tl < ND) { s->vel[tl] = pre_vel; s->vel_next[tl] = pre_acc; } }
+  else {
+    team_stage<ND, T>(tl, [&](int d) { return gload(e, FO(vel), d); }, [&](int d, float v) { s->vel[d] = v; });
+    team_stage<ND, T>(tl, [&](int d) { return aload(e, AO(acc), d); }, [&](int d, float a) { s->vel_next[d] = a; });
+  }
   team_stage<NQ, T>(tl, [&](int q) { return gload(e, FO(qpos), q); }, [&](int q, float v) { s->qpos[q] = v; });
   team_for<ND, T>(tl, [&](int d) { s->vel_next[d] = s->vel[d] + s->vel_next[d] * m.substep_dt; });
   if (tl == 0) s->valid = 1;
@@ -1079,6 +1079,14 @@ __global__ __launch_bounds__(64) void k_integrate_fk_team(Pool P, const ModelS* 
   PH(40)
   tk_kinematics<T>(m, e, s, tl, false);
   PH(41)
+}
+template <int T>
+__global__ __launch_bounds__(64) void k_integrate_fk_team(Pool P, const ModelS* __restrict__ mp) {
+  STAMP(STK_INT_FK)
+  constexpr int EPW = 64 / T;
+  __shared__ KinData lds[EPW];
+  __shared__ alignas(16) char ms_raw[MODELS_LDS_BYTES];
+  integrate_fk_body<T>(P, mp, xcd_block() * EPW + (int)threadIdx.x / T, lds, ms_raw, false, 0.0f, 0.0f);
 }
 
 // FK refresh of the current state; `cond` (device) gates the launch body: the reset path only needs it when an env was reset
@@ -1363,28 +1371,26 @@ template <int EPW> struct KinSeparate<true, EPW> { DEV KinData* at(int, void* ov
 // an HBM round trip between two kernels (the FK outputs are still written out: the collision kernel, the solver and the env kernels read them).
 // Between the two halves nothing else runs in a scene step; the control inputs of the dynamics do not depend on the kinematics and are requested at
 // the top of the kernel.
+constexpr bool KIN_OVERLAY = sizeof(KinData) <= 2 * sizeof(float) * ND * ND;         // (shape variants with few dofs: the kinematics set gets its own LDS block)
 template <int T>
-__global__ __launch_bounds__(64) void k_integrate_fk_dynamics_team(Pool P, const ModelS* __restrict__ mp) {
-  STAMP(STK_INT_FK_DYN)
-  constexpr int EPW = 64 / T;
-  __shared__ DynData lds_d[EPW];
-  __shared__ alignas(16) char ms_raw[MODELS_LDS_BYTES];
+DEV void integrate_fk_dynamics_body(const Pool& P, const ModelS* __restrict__ mp, int b, DynData* lds_d, char* ms_raw, KinSeparate<KIN_OVERLAY, 64 / T>& lds_k,
+                                    bool pre, float pre_vel, float pre_acc) {
   const ModelS& ms = *(const ModelS*)ms_raw;
   wg_dma_to_lds<(int)sizeof(ModelS)>(ms_raw, mp);
   const int tl = threadIdx.x % T, slot = threadIdx.x / T;
-  const int b = xcd_block() * EPW + slot;
   const ModelView m(&ms, mp);
   E e(P, b < P.B ? b : P.B - 1);
   DynData* d = &lds_d[slot];
   // the kinematics working set lives in the M | L words of the dynamics record, which the dynamics only start writing (mass matrix, then its factor)
   // after the kinematics are done: same LDS footprint, hence the same 8 workgroups per CU, as k_dynamics_team alone
   static_assert(offsetof(DynData, L) == offsetof(DynData, M) + sizeof(float) * ND * ND, "KinData overlay");
-  constexpr bool KIN_OVERLAY = sizeof(KinData) <= 2 * sizeof(float) * ND * ND;       // (shape variants with few dofs: the kinematics set gets its own LDS block)
-  __shared__ KinSeparate<KIN_OVERLAY, EPW> lds_k;
   KinData* s = lds_k.at(slot, d->M);
   PH_BEGIN
-  team_stage<ND, T>(tl, [&](int i) { return gload(e, FO(vel), i); }, [&](int i, float v) { s->vel[i] = v; });
-  team_stage<ND, T>(tl, [&](int i) { return aload(e, AO(acc), i); }, [&](int i, float a) { s->vel_next[i] = a; });
+  if (pre) { if (tl < ND) { s->vel[tl] = pre_vel; s->vel_next[tl] = pre_acc; } }     // (k_solve_integrate_team: taken from the solver's LDS block)
+  else {
+    team_stage<ND, T>(tl, [&](int i) { return gload(e, FO(vel), i); }, [&](int i, float v) { s->vel[i] = v; });
+    team_stage<ND, T>(tl, [&](int i) { return aload(e, AO(acc), i); }, [&](int i, float a) { s->vel_next[i] = a; });
+  }
   team_stage<NQ, T>(tl, [&](int q) { return gload(e, FO(qpos), q); }, [&](int q, float v) { s->qpos[q] = v; });
   // control inputs of the dynamics half (parked exactly as k_dynamics_team parks them)
   team_stage<ND, T>(tl, [&](int i) { return __int_as_float((int)e.ctrl_mode()[i]); }, [&](int i, float v) { d->ctrl_mode[i] = __float_as_int(v); });
@@ -1405,6 +1411,15 @@ __global__ __launch_bounds__(64) void k_integrate_fk_dynamics_team(Pool P, const
   team_sync();
   PH(41)
   tk_dynamics<T>(m, e, d, tl, true);
+}
+template <int T>
+__global__ __launch_bounds__(64) void k_integrate_fk_dynamics_team(Pool P, const ModelS* __restrict__ mp) {
+  STAMP(STK_INT_FK_DYN)
+  constexpr int EPW = 64 / T;
+  __shared__ DynData lds_d[EPW];
+  __shared__ alignas(16) char ms_raw[MODELS_LDS_BYTES];
+  __shared__ KinSeparate<KIN_OVERLAY, EPW> lds_k;
+  integrate_fk_dynamics_body<T>(P, mp, xcd_block() * EPW + (int)threadIdx.x / T, lds_d, ms_raw, lds_k, false, 0.0f, 0.0f);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -3923,13 +3938,12 @@ DEVN void ts_solve_overflow(float* Pf, int* Pi, int PB, float* Pfa, int* Pia, in
   ts_commit<T>(m, e, s, tl, nc, n_con, iters);
 }
 
+// body of k_constraint_solve_team on LDS blocks handed in by the kernel (the plain launch owns them; k_solve_integrate_team lays them over the blocks of the
+// kinematics / dynamics that follow).  Out: the env of the caller's team (b_out >= P.B: none) and whether its solve ran on the LDS block (else: global scratch).
 template <int T, int RLN>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_constraint_solve_team(Pool P, const Model* __restrict__ gm, const ModelS* __restrict__ mp, SolverData<MAXR>* __restrict__ overflow,
-                                                                                                         const int* __restrict__ lpt_rec, int* __restrict__ lpt_next, int lpt_cap) {
-  STAMP(STK_SOLVE)
+DEV void solve_body(const Pool& P, const Model* __restrict__ gm, const ModelS* __restrict__ mp, SolverData<MAXR>* __restrict__ overflow,
+                    const int* __restrict__ lpt_rec, int* __restrict__ lpt_next, int lpt_cap, SolverData<RLN>* lds, char* blk_raw, int& b_out, bool& resident_out) {
   constexpr int EPW = 64 / T;
-  __shared__ SolverData<RLN> lds[EPW];
-  __shared__ alignas(16) char blk_raw[lds_dma_bytes(SOLVER_BLOCK_BYTES)];
   const LinkS* lnk = (const LinkS*)blk_raw;
   const unsigned char* tri_i = (const unsigned char*)(blk_raw + sizeof(LinkS) * NL);
   const unsigned char* tri_j = tri_i + (NTRI + 1);
@@ -3942,6 +3956,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   const int b = lpt_take(lpt_rec, lpt_cap, P.B, EPW, slot);
   if (lpt_next && blockIdx.x == 0) for (int i = threadIdx.x; i < 8 * LPT_CLS; i += 64) lpt_next[i] = 0;   // the record of the next collide / solve pair
   const bool env_valid = b < P.B;
+  b_out = b; resident_out = false;
 #ifdef GO2SIM_BRACKET_DEBUG
   if (threadIdx.x == 0) g_brenv_of_wg[blockIdx.x] = b - slot;
 #endif
@@ -3960,6 +3975,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   const int n_con = 4 * nc + n_lim;
   if (n_con <= RLN) {
     SolverData<RLN>* s = &lds[slot];
+    resident_out = true;
     int iters = ts_solve<T>(m, e, s, tl, nc, n_con, lim_mask, ws_flag);
     PH(10)                                                               // (resets the timer: the phases of ts_solve are accounted inside it)
 #if defined(GO2SIM_REPEAT_PHASE) && GO2SIM_REPEAT_PHASE == 11
@@ -3970,6 +3986,55 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     PH(11)
   } else {
     ts_solve_overflow<T>(P.f, P.i, P.B, P.fa, P.ia, b, lnk, tri_i, tri_j, gm, &overflow[b], tl, nc, n_con, lim_mask, ws_flag);
+  }
+}
+template <int T, int RLN>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_constraint_solve_team(Pool P, const Model* __restrict__ gm, const ModelS* __restrict__ mp, SolverData<MAXR>* __restrict__ overflow,
+                                                                                                         const int* __restrict__ lpt_rec, int* __restrict__ lpt_next, int lpt_cap) {
+  STAMP(STK_SOLVE)
+  constexpr int EPW = 64 / T;
+  __shared__ SolverData<RLN> lds[EPW];
+  __shared__ alignas(16) char blk_raw[lds_dma_bytes(SOLVER_BLOCK_BYTES)];
+  int b; bool resident;
+  solve_body<T, RLN>(P, gm, mp, overflow, lpt_rec, lpt_next, lpt_cap, lds, blk_raw, b, resident);
+}
+
+// Constraint solve of substep i, then -- in the SAME wavefront, for the same environments -- kernel_step_2 of that substep (integrate, kinematics) and, between the
+// substeps (WITH_DYN), the forward dynamics of substep i + 1: k_constraint_solve_team followed by k_integrate_fk_dynamics_team / k_integrate_fk_team without the
+// launch boundary.  A solver launch lasts as long as its slowest workgroup (landing window: mean 31 us, span 66 us) and the kinematics / dynamics that follow
+// are uniform: in one launch the workgroups whose solve ends early go straight on, so the launch costs the slowest solve plus ITS kinematics instead of the
+// slowest solve plus a grid-wide join plus everybody's kinematics.  The LDS blocks of the second half are laid over the solver's (same footprint: 8 workgroups per
+// CU); velocity and acceleration of the team's dofs pass in registers.  Same code per value as the two launches: results unchanged.
+constexpr size_t cmax(size_t a, size_t b) { return a > b ? a : b; }
+template <int T, int RLN, bool WITH_DYN>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_solve_integrate_team(Pool P, const Model* __restrict__ gm, const ModelS* __restrict__ mp,
+                                                                                                        SolverData<MAXR>* __restrict__ overflow, const int* __restrict__ lpt_rec,
+                                                                                                        int* __restrict__ lpt_next, int lpt_cap) {
+  STAMP(STK_SOLVE)
+  constexpr int EPW = 64 / T;
+  constexpr size_t SOLVE_OFF = (sizeof(SolverData<RLN>) * EPW + 15) / 16 * 16, DYN_OFF = (sizeof(DynData) * EPW + 15) / 16 * 16, KIN_OFF = (sizeof(KinData) * EPW + 15) / 16 * 16;   // the DMA targets behind the blocks: 16-byte aligned
+  constexpr size_t SOLVE_BYTES = SOLVE_OFF + lds_dma_bytes(SOLVER_BLOCK_BYTES);
+  constexpr size_t DYN_BYTES = DYN_OFF + MODELS_LDS_BYTES + sizeof(KinSeparate<KIN_OVERLAY, EPW>);
+  constexpr size_t KIN_BYTES = KIN_OFF + MODELS_LDS_BYTES;
+  __shared__ alignas(16) char raw[cmax(SOLVE_BYTES, WITH_DYN ? DYN_BYTES : KIN_BYTES)];
+  const int tl = threadIdx.x % T, slot = threadIdx.x / T;
+  int b; bool resident;
+  SolverData<RLN>* lds = (SolverData<RLN>*)raw;
+  solve_body<T, RLN>(P, gm, mp, overflow, lpt_rec, lpt_next, lpt_cap, lds, raw + SOLVE_OFF, b, resident);
+  // velocity and acceleration of my dof, before the solver's block is overlaid (an env whose solve ran on the global scratch block reads them back from HBM)
+  const bool pre = b < P.B && resident;
+  const int dd = tl < ND ? tl : ND - 1;
+  const float pre_vel = pre ? lds[slot].vel[dd] : 0.0f, pre_acc = pre ? lds[slot].qacc[dd] : 0.0f;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");              // the commit's stores (acc of a scratch-block env) before the loads of the second half
+  __syncthreads();                                                    // both teams are done with the solver's LDS blocks
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  if constexpr (WITH_DYN) {
+    DynData* lds_d = (DynData*)raw;
+    char* ms_raw = raw + DYN_OFF;
+    auto& lds_k = *(KinSeparate<KIN_OVERLAY, EPW>*)(ms_raw + MODELS_LDS_BYTES);
+    integrate_fk_dynamics_body<T>(P, mp, b, lds_d, ms_raw, lds_k, pre, pre_vel, pre_acc);
+  } else {
+    integrate_fk_body<T>(P, mp, b, (KinData*)raw, raw + KIN_OFF, pre, pre_vel, pre_acc);
   }
 }
 
@@ -5512,6 +5577,7 @@ struct go2sim {
   bool use_graph = true;
   int graph_fallbacks = 0;                  // times the graph path was abandoned for plain launches (go2sim_graph_status)
   bool fuse_fk_dyn = true;                  // k_integrate_fk_dynamics_team between the substeps of a scene step (GO2SIM_NO_FUSE=1: separate launches)
+  bool fuse_solve_int = true;               // k_solve_integrate_team: the solve and the kinematics (+ next dynamics) after it in one launch (GO2SIM_NO_FUSE_SOLVE=1: separate)
   bool par_pre = false;                     // step graph: the first collision pass as a second root beside the pre-physics / dynamics launch (GO2SIM_PAR_PRE=1).
                                             // Measured slower than the chain (window 10.26 vs 10.40 M, default run 14.84 vs 15.24 M, stairs 7.51 vs 7.61 M env-steps/s):
                                             // the dynamics wavefronts take SIMDs from the collision pass instead of waiting for its early finishers
@@ -5582,7 +5648,11 @@ static bool lpt_enabled(const go2sim* h) {
   return epw_s == 1 || h->lpt_flat;
 }
 static size_t lpt_record_ints(const go2sim* h) { return (size_t)8 * LPT_CLS * (1 + h->lpt_cap); }
-static void launch_collide_solve(go2sim* h, hipStream_t s) {
+// flat ground, 32-lane teams in solver and dynamics: the solve and the kinematics (+ next dynamics) that follow it share a launch (k_solve_integrate_team);
+// GO2SIM_NO_FUSE_SOLVE=1 keeps the two launches
+static bool fuse_solve(const go2sim* h) { return h->fuse_solve_int && h->fuse_fk_dyn && !h->hm.terrain_enabled && h->solver_team == 32 && h->dyn_team == 32; }
+// fuse_mode: 0 = the solve alone; 1 = + integrate / kinematics / next dynamics; 2 = + integrate / kinematics (last substep)
+static void launch_collide_solve(go2sim* h, hipStream_t s, int fuse_mode = 0) {
   dim3 b(WG);
   const bool lpt_on = lpt_enabled(h);
   int* lpt_cur = lpt_on ? h->lpt + h->lpt_parity * lpt_record_ints(h) : nullptr;
@@ -5607,6 +5677,8 @@ static void launch_collide_solve(go2sim* h, hipStream_t s) {
       const int T = h->solver_team;
       dim3 gs((h->B + 64 / T - 1) / (64 / T));
       if (T == 16) hipLaunchKernelGGL((k_constraint_solve_team<16, RL>), gs, b, 0, s, h->P, h->dm, h->dms, h->solver_ovf, (const int*)lpt_cur, lpt_next, h->lpt_cap);
+      else if (T == 32 && fuse_mode == 1) hipLaunchKernelGGL((k_solve_integrate_team<32, RL, true>), gs, b, 0, s, h->P, h->dm, h->dms, h->solver_ovf, (const int*)lpt_cur, lpt_next, h->lpt_cap);
+      else if (T == 32 && fuse_mode == 2) hipLaunchKernelGGL((k_solve_integrate_team<32, RL, false>), gs, b, 0, s, h->P, h->dm, h->dms, h->solver_ovf, (const int*)lpt_cur, lpt_next, h->lpt_cap);
       else if (T == 32) hipLaunchKernelGGL((k_constraint_solve_team<32, RL>), gs, b, 0, s, h->P, h->dm, h->dms, h->solver_ovf, (const int*)lpt_cur, lpt_next, h->lpt_cap);
       else hipLaunchKernelGGL((k_constraint_solve_team<64, RL>), gs, b, 0, s, h->P, h->dm, h->dms, h->solver_ovf, (const int*)lpt_cur, lpt_next, h->lpt_cap);
     }
@@ -5633,6 +5705,7 @@ static void launch_integrate_dynamics(go2sim* h, hipStream_t s) {
 static int launch_substeps(go2sim* h, hipStream_t s, int n, const float* pre_actions = nullptr) {
   launch_dynamics(h, s, pre_actions);
   for (int i = 0; i < n; ++i) {
+    if (fuse_solve(h)) { launch_collide_solve(h, s, i + 1 < n ? 1 : 2); continue; }
     launch_collide_solve(h, s);
     if (i + 1 < n && h->fuse_fk_dyn) launch_integrate_dynamics(h, s);
     else { launch_integrate(h, s); if (i + 1 < n) launch_dynamics(h, s); }
@@ -5733,6 +5806,12 @@ static bool step_graph_build(go2sim* h, const float* actions, float* obs, float*
       else ok = graph_add_kernel(h, last, k_constraint_solve_team<64, RL_TERRAIN>, dim3(h->B), b64, nullptr, nullptr, nullptr, h->P, h->dm, h->dms, h->solver_ovf, (const int*)lpt_cur, lpt_next, h->lpt_cap);
     } else {
       const int T = h->solver_team; const dim3 gs = team_grid(T);
+      if (fuse_solve(h)) {                                               // solve + integrate / kinematics (+ next dynamics) in one launch
+        ok = (i + 1 < substeps) ? graph_add_kernel(h, last, k_solve_integrate_team<32, RL, true>, gs, b64, nullptr, nullptr, nullptr, h->P, h->dm, h->dms, h->solver_ovf, (const int*)lpt_cur, lpt_next, h->lpt_cap)
+                                : graph_add_kernel(h, last, k_solve_integrate_team<32, RL, false>, gs, b64, nullptr, nullptr, nullptr, h->P, h->dm, h->dms, h->solver_ovf, (const int*)lpt_cur, lpt_next, h->lpt_cap);
+        if (!ok) break;
+        continue;
+      }
       ok = T == 16 ? graph_add_kernel(h, last, k_constraint_solve_team<16, RL>, gs, b64, nullptr, nullptr, nullptr, h->P, h->dm, h->dms, h->solver_ovf, (const int*)lpt_cur, lpt_next, h->lpt_cap)
          : T == 32 ? graph_add_kernel(h, last, k_constraint_solve_team<32, RL>, gs, b64, nullptr, nullptr, nullptr, h->P, h->dm, h->dms, h->solver_ovf, (const int*)lpt_cur, lpt_next, h->lpt_cap)
                    : graph_add_kernel(h, last, k_constraint_solve_team<64, RL>, gs, b64, nullptr, nullptr, nullptr, h->P, h->dm, h->dms, h->solver_ovf, (const int*)lpt_cur, lpt_next, h->lpt_cap);
@@ -5819,6 +5898,7 @@ int go2sim_create(const void* blob, size_t nbytes, int n_envs, int device, uint6
     if (const char* t = getenv("GO2SIM_NO_GRAPH")) { if (atoi(t) != 0) h->use_graph = false; }
     if (const char* t = getenv("GO2SIM_NO_FUSE")) { if (atoi(t) != 0) h->fuse_fk_dyn = false; }
     if (const char* t = getenv("GO2SIM_PAR_PRE")) { if (atoi(t) != 0) h->par_pre = true; }
+    if (const char* t = getenv("GO2SIM_NO_FUSE_SOLVE")) { if (atoi(t) != 0) h->fuse_solve_int = false; }
     if (const char* t = getenv("GO2SIM_FK_TEAM")) { int v = atoi(t); if (v == 16 || v == 32 || v == 64) h->fk_team = v; }
     if (const char* t = getenv("GO2SIM_COLLIDE_TEAM")) { int v = atoi(t); if (v == 16 || v == 32 || v == 64) h->collide_team = v; }
     CK(hipMalloc((void**)&h->gjk_scratch, (size_t)n_envs * h->collide_team * sizeof(GjkStoreFull)));   // ~20 KB per narrow-phase lane

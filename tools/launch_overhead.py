@@ -7,7 +7,7 @@ Every workgroup of the step kernels stamps s_memrealtime (100 MHz, one clock for
 retired.  One step's stamps give, per launch k of the 9: span_k = latest end - earliest start (the time in which at least one workgroup of the
 launch may be running), ramp_k = latest start - earliest start (dispatch ramp), and gap_k = earliest start of launch k+1 - latest end of launch k:
 the time in which NO workgroup runs (end-of-kernel write-back, dependency resolution of the graph, dispatch).  sum(span) + sum(gap) is the step
-as the device sees it; the step graph is used as in the product (plain launches with GO2SIM_NO_GRAPH=1)."""
+as the device sees it; the step graph is used as in the product (plain launches with GO2SIM_NO_GRAPH=1; GO2SIM_NO_FUSE_SOLVE=1 for the nine-launch form)."""
 import ctypes
 import os
 import sys
@@ -35,8 +35,8 @@ act = make_actions(N + W, B, dev, workload="walk")
 obs = torch.zeros(B, NOBS["walk"], device=dev); priv = torch.zeros(B, NPRIV["walk"], device=dev); rew = torch.zeros(B, device=dev)
 rst = torch.zeros(B, dtype=torch.uint8, device=dev); to = torch.zeros(B, device=dev)
 KINDS, MAXWG, DEPTH = 8, 4096, 4
-NAMES = ["pre_dynamics", "collide", "solve", "integrate_fk_dynamics", "integrate_fk", "post_a", "post_b"]
-ORDER = [(0, 0), (1, 0), (2, 0), (3, 0), (1, 1), (2, 1), (4, 0), (5, 0), (6, 0)]      # (kind, which launch of that kind in the step)
+NAMES = ["pre_dynamics", "collide", "solve (+ integrate / kinematics / dynamics when fused)", "integrate_fk_dynamics", "integrate_fk", "post_a", "post_b"]
+ORDER = []      # (kind, which launch of that kind in the step), filled per step from the stamps
 stamps = np.zeros((KINDS, MAXWG, DEPTH, 2), np.uint64); counts = np.zeros((KINDS, MAXWG), np.uint32)
 for s in range(W):
     sim.env_step(act[s], obs, priv, rew, rst, to)
@@ -50,11 +50,15 @@ for s in range(W, W + N):
     host_ms.append(ev0.elapsed_time(ev1))
     lib.lib.go2sim_debug_stamps(sim.h, stamps.ctypes.data_as(ctypes.c_void_p), counts.ctypes.data_as(ctypes.c_void_p))
     launches = []
-    for kind, which in ORDER:
-        wg = np.flatnonzero(counts[kind] - before[kind] > which)
-        idx = (before[kind][wg] + which) % DEPTH
-        t0 = stamps[kind, wg, idx, 0].astype(np.int64); t1 = stamps[kind, wg, idx, 1].astype(np.int64)
-        launches.append((t0.min(), t0.max(), t1.max(), np.mean(t1 - t0), len(wg)))
+    for kind in range(len(NAMES)):                                       # every launch of the step, whatever the fusion state of the build: ordered by start
+        n_new = int((counts[kind] - before[kind]).max())
+        for which in range(n_new):
+            wg = np.flatnonzero(counts[kind] - before[kind] > which)
+            idx = (before[kind][wg] + which) % DEPTH
+            t0 = stamps[kind, wg, idx, 0].astype(np.int64); t1 = stamps[kind, wg, idx, 1].astype(np.int64)
+            launches.append((t0.min(), t0.max(), t1.max(), np.mean(t1 - t0), len(wg), kind, which))
+    launches.sort(key=lambda l: l[0])
+    ORDER = [(l[5], l[6]) for l in launches]
     rows.append(launches)
 a = np.array([[(l[2] - l[0], l[1] - l[0], l[3], l[4]) for l in r] for r in rows], np.float64)        # [step, launch, (span, ramp, mean wg, n_wg)]
 gaps = np.array([[r[k + 1][0] - r[k][2] for k in range(len(ORDER) - 1)] for r in rows], np.float64)
@@ -63,7 +67,7 @@ print(f"launch overhead, {B} envs, steps {W}..{W + N} after the reset (walk, act
 print(f"{'launch':26s} {'wgs':>5s} {'span':>8s} {'ramp':>7s} {'mean wg':>8s} {'gap after':>10s}")
 for k, (kind, which) in enumerate(ORDER):
     g = gaps[:, k].mean() * tick_us if k < len(ORDER) - 1 else float('nan')
-    print(f"{NAMES[kind] + ('' if kind not in (1, 2) else f' #{which + 1}'):26s} {int(a[0, k, 3]):5d} {a[:, k, 0].mean() * tick_us:8.2f} {a[:, k, 1].mean() * tick_us:7.2f} {a[:, k, 2].mean() * tick_us:8.2f} {g:10.2f}")
+    print(f"{(NAMES[kind] if kind != 2 else 'solve' + (' + integrate' if len(ORDER) < 9 else '')) + ('' if kind not in (1, 2) else f' #{which + 1}'):26s} {int(a[0, k, 3]):5d} {a[:, k, 0].mean() * tick_us:8.2f} {a[:, k, 1].mean() * tick_us:7.2f} {a[:, k, 2].mean() * tick_us:8.2f} {g:10.2f}")
 span_sum, gap_sum = a[:, :, 0].sum(1).mean() * tick_us, gaps.sum(1).mean() * tick_us
 first_to_last = np.mean([r[-1][2] - r[0][0] for r in rows]) * tick_us
 print(f"sum of spans {span_sum:.1f} us + sum of the {len(ORDER) - 1} gaps {gap_sum:.1f} us = {span_sum + gap_sum:.1f} us (first workgroup start to last workgroup end {first_to_last:.1f} us); "
