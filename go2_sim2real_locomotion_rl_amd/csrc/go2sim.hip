@@ -275,6 +275,7 @@ struct Model {
   // derived tree tables: links grouped by depth, children of every link in DESCENDING index order (the order in which the
   // reference's leaf->root loops add them to the parent), link of every dof
   int n_levels, level_start[NL + 1], level_links[NL], child_start[NL + 1], child_list[NL], dof_link[ND];
+  int arrow_mode;   // derived: numbering of the four leg chains (dm_arrow_mode; 0 = the Hessian has no arrow form)
 };
 
 bool parse_model(const void* blob, size_t nbytes, Model& m) {
@@ -322,6 +323,7 @@ bool parse_model(const void* blob, size_t nbytes, Model& m) {
     for (int a = 0; a < 32; ++a) { g.rim[a][0] = f[49 + 2 * a]; g.rim[a][1] = f[50 + 2 * a]; }
   }
   for (int i = 0; i < ND; ++i) for (int j = 0; j < ND; ++j) m.mass_parent_mask[i][j] = f[i * ND + j];
+  m.arrow_mode = getenv("GO2SIM_NO_ARROW") ? 0 : dm_arrow_mode(&m.mass_parent_mask[0][0], ND);   // (GO2SIM_NO_ARROW=1: diagnostic switch, keeps the row-form factorisation under test)
   f += ND * ND;
   if (f - F != nf) return false;
   const int32_t* p = I;
@@ -450,18 +452,18 @@ DEV void tri_index(const ModelS& m, int idx, int& i, int& j) { i = m.tri_i[idx];
 
 // View used by the team kernels: scalars come from the global copy through uniform (scalar) loads and live in SGPRs, tables point into LDS
 struct ModelView {
-  int n_levels, iterations, ls_iterations; float substep_dt; V3 gravity; float eps, tolerance, ls_tolerance, meaninertia;
+  int n_levels, iterations, ls_iterations, arrow_mode; float substep_dt; V3 gravity; float eps, tolerance, ls_tolerance, meaninertia;
   const LinkS* links; const Joint* joints; const Dof* dofs; const GeomS* geoms; const Entity* entities; const float* qpos0;
   const unsigned* mass_mask_bits; const int *level_start, *level_links, *child_start, *child_list, *dof_link; const unsigned char *tri_i, *tri_j;
   DEV ModelView(const ModelS* t, const ModelS* __restrict__ g)
-      : n_levels(g->n_levels), iterations(g->iterations), ls_iterations(g->ls_iterations), substep_dt(g->substep_dt), gravity(g->gravity), eps(g->eps),
+      : n_levels(g->n_levels), iterations(g->iterations), ls_iterations(g->ls_iterations), arrow_mode(0), substep_dt(g->substep_dt), gravity(g->gravity), eps(g->eps),
         tolerance(g->tolerance), ls_tolerance(g->ls_tolerance), meaninertia(g->meaninertia), links(t->links), joints(t->joints), dofs(t->dofs),
         geoms(t->geoms), entities(t->entities), qpos0(t->qpos0), mass_mask_bits(t->mass_mask_bits), level_start(t->level_start),
         level_links(t->level_links), child_start(t->child_start), child_list(t->child_list), dof_link(t->dof_link), tri_i(t->tri_i), tri_j(t->tri_j) {}
   // solver flavour: only the link table and the triangle LUT are staged in LDS; joint / dof constants are read with uniform indices and stay
   // behind scalar loads of the global model
   DEV ModelView(const LinkS* lds_links, const unsigned char* lds_tri_i, const unsigned char* lds_tri_j, const Model* __restrict__ g)
-      : n_levels(g->n_levels), iterations(g->iterations), ls_iterations(g->ls_iterations), substep_dt(g->substep_dt), gravity(g->gravity), eps(g->eps),
+      : n_levels(g->n_levels), iterations(g->iterations), ls_iterations(g->ls_iterations), arrow_mode(g->arrow_mode), substep_dt(g->substep_dt), gravity(g->gravity), eps(g->eps),
         tolerance(g->tolerance), ls_tolerance(g->ls_tolerance), meaninertia(g->meaninertia), links(lds_links), joints(g->joints), dofs(g->dofs),
         geoms(nullptr), entities(g->entities), qpos0(g->qpos0), mass_mask_bits(nullptr), level_start(nullptr), level_links(nullptr), child_start(nullptr),
         child_list(nullptr), dof_link(nullptr), tri_i(lds_tri_i), tri_j(lds_tri_j) {}
@@ -2078,14 +2080,15 @@ DEV bool terrain_prism_contact(const Model& m, const E& e, const TP& t, int i_gb
   return is_col;
 }
 
-template <int T>
+// EPW = environments per wavefront: 64 / T fills the wavefront; fewer leave the upper lanes idle (the teams of a wavefront run in lockstep, so a
+// team pays for the longest query loop and for every branch direction of its neighbours)
+template <int T, int EPW = 64 / T>
 __global__ __launch_bounds__(64) void k_collide_team(Pool P, const Model* __restrict__ mp, GjkStoreFull* __restrict__ gjk_scratch, int* __restrict__ lpt_rec, int lpt_cap, int solver_epw) {
   STAMP(STK_COLLIDE)
-  constexpr int EPW = 64 / T;
   __shared__ CollideData<T> lds[EPW];
   const int tl = threadIdx.x % T, slot = threadIdx.x / T;
   const int b = xcd_block() * EPW + slot;
-  if (b >= P.B) return;
+  if (slot >= EPW || b >= P.B) return;
   const Model& m = *mp;
   E e(P, b);
   CollideData<T>* s = &lds[slot];
@@ -2746,9 +2749,12 @@ DEV void ts_update_constraint(const MT& m, S* s, int tl, int n_con, float& cost,
 // 3 reads per multiply-add; the row factor J[c][i] * D[c] * active[c] (0 where the reference skips the row: |J[c][i]| <= eps) is formed once per block
 // row and the sum runs as a fused multiply-add chain over the rows first to last.  Teams of 64 lanes split the rows in three interleaved groups
 // (rows c = g mod 3 on lanes 21 g .. 21 g + 20) and add the partial sums as (p0 + p1) + p2.
+// Both Hessian routines return whether the entries that couple two different legs (dm_arrow_leg) are exactly zero, i.e. whether the matrix has the
+// arrow shape ts_cholesky_factor_arrow needs (the block lanes hold those values anyway).
 template <int T, class S, class MT>
-DEV void ts_hessian_direct(const MT& m, S* s, int tl, int n_con) {
+DEV bool ts_hessian_direct(const MT& m, S* s, int tl, int n_con) {
   constexpr int NB = 21, G = (T >= 3 * NB) ? 3 : 1;
+  bool cross = false;
   for (int u0 = 0; u0 < NB * G; u0 += T) {
     const int u = u0 + tl;
     const bool on = u < NB * G;
@@ -2789,15 +2795,17 @@ DEV void ts_hessian_direct(const MT& m, S* s, int tl, int n_con) {
           const float v = h[a][q] + s->M[i * DS + j];
           if constexpr (T >= NB) s->Ablk[blk * 9 + 3 * a + q] = v;       // the unfactored Hessian stays with its block lane (ts_hessian_update)
           if (j <= i) s->H[i * DS + j] = v;
+          if (i >= 6 && j >= 6 && j < i && dm_arrow_leg(m.arrow_mode, i) != dm_arrow_leg(m.arrow_mode, j)) cross = cross || (v != 0.0f);
         }
     }
   }
   team_sync();
+  return team_ballot<T>(cross) == 0ull;
 }
 // The Hessian after a change of the active set: the block lanes add / subtract the rows that flipped (first to last, fused multiply-adds on the stored
 // blocks) instead of summing all rows again, and hand the result to the factorisation.  Cost proportional to the flipped rows.
 template <int T, class S, class MT>
-DEV void ts_hessian_update(const MT& m, S* s, int tl, int n_con) {
+DEV bool ts_hessian_update(const MT& m, S* s, int tl, int n_con) {
   constexpr int NB = 21;
   static_assert(T >= NB, "one lane per block");
   const bool on = tl < NB;
@@ -2811,6 +2819,7 @@ DEV void ts_hessian_update(const MT& m, S* s, int tl, int n_con) {
     for (int q = 0; q < 3; ++q) h[a][q] = s->Ablk[blk * 9 + 3 * a + q];
   const float* Ji = &s->J[3 * bi];
   const float* Jj = &s->J[3 * bj];
+  bool cross = false;
   for (int base = 0; base < n_con; base += T) {
     const int c_me = base + tl;
     unsigned long long mask = team_ballot<T>(c_me < n_con && ((s->active[c_me] != 0) != (s->prev_active[c_me] != 0)));
@@ -2835,14 +2844,16 @@ DEV void ts_hessian_update(const MT& m, S* s, int tl, int n_con) {
         const int i = 3 * bi + a, j = 3 * bj + q;
         s->Ablk[blk * 9 + 3 * a + q] = h[a][q];
         if (j <= i) s->H[i * DS + j] = h[a][q];
+        if (i >= 6 && j >= 6 && j < i && dm_arrow_leg(m.arrow_mode, i) != dm_arrow_leg(m.arrow_mode, j)) cross = cross || (h[a][q] != 0.0f);
       }
   }
   team_sync();
+  return team_ballot<T>(cross) == 0ull;
 }
 #else
 // one lane per lower-triangle entry, rows summed first to last
 template <int T, class S, class MT>
-DEV void ts_hessian_direct(const MT& m, S* s, int tl, int n_con) {
+DEV bool ts_hessian_direct(const MT& m, S* s, int tl, int n_con) {
   for (int idx = tl; idx < ND * (ND + 1) / 2; idx += T) {
     int i, j;
     tri_index(m, idx, i, j);
@@ -2857,6 +2868,7 @@ DEV void ts_hessian_direct(const MT& m, S* s, int tl, int n_con) {
     s->H[i * DS + j] = h;
   }
   team_sync();
+  return false;
 }
 #endif
 
@@ -2917,6 +2929,144 @@ DEV void ts_cholesky_factor_rows(const MT& m, S* s, int tl) {
   }
   team_sync();
 }
+#if GO2SIM_FAST_ORDER
+// ---- FAST ORDER, arrow form ------------------------------------------------------------------------------------------------------------------
+// A floating base with four legs gives the Newton Hessian H = M + J^T D J the shape of the mass matrix as long as no constraint row touches two
+// legs: the 3 x 3 leg blocks A_l (dofs dm_arrow_dof(mode, l, 0..2); Model::arrow_mode from the mass-matrix mask) couple only to the 6 base dofs (C_l, 3 x 6),
+// never to each other.  Eliminating the legs FIRST keeps that
+// shape (no fill-in), so the factorisation of the permuted matrix [legs..., base] is
+//     A_l = L_l L_l^T  (four 3 x 3 factorisations side by side),   W_l = C_l^T L_l^-T  (6 x 3),   B' = B - sum_l W_l W_l^T,   B' = L_b L_b^T  (6 x 6)
+// -- 3 + 6 dependent pivots instead of 18, and small enough to run without any exchange between the lanes but two LDS round trips:
+// lane (l, u) = (tl / 8, tl % 8) of a team factorises the block of leg l (redundantly with the 7 other lanes of the leg), forms row u of W_l and of
+// W_l W_l^T, the four legs are added across the lanes ((l0 + l2) + (l1 + l3): v_permlane16_swap, row_ror:8), and every lane factorises the 6 x 6
+// Schur complement in registers.  Only reciprocal pivots are kept (1 / sqrt(e) = sqrt(e) * (1 / e): the division is issued beside the square root).
+// The triangular solves (ts_update_gradient_arrow) walk the same structure: 3 + 6 + 6 + 3 dependent steps instead of 36, in registers.
+// Layout of the factor in s->H (floats; the Hessian it is computed from is consumed first):
+//   leg l at 32 l:  [0..2] reciprocal pivots, [4..6] l10 l20 l21, [8 + 4 b .. +2] row b of W_l (b = 0..5);   base at 128 + 8 k: row k of L_b, the
+//   reciprocal pivot in place of the diagonal element.
+// Applies whenever the cross-leg blocks of H are exactly zero (ts_hessian_* report it); otherwise ts_cholesky_factor_rows / the row-form solves.
+// The FAST ORDER oracle mirrors the arithmetic operation for operation (cholesky_factor_arrow / cholesky_solve_arrow in oracle/go2sim_cpu.cpp).
+constexpr bool ARROW_SHAPE = (ND == 18) && (REBUILD_FLIPS <= 1);   // (rank-1 updates of the factor exist for the row form only)
+DEV float leg_sum4(float x) {                                          // (x_l + x_(l^2)) + (x_(l^1) + x_(l^3)) over the four 8-lane groups of 32 lanes
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  const float p = __uint_as_float(r[0]) + __uint_as_float(r[1]);     // lane ^ 16
+  return p + dpp_perm<0x128>(p);                                       // row_ror:8 = lane ^ 8 inside a row of 16
+}
+DEV float4 lds4(const float* p) { return *(const float4*)p; }
+template <int T, class S, class MT>
+DEV void ts_cholesky_factor_arrow(const MT& m, S* s, int tl) {
+  static_assert(T == 32 || T == 64, "four groups of eight lanes");
+  const int leg = (tl >> 3) & 3, u = tl & 7, ub = u < 6 ? u : 5;
+  const int p0 = dm_arrow_dof(m.arrow_mode, leg, 0), p1 = dm_arrow_dof(m.arrow_mode, leg, 1), p2 = dm_arrow_dof(m.arrow_mode, leg, 2);
+  const bool w_lane = tl < 32 && u < 6;
+  float* H = s->H;
+  // every input first (one round trip): the lane's leg block, its element of the three coupling rows, its row of the base block
+  const float a00 = H[p0 * DS + p0], a10 = H[p1 * DS + p0], a11 = H[p1 * DS + p1];
+  const float a20 = H[p2 * DS + p0], a21 = H[p2 * DS + p1], a22 = H[p2 * DS + p2];
+  const float c0 = H[p0 * DS + ub], c1 = H[p1 * DS + ub], c2 = H[p2 * DS + ub];
+  const float4 br0 = lds4(&H[ub * DS]); const float2 br1 = *(const float2*)&H[ub * DS + 4];
+  team_sync();                                                         // the factor is written over the Hessian
+  const float e0 = fmx(a00, m.eps), i0 = dm_sqrt(e0) * (1.0f / e0);
+  const float l10 = a10 * i0, l20 = a20 * i0;
+  const float e1 = fmx(__builtin_fmaf(-l10, l10, a11), m.eps), i1 = dm_sqrt(e1) * (1.0f / e1);
+  const float l21 = __builtin_fmaf(-l20, l10, a21) * i1;
+  const float e2 = fmx(__builtin_fmaf(-l21, l21, __builtin_fmaf(-l20, l20, a22)), m.eps), i2 = dm_sqrt(e2) * (1.0f / e2);
+  const float w0 = c0 * i0, w1 = __builtin_fmaf(-w0, l10, c1) * i1, w2 = __builtin_fmaf(-w1, l21, __builtin_fmaf(-w0, l20, c2)) * i2;
+  if (w_lane) *(float4*)&H[32 * leg + 8 + 4 * u] = make_float4(w0, w1, w2, 0.0f);
+  if (tl < 32 && u == 0) { *(float4*)&H[32 * leg] = make_float4(i0, i1, i2, 0.0f); *(float4*)&H[32 * leg + 4] = make_float4(l10, l20, l21, 0.0f); }
+  team_sync();
+  float sc[6];
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    const float4 wj = lds4(&H[32 * leg + 8 + 4 * j]);
+    sc[j] = __builtin_fmaf(w2, wj.z, __builtin_fmaf(w1, wj.y, w0 * wj.x));
+  }
+#pragma unroll
+  for (int j = 0; j < 6; ++j) sc[j] = leg_sum4(sc[j]);
+  const float bp[6] = {br0.x - sc[0], br0.y - sc[1], br0.z - sc[2], br0.w - sc[3], br1.x - sc[4], br1.y - sc[5]};
+  if (tl < 6) { *(float4*)&H[128 + 8 * tl] = make_float4(bp[0], bp[1], bp[2], bp[3]); *(float4*)&H[128 + 8 * tl + 4] = make_float4(bp[4], bp[5], 0.0f, 0.0f); }
+  team_sync();
+  float a[6][6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    const float4 lo = lds4(&H[128 + 8 * k]); const float2 hi = *(const float2*)&H[128 + 8 * k + 4];
+    a[k][0] = lo.x; a[k][1] = lo.y; a[k][2] = lo.z; a[k][3] = lo.w; a[k][4] = hi.x; a[k][5] = hi.y;
+  }
+  team_sync();                                                         // (rows are rewritten below)
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    const float e = fmx(a[k][k], m.eps), ik = dm_sqrt(e) * (1.0f / e);
+    a[k][k] = ik;
+#pragma unroll
+    for (int j = k + 1; j < 6; ++j) a[j][k] = a[j][k] * ik;
+#pragma unroll
+    for (int j = k + 1; j < 6; ++j)
+#pragma unroll
+      for (int i = k + 1; i <= j; ++i) a[j][i] = __builtin_fmaf(-a[j][k], a[i][k], a[j][i]);
+  }
+  if (tl == 0) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      *(float4*)&H[128 + 8 * k] = make_float4(a[k][0], k >= 1 ? a[k][1] : 0.0f, k >= 2 ? a[k][2] : 0.0f, k >= 3 ? a[k][3] : 0.0f);
+      *(float2*)&H[128 + 8 * k + 4] = make_float2(k >= 4 ? a[k][4] : 0.0f, k >= 5 ? a[k][5] : 0.0f);
+    }
+  }
+  team_sync();
+}
+// grad = Ma - force - qfrc;  Mgrad = H^-1 grad on the arrow factor
+template <int T, class S, class MT>
+DEV void ts_update_gradient_arrow(const MT& m, S* s, int tl) {
+  static_assert(T == 32 || T == 64, "four groups of eight lanes");
+  const int leg = (tl >> 3) & 3, u = tl & 7, ub = u < 6 ? u : 5;
+  const int p0 = dm_arrow_dof(m.arrow_mode, leg, 0), p1 = dm_arrow_dof(m.arrow_mode, leg, 1), p2 = dm_arrow_dof(m.arrow_mode, leg, 2);
+  const float* H = s->H;
+  const int row = tl < ND ? tl : ND - 1;
+  const float g_own = s->Ma[row] - s->force[row] - s->qfrc[row];
+  const float gl0 = s->Ma[p0] - s->force[p0] - s->qfrc[p0], gl1 = s->Ma[p1] - s->force[p1] - s->qfrc[p1], gl2 = s->Ma[p2] - s->force[p2] - s->qfrc[p2];
+  const float gb = s->Ma[ub] - s->force[ub] - s->qfrc[ub];
+  const float4 iv = lds4(&H[32 * leg]), lv = lds4(&H[32 * leg + 4]), wo = lds4(&H[32 * leg + 8 + 4 * ub]);
+  float4 W[6];
+#pragma unroll
+  for (int b = 0; b < 6; ++b) W[b] = lds4(&H[32 * leg + 8 + 4 * b]);
+  float L[6][6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    const float4 lo = lds4(&H[128 + 8 * k]); const float2 hi = *(const float2*)&H[128 + 8 * k + 4];
+    L[k][0] = lo.x; L[k][1] = lo.y; L[k][2] = lo.z; L[k][3] = lo.w; L[k][4] = hi.x; L[k][5] = hi.y;
+  }
+  if (tl < ND) s->grad[row] = g_own;
+  // forward: the legs, then the base with the legs' part taken out of its right-hand side
+  const float y0 = gl0 * iv.x, y1 = __builtin_fmaf(-lv.x, y0, gl1) * iv.y, y2 = __builtin_fmaf(-lv.z, y1, __builtin_fmaf(-lv.y, y0, gl2)) * iv.z;
+  const float z = leg_sum4(__builtin_fmaf(wo.z, y2, __builtin_fmaf(wo.y, y1, wo.x * y0)));
+  if (tl < 6) s->Mgrad[tl] = gb - z;                                   // (Mgrad doubles as the exchange buffer of the base right-hand side)
+  team_sync();
+  const float4 r0 = lds4(&s->Mgrad[0]); const float2 r1 = *(const float2*)&s->Mgrad[4];
+  float x[6] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y};
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    float acc = x[k];
+#pragma unroll
+    for (int j = 0; j < k; ++j) acc = __builtin_fmaf(-L[k][j], x[j], acc);
+    x[k] = acc * L[k][k];
+  }
+#pragma unroll
+  for (int k_ = 0; k_ < 6; ++k_) {
+    const int k = 5 - k_;
+    float acc = x[k];
+#pragma unroll
+    for (int j_ = 0; j_ < 5 - k; ++j_) { const int j = 5 - j_; acc = __builtin_fmaf(-L[j][k], x[j], acc); }
+    x[k] = acc * L[k][k];
+  }
+  // backward through the legs
+  float v0 = y0, v1 = y1, v2 = y2;
+#pragma unroll
+  for (int b = 0; b < 6; ++b) { v0 = __builtin_fmaf(-W[b].x, x[b], v0); v1 = __builtin_fmaf(-W[b].y, x[b], v1); v2 = __builtin_fmaf(-W[b].z, x[b], v2); }
+  const float x2 = v2 * iv.z, x1 = __builtin_fmaf(-lv.z, x2, v1) * iv.y, x0 = __builtin_fmaf(-lv.x, x1, __builtin_fmaf(-lv.y, x2, v0)) * iv.x;
+  if (tl == 0) { *(float4*)&s->Mgrad[0] = make_float4(x[0], x[1], x[2], x[3]); *(float2*)&s->Mgrad[4] = make_float2(x[4], x[5]); }
+  if (tl < 32 && u == 0) { s->Mgrad[p0] = x0; s->Mgrad[p1] = x1; s->Mgrad[p2] = x2; }
+  team_sync();
+}
+#endif
 template <int T, class S, class MT>
 DEV void ts_cholesky_factor(const MT& m, S* s, int tl) {
 #if GO2SIM_FAST_ORDER
@@ -3801,6 +3951,7 @@ DEV int ts_solve(const MT& m, const E& e, S* s, int tl, int nc, int n_con, unsig
   if (n_con > 0) {
     const float tol_scaled = (m.meaninertia * (float)imx(1, ND)) * m.tolerance;
     bool need_full = true;
+    [[maybe_unused]] bool arrow = false;                               // which form the current factor has
     for (int it = 0;; ++it) {
       if (need_full) {                       // single call site of the direct Hessian + factorisation (init and degenerate rebuild)
 #if defined(GO2SIM_REPEAT_PHASE) && GO2SIM_REPEAT_PHASE == 3
@@ -3811,19 +3962,31 @@ DEV int ts_solve(const MT& m, const E& e, S* s, int tl, int nc, int n_con, unsig
         ts_hessian_direct<T>(m, s, tl, n_con);
 #endif
 #if GO2SIM_FAST_ORDER
-        if constexpr (T >= 21) { if (it == 0) ts_hessian_direct<T>(m, s, tl, n_con); else ts_hessian_update<T>(m, s, tl, n_con); }
-        else ts_hessian_direct<T>(m, s, tl, n_con);
+        bool uncoupled;
+        if constexpr (T >= 21) uncoupled = (it == 0) ? ts_hessian_direct<T>(m, s, tl, n_con) : ts_hessian_update<T>(m, s, tl, n_con);
+        else uncoupled = ts_hessian_direct<T>(m, s, tl, n_con);
+        PH(3)
+#ifndef GO2SIM_NO_ARROW
+        if constexpr (ARROW_SHAPE && (T == 32 || T == 64)) arrow = uncoupled && m.arrow_mode != 0;
+#endif
+        if constexpr (ARROW_SHAPE && (T == 32 || T == 64)) { if (arrow) ts_cholesky_factor_arrow<T>(m, s, tl); else ts_cholesky_factor<T>(m, s, tl); }
+        else ts_cholesky_factor<T>(m, s, tl);
 #else
         ts_hessian_direct<T>(m, s, tl, n_con);
-#endif
         PH(3)
         ts_cholesky_factor<T>(m, s, tl);
+#endif
         PH(4)
       }
 #if defined(GO2SIM_REPEAT_PHASE) && GO2SIM_REPEAT_PHASE == 5
       ts_update_gradient<T>(s, tl);
 #endif
+#if GO2SIM_FAST_ORDER
+      if constexpr (ARROW_SHAPE && (T == 32 || T == 64)) { if (arrow) ts_update_gradient_arrow<T>(m, s, tl); else ts_update_gradient<T>(s, tl); }
+      else ts_update_gradient<T>(s, tl);
+#else
       ts_update_gradient<T>(s, tl);
+#endif
       PH(5)
       if (it > 0) {
         float improvement = prev_cost - cost;
@@ -5584,6 +5747,7 @@ struct go2sim {
   int dyn_team = 32;                        // lanes per environment in k_dynamics_team
   int fk_team = 16;                         // lanes per environment in k_integrate_fk_team / k_fk_team
   int collide_team = 16;                    // lanes per environment in k_collide_team
+  int collide_epw = 0;                      // environments per wavefront in k_collide_team<16> (0 = 4, a full wavefront; GO2SIM_COLLIDE_EPW = 1 / 2 leave lanes idle)
   int solver_team = 32;                     // lanes per environment in k_constraint_solve_team
   int terrain_solver_team = 64;             // ... on heightfield terrain (96 LDS rows)
   uint32_t step_count = 0; int action_write_idx = 0;
@@ -5638,12 +5802,13 @@ static void launch_dynamics(go2sim* h, hipStream_t s, const float* actions = nul
   else if (T == 32) hipLaunchKernelGGL(k_dynamics_team<32>, gd, b, 0, s, h->P, h->dms);
   else hipLaunchKernelGGL(k_dynamics_team<64>, gd, b, 0, s, h->P, h->dms);
 }
+static int collide_epw(const go2sim* h) { return (h->collide_team == 16 && h->collide_epw > 0) ? h->collide_epw : 64 / h->collide_team; }
 static int solver_epw(const go2sim* h) { return 64 / (h->hm.terrain_enabled ? h->terrain_solver_team : h->solver_team); }
 // the envs of a solver block must sit in one collision wavefront (their contact counts meet there).  On flat ground (two envs per solver wavefront, one
 // residency round) the sorted order measured 1-3 % SLOWER than the identity order, with single envs as well as with adjacent pairs as the sorted unit
 // (the record lookup delays every workgroup's first loads; there is no second round to win it back): off unless GO2SIM_LPT_FLAT=1
 static bool lpt_enabled(const go2sim* h) {
-  const int epw_c = 64 / h->collide_team, epw_s = solver_epw(h);
+  const int epw_c = collide_epw(h), epw_s = solver_epw(h);
   if (!h->use_lpt || epw_s > epw_c || epw_c % epw_s != 0) return false;
   return epw_s == 1 || h->lpt_flat;
 }
@@ -5662,8 +5827,11 @@ static void launch_collide_solve(go2sim* h, hipStream_t s, int fuse_mode = 0) {
   {
     ScopedTimer t(h, s, T_COLLIDE);
     const int T = h->collide_team;
-    dim3 gc((h->B + 64 / T - 1) / (64 / T));
-    if (T == 16) hipLaunchKernelGGL(k_collide_team<16>, gc, b, 0, s, h->P, h->dm, h->gjk_scratch, lpt_cur, h->lpt_cap, epw_s);
+    const int epw_c = collide_epw(h);
+    dim3 gc((h->B + epw_c - 1) / epw_c);
+    if (T == 16 && epw_c == 2) hipLaunchKernelGGL((k_collide_team<16, 2>), gc, b, 0, s, h->P, h->dm, h->gjk_scratch, lpt_cur, h->lpt_cap, epw_s);
+    else if (T == 16 && epw_c == 1) hipLaunchKernelGGL((k_collide_team<16, 1>), gc, b, 0, s, h->P, h->dm, h->gjk_scratch, lpt_cur, h->lpt_cap, epw_s);
+    else if (T == 16) hipLaunchKernelGGL(k_collide_team<16>, gc, b, 0, s, h->P, h->dm, h->gjk_scratch, lpt_cur, h->lpt_cap, epw_s);
     else if (T == 32) hipLaunchKernelGGL(k_collide_team<32>, gc, b, 0, s, h->P, h->dm, h->gjk_scratch, lpt_cur, h->lpt_cap, epw_s);
     else hipLaunchKernelGGL(k_collide_team<64>, gc, b, 0, s, h->P, h->dm, h->gjk_scratch, lpt_cur, h->lpt_cap, epw_s);
   }
@@ -5795,8 +5963,10 @@ static bool step_graph_build(go2sim* h, const float* actions, float* obs, float*
     // leave.  Tried and measured slower: off unless GO2SIM_PAR_PRE=1 (go2sim::par_pre).
     hipGraphNode_t pre_node = nullptr;
     if (i == 0 && fuse_pre(h) && h->par_pre) { pre_node = last; last = nullptr; }
-    { const int T = h->collide_team; const dim3 gc = team_grid(T);
-      ok = T == 16 ? graph_add_kernel(h, last, k_collide_team<16>, gc, b64, nullptr, nullptr, nullptr, h->P, h->dm, h->gjk_scratch, lpt_cur, h->lpt_cap, epw_s)
+    { const int T = h->collide_team; const int epw_c = collide_epw(h); const dim3 gc((h->B + epw_c - 1) / epw_c);
+      ok = T == 16 && epw_c == 2 ? graph_add_kernel(h, last, k_collide_team<16, 2>, gc, b64, nullptr, nullptr, nullptr, h->P, h->dm, h->gjk_scratch, lpt_cur, h->lpt_cap, epw_s)
+         : T == 16 && epw_c == 1 ? graph_add_kernel(h, last, k_collide_team<16, 1>, gc, b64, nullptr, nullptr, nullptr, h->P, h->dm, h->gjk_scratch, lpt_cur, h->lpt_cap, epw_s)
+         : T == 16 ? graph_add_kernel(h, last, k_collide_team<16>, gc, b64, nullptr, nullptr, nullptr, h->P, h->dm, h->gjk_scratch, lpt_cur, h->lpt_cap, epw_s)
          : T == 32 ? graph_add_kernel(h, last, k_collide_team<32>, gc, b64, nullptr, nullptr, nullptr, h->P, h->dm, h->gjk_scratch, lpt_cur, h->lpt_cap, epw_s)
                    : graph_add_kernel(h, last, k_collide_team<64>, gc, b64, nullptr, nullptr, nullptr, h->P, h->dm, h->gjk_scratch, lpt_cur, h->lpt_cap, epw_s); }
     if (!ok) break;
@@ -5901,6 +6071,7 @@ int go2sim_create(const void* blob, size_t nbytes, int n_envs, int device, uint6
     if (const char* t = getenv("GO2SIM_NO_FUSE_SOLVE")) { if (atoi(t) != 0) h->fuse_solve_int = false; }
     if (const char* t = getenv("GO2SIM_FK_TEAM")) { int v = atoi(t); if (v == 16 || v == 32 || v == 64) h->fk_team = v; }
     if (const char* t = getenv("GO2SIM_COLLIDE_TEAM")) { int v = atoi(t); if (v == 16 || v == 32 || v == 64) h->collide_team = v; }
+    if (const char* t = getenv("GO2SIM_COLLIDE_EPW")) { int v = atoi(t); if (v == 1 || v == 2) h->collide_epw = v; }
     CK(hipMalloc((void**)&h->gjk_scratch, (size_t)n_envs * h->collide_team * sizeof(GjkStoreFull)));   // ~20 KB per narrow-phase lane
     if (const char* t = getenv("GO2SIM_SOLVER_TEAM")) { int v = atoi(t); if (v == 16 || v == 32 || v == 64) h->solver_team = v; }
     if (const char* t = getenv("GO2SIM_TERRAIN_SOLVER_TEAM")) { int v = atoi(t); if (v == 32 || v == 64) h->terrain_solver_team = v; }

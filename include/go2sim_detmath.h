@@ -29,6 +29,24 @@ DM_FN uint32_t dm_f2bits(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
 
 DM_FN float dm_sqrt(float x) { return sqrtf(x); } /* correctly rounded on both targets */
 DM_FN float dm_abs(float x) { return dm_bits2f(dm_f2bits(x) & 0x7fffffffu); }
+/* Arrow shape of an 18-dof floating-base quadruped (FAST ORDER factorisation of the Newton Hessian): dofs 0..5 are the base, the other twelve form four
+ * chains of three that meet only in the base.  `mask` is mass_parent_mask (row-major nd x nd, lower triangle read).  Returns how the chains are numbered:
+ * 1 = breadth-first (leg l holds dofs 6 + l, 10 + l, 14 + l: the order Genesis gives Go2 and ANYmal), 2 = depth-first (6 + 3 l .. 8 + 3 l), 0 = neither. */
+DM_FN int dm_arrow_leg(int mode, int d) { return mode == 1 ? ((d - 6) & 3) : ((d - 6) / 3); }
+DM_FN int dm_arrow_dof(int mode, int leg, int t) { return mode == 1 ? (6 + leg + 4 * t) : (6 + 3 * leg + t); }
+static inline int dm_arrow_mode(const float* mask, int nd) {
+  if (nd != 18) return 0;
+  for (int mode = 1; mode <= 2; ++mode) {
+    int ok = 1;
+    for (int i = 0; i < nd && ok; ++i)
+      for (int j = 0; j <= i && ok; ++j) {
+        const int expect = (i < 6 || j < 6) ? 1 : (dm_arrow_leg(mode, i) == dm_arrow_leg(mode, j));
+        ok = ((mask[i * nd + j] != 0.0f) ? 1 : 0) == expect;
+      }
+    if (ok) return mode;
+  }
+  return 0;
+}
 DM_FN float dm_floor(float x) { return floorf(x); }
 DM_FN float dm_ceil(float x) { return ceilf(x); }
 

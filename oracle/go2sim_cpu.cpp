@@ -229,6 +229,7 @@ struct Model {
       ccd_eps, ccd_tolerance;
   Link links[NL]; Joint joints[NJ]; Dof dofs[ND]; Geom geoms[NG]; Entity entities[2];
   real qpos0[NQ]; real mass_parent_mask[ND][ND]; int pair_idx[NG][NG]; int theta_to_ring[180];
+  int arrow_mode;   // derived (dm_arrow_mode): numbering of the four leg chains, 0 = no arrow form
   // heightfield terrain replacing the ground slab (go2sim_cpu_set_terrain; collider.py:374-394)
   int terrain_enabled, terrain_rows, terrain_cols; real terrain_hs; real terrain_xyz_maxmin[6]; std::vector<real> terrain_hf;
 };
@@ -282,6 +283,7 @@ bool parse_model(const void* blob, size_t nbytes, Model& m) {
     for (int a = 0; a < 32; ++a) { g.rim[a][0] = f[49 + 2 * a]; g.rim[a][1] = f[50 + 2 * a]; }
   }
   for (int i = 0; i < ND; ++i) for (int j = 0; j < ND; ++j) m.mass_parent_mask[i][j] = f[i * ND + j];
+  m.arrow_mode = getenv("GO2SIM_NO_ARROW") ? 0 : dm_arrow_mode(&m.mass_parent_mask[0][0], ND);   // (GO2SIM_NO_ARROW=1: diagnostic switch, keeps the row-form factorisation under test)
   f += ND * ND;
   if (f - F != nf) return false;
   const int32_t* p = I;
@@ -348,6 +350,8 @@ struct Env {
   real qacc[ND], Ma[ND], grad[ND], Mgrad[ND], search[ND], mv[ND], qfrc_constraint[ND], nt_vec[ND];
   real H[ND][ND];
   real Hunf[ND][ND];   // FAST ORDER: the unfactored Hessian of the running Newton solve (lower triangle), updated by the rows that flip
+  // FAST ORDER, arrow form of the factor (cholesky_factor_arrow): per leg the reciprocal pivots, l10 l20 l21 and W (6 x 3); the base factor with reciprocal pivots on its diagonal
+  bool arrow; int af_p[4][3]; real af_i[4][3], af_l[4][3], af_w[4][6][3], af_b[6][6];
   real cost, prev_cost, gauss, quad_gauss[3], gtol; int ls_it, ls_result, improved, solver_iters;
   V3 contact_force[NL];
   real vel_next[ND], qpos_next[NQ];
@@ -1445,9 +1449,90 @@ void hessian_update(const Model& m, Env& e) {
   for (int i = 0; i < ND; ++i) for (int j = 0; j < i + 1; ++j) e.H[i][j] = e.Hunf[i][j];
 }
 #endif
+#ifdef GO2SIM_FAST_ORDER
+// ts_cholesky_factor_arrow of csrc/go2sim.hip: when no Hessian entry couples two legs (dof groups 6..8, 9..11, 12..14, 15..17), the legs are eliminated
+// first -- four 3 x 3 factorisations, W_l = C_l^T L_l^-T, the 6 x 6 Schur complement of the base with the legs added as (l0 + l2) + (l1 + l3) -- with
+// reciprocal pivots sqrt(e) * (1 / e) and fused multiply-adds
+bool hessian_is_arrow(const Model& m, const Env& e) {
+  if (ND != 18 || m.arrow_mode == 0) return false;
+#if defined(GO2SIM_NO_ARROW) || GO2SIM_REBUILD_FLIPS > 1
+  return false;
+#endif
+  for (int i = 7; i < ND; ++i)
+    for (int j = 6; j < i; ++j)
+      if (dm_arrow_leg(m.arrow_mode, i) != dm_arrow_leg(m.arrow_mode, j) && e.H[i][j] != 0.0f) return false;
+  return true;
+}
+void cholesky_factor_arrow(const Model& m, Env& e) {
+  real sc[4][6][6];
+  for (int l = 0; l < 4; ++l) {
+    const int p0 = dm_arrow_dof(m.arrow_mode, l, 0), p1 = dm_arrow_dof(m.arrow_mode, l, 1), p2 = dm_arrow_dof(m.arrow_mode, l, 2);
+    const real a00 = e.H[p0][p0], a10 = e.H[p1][p0], a11 = e.H[p1][p1], a20 = e.H[p2][p0], a21 = e.H[p2][p1], a22 = e.H[p2][p2];
+    const real e0 = std::max(a00, m.eps), i0 = dm_sqrt(e0) * (1.0f / e0);
+    const real l10 = a10 * i0, l20 = a20 * i0;
+    const real e1 = std::max(std::fma(-l10, l10, a11), m.eps), i1 = dm_sqrt(e1) * (1.0f / e1);
+    const real l21 = std::fma(-l20, l10, a21) * i1;
+    const real e2 = std::max(std::fma(-l21, l21, std::fma(-l20, l20, a22)), m.eps), i2 = dm_sqrt(e2) * (1.0f / e2);
+    e.af_p[l][0] = p0; e.af_p[l][1] = p1; e.af_p[l][2] = p2;
+    e.af_i[l][0] = i0; e.af_i[l][1] = i1; e.af_i[l][2] = i2; e.af_l[l][0] = l10; e.af_l[l][1] = l20; e.af_l[l][2] = l21;
+    for (int b = 0; b < 6; ++b) {
+      const real c0 = e.H[p0][b], c1 = e.H[p1][b], c2 = e.H[p2][b];
+      const real w0 = c0 * i0, w1 = std::fma(-w0, l10, c1) * i1, w2 = std::fma(-w1, l21, std::fma(-w0, l20, c2)) * i2;
+      e.af_w[l][b][0] = w0; e.af_w[l][b][1] = w1; e.af_w[l][b][2] = w2;
+    }
+    for (int u = 0; u < 6; ++u)
+      for (int j = 0; j < 6; ++j) sc[l][u][j] = std::fma(e.af_w[l][u][2], e.af_w[l][j][2], std::fma(e.af_w[l][u][1], e.af_w[l][j][1], e.af_w[l][u][0] * e.af_w[l][j][0]));
+  }
+  real a[6][6];
+  for (int u = 0; u < 6; ++u)
+    for (int j = 0; j <= u; ++j) a[u][j] = e.H[u][j] - ((sc[0][u][j] + sc[2][u][j]) + (sc[1][u][j] + sc[3][u][j]));
+  for (int k = 0; k < 6; ++k) {
+    const real ee = std::max(a[k][k], m.eps), ik = dm_sqrt(ee) * (1.0f / ee);
+    a[k][k] = ik;
+    for (int j = k + 1; j < 6; ++j) a[j][k] = a[j][k] * ik;
+    for (int j = k + 1; j < 6; ++j)
+      for (int i = k + 1; i <= j; ++i) a[j][i] = std::fma(-a[j][k], a[i][k], a[j][i]);
+  }
+  for (int k = 0; k < 6; ++k) for (int j = 0; j <= k; ++j) e.af_b[k][j] = a[k][j];
+}
+// ts_update_gradient_arrow of csrc/go2sim.hip
+void cholesky_solve_arrow(Env& e) {
+  real y[4][3], z[4][6], x[6];
+  for (int l = 0; l < 4; ++l) {
+    const int p0 = e.af_p[l][0], p1 = e.af_p[l][1], p2 = e.af_p[l][2];
+    const real* iv = e.af_i[l]; const real* lv = e.af_l[l];
+    y[l][0] = e.grad[p0] * iv[0];
+    y[l][1] = std::fma(-lv[0], y[l][0], e.grad[p1]) * iv[1];
+    y[l][2] = std::fma(-lv[2], y[l][1], std::fma(-lv[1], y[l][0], e.grad[p2])) * iv[2];
+    for (int b = 0; b < 6; ++b) z[l][b] = std::fma(e.af_w[l][b][2], y[l][2], std::fma(e.af_w[l][b][1], y[l][1], e.af_w[l][b][0] * y[l][0]));
+  }
+  for (int b = 0; b < 6; ++b) x[b] = e.grad[b] - ((z[0][b] + z[2][b]) + (z[1][b] + z[3][b]));
+  for (int k = 0; k < 6; ++k) {
+    real acc = x[k];
+    for (int j = 0; j < k; ++j) acc = std::fma(-e.af_b[k][j], x[j], acc);
+    x[k] = acc * e.af_b[k][k];
+  }
+  for (int k = 5; k >= 0; --k) {
+    real acc = x[k];
+    for (int j = 5; j > k; --j) acc = std::fma(-e.af_b[j][k], x[j], acc);
+    x[k] = acc * e.af_b[k][k];
+  }
+  for (int b = 0; b < 6; ++b) e.Mgrad[b] = x[b];
+  for (int l = 0; l < 4; ++l) {
+    const int p0 = e.af_p[l][0], p1 = e.af_p[l][1], p2 = e.af_p[l][2];
+    const real* iv = e.af_i[l]; const real* lv = e.af_l[l];
+    real v0 = y[l][0], v1 = y[l][1], v2 = y[l][2];
+    for (int b = 0; b < 6; ++b) { v0 = std::fma(-e.af_w[l][b][0], x[b], v0); v1 = std::fma(-e.af_w[l][b][1], x[b], v1); v2 = std::fma(-e.af_w[l][b][2], x[b], v2); }
+    const real x2 = v2 * iv[2], x1 = std::fma(-lv[2], x2, v1) * iv[1], x0 = std::fma(-lv[0], x1, std::fma(-lv[1], x2, v0)) * iv[0];
+    e.Mgrad[p0] = x0; e.Mgrad[p1] = x1; e.Mgrad[p2] = x2;
+  }
+}
+#endif
 // func_cholesky_factor_direct_batch, solver.py:1467-1494
 void cholesky_factor_direct(const Model& m, Env& e) {
 #ifdef GO2SIM_FAST_ORDER
+  e.arrow = hessian_is_arrow(m, e);
+  if (e.arrow) { cholesky_factor_arrow(m, e); return; }
   // ts_cholesky_factor of csrc/go2sim.hip: right-looking, the column scaled by the reciprocal diagonal, fused multiply-add updates of the rows below
   for (int k = 0; k < ND; ++k) {
     const real d = dm_sqrt(std::max(e.H[k][k], m.eps));
@@ -1518,6 +1603,7 @@ bool cholesky_incremental(const Model& m, Env& e) {
 // func_cholesky_solve_batch, solver.py:1747-1765
 void cholesky_solve(Env& e) {
 #ifdef GO2SIM_FAST_ORDER
+  if (e.arrow) { cholesky_solve_arrow(e); return; }
   real linv[ND], cur[ND];                                          // column-oriented substitutions with the reciprocal diagonal
   for (int i = 0; i < ND; ++i) { linv[i] = 1.0f / e.H[i][i]; cur[i] = e.grad[i]; }
   for (int j = 0; j < ND; ++j) {

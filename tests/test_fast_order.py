@@ -96,3 +96,26 @@ def test_free_run_statistics_agree(oracle_strict_lib, oracle_fast_lib, blob, tas
     assert abs(r_s - r_f) <= 0.03 * abs(r_s) + 1e-3, f"mean reward {r_s:.5f} vs {r_f:.5f}"
     assert abs(n_s - n_f) <= 0.05 * n_s + 3, f"resets {n_s} vs {n_f}"
     assert abs(c_s - c_f) <= 0.02 * c_s + 0.02, f"mean contacts {c_s:.4f} vs {c_f:.4f}"
+
+
+def test_arrow_form_against_row_form(oracle_fast_lib, blob, monkeypatch):
+    """The FAST ORDER factorisation of the Newton Hessian has two forms: the arrow form (legs eliminated first, csrc/go2sim.hip ts_cholesky_factor_arrow /
+    oracle cholesky_factor_arrow) whenever no Hessian entry couples two legs, and the dense row form otherwise.  GO2SIM_NO_ARROW=1 (read when a model is
+    parsed) switches the arrow form off; both solve the same systems, so short free runs agree like fast against strict."""
+    n, steps = 64, 4
+    arrow = CpuEnv(oracle_fast_lib, blob, n, seed=9, task="walk")
+    monkeypatch.setenv("GO2SIM_NO_ARROW", "1")
+    rows = CpuEnv(oracle_fast_lib, blob, n, seed=9, task="walk")
+    monkeypatch.delenv("GO2SIM_NO_ARROW")
+    arrow.reset(); rows.reset()
+    acts = make_actions(24, n, seed=9, kind="0.5", n_act=arrow.n_act)
+    differ = False
+    for s in range(steps):
+        o_a, p_a, r_a, d_a, t_a = arrow.step(acts[s])
+        o_r, p_r, r_r, d_r, t_r = rows.step(acts[s])
+        assert np.array_equal(d_a, d_r) and np.array_equal(arrow.field("I_N_CONTACTS"), rows.field("I_N_CONTACTS")), f"step {s}"
+        assert np.abs(o_a - o_r).max() <= 2e-4 and np.abs(r_a - r_r).max() <= 2e-5, f"step {s}: {np.abs(o_a - o_r).max():.2e}"
+    for s in range(steps, 24):                                          # (contacts begin after a few steps: the two forms must then differ in the last bits)
+        o_a = arrow.step(acts[s])[0]; o_r = rows.step(acts[s])[0]
+        differ = differ or not np.array_equal(o_a, o_r)
+    assert differ, "the switch had no effect: the arrow form was not taken"

@@ -413,3 +413,24 @@ def test_mass_matrix_field_semantics(oracle_lib, hip_lib, blob):
     sym = (low + np.tril(low, -1).T)[:, :, None] * np.linspace(1.0, 2.0, n, dtype=np.float32)[None, None, :]
     gpu.set_field("F_MASS_MAT", sym.reshape(18 * 18, n).astype(np.float32))
     assert bits_equal(gpu.field("F_MASS_MAT"), sym.reshape(18 * 18, n).astype(np.float32))
+
+
+def test_row_form_factorisation_bit_exact(oracle_lib, hip_lib, blob, monkeypatch):
+    """GO2SIM_NO_ARROW=1 (read when a model is parsed, both libraries): the dense row-form factorisation and solves of the Newton Hessian, which the product
+    takes only when a constraint row couples two legs, for every solve -- HIP against the fast oracle, bit for bit."""
+    monkeypatch.setenv("GO2SIM_NO_ARROW", "1")
+    n_envs, steps = 64, 60
+    cpu, gpu = CpuEnv(oracle_lib, blob, n_envs, seed=5), GpuEnv(hip_lib, blob, n_envs, seed=5)
+    monkeypatch.delenv("GO2SIM_NO_ARROW")
+    cpu.reset(); gpu.reset()
+    acts = make_actions(steps, n_envs, seed=5, kind="mixed")
+    for s, a in enumerate(acts):
+        oc, pc, rc, dc, tc = cpu.step(a)
+        og, pg, rg, dg, tg = gpu.step(a)
+        assert np.array_equal(dc, dg) and bits_equal(oc, og) and bits_equal(pc, pg) and bits_equal(rc, rg), f"step {s}"
+    _compare_fields(cpu, gpu, "final")
+    ref = CpuEnv(oracle_lib, blob, n_envs, seed=5)                      # the arrow form gives other last bits: the switch did something
+    ref.reset()
+    for a in acts:
+        o_ref = ref.step(a)[0]
+    assert not np.array_equal(o_ref, oc)
