@@ -2749,12 +2749,9 @@ DEV void ts_update_constraint(const MT& m, S* s, int tl, int n_con, float& cost,
 // 3 reads per multiply-add; the row factor J[c][i] * D[c] * active[c] (0 where the reference skips the row: |J[c][i]| <= eps) is formed once per block
 // row and the sum runs as a fused multiply-add chain over the rows first to last.  Teams of 64 lanes split the rows in three interleaved groups
 // (rows c = g mod 3 on lanes 21 g .. 21 g + 20) and add the partial sums as (p0 + p1) + p2.
-// Both Hessian routines return whether the entries that couple two different legs (dm_arrow_leg) are exactly zero, i.e. whether the matrix has the
-// arrow shape ts_cholesky_factor_arrow needs (the block lanes hold those values anyway).
 template <int T, class S, class MT>
-DEV bool ts_hessian_direct(const MT& m, S* s, int tl, int n_con) {
+DEV void ts_hessian_direct(const MT& m, S* s, int tl, int n_con) {
   constexpr int NB = 21, G = (T >= 3 * NB) ? 3 : 1;
-  bool cross = false;
   for (int u0 = 0; u0 < NB * G; u0 += T) {
     const int u = u0 + tl;
     const bool on = u < NB * G;
@@ -2795,17 +2792,15 @@ DEV bool ts_hessian_direct(const MT& m, S* s, int tl, int n_con) {
           const float v = h[a][q] + s->M[i * DS + j];
           if constexpr (T >= NB) s->Ablk[blk * 9 + 3 * a + q] = v;       // the unfactored Hessian stays with its block lane (ts_hessian_update)
           if (j <= i) s->H[i * DS + j] = v;
-          if (i >= 6 && j >= 6 && j < i && dm_arrow_leg(m.arrow_mode, i) != dm_arrow_leg(m.arrow_mode, j)) cross = cross || (v != 0.0f);
         }
     }
   }
   team_sync();
-  return team_ballot<T>(cross) == 0ull;
 }
 // The Hessian after a change of the active set: the block lanes add / subtract the rows that flipped (first to last, fused multiply-adds on the stored
 // blocks) instead of summing all rows again, and hand the result to the factorisation.  Cost proportional to the flipped rows.
 template <int T, class S, class MT>
-DEV bool ts_hessian_update(const MT& m, S* s, int tl, int n_con) {
+DEV void ts_hessian_update(const MT& m, S* s, int tl, int n_con) {
   constexpr int NB = 21;
   static_assert(T >= NB, "one lane per block");
   const bool on = tl < NB;
@@ -2819,7 +2814,6 @@ DEV bool ts_hessian_update(const MT& m, S* s, int tl, int n_con) {
     for (int q = 0; q < 3; ++q) h[a][q] = s->Ablk[blk * 9 + 3 * a + q];
   const float* Ji = &s->J[3 * bi];
   const float* Jj = &s->J[3 * bj];
-  bool cross = false;
   for (int base = 0; base < n_con; base += T) {
     const int c_me = base + tl;
     unsigned long long mask = team_ballot<T>(c_me < n_con && ((s->active[c_me] != 0) != (s->prev_active[c_me] != 0)));
@@ -2844,16 +2838,14 @@ DEV bool ts_hessian_update(const MT& m, S* s, int tl, int n_con) {
         const int i = 3 * bi + a, j = 3 * bj + q;
         s->Ablk[blk * 9 + 3 * a + q] = h[a][q];
         if (j <= i) s->H[i * DS + j] = h[a][q];
-        if (i >= 6 && j >= 6 && j < i && dm_arrow_leg(m.arrow_mode, i) != dm_arrow_leg(m.arrow_mode, j)) cross = cross || (h[a][q] != 0.0f);
       }
   }
   team_sync();
-  return team_ballot<T>(cross) == 0ull;
 }
 #else
 // one lane per lower-triangle entry, rows summed first to last
 template <int T, class S, class MT>
-DEV bool ts_hessian_direct(const MT& m, S* s, int tl, int n_con) {
+DEV void ts_hessian_direct(const MT& m, S* s, int tl, int n_con) {
   for (int idx = tl; idx < ND * (ND + 1) / 2; idx += T) {
     int i, j;
     tri_index(m, idx, i, j);
@@ -2868,7 +2860,6 @@ DEV bool ts_hessian_direct(const MT& m, S* s, int tl, int n_con) {
     s->H[i * DS + j] = h;
   }
   team_sync();
-  return false;
 }
 #endif
 
@@ -2944,7 +2935,8 @@ DEV void ts_cholesky_factor_rows(const MT& m, S* s, int tl) {
 // Layout of the factor in s->H (floats; the Hessian it is computed from is consumed first):
 //   leg l at 32 l:  [0..2] reciprocal pivots, [4..6] l10 l20 l21, [8 + 4 b .. +2] row b of W_l (b = 0..5);   base at 128 + 8 k: row k of L_b, the
 //   reciprocal pivot in place of the diagonal element.
-// Applies whenever the cross-leg blocks of H are exactly zero (ts_hessian_* report it); otherwise ts_cholesky_factor_rows / the row-form solves.
+// Applies to a solve none of whose contacts joins links of two different legs (found while the rows are built: the link chains a row walks up);
+// otherwise ts_cholesky_factor_rows / the row-form solves.
 // The FAST ORDER oracle mirrors the arithmetic operation for operation (cholesky_factor_arrow / cholesky_solve_arrow in oracle/go2sim_cpu.cpp).
 constexpr bool ARROW_SHAPE = (ND == 18) && (REBUILD_FLIPS <= 1);   // (rank-1 updates of the factor exist for the row form only)
 DEV float leg_sum4(float x) {                                          // (x_l + x_(l^2)) + (x_(l^1) + x_(l^3)) over the four 8-lane groups of 32 lanes
@@ -3845,6 +3837,7 @@ DEV int ts_solve(const MT& m, const E& e, S* s, int tl, int nc, int n_con, unsig
   for (int rep_rows = 0; rep_rows < (GO2SIM_REPEAT_PHASE == 1 ? 2 : 1); ++rep_rows) {
 #endif
   PH(0)
+  bool rows_coupled = false;                                           // does a contact row of this lane join two legs? (arrow form of the Newton Hessian)
   // ---- contact rows: one lane per row ----
 #if defined(GO2SIM_REPEAT_PHASE) && GO2SIM_REPEAT_PHASE == 13
   for (int rep_c = 0; rep_c < 2; ++rep_c)
@@ -3868,12 +3861,14 @@ DEV int ts_solve(const MT& m, const E& e, S* s, int tl, int nc, int n_con, unsig
 #pragma unroll
     for (int i_d = 0; i_d < DS; ++i_d) row[i_d] = 0.0f;
     float jac_qvel = 0.0f;
+    unsigned legs = 0u;                                                  // legs whose dofs the row has entries for
     for (int i_ab = 0; i_ab < 2; ++i_ab) {
       float sign = -1.0f; int link = link_a;
       if (i_ab == 1) { sign = 1.0f; link = link_b; }
       while (link > -1) {
         V3 t_pos = cpos - v3(s->root_com[3 * link], s->root_com[3 * link + 1], s->root_com[3 * link + 2]);
         const int nd = m.links[link].n_dofs, de = m.links[link].dof_end;
+        if (nd > 0 && de > 6) legs |= 1u << dm_arrow_leg(m.arrow_mode, de - 1);
         for (int i_d_ = 0; i_d_ < nd; ++i_d_) {
           int i_d = de - 1 - i_d_;
           V3 ca = v3(s->cdof_ang[3 * i_d], s->cdof_ang[3 * i_d + 1], s->cdof_ang[3 * i_d + 2]);
@@ -3893,6 +3888,7 @@ DEV int ts_solve(const MT& m, const E& e, S* s, int tl, int nc, int n_con, unsig
     diag *= 2.0f * friction * friction * (1.0f - imp) / imp;
     diag = fmx(diag, m.eps);
     s->aref[r] = aref; s->efc_D[r] = 1.0f / diag;
+    rows_coupled = rows_coupled || (legs & (legs - 1u)) != 0u;
   }
   // ---- joint-limit rows: one lane per joint, ordered compaction ----
 #if defined(GO2SIM_REPEAT_PHASE) && GO2SIM_REPEAT_PHASE == 14
@@ -3951,7 +3947,10 @@ DEV int ts_solve(const MT& m, const E& e, S* s, int tl, int nc, int n_con, unsig
   if (n_con > 0) {
     const float tol_scaled = (m.meaninertia * (float)imx(1, ND)) * m.tolerance;
     bool need_full = true;
-    [[maybe_unused]] bool arrow = false;                               // which form the current factor has
+    [[maybe_unused]] bool arrow = false;                               // which form the factor of this solve has
+#if GO2SIM_FAST_ORDER
+    if constexpr (ARROW_SHAPE && (T == 32 || T == 64)) arrow = m.arrow_mode != 0 && team_ballot<T>(rows_coupled) == 0ull;
+#endif
     for (int it = 0;; ++it) {
       if (need_full) {                       // single call site of the direct Hessian + factorisation (init and degenerate rebuild)
 #if defined(GO2SIM_REPEAT_PHASE) && GO2SIM_REPEAT_PHASE == 3
@@ -3962,13 +3961,9 @@ DEV int ts_solve(const MT& m, const E& e, S* s, int tl, int nc, int n_con, unsig
         ts_hessian_direct<T>(m, s, tl, n_con);
 #endif
 #if GO2SIM_FAST_ORDER
-        bool uncoupled;
-        if constexpr (T >= 21) uncoupled = (it == 0) ? ts_hessian_direct<T>(m, s, tl, n_con) : ts_hessian_update<T>(m, s, tl, n_con);
-        else uncoupled = ts_hessian_direct<T>(m, s, tl, n_con);
+        if constexpr (T >= 21) { if (it == 0) ts_hessian_direct<T>(m, s, tl, n_con); else ts_hessian_update<T>(m, s, tl, n_con); }
+        else ts_hessian_direct<T>(m, s, tl, n_con);
         PH(3)
-#ifndef GO2SIM_NO_ARROW
-        if constexpr (ARROW_SHAPE && (T == 32 || T == 64)) arrow = uncoupled && m.arrow_mode != 0;
-#endif
         if constexpr (ARROW_SHAPE && (T == 32 || T == 64)) { if (arrow) ts_cholesky_factor_arrow<T>(m, s, tl); else ts_cholesky_factor<T>(m, s, tl); }
         else ts_cholesky_factor<T>(m, s, tl);
 #else

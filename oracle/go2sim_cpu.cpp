@@ -1450,17 +1450,21 @@ void hessian_update(const Model& m, Env& e) {
 }
 #endif
 #ifdef GO2SIM_FAST_ORDER
-// ts_cholesky_factor_arrow of csrc/go2sim.hip: when no Hessian entry couples two legs (dof groups 6..8, 9..11, 12..14, 15..17), the legs are eliminated
+// ts_cholesky_factor_arrow of csrc/go2sim.hip: when no contact joins links of two different legs (dm_arrow_leg), the legs are eliminated
 // first -- four 3 x 3 factorisations, W_l = C_l^T L_l^-T, the 6 x 6 Schur complement of the base with the legs added as (l0 + l2) + (l1 + l3) -- with
 // reciprocal pivots sqrt(e) * (1 / e) and fused multiply-adds
-bool hessian_is_arrow(const Model& m, const Env& e) {
+bool rows_uncoupled(const Model& m, const Env& e) {                 // no contact joins links of two different legs (the link chains a contact row walks up, ts_solve)
   if (ND != 18 || m.arrow_mode == 0) return false;
-#if defined(GO2SIM_NO_ARROW) || GO2SIM_REBUILD_FLIPS > 1
+#if GO2SIM_REBUILD_FLIPS > 1
   return false;
 #endif
-  for (int i = 7; i < ND; ++i)
-    for (int j = 6; j < i; ++j)
-      if (dm_arrow_leg(m.arrow_mode, i) != dm_arrow_leg(m.arrow_mode, j) && e.H[i][j] != 0.0f) return false;
+  for (int i_c = 0; i_c < e.n_contacts; ++i_c) {
+    unsigned legs = 0u;
+    for (int i_ab = 0; i_ab < 2; ++i_ab)
+      for (int link = i_ab ? e.contacts[i_c].link_b : e.contacts[i_c].link_a; link > -1; link = m.links[link].parent)
+        if (m.links[link].n_dofs > 0 && m.links[link].dof_end > 6) legs |= 1u << dm_arrow_leg(m.arrow_mode, m.links[link].dof_end - 1);
+    if (legs & (legs - 1u)) return false;
+  }
   return true;
 }
 void cholesky_factor_arrow(const Model& m, Env& e) {
@@ -1531,7 +1535,7 @@ void cholesky_solve_arrow(Env& e) {
 // func_cholesky_factor_direct_batch, solver.py:1467-1494
 void cholesky_factor_direct(const Model& m, Env& e) {
 #ifdef GO2SIM_FAST_ORDER
-  e.arrow = hessian_is_arrow(m, e);
+  e.arrow = rows_uncoupled(m, e);
   if (e.arrow) { cholesky_factor_arrow(m, e); return; }
   // ts_cholesky_factor of csrc/go2sim.hip: right-looking, the column scaled by the reciprocal diagonal, fused multiply-add updates of the rows below
   for (int k = 0; k < ND; ++k) {
