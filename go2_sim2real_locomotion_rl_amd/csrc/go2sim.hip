@@ -397,7 +397,7 @@ struct GeomS { int type, link; V3 pos; Q4 quat; };
 struct JLim { int q_start, dof_start; float lo, hi; };   // revolute joints; q_start = -1 for the others (add_joint_limit_constraints, solver.py:1088-1143)
 constexpr int NTRI = ND * (ND + 1) / 2;
 struct alignas(16) ModelS {
-  int n_levels, iterations, ls_iterations, pad0;
+  int n_levels, iterations, ls_iterations, arrow_mode;
   float substep_dt; V3 gravity; float eps, tolerance, ls_tolerance, meaninertia;
   // ---- block staged by the constraint solver (contiguous: links, triangle LUT, joint-limit table) ----
   LinkS links[NL];
@@ -413,7 +413,7 @@ static_assert(sizeof(ModelS) % 16 == 0 && (2 * (NTRI + 1)) % 4 == 0 && offsetof(
 
 bool build_model_s(const Model& m, ModelS& o) {
   memset(&o, 0, sizeof(o));
-  o.n_levels = m.n_levels; o.iterations = m.iterations; o.ls_iterations = m.ls_iterations;
+  o.n_levels = m.n_levels; o.iterations = m.iterations; o.ls_iterations = m.ls_iterations; o.arrow_mode = m.arrow_mode;
   o.substep_dt = m.substep_dt; o.gravity = m.gravity; o.eps = m.eps; o.tolerance = m.tolerance; o.ls_tolerance = m.ls_tolerance; o.meaninertia = m.meaninertia;
   for (int i = 0; i < NL; ++i) {
     const Link& a = m.links[i]; LinkS& b = o.links[i];
@@ -456,7 +456,7 @@ struct ModelView {
   const LinkS* links; const Joint* joints; const Dof* dofs; const GeomS* geoms; const Entity* entities; const float* qpos0;
   const unsigned* mass_mask_bits; const int *level_start, *level_links, *child_start, *child_list, *dof_link; const unsigned char *tri_i, *tri_j;
   DEV ModelView(const ModelS* t, const ModelS* __restrict__ g)
-      : n_levels(g->n_levels), iterations(g->iterations), ls_iterations(g->ls_iterations), arrow_mode(0), substep_dt(g->substep_dt), gravity(g->gravity), eps(g->eps),
+      : n_levels(g->n_levels), iterations(g->iterations), ls_iterations(g->ls_iterations), arrow_mode(g->arrow_mode), substep_dt(g->substep_dt), gravity(g->gravity), eps(g->eps),
         tolerance(g->tolerance), ls_tolerance(g->ls_tolerance), meaninertia(g->meaninertia), links(t->links), joints(t->joints), dofs(t->dofs),
         geoms(t->geoms), entities(t->entities), qpos0(t->qpos0), mass_mask_bits(t->mass_mask_bits), level_start(t->level_start),
         level_links(t->level_links), child_start(t->child_start), child_list(t->child_list), dof_link(t->dof_link), tri_i(t->tri_i), tri_j(t->tri_j) {}
@@ -822,6 +822,150 @@ struct KinData {
   int valid;
 };
 
+#ifndef GO2SIM_FAST_ORDER
+#define GO2SIM_FAST_ORDER 1
+#endif
+#ifndef REBUILD_FLIPS
+#define REBUILD_FLIPS 1
+#endif
+template <int CTRL>
+DEV float dpp_perm(float x) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, true)); }
+#if GO2SIM_FAST_ORDER
+// ---- FAST ORDER, arrow form ------------------------------------------------------------------------------------------------------------------
+// A floating base with four legs gives the mass matrix M -- and the Newton Hessian H = M + J^T D J as long as no contact joins links of two legs -- an
+// arrow shape: the 3 x 3 leg blocks A_l (dofs dm_arrow_dof(mode, l, 0..2); Model::arrow_mode from the mass-matrix mask) couple only to the 6 base dofs
+// (C_l, 3 x 6), never to each other.  Eliminating the legs FIRST keeps that shape (no fill-in), so the factorisation of the permuted matrix [legs..., base] is
+//     A_l = L_l L_l^T  (four 3 x 3 factorisations side by side),   W_l = C_l^T L_l^-T  (6 x 3),   B' = B - sum_l W_l W_l^T,   B' = L_b L_b^T  (6 x 6)
+// -- 3 + 6 dependent pivots instead of 18, and small enough to run without any exchange between the lanes but two LDS round trips:
+// lane (l, u) = (tl / 8, tl % 8) of a team factorises the block of leg l (redundantly with the 7 other lanes of the leg), forms row u of W_l and of
+// W_l W_l^T, the four legs are added across the lanes ((l0 + l2) + (l1 + l3): v_permlane16_swap, row_ror:8), and every lane factorises the 6 x 6
+// Schur complement in registers.  Only reciprocal pivots are kept (1 / sqrt(e) = sqrt(e) * (1 / e): the division is issued beside the square root).
+// The triangular solves (arrow_solve) walk the same structure: 3 + 6 + 6 + 3 dependent steps instead of 36, in registers.
+// Layout of the factor F (176 floats, 16-byte aligned; may lie over the matrix it is computed from, which is consumed first):
+//   leg l at 32 l:  [0..2] reciprocal pivots, [4..6] l10 l20 l21, [8 + 4 b .. +2] row b of W_l (b = 0..5);   base at 128 + 8 k: row k of L_b, the
+//   reciprocal pivot in place of the diagonal element.
+// Users: the constraint solver (ts_solve: a solve none of whose contacts joins links of two different legs -- found while the rows are built from the link
+// chains a row walks up; otherwise ts_cholesky_factor_rows / the row-form solves) and the forward dynamics (tk_dynamics: acc_smooth = M^-1 force instead of
+// the reverse LDL^T of the strict build).  The FAST ORDER oracle mirrors the arithmetic operation for operation (arrow_factor / arrow_solve in
+// oracle/go2sim_cpu.cpp).
+constexpr bool ARROW_SHAPE = (ND == 18);
+constexpr bool ARROW_SOLVER = ARROW_SHAPE && (REBUILD_FLIPS <= 1);    // (rank-1 updates of the Newton factor exist for the row form only)
+DEV float leg_sum4(float x) {                                          // (x_l + x_(l^2)) + (x_(l^1) + x_(l^3)) over the four 8-lane groups of 32 lanes
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  const float p = __uint_as_float(r[0]) + __uint_as_float(r[1]);     // lane ^ 16
+  return p + dpp_perm<0x128>(p);                                       // row_ror:8 = lane ^ 8 inside a row of 16
+}
+DEV float4 lds4(const float* p) { return *(const float4*)p; }
+// A: lower triangle of the matrix, row stride STRIDE floats
+template <int T, int STRIDE>
+DEV void arrow_factor(const int mode, const float eps, const float* A, float* F, int tl) {
+  static_assert(T == 32 || T == 64, "four groups of eight lanes");
+  const int leg = (tl >> 3) & 3, u = tl & 7, ub = u < 6 ? u : 5;
+  const int p0 = dm_arrow_dof(mode, leg, 0), p1 = dm_arrow_dof(mode, leg, 1), p2 = dm_arrow_dof(mode, leg, 2);
+  const bool w_lane = tl < 32 && u < 6;
+  // every input first (one round trip): the lane's leg block, its element of the three coupling rows, its row of the base block
+  const float a00 = A[p0 * STRIDE + p0], a10 = A[p1 * STRIDE + p0], a11 = A[p1 * STRIDE + p1];
+  const float a20 = A[p2 * STRIDE + p0], a21 = A[p2 * STRIDE + p1], a22 = A[p2 * STRIDE + p2];
+  const float c0 = A[p0 * STRIDE + ub], c1 = A[p1 * STRIDE + ub], c2 = A[p2 * STRIDE + ub];
+  float br[6];
+#pragma unroll
+  for (int j = 0; j < 6; ++j) br[j] = A[ub * STRIDE + j];              // (entries right of the diagonal are don't-care values)
+  team_sync();                                                         // the factor may be written over the matrix
+  const float e0 = fmx(a00, eps), i0 = dm_sqrt(e0) * (1.0f / e0);
+  const float l10 = a10 * i0, l20 = a20 * i0;
+  const float e1 = fmx(__builtin_fmaf(-l10, l10, a11), eps), i1 = dm_sqrt(e1) * (1.0f / e1);
+  const float l21 = __builtin_fmaf(-l20, l10, a21) * i1;
+  const float e2 = fmx(__builtin_fmaf(-l21, l21, __builtin_fmaf(-l20, l20, a22)), eps), i2 = dm_sqrt(e2) * (1.0f / e2);
+  const float w0 = c0 * i0, w1 = __builtin_fmaf(-w0, l10, c1) * i1, w2 = __builtin_fmaf(-w1, l21, __builtin_fmaf(-w0, l20, c2)) * i2;
+  if (w_lane) *(float4*)&F[32 * leg + 8 + 4 * u] = make_float4(w0, w1, w2, 0.0f);
+  if (tl < 32 && u == 0) { *(float4*)&F[32 * leg] = make_float4(i0, i1, i2, 0.0f); *(float4*)&F[32 * leg + 4] = make_float4(l10, l20, l21, 0.0f); }
+  team_sync();
+  float sc[6];
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    const float4 wj = lds4(&F[32 * leg + 8 + 4 * j]);
+    sc[j] = __builtin_fmaf(w2, wj.z, __builtin_fmaf(w1, wj.y, w0 * wj.x));
+  }
+#pragma unroll
+  for (int j = 0; j < 6; ++j) sc[j] = leg_sum4(sc[j]);
+  const float bp[6] = {br[0] - sc[0], br[1] - sc[1], br[2] - sc[2], br[3] - sc[3], br[4] - sc[4], br[5] - sc[5]};
+  if (tl < 6) { *(float4*)&F[128 + 8 * tl] = make_float4(bp[0], bp[1], bp[2], bp[3]); *(float4*)&F[128 + 8 * tl + 4] = make_float4(bp[4], bp[5], 0.0f, 0.0f); }
+  team_sync();
+  float a[6][6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    const float4 lo = lds4(&F[128 + 8 * k]); const float2 hi = *(const float2*)&F[128 + 8 * k + 4];
+    a[k][0] = lo.x; a[k][1] = lo.y; a[k][2] = lo.z; a[k][3] = lo.w; a[k][4] = hi.x; a[k][5] = hi.y;
+  }
+  team_sync();                                                         // (rows are rewritten below)
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    const float e = fmx(a[k][k], eps), ik = dm_sqrt(e) * (1.0f / e);
+    a[k][k] = ik;
+#pragma unroll
+    for (int j = k + 1; j < 6; ++j) a[j][k] = a[j][k] * ik;
+#pragma unroll
+    for (int j = k + 1; j < 6; ++j)
+#pragma unroll
+      for (int i = k + 1; i <= j; ++i) a[j][i] = __builtin_fmaf(-a[j][k], a[i][k], a[j][i]);
+  }
+  if (tl == 0) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      *(float4*)&F[128 + 8 * k] = make_float4(a[k][0], k >= 1 ? a[k][1] : 0.0f, k >= 2 ? a[k][2] : 0.0f, k >= 3 ? a[k][3] : 0.0f);
+      *(float2*)&F[128 + 8 * k + 4] = make_float2(k >= 4 ? a[k][4] : 0.0f, k >= 5 ? a[k][5] : 0.0f);
+    }
+  }
+  team_sync();
+}
+// x = (L L^T)^-1 g on the arrow factor F.  The caller hands in the lane's right-hand-side elements (its leg's three dofs, base dof min(tl % 8, 5)); `x6` is a
+// 6-float exchange buffer (8-byte aligned); out: the base part in xb[0..5] of every lane, the lane's leg part in xl0..2
+template <int T>
+DEV void arrow_solve(const float* F, float gl0, float gl1, float gl2, float gb, float* x6, int tl, float (&xb)[6], float& xl0, float& xl1, float& xl2) {
+  static_assert(T == 32 || T == 64, "four groups of eight lanes");
+  const int leg = (tl >> 3) & 3, u = tl & 7, ub = u < 6 ? u : 5;
+  const float4 iv = lds4(&F[32 * leg]), lv = lds4(&F[32 * leg + 4]), wo = lds4(&F[32 * leg + 8 + 4 * ub]);
+  float4 W[6];
+#pragma unroll
+  for (int b = 0; b < 6; ++b) W[b] = lds4(&F[32 * leg + 8 + 4 * b]);
+  float L[6][6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    const float4 lo = lds4(&F[128 + 8 * k]); const float2 hi = *(const float2*)&F[128 + 8 * k + 4];
+    L[k][0] = lo.x; L[k][1] = lo.y; L[k][2] = lo.z; L[k][3] = lo.w; L[k][4] = hi.x; L[k][5] = hi.y;
+  }
+  // forward: the legs, then the base with the legs' part taken out of its right-hand side
+  const float y0 = gl0 * iv.x, y1 = __builtin_fmaf(-lv.x, y0, gl1) * iv.y, y2 = __builtin_fmaf(-lv.z, y1, __builtin_fmaf(-lv.y, y0, gl2)) * iv.z;
+  const float z = leg_sum4(__builtin_fmaf(wo.z, y2, __builtin_fmaf(wo.y, y1, wo.x * y0)));
+  if (tl < 6) x6[tl] = gb - z;
+  team_sync();
+  const float2 r0 = *(const float2*)&x6[0], r1 = *(const float2*)&x6[2], r2 = *(const float2*)&x6[4];
+  float x[6] = {r0.x, r0.y, r1.x, r1.y, r2.x, r2.y};
+  team_sync();                                                         // (the caller may write its result over the exchange buffer)
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    float acc = x[k];
+#pragma unroll
+    for (int j = 0; j < k; ++j) acc = __builtin_fmaf(-L[k][j], x[j], acc);
+    x[k] = acc * L[k][k];
+  }
+#pragma unroll
+  for (int k_ = 0; k_ < 6; ++k_) {
+    const int k = 5 - k_;
+    float acc = x[k];
+#pragma unroll
+    for (int j_ = 0; j_ < 5 - k; ++j_) { const int j = 5 - j_; acc = __builtin_fmaf(-L[j][k], x[j], acc); }
+    x[k] = acc * L[k][k];
+  }
+  // backward through the legs
+  float v0 = y0, v1 = y1, v2 = y2;
+#pragma unroll
+  for (int b = 0; b < 6; ++b) { v0 = __builtin_fmaf(-W[b].x, x[b], v0); v1 = __builtin_fmaf(-W[b].y, x[b], v1); v2 = __builtin_fmaf(-W[b].z, x[b], v2); }
+  xl2 = v2 * iv.z; xl1 = __builtin_fmaf(-lv.z, xl2, v1) * iv.y; xl0 = __builtin_fmaf(-lv.x, xl1, __builtin_fmaf(-lv.y, xl2, v0)) * iv.x;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) xb[k] = x[k];
+}
+#endif
 struct DynData {
   float cinr_I[NL * 9], cinr_pos[NL * 3], cinr_mass[NL];
   float crb_I[NL * 9], crb_pos[NL * 3], crb_mass[NL];
@@ -1161,7 +1305,21 @@ DEV void tk_dynamics(const MT& m, const E& e, DynData* s, int tl, bool env_valid
   team_sync();
   PH(22)
   // ---- reverse-order LDL^T (func_factor_mass, forward_dynamics.py) ----
-  if constexpr (T >= ND) {
+#if GO2SIM_FAST_ORDER
+  // FAST ORDER: the mass matrix of a floating base with four legs has the arrow shape; acc_smooth = M^-1 force comes from its arrow-form Cholesky
+  // factorisation (3 + 6 dependent pivots in registers instead of 18 published rows; below: 18 dependent substitution steps instead of 36)
+  const bool arrow = ARROW_SHAPE && (T == 32 || T == 64) && m.arrow_mode != 0;
+  float* const AF = (float*)(((uintptr_t)s->L + 15) & ~(uintptr_t)15);  // 176 floats of the 324 of s->L, 16-byte aligned
+#else
+  const bool arrow = false;
+#endif
+  if constexpr (T == 32 || T == 64) {
+#if GO2SIM_FAST_ORDER
+    if (arrow) arrow_factor<T, ND>(m.arrow_mode, m.eps, s->M, AF, tl);
+#endif
+  }
+  if (arrow) {
+  } else if constexpr (T >= ND) {
     // Lane j keeps row j of the factor in registers.  Step i (i = ND-1 .. 0): lane i publishes its (final, unscaled) row in its LDS home, every
     // row j < i reads it and does L[j][k] -= (L[i][j] * D_inv) * L[i][k] for k <= j -- the same operands in the same order as the element loop of
     // the reference, one LDS round trip and one fence per step.  Row i's own scaling by D_inv touches nothing a later step reads, so every
@@ -1290,7 +1448,24 @@ DEV void tk_dynamics(const MT& m, const E& e, DynData* s, int tl, bool env_valid
   team_sync();
   PH(24)
   // ---- acc_smooth = L^-T D^-1 L^-1 force: serial chains, evaluated redundantly by every lane on the LDS copy ----
-  {
+  bool solved = false;
+#if GO2SIM_FAST_ORDER
+  if constexpr (T == 32 || T == 64) {
+    if (arrow) {
+      const int leg = (tl >> 3) & 3, u = tl & 7, ub = u < 6 ? u : 5;
+      const int p0 = dm_arrow_dof(m.arrow_mode, leg, 0), p1 = dm_arrow_dof(m.arrow_mode, leg, 1), p2 = dm_arrow_dof(m.arrow_mode, leg, 2);
+      float xb[6], x0, x1, x2;
+      arrow_solve<T>(AF, s->force[p0], s->force[p1], s->force[p2], s->force[ub], s->Dinv, tl, xb, x0, x1, x2);   // (Dinv is idle in this form: exchange buffer)
+      if (tl == 0) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) s->out[k] = xb[k];
+      }
+      if (tl < 32 && u == 0) { s->out[p0] = x0; s->out[p1] = x1; s->out[p2] = x2; }
+      solved = true;
+    }
+  }
+#endif
+  if (!solved) {
     float y[ND];                                                       // statically unrolled: the running vector stays in registers
 #pragma unroll
     for (int i_d_ = 0; i_d_ < ND; ++i_d_) {
@@ -2630,14 +2805,7 @@ DEV void team_serial_sum(const float (&x)[NQ], const float (&base)[NQ], int tl, 
 //     reciprocal diagonal carried from update to update.
 // The FAST ORDER build of the CPU oracle (oracle/go2sim_cpu.cpp with -DGO2SIM_FAST_ORDER) mirrors this arithmetic operation for operation (tolerance 0 in the GPU
 // parity tests); tests/test_fast_order.py bounds fast against strict.
-#ifndef GO2SIM_FAST_ORDER
-#define GO2SIM_FAST_ORDER 1
-#endif
-#ifndef REBUILD_FLIPS
-#define REBUILD_FLIPS 1
-#endif
-template <int CTRL>
-DEV float dpp_perm(float x) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, true)); }
+// (GO2SIM_FAST_ORDER / REBUILD_FLIPS defaults and dpp_perm: defined with the arrow-form helpers above the dynamics)
 // butterfly sum over the T lanes of a team (every lane ends with the total); `x` = the lane's own partial sum
 template <int T, int NQ>
 DEV void team_tree_sum(const float (&x)[NQ], float (&total)[NQ]) {
@@ -2921,140 +3089,21 @@ DEV void ts_cholesky_factor_rows(const MT& m, S* s, int tl) {
   team_sync();
 }
 #if GO2SIM_FAST_ORDER
-// ---- FAST ORDER, arrow form ------------------------------------------------------------------------------------------------------------------
-// A floating base with four legs gives the Newton Hessian H = M + J^T D J the shape of the mass matrix as long as no constraint row touches two
-// legs: the 3 x 3 leg blocks A_l (dofs dm_arrow_dof(mode, l, 0..2); Model::arrow_mode from the mass-matrix mask) couple only to the 6 base dofs (C_l, 3 x 6),
-// never to each other.  Eliminating the legs FIRST keeps that
-// shape (no fill-in), so the factorisation of the permuted matrix [legs..., base] is
-//     A_l = L_l L_l^T  (four 3 x 3 factorisations side by side),   W_l = C_l^T L_l^-T  (6 x 3),   B' = B - sum_l W_l W_l^T,   B' = L_b L_b^T  (6 x 6)
-// -- 3 + 6 dependent pivots instead of 18, and small enough to run without any exchange between the lanes but two LDS round trips:
-// lane (l, u) = (tl / 8, tl % 8) of a team factorises the block of leg l (redundantly with the 7 other lanes of the leg), forms row u of W_l and of
-// W_l W_l^T, the four legs are added across the lanes ((l0 + l2) + (l1 + l3): v_permlane16_swap, row_ror:8), and every lane factorises the 6 x 6
-// Schur complement in registers.  Only reciprocal pivots are kept (1 / sqrt(e) = sqrt(e) * (1 / e): the division is issued beside the square root).
-// The triangular solves (ts_update_gradient_arrow) walk the same structure: 3 + 6 + 6 + 3 dependent steps instead of 36, in registers.
-// Layout of the factor in s->H (floats; the Hessian it is computed from is consumed first):
-//   leg l at 32 l:  [0..2] reciprocal pivots, [4..6] l10 l20 l21, [8 + 4 b .. +2] row b of W_l (b = 0..5);   base at 128 + 8 k: row k of L_b, the
-//   reciprocal pivot in place of the diagonal element.
-// Applies to a solve none of whose contacts joins links of two different legs (found while the rows are built: the link chains a row walks up);
-// otherwise ts_cholesky_factor_rows / the row-form solves.
-// The FAST ORDER oracle mirrors the arithmetic operation for operation (cholesky_factor_arrow / cholesky_solve_arrow in oracle/go2sim_cpu.cpp).
-constexpr bool ARROW_SHAPE = (ND == 18) && (REBUILD_FLIPS <= 1);   // (rank-1 updates of the factor exist for the row form only)
-DEV float leg_sum4(float x) {                                          // (x_l + x_(l^2)) + (x_(l^1) + x_(l^3)) over the four 8-lane groups of 32 lanes
-  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
-  const float p = __uint_as_float(r[0]) + __uint_as_float(r[1]);     // lane ^ 16
-  return p + dpp_perm<0x128>(p);                                       // row_ror:8 = lane ^ 8 inside a row of 16
-}
-DEV float4 lds4(const float* p) { return *(const float4*)p; }
+// the Newton Hessian in arrow form (arrow_factor / arrow_solve, above the dynamics): in place over s->H;  grad = Ma - force - qfrc, Mgrad = H^-1 grad
 template <int T, class S, class MT>
-DEV void ts_cholesky_factor_arrow(const MT& m, S* s, int tl) {
-  static_assert(T == 32 || T == 64, "four groups of eight lanes");
-  const int leg = (tl >> 3) & 3, u = tl & 7, ub = u < 6 ? u : 5;
-  const int p0 = dm_arrow_dof(m.arrow_mode, leg, 0), p1 = dm_arrow_dof(m.arrow_mode, leg, 1), p2 = dm_arrow_dof(m.arrow_mode, leg, 2);
-  const bool w_lane = tl < 32 && u < 6;
-  float* H = s->H;
-  // every input first (one round trip): the lane's leg block, its element of the three coupling rows, its row of the base block
-  const float a00 = H[p0 * DS + p0], a10 = H[p1 * DS + p0], a11 = H[p1 * DS + p1];
-  const float a20 = H[p2 * DS + p0], a21 = H[p2 * DS + p1], a22 = H[p2 * DS + p2];
-  const float c0 = H[p0 * DS + ub], c1 = H[p1 * DS + ub], c2 = H[p2 * DS + ub];
-  const float4 br0 = lds4(&H[ub * DS]); const float2 br1 = *(const float2*)&H[ub * DS + 4];
-  team_sync();                                                         // the factor is written over the Hessian
-  const float e0 = fmx(a00, m.eps), i0 = dm_sqrt(e0) * (1.0f / e0);
-  const float l10 = a10 * i0, l20 = a20 * i0;
-  const float e1 = fmx(__builtin_fmaf(-l10, l10, a11), m.eps), i1 = dm_sqrt(e1) * (1.0f / e1);
-  const float l21 = __builtin_fmaf(-l20, l10, a21) * i1;
-  const float e2 = fmx(__builtin_fmaf(-l21, l21, __builtin_fmaf(-l20, l20, a22)), m.eps), i2 = dm_sqrt(e2) * (1.0f / e2);
-  const float w0 = c0 * i0, w1 = __builtin_fmaf(-w0, l10, c1) * i1, w2 = __builtin_fmaf(-w1, l21, __builtin_fmaf(-w0, l20, c2)) * i2;
-  if (w_lane) *(float4*)&H[32 * leg + 8 + 4 * u] = make_float4(w0, w1, w2, 0.0f);
-  if (tl < 32 && u == 0) { *(float4*)&H[32 * leg] = make_float4(i0, i1, i2, 0.0f); *(float4*)&H[32 * leg + 4] = make_float4(l10, l20, l21, 0.0f); }
-  team_sync();
-  float sc[6];
-#pragma unroll
-  for (int j = 0; j < 6; ++j) {
-    const float4 wj = lds4(&H[32 * leg + 8 + 4 * j]);
-    sc[j] = __builtin_fmaf(w2, wj.z, __builtin_fmaf(w1, wj.y, w0 * wj.x));
-  }
-#pragma unroll
-  for (int j = 0; j < 6; ++j) sc[j] = leg_sum4(sc[j]);
-  const float bp[6] = {br0.x - sc[0], br0.y - sc[1], br0.z - sc[2], br0.w - sc[3], br1.x - sc[4], br1.y - sc[5]};
-  if (tl < 6) { *(float4*)&H[128 + 8 * tl] = make_float4(bp[0], bp[1], bp[2], bp[3]); *(float4*)&H[128 + 8 * tl + 4] = make_float4(bp[4], bp[5], 0.0f, 0.0f); }
-  team_sync();
-  float a[6][6];
-#pragma unroll
-  for (int k = 0; k < 6; ++k) {
-    const float4 lo = lds4(&H[128 + 8 * k]); const float2 hi = *(const float2*)&H[128 + 8 * k + 4];
-    a[k][0] = lo.x; a[k][1] = lo.y; a[k][2] = lo.z; a[k][3] = lo.w; a[k][4] = hi.x; a[k][5] = hi.y;
-  }
-  team_sync();                                                         // (rows are rewritten below)
-#pragma unroll
-  for (int k = 0; k < 6; ++k) {
-    const float e = fmx(a[k][k], m.eps), ik = dm_sqrt(e) * (1.0f / e);
-    a[k][k] = ik;
-#pragma unroll
-    for (int j = k + 1; j < 6; ++j) a[j][k] = a[j][k] * ik;
-#pragma unroll
-    for (int j = k + 1; j < 6; ++j)
-#pragma unroll
-      for (int i = k + 1; i <= j; ++i) a[j][i] = __builtin_fmaf(-a[j][k], a[i][k], a[j][i]);
-  }
-  if (tl == 0) {
-#pragma unroll
-    for (int k = 0; k < 6; ++k) {
-      *(float4*)&H[128 + 8 * k] = make_float4(a[k][0], k >= 1 ? a[k][1] : 0.0f, k >= 2 ? a[k][2] : 0.0f, k >= 3 ? a[k][3] : 0.0f);
-      *(float2*)&H[128 + 8 * k + 4] = make_float2(k >= 4 ? a[k][4] : 0.0f, k >= 5 ? a[k][5] : 0.0f);
-    }
-  }
-  team_sync();
-}
-// grad = Ma - force - qfrc;  Mgrad = H^-1 grad on the arrow factor
+DEV void ts_cholesky_factor_arrow(const MT& m, S* s, int tl) { arrow_factor<T, DS>(m.arrow_mode, m.eps, s->H, s->H, tl); }
 template <int T, class S, class MT>
 DEV void ts_update_gradient_arrow(const MT& m, S* s, int tl) {
-  static_assert(T == 32 || T == 64, "four groups of eight lanes");
   const int leg = (tl >> 3) & 3, u = tl & 7, ub = u < 6 ? u : 5;
   const int p0 = dm_arrow_dof(m.arrow_mode, leg, 0), p1 = dm_arrow_dof(m.arrow_mode, leg, 1), p2 = dm_arrow_dof(m.arrow_mode, leg, 2);
-  const float* H = s->H;
   const int row = tl < ND ? tl : ND - 1;
   const float g_own = s->Ma[row] - s->force[row] - s->qfrc[row];
   const float gl0 = s->Ma[p0] - s->force[p0] - s->qfrc[p0], gl1 = s->Ma[p1] - s->force[p1] - s->qfrc[p1], gl2 = s->Ma[p2] - s->force[p2] - s->qfrc[p2];
   const float gb = s->Ma[ub] - s->force[ub] - s->qfrc[ub];
-  const float4 iv = lds4(&H[32 * leg]), lv = lds4(&H[32 * leg + 4]), wo = lds4(&H[32 * leg + 8 + 4 * ub]);
-  float4 W[6];
-#pragma unroll
-  for (int b = 0; b < 6; ++b) W[b] = lds4(&H[32 * leg + 8 + 4 * b]);
-  float L[6][6];
-#pragma unroll
-  for (int k = 0; k < 6; ++k) {
-    const float4 lo = lds4(&H[128 + 8 * k]); const float2 hi = *(const float2*)&H[128 + 8 * k + 4];
-    L[k][0] = lo.x; L[k][1] = lo.y; L[k][2] = lo.z; L[k][3] = lo.w; L[k][4] = hi.x; L[k][5] = hi.y;
-  }
   if (tl < ND) s->grad[row] = g_own;
-  // forward: the legs, then the base with the legs' part taken out of its right-hand side
-  const float y0 = gl0 * iv.x, y1 = __builtin_fmaf(-lv.x, y0, gl1) * iv.y, y2 = __builtin_fmaf(-lv.z, y1, __builtin_fmaf(-lv.y, y0, gl2)) * iv.z;
-  const float z = leg_sum4(__builtin_fmaf(wo.z, y2, __builtin_fmaf(wo.y, y1, wo.x * y0)));
-  if (tl < 6) s->Mgrad[tl] = gb - z;                                   // (Mgrad doubles as the exchange buffer of the base right-hand side)
-  team_sync();
-  const float4 r0 = lds4(&s->Mgrad[0]); const float2 r1 = *(const float2*)&s->Mgrad[4];
-  float x[6] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y};
-#pragma unroll
-  for (int k = 0; k < 6; ++k) {
-    float acc = x[k];
-#pragma unroll
-    for (int j = 0; j < k; ++j) acc = __builtin_fmaf(-L[k][j], x[j], acc);
-    x[k] = acc * L[k][k];
-  }
-#pragma unroll
-  for (int k_ = 0; k_ < 6; ++k_) {
-    const int k = 5 - k_;
-    float acc = x[k];
-#pragma unroll
-    for (int j_ = 0; j_ < 5 - k; ++j_) { const int j = 5 - j_; acc = __builtin_fmaf(-L[j][k], x[j], acc); }
-    x[k] = acc * L[k][k];
-  }
-  // backward through the legs
-  float v0 = y0, v1 = y1, v2 = y2;
-#pragma unroll
-  for (int b = 0; b < 6; ++b) { v0 = __builtin_fmaf(-W[b].x, x[b], v0); v1 = __builtin_fmaf(-W[b].y, x[b], v1); v2 = __builtin_fmaf(-W[b].z, x[b], v2); }
-  const float x2 = v2 * iv.z, x1 = __builtin_fmaf(-lv.z, x2, v1) * iv.y, x0 = __builtin_fmaf(-lv.x, x1, __builtin_fmaf(-lv.y, x2, v0)) * iv.x;
-  if (tl == 0) { *(float4*)&s->Mgrad[0] = make_float4(x[0], x[1], x[2], x[3]); *(float2*)&s->Mgrad[4] = make_float2(x[4], x[5]); }
+  float xb[6], x0, x1, x2;
+  arrow_solve<T>(s->H, gl0, gl1, gl2, gb, s->Mgrad, tl, xb, x0, x1, x2);   // (Mgrad doubles as the exchange buffer of the base right-hand side)
+  if (tl == 0) { *(float4*)&s->Mgrad[0] = make_float4(xb[0], xb[1], xb[2], xb[3]); *(float2*)&s->Mgrad[4] = make_float2(xb[4], xb[5]); }
   if (tl < 32 && u == 0) { s->Mgrad[p0] = x0; s->Mgrad[p1] = x1; s->Mgrad[p2] = x2; }
   team_sync();
 }
@@ -3949,7 +3998,7 @@ DEV int ts_solve(const MT& m, const E& e, S* s, int tl, int nc, int n_con, unsig
     bool need_full = true;
     [[maybe_unused]] bool arrow = false;                               // which form the factor of this solve has
 #if GO2SIM_FAST_ORDER
-    if constexpr (ARROW_SHAPE && (T == 32 || T == 64)) arrow = m.arrow_mode != 0 && team_ballot<T>(rows_coupled) == 0ull;
+    if constexpr (ARROW_SOLVER && (T == 32 || T == 64)) arrow = m.arrow_mode != 0 && team_ballot<T>(rows_coupled) == 0ull;
 #endif
     for (int it = 0;; ++it) {
       if (need_full) {                       // single call site of the direct Hessian + factorisation (init and degenerate rebuild)
@@ -3964,7 +4013,7 @@ DEV int ts_solve(const MT& m, const E& e, S* s, int tl, int nc, int n_con, unsig
         if constexpr (T >= 21) { if (it == 0) ts_hessian_direct<T>(m, s, tl, n_con); else ts_hessian_update<T>(m, s, tl, n_con); }
         else ts_hessian_direct<T>(m, s, tl, n_con);
         PH(3)
-        if constexpr (ARROW_SHAPE && (T == 32 || T == 64)) { if (arrow) ts_cholesky_factor_arrow<T>(m, s, tl); else ts_cholesky_factor<T>(m, s, tl); }
+        if constexpr (ARROW_SOLVER && (T == 32 || T == 64)) { if (arrow) ts_cholesky_factor_arrow<T>(m, s, tl); else ts_cholesky_factor<T>(m, s, tl); }
         else ts_cholesky_factor<T>(m, s, tl);
 #else
         ts_hessian_direct<T>(m, s, tl, n_con);
@@ -3977,7 +4026,7 @@ DEV int ts_solve(const MT& m, const E& e, S* s, int tl, int nc, int n_con, unsig
       ts_update_gradient<T>(s, tl);
 #endif
 #if GO2SIM_FAST_ORDER
-      if constexpr (ARROW_SHAPE && (T == 32 || T == 64)) { if (arrow) ts_update_gradient_arrow<T>(m, s, tl); else ts_update_gradient<T>(s, tl); }
+      if constexpr (ARROW_SOLVER && (T == 32 || T == 64)) { if (arrow) ts_update_gradient_arrow<T>(m, s, tl); else ts_update_gradient<T>(s, tl); }
       else ts_update_gradient<T>(s, tl);
 #else
       ts_update_gradient<T>(s, tl);
@@ -4865,7 +4914,10 @@ DEV void env_globals_body(const DCfg& c, Glob& g, Acc* acc, uint64_t seed, int c
 // are dealt to the waves (term k runs on one wave, its value goes to LDS), and wave 0 then adds them in the reference's order and makes every store.
 // The three terms that touch env state beyond their own value (feet_air_time writes and feet_stance reads _feet_air_time, go2_env_walk.py:1303-1314;
 // forward_progress moves _last_base_pos_x) stay together on wave 0, in order.  Same operations per value and the same sum order: results unchanged.
-constexpr int POST_A_WAVES = 4;
+#ifndef GO2SIM_POST_A_WAVES
+#define GO2SIM_POST_A_WAVES 4
+#endif
+constexpr int POST_A_WAVES = GO2SIM_POST_A_WAVES;   // (<= 8: the workgroup has to fit one CU at two wavefronts per SIMD)
 __global__ __launch_bounds__(WG * POST_A_WAVES) void k_env_post_a(Pool P, const Model* __restrict__ mp, const DCfg cv, Glob* gp,
                                                    Acc* acc, uint64_t seed, uint32_t step_count) {
   STAMP(STK_POST_A)
@@ -4984,7 +5036,7 @@ __global__ __launch_bounds__(WG * POST_A_WAVES) void k_env_post_a(Pool P, const 
       const int id = id_next; const float scale = scale_next;
       { const int kn = (k + 1 < NREW) ? k + 1 : k; id_next = c.i[GO2SIM_IC_REWARD_ID0 + kn]; scale_next = c.f[GO2SIM_FC_REWARD_SCALE0 + kn]; }   // the table reads of the next term overlap this one
       const bool stateful = id == GO2SIM_R_FEET_AIR_TIME || id == GO2SIM_R_FEET_STANCE || id == GO2SIM_R_FORWARD_PROGRESS;
-      const int owner = stateful ? 0 : (1 + j) % POST_A_WAVES;
+      const int owner = stateful ? 0 : (POST_A_WAVES > 4 ? 1 + j % (POST_A_WAVES - 1) : (1 + j) % POST_A_WAVES);
       j += stateful ? 0 : 1;
       if (wv == owner) s_r[k][ln] = reward_term(m, c, rs, id, rc, gates) * scale;
     }

@@ -314,6 +314,9 @@ bool parse_model(const void* blob, size_t nbytes, Model& m) {
 struct Contact {
   int geom_a, geom_b, link_a, link_b; V3 pos, normal, force; real penetration, friction, sol_params[7];
 };
+// FAST ORDER, arrow form of a Cholesky factor (arrow_factor below): per leg its dofs, the reciprocal pivots, l10 l20 l21 and W (6 x 3); the base factor with
+// reciprocal pivots on its diagonal
+struct ArrowFactor { int p[4][3]; real i[4][3], l[4][3], w[4][6][3], b[6][6]; };
 struct Env {
   // persistent rigid state
   real qpos[NQ], vel[ND], acc[ND], qacc_ws[ND];
@@ -350,8 +353,9 @@ struct Env {
   real qacc[ND], Ma[ND], grad[ND], Mgrad[ND], search[ND], mv[ND], qfrc_constraint[ND], nt_vec[ND];
   real H[ND][ND];
   real Hunf[ND][ND];   // FAST ORDER: the unfactored Hessian of the running Newton solve (lower triangle), updated by the rows that flip
-  // FAST ORDER, arrow form of the factor (cholesky_factor_arrow): per leg the reciprocal pivots, l10 l20 l21 and W (6 x 3); the base factor with reciprocal pivots on its diagonal
-  bool arrow; int af_p[4][3]; real af_i[4][3], af_l[4][3], af_w[4][6][3], af_b[6][6];
+  // FAST ORDER, arrow form of a factor (arrow_factor)
+  bool arrow; ArrowFactor af;      // ... of the Newton Hessian
+  bool mass_arrow; ArrowFactor maf;   // ... of the mass matrix (factor_mass / solve_mass)
   real cost, prev_cost, gauss, quad_gauss[3], gtol; int ls_it, ls_result, improved, solver_iters;
   V3 contact_force[NL];
   real vel_next[ND], qpos_next[NQ];
@@ -552,8 +556,81 @@ void compute_mass_matrix(const Model& m, Env& e, bool implicit_damping) {
   }
 }
 
+#ifdef GO2SIM_FAST_ORDER
+// arrow_factor / arrow_solve of csrc/go2sim.hip: a symmetric positive definite 18 x 18 matrix (lower triangle in A) whose leg blocks (dofs dm_arrow_dof(mode, l, 0..2))
+// couple only to the six base dofs: the legs are eliminated first -- four 3 x 3 factorisations, W_l = C_l^T L_l^-T, the 6 x 6 Schur complement of the base with
+// the legs added as (l0 + l2) + (l1 + l3) -- with reciprocal pivots sqrt(e) * (1 / e) and fused multiply-adds
+void arrow_factor(int mode, real eps, const real (*A)[ND], ArrowFactor& f) {
+  real sc[4][6][6];
+  for (int l = 0; l < 4; ++l) {
+    const int p0 = dm_arrow_dof(mode, l, 0), p1 = dm_arrow_dof(mode, l, 1), p2 = dm_arrow_dof(mode, l, 2);
+    const real a00 = A[p0][p0], a10 = A[p1][p0], a11 = A[p1][p1], a20 = A[p2][p0], a21 = A[p2][p1], a22 = A[p2][p2];
+    const real e0 = std::max(a00, eps), i0 = dm_sqrt(e0) * (1.0f / e0);
+    const real l10 = a10 * i0, l20 = a20 * i0;
+    const real e1 = std::max(std::fma(-l10, l10, a11), eps), i1 = dm_sqrt(e1) * (1.0f / e1);
+    const real l21 = std::fma(-l20, l10, a21) * i1;
+    const real e2 = std::max(std::fma(-l21, l21, std::fma(-l20, l20, a22)), eps), i2 = dm_sqrt(e2) * (1.0f / e2);
+    f.p[l][0] = p0; f.p[l][1] = p1; f.p[l][2] = p2;
+    f.i[l][0] = i0; f.i[l][1] = i1; f.i[l][2] = i2; f.l[l][0] = l10; f.l[l][1] = l20; f.l[l][2] = l21;
+    for (int b = 0; b < 6; ++b) {
+      const real c0 = A[p0][b], c1 = A[p1][b], c2 = A[p2][b];
+      const real w0 = c0 * i0, w1 = std::fma(-w0, l10, c1) * i1, w2 = std::fma(-w1, l21, std::fma(-w0, l20, c2)) * i2;
+      f.w[l][b][0] = w0; f.w[l][b][1] = w1; f.w[l][b][2] = w2;
+    }
+    for (int u = 0; u < 6; ++u)
+      for (int j = 0; j < 6; ++j) sc[l][u][j] = std::fma(f.w[l][u][2], f.w[l][j][2], std::fma(f.w[l][u][1], f.w[l][j][1], f.w[l][u][0] * f.w[l][j][0]));
+  }
+  real a[6][6];
+  for (int u = 0; u < 6; ++u)
+    for (int j = 0; j <= u; ++j) a[u][j] = A[u][j] - ((sc[0][u][j] + sc[2][u][j]) + (sc[1][u][j] + sc[3][u][j]));
+  for (int k = 0; k < 6; ++k) {
+    const real ee = std::max(a[k][k], eps), ik = dm_sqrt(ee) * (1.0f / ee);
+    a[k][k] = ik;
+    for (int j = k + 1; j < 6; ++j) a[j][k] = a[j][k] * ik;
+    for (int j = k + 1; j < 6; ++j)
+      for (int i = k + 1; i <= j; ++i) a[j][i] = std::fma(-a[j][k], a[i][k], a[j][i]);
+  }
+  for (int k = 0; k < 6; ++k) for (int j = 0; j <= k; ++j) f.b[k][j] = a[k][j];
+}
+void arrow_solve(const ArrowFactor& f, const real* g, real* out) {
+  real y[4][3], z[4][6], x[6];
+  for (int l = 0; l < 4; ++l) {
+    const int p0 = f.p[l][0], p1 = f.p[l][1], p2 = f.p[l][2];
+    const real* iv = f.i[l]; const real* lv = f.l[l];
+    y[l][0] = g[p0] * iv[0];
+    y[l][1] = std::fma(-lv[0], y[l][0], g[p1]) * iv[1];
+    y[l][2] = std::fma(-lv[2], y[l][1], std::fma(-lv[1], y[l][0], g[p2])) * iv[2];
+    for (int b = 0; b < 6; ++b) z[l][b] = std::fma(f.w[l][b][2], y[l][2], std::fma(f.w[l][b][1], y[l][1], f.w[l][b][0] * y[l][0]));
+  }
+  for (int b = 0; b < 6; ++b) x[b] = g[b] - ((z[0][b] + z[2][b]) + (z[1][b] + z[3][b]));
+  for (int k = 0; k < 6; ++k) {
+    real acc = x[k];
+    for (int j = 0; j < k; ++j) acc = std::fma(-f.b[k][j], x[j], acc);
+    x[k] = acc * f.b[k][k];
+  }
+  for (int k = 5; k >= 0; --k) {
+    real acc = x[k];
+    for (int j = 5; j > k; --j) acc = std::fma(-f.b[j][k], x[j], acc);
+    x[k] = acc * f.b[k][k];
+  }
+  real xl[4][3];
+  for (int l = 0; l < 4; ++l) {
+    const real* iv = f.i[l]; const real* lv = f.l[l];
+    real v0 = y[l][0], v1 = y[l][1], v2 = y[l][2];
+    for (int b = 0; b < 6; ++b) { v0 = std::fma(-f.w[l][b][0], x[b], v0); v1 = std::fma(-f.w[l][b][1], x[b], v1); v2 = std::fma(-f.w[l][b][2], x[b], v2); }
+    xl[l][2] = v2 * iv[2]; xl[l][1] = std::fma(-lv[2], xl[l][2], v1) * iv[1]; xl[l][0] = std::fma(-lv[0], xl[l][1], std::fma(-lv[1], xl[l][2], v0)) * iv[0];
+  }
+  for (int b = 0; b < 6; ++b) out[b] = x[b];                       // (g and out may be the same array)
+  for (int l = 0; l < 4; ++l) for (int t = 0; t < 3; ++t) out[f.p[l][t]] = xl[l][t];
+}
+#endif
 // func_factor_mass, serial branch, forward_dynamics.py:560-604 (implicit_damping=False)
 void factor_mass(const Model& m, Env& e) {
+#ifdef GO2SIM_FAST_ORDER
+  // tk_dynamics of csrc/go2sim.hip: the mass matrix of a floating base with four legs always has the arrow shape; acc_smooth comes from its arrow-form Cholesky factor
+  e.mass_arrow = ND == 18 && m.arrow_mode != 0;
+  if (e.mass_arrow) { arrow_factor(m.arrow_mode, m.eps, e.mass_mat, e.maf); return; }
+#endif
   for (int i_e = 0; i_e < m.n_entities; ++i_e) {
     const Entity& en = m.entities[i_e];
     int ds = en.dof_start, de = en.dof_end, n = de - ds;
@@ -576,6 +653,9 @@ void factor_mass(const Model& m, Env& e) {
 
 // func_solve_mass_entity, forward_dynamics.py:818-900
 void solve_mass(const Model& m, const Env& e, const real* vec, real* out) {
+#ifdef GO2SIM_FAST_ORDER
+  if (e.mass_arrow) { arrow_solve(e.maf, vec, out); return; }
+#endif
   for (int i_e = 0; i_e < m.n_entities; ++i_e) {
     const Entity& en = m.entities[i_e];
     int ds = en.dof_start, de = en.dof_end, n = de - ds;
@@ -1467,70 +1547,8 @@ bool rows_uncoupled(const Model& m, const Env& e) {                 // no contac
   }
   return true;
 }
-void cholesky_factor_arrow(const Model& m, Env& e) {
-  real sc[4][6][6];
-  for (int l = 0; l < 4; ++l) {
-    const int p0 = dm_arrow_dof(m.arrow_mode, l, 0), p1 = dm_arrow_dof(m.arrow_mode, l, 1), p2 = dm_arrow_dof(m.arrow_mode, l, 2);
-    const real a00 = e.H[p0][p0], a10 = e.H[p1][p0], a11 = e.H[p1][p1], a20 = e.H[p2][p0], a21 = e.H[p2][p1], a22 = e.H[p2][p2];
-    const real e0 = std::max(a00, m.eps), i0 = dm_sqrt(e0) * (1.0f / e0);
-    const real l10 = a10 * i0, l20 = a20 * i0;
-    const real e1 = std::max(std::fma(-l10, l10, a11), m.eps), i1 = dm_sqrt(e1) * (1.0f / e1);
-    const real l21 = std::fma(-l20, l10, a21) * i1;
-    const real e2 = std::max(std::fma(-l21, l21, std::fma(-l20, l20, a22)), m.eps), i2 = dm_sqrt(e2) * (1.0f / e2);
-    e.af_p[l][0] = p0; e.af_p[l][1] = p1; e.af_p[l][2] = p2;
-    e.af_i[l][0] = i0; e.af_i[l][1] = i1; e.af_i[l][2] = i2; e.af_l[l][0] = l10; e.af_l[l][1] = l20; e.af_l[l][2] = l21;
-    for (int b = 0; b < 6; ++b) {
-      const real c0 = e.H[p0][b], c1 = e.H[p1][b], c2 = e.H[p2][b];
-      const real w0 = c0 * i0, w1 = std::fma(-w0, l10, c1) * i1, w2 = std::fma(-w1, l21, std::fma(-w0, l20, c2)) * i2;
-      e.af_w[l][b][0] = w0; e.af_w[l][b][1] = w1; e.af_w[l][b][2] = w2;
-    }
-    for (int u = 0; u < 6; ++u)
-      for (int j = 0; j < 6; ++j) sc[l][u][j] = std::fma(e.af_w[l][u][2], e.af_w[l][j][2], std::fma(e.af_w[l][u][1], e.af_w[l][j][1], e.af_w[l][u][0] * e.af_w[l][j][0]));
-  }
-  real a[6][6];
-  for (int u = 0; u < 6; ++u)
-    for (int j = 0; j <= u; ++j) a[u][j] = e.H[u][j] - ((sc[0][u][j] + sc[2][u][j]) + (sc[1][u][j] + sc[3][u][j]));
-  for (int k = 0; k < 6; ++k) {
-    const real ee = std::max(a[k][k], m.eps), ik = dm_sqrt(ee) * (1.0f / ee);
-    a[k][k] = ik;
-    for (int j = k + 1; j < 6; ++j) a[j][k] = a[j][k] * ik;
-    for (int j = k + 1; j < 6; ++j)
-      for (int i = k + 1; i <= j; ++i) a[j][i] = std::fma(-a[j][k], a[i][k], a[j][i]);
-  }
-  for (int k = 0; k < 6; ++k) for (int j = 0; j <= k; ++j) e.af_b[k][j] = a[k][j];
-}
-// ts_update_gradient_arrow of csrc/go2sim.hip
-void cholesky_solve_arrow(Env& e) {
-  real y[4][3], z[4][6], x[6];
-  for (int l = 0; l < 4; ++l) {
-    const int p0 = e.af_p[l][0], p1 = e.af_p[l][1], p2 = e.af_p[l][2];
-    const real* iv = e.af_i[l]; const real* lv = e.af_l[l];
-    y[l][0] = e.grad[p0] * iv[0];
-    y[l][1] = std::fma(-lv[0], y[l][0], e.grad[p1]) * iv[1];
-    y[l][2] = std::fma(-lv[2], y[l][1], std::fma(-lv[1], y[l][0], e.grad[p2])) * iv[2];
-    for (int b = 0; b < 6; ++b) z[l][b] = std::fma(e.af_w[l][b][2], y[l][2], std::fma(e.af_w[l][b][1], y[l][1], e.af_w[l][b][0] * y[l][0]));
-  }
-  for (int b = 0; b < 6; ++b) x[b] = e.grad[b] - ((z[0][b] + z[2][b]) + (z[1][b] + z[3][b]));
-  for (int k = 0; k < 6; ++k) {
-    real acc = x[k];
-    for (int j = 0; j < k; ++j) acc = std::fma(-e.af_b[k][j], x[j], acc);
-    x[k] = acc * e.af_b[k][k];
-  }
-  for (int k = 5; k >= 0; --k) {
-    real acc = x[k];
-    for (int j = 5; j > k; --j) acc = std::fma(-e.af_b[j][k], x[j], acc);
-    x[k] = acc * e.af_b[k][k];
-  }
-  for (int b = 0; b < 6; ++b) e.Mgrad[b] = x[b];
-  for (int l = 0; l < 4; ++l) {
-    const int p0 = e.af_p[l][0], p1 = e.af_p[l][1], p2 = e.af_p[l][2];
-    const real* iv = e.af_i[l]; const real* lv = e.af_l[l];
-    real v0 = y[l][0], v1 = y[l][1], v2 = y[l][2];
-    for (int b = 0; b < 6; ++b) { v0 = std::fma(-e.af_w[l][b][0], x[b], v0); v1 = std::fma(-e.af_w[l][b][1], x[b], v1); v2 = std::fma(-e.af_w[l][b][2], x[b], v2); }
-    const real x2 = v2 * iv[2], x1 = std::fma(-lv[2], x2, v1) * iv[1], x0 = std::fma(-lv[0], x1, std::fma(-lv[1], x2, v0)) * iv[0];
-    e.Mgrad[p0] = x0; e.Mgrad[p1] = x1; e.Mgrad[p2] = x2;
-  }
-}
+void cholesky_factor_arrow(const Model& m, Env& e) { arrow_factor(m.arrow_mode, m.eps, e.H, e.af); }
+void cholesky_solve_arrow(Env& e) { arrow_solve(e.af, e.grad, e.Mgrad); }
 #endif
 // func_cholesky_factor_direct_batch, solver.py:1467-1494
 void cholesky_factor_direct(const Model& m, Env& e) {

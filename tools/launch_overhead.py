@@ -25,7 +25,7 @@ from go2_sim2real_locomotion_rl_amd.model_blob import pack_model
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 W = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 N = int(sys.argv[3]) if len(sys.argv) > 3 else 20
-so = build.build_hip_variant("stamp", ["-DGO2SIM_STAMP"], verbose=False)
+so = build.build_hip_variant(os.environ.get("GO2SIM_STAMP_VARIANT", "stamp"), ["-DGO2SIM_STAMP"] + os.environ.get("GO2SIM_STAMP_FLAGS", "").split(), verbose=False)
 lib = capi.Go2SimLib(so, "go2sim_")
 dev = torch.device("cuda", 0)
 sim = capi.Go2Sim(lib, pack_model(), B, 0, 1)
