@@ -991,6 +991,7 @@ DEV void tk_stage_links(const E& e, KinData* s, int tl) {
 template <int T, class MT>
 DEV void tk_kinematics(const MT& m, const E& e, KinData* s, int tl, bool force_update_fixed, DynData* dk = nullptr) {
   // s->l_pos / s->l_quat hold the current link poses (tk_stage_links, issued with the kernel's other staging loads)
+  PH_BEGIN                                                             // (profiling builds: 18 = link poses by level, 19 = COM / inertia / cdof / geoms, 55 = velocities by level)
   for (int lev = 0; lev < m.n_levels; ++lev) {
     for (int k = m.level_start[lev] + tl; k < m.level_start[lev + 1]; k += T) {
       int i_l = m.level_links[k];
@@ -1031,6 +1032,7 @@ DEV void tk_kinematics(const MT& m, const E& e, KinData* s, int tl, bool force_u
     }
     team_sync();
   }
+  PH(18)
   // centre of mass of each kinematic tree
   for (int i_l = tl; i_l < NL; i_l += T) {
     const auto& L = m.links[i_l];
@@ -1109,6 +1111,7 @@ DEV void tk_kinematics(const MT& m, const E& e, KinData* s, int tl, bool force_u
     }
   }
   team_sync();
+  PH(19)
   // forward velocity
   for (int lev = 0; lev < m.n_levels; ++lev) {
     for (int k = m.level_start[lev] + tl; k < m.level_start[lev + 1]; k += T) {
@@ -1158,6 +1161,7 @@ DEV void tk_kinematics(const MT& m, const E& e, KinData* s, int tl, bool force_u
     }
     team_sync();
   }
+  PH(55)
 }
 
 // func_integrate (forward_dynamics.py:1558-1699) + func_copy_next_to_curr (abd/diff.py:25-54) on the staged state: s->vel_next holds v + a dt

@@ -33,7 +33,7 @@ for s in range(W):
 PH_MAX_WG = 8192
 out = (ctypes.c_ulonglong * (64 * PH_MAX_WG))()
 lib.lib.go2sim_debug_phases(sim.h, out, 1)
-GROUPS_ = {"post_a": [12, 13, 14, 15, 16, 17], "solver": [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 11], "dynamics": list(range(20, 26)), "collide": list(range(30, 34)) + [26, 27, 28, 29], "integrate_fk": [40, 41]}
+GROUPS_ = {"post_a": [12, 13, 14, 15, 16, 17], "solver": [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 11], "dynamics": list(range(20, 26)), "collide": list(range(30, 34)) + [26, 27, 28, 29], "integrate_fk": [40, 41, 18, 19, 55]}
 def xcd_block(bid, n):
     """logical block of physical workgroup `bid` in a grid of n (xcd_block() of csrc/go2sim.hip)"""
     q, r, x, i = n >> 3, n & 7, bid & 7, bid >> 3
@@ -97,7 +97,7 @@ for s in range(W, W + N):
 lib.lib.go2sim_debug_phases(sim.h, out, 1)
 a = np.frombuffer(out, dtype=np.uint64).reshape(PH_MAX_WG, 64).astype(np.float64)
 launches = 2 * N                                   # substep kernels: two launches per env step
-GROUPS = {"solver": [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 11], "dynamics": list(range(20, 26)), "collide": list(range(30, 34)) + [26, 27, 28, 29], "integrate_fk": [40, 41]}   # (ids 34-39, 42-49: PHD sections, printed above)
+GROUPS = {"solver": [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 11], "dynamics": list(range(20, 26)), "collide": list(range(30, 34)) + [26, 27, 28, 29], "integrate_fk": [40, 41, 18, 19, 55]}   # (18 / 19 / 55: parts of 41; ids 34-39, 42-49: PHD sections, printed above)
 NAMES = {0: "stage", 1: "rows", 2: "init Ma/Jaref/update", 3: "Hessian", 4: "Cholesky factor", 5: "gradient solve", 6: "line search", 7: "qacc/constraint update",
          8: "active-set change test (FAST ORDER) / incremental Cholesky", 9: "prologue", 11: "commit", 30: "AABB + clear", 31: "endpoint sort", 32: "candidate pairs", 33: "narrow phase", 26: "terrain pair setup/count", 27: "terrain descriptors", 28: "terrain prism MPR", 29: "terrain replay"}
 # sections inside lane-divergent code (PHD): cycles at id, number of executions at id + 1
