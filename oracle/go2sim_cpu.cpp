@@ -3300,4 +3300,23 @@ int go2sim_cpu_debug_get(go2sim* h, const char* name, float* dst, int* k_out) {
   return GO2SIM_E_OK;
 }
 
+// test aids for the arrow form (tests/test_arrow_form.py): the numbering rule on a mask, and factor + solve on a matrix handed in (FAST ORDER build, ND = 18)
+int go2sim_cpu_debug_arrow_mode(const float* mask, int nd) { return mask ? dm_arrow_mode(mask, nd) : -1; }
+int go2sim_cpu_debug_arrow_solve(int mode, float eps, const float* A, const float* g, float* x) {
+#ifdef GO2SIM_FAST_ORDER
+  if (ND != 18 || (mode != 1 && mode != 2) || !A || !g || !x) return GO2SIM_E_BADARG;
+  static real Am[ND][ND];
+  ArrowFactor f;
+  real gg[ND], xx[ND];
+  for (int i = 0; i < ND; ++i) { gg[i] = g[i]; for (int j = 0; j < ND; ++j) Am[i][j] = A[i * ND + j]; }
+  arrow_factor(mode, eps, Am, f);
+  arrow_solve(f, gg, xx);
+  for (int i = 0; i < ND; ++i) x[i] = xx[i];
+  return GO2SIM_E_OK;
+#else
+  (void)mode; (void)eps; (void)A; (void)g; (void)x;
+  return GO2SIM_E_BADARG;
+#endif
+}
+
 }  // extern "C"
