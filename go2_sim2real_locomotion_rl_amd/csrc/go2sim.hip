@@ -2331,16 +2331,30 @@ __global__ __launch_bounds__(64) void k_collide_team(Pool P, const Model* __rest
     s->bp.skey[i] = ((unsigned long long)u << 8) | (unsigned long long)i;
   }
   team_sync();
-  for (int i = tl; i < n2; i += T) {
-    float v = s->bp.sval[i];
-    const unsigned long long key = s->bp.skey[i];
-    int r = 0;
+  {
+    // a lane ranks its (up to) NK endpoints at once: every key is read once (the same address for all lanes of the team) and compared with all of them,
+    // instead of one pass over the keys per endpoint
+    constexpr int NK = (2 * NG + T - 1) / T;
+    unsigned long long key[NK]; int r[NK];
 #pragma unroll
-    for (int j = 0; j < 2 * NG; ++j) r += (s->bp.skey[j] < key) ? 1 : 0;
-    int sg = s->bp.sig[i];
-    s->bp.sval_sorted[r] = v; s->bp.sig_sorted[r] = sg;
-    s->bp.rank_mm[2 * (sg & 0xff) + ((sg & 0x100) ? 1 : 0)] = r;
-    e.sort_value()[r] = v; e.sort_ig()[r] = sg;
+    for (int q = 0; q < NK; ++q) { const int i = tl + q * T; key[q] = s->bp.skey[i < n2 ? i : n2 - 1]; r[q] = 0; }
+#pragma unroll
+    for (int j = 0; j < 2 * NG; ++j) {
+      const unsigned long long kj = s->bp.skey[j];
+#pragma unroll
+      for (int q = 0; q < NK; ++q) r[q] += (kj < key[q]) ? 1 : 0;
+    }
+#pragma unroll
+    for (int q = 0; q < NK; ++q) {
+      const int i = tl + q * T;
+      if (i < n2) {
+        const float v = s->bp.sval[i];
+        const int sg = s->bp.sig[i];
+        s->bp.sval_sorted[r[q]] = v; s->bp.sig_sorted[r[q]] = sg;
+        s->bp.rank_mm[2 * (sg & 0xff) + ((sg & 0x100) ? 1 : 0)] = r[q];
+        e.sort_value()[r[q]] = v; e.sort_ig()[r[q]] = sg;
+      }
+    }
   }
 #if defined(GO2SIM_REPEAT_PHASE) && GO2SIM_REPEAT_PHASE == 31
   }
@@ -2356,6 +2370,10 @@ __global__ __launch_bounds__(64) void k_collide_team(Pool P, const Model* __rest
   // the pair table is fetched for all rounds up front and every LDS operand of a test is read unconditionally, so that the reads of a
   // round are in flight together; only the ballot compaction is sequential
   unsigned cmask = 0; int key_[NPI];
+  // normal_cache[pidx] := 0 for every separated pair: the lanes' verdicts of a round are collected with one ballot (pair pidx = it * T + tl is bit pidx of the
+  // mask) and lane w gathers word w, instead of one LDS atomic per pair (16 lanes of a team on one word)
+  unsigned ncv_clear = 0u;
+  static_assert(NCV <= T, "one lane per word of the normal-cache mask");
 #pragma unroll
   for (int it = 0; it < NPI; ++it) {                                   // the rounds are independent: candidates are only marked here
     const int pidx = it * T + tl;
@@ -2367,13 +2385,17 @@ __global__ __launch_bounds__(64) void k_collide_team(Pool P, const Model* __rest
     const int rs = (ra < rb) ? rb : ra, rf = (ra < rb) ? ra : rb;
     const int rmax_first = (ra < rb) ? rka.y : rkb.y;
     key_[it] = rs * 64 + rf;
-    if (packed >= 0 && rs < rmax_first) {
-      bool any1 = (amx.x <= bmn.x) || (amx.y <= bmn.y) || (amx.z <= bmn.z);
-      bool any2 = (amn.x >= bmx.x) || (amn.y >= bmx.y) || (amn.z >= bmx.z);
-      if (any1 || any2) atomicAnd(&s->ncv[pidx >> 5], ~(1u << (pidx & 31)));   // normal_cache[pidx] := 0
-      else cmask |= 1u << it;
-    }
+    const bool swept = packed >= 0 && rs < rmax_first;
+    const bool any1 = (amx.x <= bmn.x) || (amx.y <= bmn.y) || (amx.z <= bmn.z);
+    const bool any2 = (amn.x >= bmx.x) || (amn.y >= bmx.y) || (amn.z >= bmx.z);
+    if (swept && !(any1 || any2)) cmask |= 1u << it;
+    const unsigned long long sep = team_ballot<T>(swept && (any1 || any2));
+    (void)pidx;
+    if constexpr (T < 32) { if (tl == ((it * T) >> 5)) ncv_clear |= (unsigned)(sep << ((it * T) & 31)); }
+    else if constexpr (T == 32) { if (tl == it) ncv_clear |= (unsigned)sep; }
+    else { if (tl == 2 * it) ncv_clear |= (unsigned)sep; if (tl == 2 * it + 1) ncv_clear |= (unsigned)(sep >> 32); }
   }
+  if (tl < NCV) s->ncv[tl] &= ~ncv_clear;
   {                                                                    // compaction; the list is sorted by key below, so its order is free
     const int mine = __popc(cmask);
     s->cnt[tl] = mine;
