@@ -2,7 +2,9 @@
 
 Genesis holds no stored vectors for the physics of this path; what its own tests hold are closed-form answers on small models
 (tests/test_rigid_physics.py): `test_pendulum_links_acc` (:705-757: a 1 m massless arm with a 1 kg point mass about x, alpha = -sin(theta) g, then held by
-a PD controller), `test_double_pendulum_links_acc` (:760-834) and the cube of `test_contact_forces` (:1749-1800: net contact force = weight).  Those
+a PD controller), `test_double_pendulum_links_acc` (:760-834), the kinematic cases of `test_link_velocity` (:638-706: two aligned hinges), the cube of
+`test_contact_forces` (:1749-1800: net contact force = weight), and on the same cube away from the ground `test_gravity` (:2910-2936) and the hovering body of
+`test_apply_external_forces` (:1860-1890).  Those
 models have another SHAPE than Go2 (fixed base, 1 / 2 / 6 dofs), so they run on shape variants: the same sources compiled with other link / dof /
 geom counts (build.SHAPES, -DGO2SIM_NL=... ; the reference's summation order), models from tools/compile_go2_model.py --robot pendulum |
 double_pendulum | box, which re-expresses `_build_multi_pendulum` (:225-277) and gs.morphs.Box.  Re-expressed where the reference reads link
@@ -168,17 +170,116 @@ def run_box(lib, gpu, n_envs=8, steps=60):
     return np.stack(log)
 
 
-RUNS = {"pendulum": run_pendulum, "double_pendulum": run_double_pendulum, "box": run_box}
+def run_two_aligned_hinges(lib, gpu, n_envs=4):
+    """`test_link_velocity` (tests/test_rigid_physics.py:638-706) on the `two_aligned_hinges` model (:165-177; here tools/compile_go2_model.py
+    synth_two_aligned_hinges: bodies of 0.5 m along x, hinges about z, centres of mass in the middle, equal masses): forward kinematics, the centre of
+    mass of the tree and the spatial velocities of the links (rows a2, a3, a5) against the reference's closed forms, case by case.  Links: 0 plane,
+    1 fixed base, 2 body0, 3 body1.  Re-expressed where the reference reads accessors this C ABI does not have: the joint anchor of body1 is its link
+    position (the reference asserts exactly that, :692), `get_links_pos(ref="link_com")` = pos + R(quat) inertial_pos and `get_links_vel(ref=...)` =
+    cd_vel + cd_ang x (point - root_COM) (rigid_solver.get_links_vel) are formed here from the exported fields."""
+    m = model_of("two_aligned_hinges")
+    s = Sim(lib, m, n_envs, gpu)
+    tol = TOL_SINGLE
+    log = []
+
+    def init(qpos=(0.0, 0.0), qvel=(0.0, 0.0)):
+        s.set_state(np.tile(np.array(qpos, np.float32)[:, None], (1, n_envs)), np.tile(np.array(qvel, np.float32)[:, None], (1, n_envs)))
+        out = {k: s.get(f) for k, f in (("pos", "F_LINK_POS"), ("quat", "F_LINK_QUAT"), ("cd_vel", "F_LINK_CDVEL"), ("cd_ang", "F_LINK_CDANG"), ("com", "F_ROOT_COM"))}
+        log.extend(v.copy().reshape(-1) for v in out.values())
+        for v in out.values():
+            assert np.all(v == v[:, :1]), "every env holds the same state"
+        link = lambda a, i, k=3: a[k * i:k * i + k, 0].astype(np.float64)
+        return dict(pos=[link(out["pos"], i) for i in (2, 3)], quat=[link(out["quat"], i, 4) for i in (2, 3)], cd_vel=[link(out["cd_vel"], i) for i in (2, 3)],
+                    cd_ang=[link(out["cd_ang"], i) for i in (2, 3)], com=out["com"][:, 0].astype(np.float64))
+
+    def close(a, b, what):
+        assert np.abs(np.asarray(a) - np.asarray(b)).max() <= tol, (what, a, b)
+
+    # :640-641  only the second hinge turns: the centre of mass of the tree sits on its axis, the spatial velocity referred to it vanishes
+    r = init(qvel=(0.0, 1.0))
+    close(r["cd_vel"][0], 0.0, "cd_vel body0"); close(r["cd_vel"][1], 0.0, "cd_vel body1")
+    # :643-646
+    r = init(qvel=(1.0, 0.0))
+    close(r["cd_vel"][0], [0.0, 0.5, 0.0], "cd_vel body0"); close(r["cd_vel"][1], [0.0, 0.5, 0.0], "cd_vel body1")
+    # :648-655
+    r = init(qpos=(0.0, np.pi / 2.0), qvel=(0.0, 1.2))
+    close(r["com"], [0.375, 0.125, 0.0], "root COM")
+    close(r["pos"][1], [0.5, 0.0, 0.0], "anchor of the second hinge")
+    close(r["cd_vel"][0], 0.0, "cd_vel body0")
+    close(r["cd_vel"][1], [-1.2 * (0.125 - 0.0), 1.2 * (0.375 - 0.5), 0.0], "cd_vel body1")
+    # :657-706  a random configuration
+    th0, th1, w0, w1 = -0.7, 0.2, 3.0, 13.0
+    r = init(qpos=(th0, th1), qvel=(w0, w1))
+    th0, th1 = np.float64(np.float32(th0)), np.float64(np.float32(th1))
+    anchor = r["pos"][1]
+    close(anchor[:2], [0.5 * np.cos(th0), 0.5 * np.sin(th0)], "anchor")
+    com0 = np.array([0.25 * np.cos(th0), 0.25 * np.sin(th0), 0.0])
+    com1 = np.array([0.5 * np.cos(th0) + 0.25 * np.cos(th0 + th1), 0.5 * np.sin(th0) + 0.25 * np.sin(th0 + th1), 0.0])
+
+    def rot(q, v):                                                          # R(q) v, float64
+        w, x, y, z = q
+        R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)], [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                      [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+        return R @ v
+    ipos = [np.array(m["links"][i]["inertial_pos"], np.float64) for i in (2, 3)]
+    lcom = [r["pos"][k] + rot(r["quat"][k], ipos[k]) for k in (0, 1)]
+    close(lcom[0], com0, "link COM 0"); close(lcom[1], com1, "link COM 1")
+    close(r["com"], 0.5 * (com0 + com1), "root COM")
+    om0, om1 = r["cd_ang"][0][2], r["cd_ang"][1][2]
+    close(om0, 3.0, "omega 0"); close(om1 - om0, 13.0, "omega 1 - omega 0")
+    com = r["com"]
+    close(r["cd_vel"][0], om0 * np.array([-com[1], com[0], 0.0]), "cd_vel body0")
+    close(r["cd_vel"][1], r["cd_vel"][0] + (om1 - om0) * np.array([anchor[1] - com[1], com[0] - anchor[0], 0.0]), "cd_vel body1")
+    close(r["pos"][0], 0.0, "body0 sits at the origin")
+    vel_at = lambda k, p: r["cd_vel"][k] + np.cross(r["cd_ang"][k], p - com)                     # get_links_vel: velocity of the link's point at p
+    close(vel_at(0, r["pos"][0]), 0.0, "link-origin velocity 0")
+    close(vel_at(1, r["pos"][1]), om0 * np.array([-anchor[1], anchor[0], 0.0]), "link-origin velocity 1")
+    close(vel_at(0, lcom[0]), om0 * np.array([-com0[1], com0[0], 0.0]), "link-COM velocity 0")
+    close(vel_at(1, lcom[1]), om0 * np.array([-com1[1], com1[0], 0.0]) + (om1 - om0) * np.array([anchor[1] - com1[1], com1[0] - anchor[0], 0.0]), "link-COM velocity 1")
+    return np.concatenate(log)
+
+
+def run_box_free(lib, gpu, n_envs=4):
+    """A free body away from the ground: its acceleration is gravity (`test_gravity`, tests/test_rigid_physics.py:2910-2936: `get_links_acc() == gravity` after one
+    step; here the model's own gravity vector on the cube of `test_contact_forces`), and an external force equal to its weight, applied at its centre of mass
+    before every step, keeps it where it is (`test_apply_external_forces`, :1860-1890: the duck under `force = mass x gravity` stays at (1, 0, 1) within 1e-3
+    for 800 steps; re-expressed with the raw cfrc_applied field, which holds MINUS the applied force like the reference's, abd/misc.py:695-715)."""
+    m = model_of("box")
+    s = Sim(lib, m, n_envs, gpu)
+    mass = m["links"][1]["inertial_mass"]
+    q = np.zeros((7, n_envs), np.float32); q[0] = 0.65; q[2] = 1.0; q[3] = 1.0
+    s.set_state(q, np.zeros((6, n_envs), np.float32))
+    s.step()
+    acc = s.get("F_ACC")
+    assert int(s.get("I_N_CONTACTS").max()) == 0
+    assert np.abs(acc[:3] - np.array([[0.0], [0.0], [-G]])).max() <= TOL_SINGLE * G and np.abs(acc[3:]).max() <= TOL_SINGLE, acc[:, 0]
+    log = [acc.copy().reshape(-1)]
+    s.set_state(q, np.zeros((6, n_envs), np.float32))
+    ext = np.zeros((12, n_envs), np.float32); ext[6 + 5] = -np.float32(mass * G)           # [link 1][vel z] -= +m g
+    for _ in range(800):
+        s.put("F_EXT_FORCE", ext)
+        s.step()
+    pos, vel = s.get("F_QPOS"), s.get("F_VEL")
+    # the reference asserts the position (tol 1e-3).  (The centre of mass of the tree is (m x) / m in float32, 6e-8 m beside the cube's own: the force through it
+    # turns the 12.8 g cube by a few hundredths of a radian per second over the 800 steps -- the same arithmetic as the reference's -- so only the linear velocity
+    # is asserted to vanish.)
+    assert np.abs(pos[:3] - q[:3]).max() <= 1e-3 and np.abs(vel[:3]).max() <= 1e-4 and np.abs(vel[3:]).max() <= 5e-2, (pos[:3, 0], vel[:, 0])
+    log.append(pos.copy().reshape(-1)); log.append(vel.copy().reshape(-1))
+    return np.concatenate(log)
+
+
+RUNS = {"pendulum": run_pendulum, "double_pendulum": run_double_pendulum, "box": run_box, "two_aligned_hinges": run_two_aligned_hinges, "box_free": run_box_free}
+LIB_SHAPE = {"two_aligned_hinges": "double_pendulum", "box_free": "box"}       # same link / dof / geom counts: the libraries of that shape
 
 
 @pytest.mark.parametrize("shape", sorted(RUNS))
 def test_oracle_reproduces_the_references_analytic_answers(shape_libs, shape):
-    RUNS[shape](shape_libs(shape, False), False)
+    RUNS[shape](shape_libs(LIB_SHAPE.get(shape, shape), False), False)
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("shape", sorted(RUNS))
 def test_hip_reproduces_the_references_analytic_answers_and_equals_the_oracle(shape_libs, shape):
-    a = RUNS[shape](shape_libs(shape, True), True)
-    b = RUNS[shape](shape_libs(shape, False), False)
+    a = RUNS[shape](shape_libs(LIB_SHAPE.get(shape, shape), True), True)
+    b = RUNS[shape](shape_libs(LIB_SHAPE.get(shape, shape), False), False)
     assert np.array_equal(a.view(np.int32), b.view(np.int32)), "HIP shape variant == oracle shape variant, bit for bit"

@@ -582,6 +582,24 @@ def synth_multi_pendulum(n):
     return "".join(x)
 
 
+def synth_two_aligned_hinges():
+    """The `two_aligned_hinges` model of the reference's tests (tests/test_rigid_physics.py:165-177, used by `test_link_velocity` :638-706), re-expressed as URDF
+    text: two 0.5 m bodies along x, hinges about z at the origin and at (0.5, 0, 0), centres of mass in the middle of the bodies, equal masses.  The
+    reference's capsule geoms are replaced by small spheres at the centres of mass (the test is kinematic; mass and inertia values do not enter it beyond
+    the two masses being equal); same link / dof / geom counts as the double pendulum, so it runs on that shape variant of the libraries."""
+    x = ['<robot name="two_aligned_hinges">', '<link name="base"/>']
+    parent, origin = "base", "0 0 0"
+    for i in range(2):
+        x.append(f'<joint name="joint{i}" type="continuous"><origin xyz="{origin}" rpy="0 0 0"/><axis xyz="0 0 1"/><parent link="{parent}"/>'
+                 f'<child link="body{i}"/><limit effort="100.0" velocity="30.0"/><dynamics damping="0.0" friction="0.0"/></joint>')
+        x.append(f'<link name="body{i}"><inertial><origin xyz="0.25 0 0" rpy="0 0 0"/><mass value="1.0"/>'
+                 '<inertia ixx="0.001" ixy="0" ixz="0" iyy="0.02" iyz="0" izz="0.02"/></inertial>'
+                 '<collision><origin xyz="0.25 0 0" rpy="0 0 0"/><geometry><sphere radius="0.05"/></geometry></collision></link>')
+        parent, origin = f"body{i}", "0.5 0 0"
+    x.append("</robot>")
+    return "".join(x)
+
+
 def synth_box(size=0.04, density=200.0):
     """A free cube (gs.morphs.Box(size=(0.04, 0.04, 0.04)) of tests/test_rigid_physics.py:1750-1800, default material density 200 kg / m^3): mass rho s^3,
     inertia m s^2 / 6."""
@@ -598,6 +616,8 @@ SHAPE_ROBOTS = {
     "pendulum": dict(urdf=synth_multi_pendulum(1), fixed=True, base_init_pos=(0.0, 0.0, 5.0), substep_dt=0.002, armature=0.0),
     "double_pendulum": dict(urdf=synth_multi_pendulum(2), fixed=True, base_init_pos=(0.0, 0.0, 5.0), substep_dt=0.002, armature=0.0),
     "box": dict(urdf=synth_box(), fixed=False, base_init_pos=(0.65, 0.0, 0.02), substep_dt=0.01, armature=0.0),
+    # kinematic known answers only (forward kinematics, no stepping: the mechanism lies in the ground plane like the reference's); libraries: the double_pendulum shape
+    "two_aligned_hinges": dict(urdf=synth_two_aligned_hinges(), fixed=True, base_init_pos=(0.0, 0.0, 0.0), substep_dt=0.002, armature=0.0),
 }
 
 
