@@ -268,8 +268,23 @@ def run_box_free(lib, gpu, n_envs=4):
     return np.concatenate(log)
 
 
-RUNS = {"pendulum": run_pendulum, "double_pendulum": run_double_pendulum, "box": run_box, "two_aligned_hinges": run_two_aligned_hinges, "box_free": run_box_free}
-LIB_SHAPE = {"two_aligned_hinges": "double_pendulum", "box_free": "box"}       # same link / dof / geom counts: the libraries of that shape
+def run_box01(lib, gpu, n_envs=4):
+    """`test_axis_aligned_bounding_boxes` (tests/test_rigid_physics.py:3844-3912): the cube of size 0.1 at (0.5, 0, 0.05) has the AABB (0.45, -0.05, 0.0) .. (0.55, 0.05, 0.1).
+    The C ABI exports the broad phase's sorted x endpoints (sort_buffer.value), so the x extent is what is compared; one step runs the collision pass that fills it."""
+    s = Sim(lib, model_of("box01"), n_envs, gpu)
+    s.step()
+    sv, ig = s.get("F_SORT_VALUE"), s.get("I_SORT_IG")
+    cube = 1                                                                # geom 0 is the ground box
+    lo = sv[np.nonzero(ig[:, 0] == cube)[0][0]]; hi = sv[np.nonzero(ig[:, 0] == (cube | 0x100))[0][0]]
+    assert np.abs(lo - 0.45).max() <= 1e-6 and np.abs(hi - 0.55).max() <= 1e-6, (lo, hi)
+    for _ in range(20):                                                     # (it starts exactly ON the ground: no overlap yet; gravity brings the pair into the broad phase)
+        s.step()
+    assert int(s.get("I_N_BROAD").min()) == 1 and int(s.get("I_N_CONTACTS").min()) >= 1, "the cube rests on the ground"
+    return np.concatenate([sv.reshape(-1), s.get("F_SORT_VALUE").reshape(-1), s.get("F_CONTACT_PEN").reshape(-1)])
+
+
+RUNS = {"box01": run_box01, "pendulum": run_pendulum, "double_pendulum": run_double_pendulum, "box": run_box, "two_aligned_hinges": run_two_aligned_hinges, "box_free": run_box_free}
+LIB_SHAPE = {"two_aligned_hinges": "double_pendulum", "box_free": "box", "box01": "box"}       # same link / dof / geom counts: the libraries of that shape
 
 
 @pytest.mark.parametrize("shape", sorted(RUNS))

@@ -616,6 +616,8 @@ SHAPE_ROBOTS = {
     "pendulum": dict(urdf=synth_multi_pendulum(1), fixed=True, base_init_pos=(0.0, 0.0, 5.0), substep_dt=0.002, armature=0.0),
     "double_pendulum": dict(urdf=synth_multi_pendulum(2), fixed=True, base_init_pos=(0.0, 0.0, 5.0), substep_dt=0.002, armature=0.0),
     "box": dict(urdf=synth_box(), fixed=False, base_init_pos=(0.65, 0.0, 0.02), substep_dt=0.01, armature=0.0),
+    # the cube of `test_axis_aligned_bounding_boxes` (tests/test_rigid_physics.py:3853-3858: size 0.1 at (0.5, 0, 0.05)); libraries: the box shape
+    "box01": dict(urdf=synth_box(size=0.1), fixed=False, base_init_pos=(0.5, 0.0, 0.05), substep_dt=0.01, armature=0.0),
     # kinematic known answers only (forward kinematics, no stepping: the mechanism lies in the ground plane like the reference's); libraries: the double_pendulum shape
     "two_aligned_hinges": dict(urdf=synth_two_aligned_hinges(), fixed=True, base_init_pos=(0.0, 0.0, 0.0), substep_dt=0.002, armature=0.0),
 }
