@@ -4,7 +4,8 @@ Genesis holds no stored vectors for the physics of this path; what its own tests
 (tests/test_rigid_physics.py): `test_pendulum_links_acc` (:705-757: a 1 m massless arm with a 1 kg point mass about x, alpha = -sin(theta) g, then held by
 a PD controller), `test_double_pendulum_links_acc` (:760-834), the kinematic cases of `test_link_velocity` (:638-706: two aligned hinges), the cube of
 `test_contact_forces` (:1749-1800: net contact force = weight), and on the same cube away from the ground `test_gravity` (:2910-2936) and the hovering body of
-`test_apply_external_forces` (:1860-1890).  Those
+`test_apply_external_forces` (:1860-1890), the AABB of the cube of `test_axis_aligned_bounding_boxes` (:3844-3912) and the PD / force-control equivalence of
+`test_position_control` (:1193-1272).  Those
 models have another SHAPE than Go2 (fixed base, 1 / 2 / 6 dofs), so they run on shape variants: the same sources compiled with other link / dof /
 geom counts (build.SHAPES, -DGO2SIM_NL=... ; the reference's summation order), models from tools/compile_go2_model.py --robot pendulum |
 double_pendulum | box, which re-expresses `_build_multi_pendulum` (:225-277) and gs.morphs.Box.  Re-expressed where the reference reads link
@@ -283,8 +284,50 @@ def run_box01(lib, gpu, n_envs=4):
     return np.concatenate([sv.reshape(-1), s.get("F_SORT_VALUE").reshape(-1), s.get("F_CONTACT_PEN").reshape(-1)])
 
 
-RUNS = {"box01": run_box01, "pendulum": run_pendulum, "double_pendulum": run_double_pendulum, "box": run_box, "two_aligned_hinges": run_two_aligned_hinges, "box_free": run_box_free}
-LIB_SHAPE = {"two_aligned_hinges": "double_pendulum", "box_free": "box", "box01": "box"}       # same link / dof / geom counts: the libraries of that shape
+def run_position_control(lib, gpu, n_envs=4, steps=200):
+    """`test_position_control` (tests/test_rigid_physics.py:1193-1272), its first half, on the double pendulum: with the approximate_implicitfast integrator the
+    engine's PD position / velocity control is the same as explicit force control with the torque kp (q* - q) + kd (v* - v), clamped to the force range, on
+    a model whose armature is raised by kd dt (the first-order term of the implicit scheme; invweights untouched, as the reference insists).  The reference
+    asserts the applied torques of the two formulations equal within 1e-6 over 200 steps; here the two are separate handles (the armature is a model
+    constant in this C ABI) and what is compared are the accelerations and the states they produce."""
+    import copy
+
+    m_pd = model_of("double_pendulum")
+    kp, kd = np.array([4500.0, 3500.0], np.float32), np.array([450.0, 350.0], np.float32)
+    q_t = np.array([0.69, -0.11], np.float32)
+    v_t = np.random.default_rng(12).random(2).astype(np.float32)                 # torch.rand_like(MOTORS_POS_TARGET)
+    m_force = copy.deepcopy(m_pd)
+    for i in range(2):
+        m_force["dofs"][i]["armature"] = float(np.float32(m_force["dofs"][i]["armature"]) + kd[i] * np.float32(m_pd["substep_dt"]))
+    a, b, c = Sim(lib, m_pd, n_envs, gpu), Sim(lib, m_force, n_envs, gpu), Sim(lib, m_pd, n_envs, gpu)   # c: force control WITHOUT the armature term (must differ)
+    rng = np.random.default_rng(5)
+    q0, v0 = rng.random((2, n_envs)), rng.random((2, n_envs))
+    a.set_state(q0, v0); b.set_state(q0, v0); c.set_state(q0, v0)
+    for i in range(2):
+        a.sim.set_dof_gains(i, float(kp[i]), float(kd[i]), *[float(x) for x in m_pd["dofs"][i]["force_range"]])
+    a.put("F_CTRL_POS", np.tile(q_t[:, None], (1, n_envs))); a.put("F_CTRL_VEL", np.tile(v_t[:, None], (1, n_envs))); a.put("I_CTRL_MODE", np.full((2, n_envs), 2, np.int32))
+    lo = np.array([d["force_range"][0] for d in m_pd["dofs"]], np.float32)[:, None]; hi = np.array([d["force_range"][1] for d in m_pd["dofs"]], np.float32)[:, None]
+    log, saturated, free, without = [], 0, 0, 0.0
+    torque = lambda sim: kp[:, None] * (q_t[:, None] - sim.get("F_QPOS")) + kd[:, None] * (v_t[:, None] - sim.get("F_VEL"))
+    for _ in range(steps):
+        tau = torque(b)
+        saturated += int(((tau < lo) | (tau > hi)).sum()); free += int(((tau >= lo) & (tau <= hi)).sum())
+        b.put("F_CTRL_FORCE", np.clip(tau, lo, hi).astype(np.float32)); b.put("I_CTRL_MODE", np.zeros((2, n_envs), np.int32))
+        c.put("F_CTRL_FORCE", np.clip(torque(c), lo, hi).astype(np.float32)); c.put("I_CTRL_MODE", np.zeros((2, n_envs), np.int32))
+        a.step(); b.step(); c.step()
+        acc_a, acc_b = a.get("F_ACC"), b.get("F_ACC")
+        # the reference's tolerance (1e-6, on torques of a few hundred N m), relative to the acceleration scale (measured: the two formulations are bit-equal here)
+        assert np.abs(acc_a - acc_b).max() <= 1e-6 * max(1.0, np.abs(acc_a).max()), (np.abs(acc_a - acc_b).max(), np.abs(acc_a).max())
+        assert np.abs(a.get("F_QPOS") - b.get("F_QPOS")).max() <= 1e-6 and np.abs(a.get("F_VEL") - b.get("F_VEL")).max() <= 1e-5
+        without = max(without, float(np.abs(acc_a - c.get("F_ACC")).max() / max(1.0, np.abs(acc_a).max())))
+        log.append(acc_a.copy().reshape(-1)); log.append(acc_b.copy().reshape(-1))
+    assert saturated > 0 and free > 0, "the run passes through the clamped and the unclamped regime"
+    assert without > 1e-2, "without the kd dt armature term explicit force control is a different system: the comparison is not vacuous"
+    return np.concatenate(log)
+
+
+RUNS = {"box01": run_box01, "position_control": run_position_control, "pendulum": run_pendulum, "double_pendulum": run_double_pendulum, "box": run_box, "two_aligned_hinges": run_two_aligned_hinges, "box_free": run_box_free}
+LIB_SHAPE = {"two_aligned_hinges": "double_pendulum", "box_free": "box", "box01": "box", "position_control": "double_pendulum"}       # same link / dof / geom counts: the libraries of that shape
 
 
 @pytest.mark.parametrize("shape", sorted(RUNS))
