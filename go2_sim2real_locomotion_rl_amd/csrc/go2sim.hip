@@ -3118,8 +3118,9 @@ DEV void ts_cholesky_factor_rows(const MT& m, S* s, int tl) {
 // the Newton Hessian in arrow form (arrow_factor / arrow_solve, above the dynamics): in place over s->H;  grad = Ma - force - qfrc, Mgrad = H^-1 grad
 template <int T, class S, class MT>
 DEV void ts_cholesky_factor_arrow(const MT& m, S* s, int tl) { arrow_factor<T, DS>(m.arrow_mode, m.eps, s->H, s->H, tl); }
+// (also returns |grad|^2: its butterfly has nothing to wait for and runs under the loads of the factor instead of after the solve)
 template <int T, class S, class MT>
-DEV void ts_update_gradient_arrow(const MT& m, S* s, int tl) {
+DEV float ts_update_gradient_arrow(const MT& m, S* s, int tl) {
   const int leg = (tl >> 3) & 3, u = tl & 7, ub = u < 6 ? u : 5;
   const int p0 = dm_arrow_dof(m.arrow_mode, leg, 0), p1 = dm_arrow_dof(m.arrow_mode, leg, 1), p2 = dm_arrow_dof(m.arrow_mode, leg, 2);
   const int row = tl < ND ? tl : ND - 1;
@@ -3127,11 +3128,13 @@ DEV void ts_update_gradient_arrow(const MT& m, S* s, int tl) {
   const float gl0 = s->Ma[p0] - s->force[p0] - s->qfrc[p0], gl1 = s->Ma[p1] - s->force[p1] - s->qfrc[p1], gl2 = s->Ma[p2] - s->force[p2] - s->qfrc[p2];
   const float gb = s->Ma[ub] - s->force[ub] - s->qfrc[ub];
   if (tl < ND) s->grad[row] = g_own;
+  const float grad_sq = team_tree_sum1<T>(tl < ND ? g_own * g_own : 0.0f);
   float xb[6], x0, x1, x2;
   arrow_solve<T>(s->H, gl0, gl1, gl2, gb, s->Mgrad, tl, xb, x0, x1, x2);   // (Mgrad doubles as the exchange buffer of the base right-hand side)
   if (tl == 0) { *(float4*)&s->Mgrad[0] = make_float4(xb[0], xb[1], xb[2], xb[3]); *(float2*)&s->Mgrad[4] = make_float2(xb[4], xb[5]); }
   if (tl < 32 && u == 0) { s->Mgrad[p0] = x0; s->Mgrad[p1] = x1; s->Mgrad[p2] = x2; }
   team_sync();
+  return grad_sq;
 }
 #endif
 template <int T, class S, class MT>
@@ -3676,18 +3679,157 @@ __device__ float g_brlog[BRLOG_ENVS * BRLOG_CAP * BRLOG_W];
 __device__ int g_brcnt[BRLOG_ENVS];
 __device__ int g_brenv_of_wg[65536];
 #endif
+#if defined(GO2SIM_PHASE_PROFILE) && GO2SIM_FAST_ORDER   // where a line search spends its cycles: 50 set-up (mv, jv, coefficients, p0), 51 the 1-D Newton steps (52: their number),
+#define LS_TIMER unsigned long long ls_t0 = __builtin_readcyclecounter();   // 53 the bracket refinement (54: its rounds of three points)
+#define LS_MARK(id) { const unsigned long long ls_n = __builtin_readcyclecounter(); PHC(id, ls_n - ls_t0) ls_t0 = ls_n; }
+#else
+#define LS_TIMER
+#define LS_MARK(id)
+#endif
+// the search proper (1-D Newton steps, then the bracket refinement) from the point alpha = 0
+template <int T, class S, class MT>
+DEV float ts_linesearch_tail(const MT& m, S* s, int tl, int n_con, int nseg, const LsRow& rw, float gtol, float qg0, float qg1, float qg2, LsPoint p0) {
+  LS_TIMER
+  int ls_it = 1;
+  float res_alpha = 0.0f;
+  bool done = false;
+  LsPoint p1 = ts_ls_point<T>(m, s, tl, n_con, nseg, rw, p0.alpha - p0.grad / p0.hess, qg0, qg1, qg2);
+  ls_it += 1;
+  if (p0.cost < p1.cost) p1 = p0;
+  if (dm_abs(p1.grad) < gtol) { LS_MARK(51) PHC(52, 1) return p1.alpha; }
+  int direction = (p1.grad < 0) * 2 - 1;
+  int p2update = 0;
+  LsPoint p2 = p1;
+  while (p1.grad * (float)direction <= -gtol && ls_it < m.ls_iterations) {
+    p2 = p1; p2update = 1;
+    p1 = ts_ls_point<T>(m, s, tl, n_con, nseg, rw, p1.alpha - p1.grad / p1.hess, qg0, qg1, qg2);
+    ls_it += 1;
+    if (dm_abs(p1.grad) < gtol) { res_alpha = p1.alpha; done = true; break; }
+  }
+  LS_MARK(51) PHC(52, ls_it - 1)
+  if (done) return res_alpha;
+  if (ls_it >= m.ls_iterations) return p1.alpha;
+  if (!p2update) return p1.alpha;
+  float al[3];
+  al[0] = p1.alpha - p1.grad / p1.hess; al[1] = p1.alpha; al[2] = (p1.alpha + p2.alpha) * 0.5f;
+  while (ls_it < m.ls_iterations) {
+    float costs[3], grads[3], hess[3];
+    ts_ls_point3<T>(m, s, tl, n_con, nseg, rw, al, qg0, qg1, qg2, costs, grads, hess);
+    ls_it += 3;
+    float p1_next_alpha = al[0], p2_next_alpha = al[1];
+    float best_alpha = 0.0f, best_cost = 0.0f; bool best_found = false;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+      if (dm_abs(grads[i]) < gtol && (!best_found || costs[i] < best_cost)) { best_alpha = al[i]; best_cost = costs[i]; best_found = true; }
+    PHC(54, 1)
+    if (best_found) { LS_MARK(53) return best_alpha; }
+#ifdef GO2SIM_BRACKET_DEBUG
+    const LsPoint p1_in = p1, p2_in = p2;
+#endif
+#if !defined(GO2SIM_BRACKET_INLINE) && !defined(GO2SIM_BRACKET_BYREF)
+    const BrOut o1 = update_bracket_v(p1.alpha, p1.cost, p1.grad, p1.hess, al[0], al[1], al[2], costs[0], costs[1], costs[2], grads[0], grads[1], grads[2], hess[0], hess[1], hess[2]);
+    p1.alpha = o1.alpha; p1.cost = o1.cost; p1.grad = o1.grad; p1.hess = o1.hess; p1_next_alpha = o1.next_alpha;
+    const int b1 = o1.flag;
+    const BrOut o2 = update_bracket_v(p2.alpha, p2.cost, p2.grad, p2.hess, al[0], al[1], al[2], costs[0], costs[1], costs[2], grads[0], grads[1], grads[2], hess[0], hess[1], hess[2]);
+    p2.alpha = o2.alpha; p2.cost = o2.cost; p2.grad = o2.grad; p2.hess = o2.hess; p2_next_alpha = o2.next_alpha;
+    const int b2 = o2.flag;
+#else
+    int b1 = update_bracket(p1, al, costs, grads, hess, p1_next_alpha);
+#ifdef GO2SIM_BRACKET_FENCE   // investigation builds (tools/repro_bracket/README.md): value barriers around the inlined bracket step
+    asm volatile("" : "+v"(p1.alpha), "+v"(p1.cost), "+v"(p1.grad), "+v"(p1.hess), "+v"(p1_next_alpha), "+v"(b1));
+#endif
+    int b2 = update_bracket(p2, al, costs, grads, hess, p2_next_alpha);
+#ifdef GO2SIM_BRACKET_FENCE
+    asm volatile("" : "+v"(p2.alpha), "+v"(p2.cost), "+v"(p2.grad), "+v"(p2.hess), "+v"(p2_next_alpha), "+v"(b2));
+#endif
+#endif
+#ifdef GO2SIM_BRACKET_DEBUG
+    {
+      const int env = g_brenv_of_wg[blockIdx.x] + (int)(threadIdx.x / T);
+      if (tl == 0 && env < BRLOG_ENVS) {
+        const int k = g_brcnt[env];
+        if (k < BRLOG_CAP) {
+          float* o = &g_brlog[((size_t)env * BRLOG_CAP + k) * BRLOG_W];
+          int q = 0;
+          o[q++] = (float)ls_it; o[q++] = gtol;
+          for (int i = 0; i < 3; ++i) o[q++] = al[i];
+          for (int i = 0; i < 3; ++i) o[q++] = costs[i];
+          for (int i = 0; i < 3; ++i) o[q++] = grads[i];
+          for (int i = 0; i < 3; ++i) o[q++] = hess[i];
+          o[q++] = p1_in.alpha; o[q++] = p1_in.cost; o[q++] = p1_in.grad; o[q++] = p1_in.hess;
+          o[q++] = p2_in.alpha; o[q++] = p2_in.cost; o[q++] = p2_in.grad; o[q++] = p2_in.hess;
+          o[q++] = p1.alpha; o[q++] = p1.cost; o[q++] = p1.grad; o[q++] = p1.hess;
+          o[q++] = p2.alpha; o[q++] = p2.cost; o[q++] = p2.grad; o[q++] = p2.hess;
+          o[q++] = p1_next_alpha; o[q++] = p2_next_alpha; o[q++] = (float)b1; o[q++] = (float)b2;
+          g_brcnt[env] = k + 1;
+        }
+      }
+    }
+#endif
+    if (b1 == 0 && b2 == 0) { LS_MARK(53) return al[2]; }
+    al[0] = p1_next_alpha; al[1] = p2_next_alpha; al[2] = (p1.alpha + p2.alpha) * 0.5f;
+  }
+  LS_MARK(53)
+  if (p1.cost <= p2.cost && p1.cost < p0.cost) return p1.alpha;
+  if (p2.cost <= p1.cost && p2.cost < p0.cost) return p2.alpha;
+  return 0.0f;
+}
+
 // func_linesearch_batch, solver.py:2246-2417
 template <int T, class S, class MT>
 DEV float ts_linesearch(const MT& m, S* s, int tl, int n_con, float gauss) {
-#if defined(GO2SIM_PHASE_PROFILE) && GO2SIM_FAST_ORDER   // where a line search spends its cycles: 50 set-up (mv, jv, coefficients, p0), 51 the 1-D Newton steps (52: their number),
-  unsigned long long ls_t0 = __builtin_readcyclecounter();   // 53 the bracket refinement (54: its rounds of three points)
-#define LS_MARK(id) { const unsigned long long ls_n = __builtin_readcyclecounter(); PHC(id, ls_n - ls_t0) ls_t0 = ls_n; }
-#else
-#define LS_MARK(id)
-#endif
+  LS_TIMER
   float sr[ND];
 #pragma unroll
   for (int d = 0; d < ND; ++d) sr[d] = s->search[d];
+#if GO2SIM_FAST_ORDER
+  if constexpr (T >= 32) {
+    // FAST ORDER, teams of 32 / 64 lanes: the six sums of the set-up (|search|^2, the two gradient coefficients, the three coefficients of the point alpha = 0) need
+    // nothing from each other, so their butterflies run as ONE (every value sees the same additions as in three separate trees: same bits, a third of the
+    // dependent steps).  Lane d owns mv[d], lane c % T the rows c.
+    const int d = tl < ND ? tl : ND - 1;
+    float mv_own = 0.0f;
+    for (int d1 = tl; d1 < ND; d1 += T) {
+      float mv = 0.0f;
+#pragma unroll
+      for (int d2 = 0; d2 < ND; ++d2) mv = mv + s->M[d1 * DS + d2] * sr[d2];
+      s->mv[d1] = mv; mv_own = mv;
+    }
+    LsRow rw = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    float pp[3] = {0.0f, 0.0f, 0.0f};
+    bool first = true;
+    for (int c = tl; c < n_con; c += T) {
+      float jv = 0.0f;
+#pragma unroll
+      for (int dd = 0; dd < ND; ++dd) jv = jv + s->J[c * DS + dd] * sr[dd];
+      s->jv[c] = jv;
+      float Ja = s->Jaref[c], D = s->efc_D[c];
+      const float q0 = D * (0.5f * Ja * Ja), q1 = D * (jv * Ja), q2 = D * (0.5f * jv * jv);
+      s->qf0[c] = q0; s->qf1[c] = q1; s->qf2[c] = q2;
+      rw.Ja = Ja; rw.jv = jv; rw.q0 = q0; rw.q1 = q1; rw.q2 = q2;       // (the lane's row when rows sit one per lane)
+      const float active = (float)(Ja < 0.0f);
+      const float a0 = q0 * active, a1 = q1 * active, a2 = q2 * active;
+      pp[0] = first ? a0 : pp[0] + a0; pp[1] = first ? a1 : pp[1] + a1; pp[2] = first ? a2 : pp[2] + a2;
+      first = false;
+    }
+    const float sd = s->search[d];
+    const float xs[6] = {tl < ND ? sd * sd : 0.0f, tl < ND ? (sd * s->Ma[d] - sd * s->force[d]) : 0.0f, tl < ND ? 0.5f * sd * mv_own : 0.0f, pp[0], pp[1], pp[2]};
+    float tot[6];
+    team_tree_sum<T, 6>(xs, tot);
+    team_sync();
+    const float snorm = dm_sqrt(tot[0]);
+    const float scale = m.meaninertia * (float)imx(1, ND);
+    const float gtol = m.tolerance * m.ls_tolerance * snorm * scale;
+    if (snorm < m.eps) return 0.0f;
+    const int nseg = 0;
+    const float qg0 = gauss, qg1 = tot[1], qg2 = tot[2];
+    LsPoint p0;
+    p0.alpha = 0.0f; p0.cost = tot[3] + qg0; p0.grad = tot[4] + qg1; p0.hess = 2.0f * (tot[5] + qg2);
+    if (p0.hess <= 0.0f) p0.hess = m.eps;
+    LS_MARK(50)
+    return ts_linesearch_tail<T>(m, s, tl, n_con, nseg, rw, gtol, qg0, qg1, qg2, p0);
+  }
+#endif
   float snorm = 0.0f;
   if constexpr (T >= 32) {
     const float my = s->search[tl < ND ? tl : ND - 1];
@@ -3800,89 +3942,7 @@ DEV float ts_linesearch(const MT& m, S* s, int tl, int n_con, float gauss) {
     if (p0.hess <= 0.0f) p0.hess = m.eps;
   }
   LS_MARK(50)
-  int ls_it = 1;
-  float res_alpha = 0.0f;
-  bool done = false;
-  LsPoint p1 = ts_ls_point<T>(m, s, tl, n_con, nseg, rw, p0.alpha - p0.grad / p0.hess, qg0, qg1, qg2);
-  ls_it += 1;
-  if (p0.cost < p1.cost) p1 = p0;
-  if (dm_abs(p1.grad) < gtol) { LS_MARK(51) PHC(52, 1) return p1.alpha; }
-  int direction = (p1.grad < 0) * 2 - 1;
-  int p2update = 0;
-  LsPoint p2 = p1;
-  while (p1.grad * (float)direction <= -gtol && ls_it < m.ls_iterations) {
-    p2 = p1; p2update = 1;
-    p1 = ts_ls_point<T>(m, s, tl, n_con, nseg, rw, p1.alpha - p1.grad / p1.hess, qg0, qg1, qg2);
-    ls_it += 1;
-    if (dm_abs(p1.grad) < gtol) { res_alpha = p1.alpha; done = true; break; }
-  }
-  LS_MARK(51) PHC(52, ls_it - 1)
-  if (done) return res_alpha;
-  if (ls_it >= m.ls_iterations) return p1.alpha;
-  if (!p2update) return p1.alpha;
-  float al[3];
-  al[0] = p1.alpha - p1.grad / p1.hess; al[1] = p1.alpha; al[2] = (p1.alpha + p2.alpha) * 0.5f;
-  while (ls_it < m.ls_iterations) {
-    float costs[3], grads[3], hess[3];
-    ts_ls_point3<T>(m, s, tl, n_con, nseg, rw, al, qg0, qg1, qg2, costs, grads, hess);
-    ls_it += 3;
-    float p1_next_alpha = al[0], p2_next_alpha = al[1];
-    float best_alpha = 0.0f, best_cost = 0.0f; bool best_found = false;
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-      if (dm_abs(grads[i]) < gtol && (!best_found || costs[i] < best_cost)) { best_alpha = al[i]; best_cost = costs[i]; best_found = true; }
-    PHC(54, 1)
-    if (best_found) { LS_MARK(53) return best_alpha; }
-#ifdef GO2SIM_BRACKET_DEBUG
-    const LsPoint p1_in = p1, p2_in = p2;
-#endif
-#if !defined(GO2SIM_BRACKET_INLINE) && !defined(GO2SIM_BRACKET_BYREF)
-    const BrOut o1 = update_bracket_v(p1.alpha, p1.cost, p1.grad, p1.hess, al[0], al[1], al[2], costs[0], costs[1], costs[2], grads[0], grads[1], grads[2], hess[0], hess[1], hess[2]);
-    p1.alpha = o1.alpha; p1.cost = o1.cost; p1.grad = o1.grad; p1.hess = o1.hess; p1_next_alpha = o1.next_alpha;
-    const int b1 = o1.flag;
-    const BrOut o2 = update_bracket_v(p2.alpha, p2.cost, p2.grad, p2.hess, al[0], al[1], al[2], costs[0], costs[1], costs[2], grads[0], grads[1], grads[2], hess[0], hess[1], hess[2]);
-    p2.alpha = o2.alpha; p2.cost = o2.cost; p2.grad = o2.grad; p2.hess = o2.hess; p2_next_alpha = o2.next_alpha;
-    const int b2 = o2.flag;
-#else
-    int b1 = update_bracket(p1, al, costs, grads, hess, p1_next_alpha);
-#ifdef GO2SIM_BRACKET_FENCE   // investigation builds (tools/repro_bracket/README.md): value barriers around the inlined bracket step
-    asm volatile("" : "+v"(p1.alpha), "+v"(p1.cost), "+v"(p1.grad), "+v"(p1.hess), "+v"(p1_next_alpha), "+v"(b1));
-#endif
-    int b2 = update_bracket(p2, al, costs, grads, hess, p2_next_alpha);
-#ifdef GO2SIM_BRACKET_FENCE
-    asm volatile("" : "+v"(p2.alpha), "+v"(p2.cost), "+v"(p2.grad), "+v"(p2.hess), "+v"(p2_next_alpha), "+v"(b2));
-#endif
-#endif
-#ifdef GO2SIM_BRACKET_DEBUG
-    {
-      const int env = g_brenv_of_wg[blockIdx.x] + (int)(threadIdx.x / T);
-      if (tl == 0 && env < BRLOG_ENVS) {
-        const int k = g_brcnt[env];
-        if (k < BRLOG_CAP) {
-          float* o = &g_brlog[((size_t)env * BRLOG_CAP + k) * BRLOG_W];
-          int q = 0;
-          o[q++] = (float)ls_it; o[q++] = gtol;
-          for (int i = 0; i < 3; ++i) o[q++] = al[i];
-          for (int i = 0; i < 3; ++i) o[q++] = costs[i];
-          for (int i = 0; i < 3; ++i) o[q++] = grads[i];
-          for (int i = 0; i < 3; ++i) o[q++] = hess[i];
-          o[q++] = p1_in.alpha; o[q++] = p1_in.cost; o[q++] = p1_in.grad; o[q++] = p1_in.hess;
-          o[q++] = p2_in.alpha; o[q++] = p2_in.cost; o[q++] = p2_in.grad; o[q++] = p2_in.hess;
-          o[q++] = p1.alpha; o[q++] = p1.cost; o[q++] = p1.grad; o[q++] = p1.hess;
-          o[q++] = p2.alpha; o[q++] = p2.cost; o[q++] = p2.grad; o[q++] = p2.hess;
-          o[q++] = p1_next_alpha; o[q++] = p2_next_alpha; o[q++] = (float)b1; o[q++] = (float)b2;
-          g_brcnt[env] = k + 1;
-        }
-      }
-    }
-#endif
-    if (b1 == 0 && b2 == 0) { LS_MARK(53) return al[2]; }
-    al[0] = p1_next_alpha; al[1] = p2_next_alpha; al[2] = (p1.alpha + p2.alpha) * 0.5f;
-  }
-  LS_MARK(53)
-  if (p1.cost <= p2.cost && p1.cost < p0.cost) return p1.alpha;
-  if (p2.cost <= p1.cost && p2.cost < p0.cost) return p2.alpha;
-  return 0.0f;
+  return ts_linesearch_tail<T>(m, s, tl, n_con, nseg, rw, gtol, qg0, qg1, qg2, p0);
 }
 
 #undef LS_MARK
@@ -4052,7 +4112,8 @@ DEV int ts_solve(const MT& m, const E& e, S* s, int tl, int nc, int n_con, unsig
       ts_update_gradient<T>(s, tl);
 #endif
 #if GO2SIM_FAST_ORDER
-      if constexpr (ARROW_SOLVER && (T == 32 || T == 64)) { if (arrow) ts_update_gradient_arrow<T>(m, s, tl); else ts_update_gradient<T>(s, tl); }
+      [[maybe_unused]] float grad_sq_arrow = 0.0f;
+      if constexpr (ARROW_SOLVER && (T == 32 || T == 64)) { if (arrow) grad_sq_arrow = ts_update_gradient_arrow<T>(m, s, tl); else ts_update_gradient<T>(s, tl); }
       else ts_update_gradient<T>(s, tl);
 #else
       ts_update_gradient<T>(s, tl);
@@ -4064,7 +4125,8 @@ DEV int ts_solve(const MT& m, const E& e, S* s, int tl, int nc, int n_con, unsig
         if constexpr (T >= 32) {
           const float g = s->grad[tl < ND ? tl : ND - 1];
 #if GO2SIM_FAST_ORDER
-          grad_norm = team_tree_sum1<T>(tl < ND ? g * g : 0.0f);
+          if (ARROW_SOLVER && (T == 32 || T == 64) && arrow) grad_norm = grad_sq_arrow;
+          else grad_norm = team_tree_sum1<T>(tl < ND ? g * g : 0.0f);
 #else
           const float xq[1] = {tl < ND ? g * g : 0.0f}, zero[1] = {0.0f};
           float tot[1];
