@@ -19,7 +19,8 @@ Rank 0 prints ONE JSON line.  Besides the contract keys it carries (N=1 only, al
                   counter file under profiles/), and the single-env latency floor (step time at 256 envs, measured live)
   rollouts      : closed collection loops (policy + env + storage): stairs = the counterpart of the reference's logged collection time
   steady_state  : the SAME handle continued: settle phase, then >= 1000 timed steps (+ per-kernel ms from 200 event-timed steps)
-  action_sets   : SURVEY 8d sets A (zeros), B (0.5*N(0,1): falls / resets) and C (sine gait), each 200 warm-up + 1000 timed steps
+  action_sets   : SURVEY 8d sets A (zeros), B (0.5*N(0,1): falls / resets) and C (sine gait), each 200 warm-up + 1000 timed steps; C_staggered_resets = set C with
+                  the episode counters spread over the episode, so that a few envs are reset on every step (what a training run looks like)
   curriculum_live : set C with the metric-gated curriculum running (not frozen)
   workloads     : BASELINE configs[2] (stairs) and configs[4] (jump + per-env mass / friction DR) at the same env count
   ref_protocol_fps : the reference's own `go2` benchmark protocol (tests/test_rigid_benchmarks.py:316-374) through go2sim_scene_step
@@ -247,9 +248,13 @@ def kernel_ms(sim, actions, first, n, buf, stream):
     return ms, cnt
 
 
-def protocol_run(B, device, local_rank, seed, workload, kind, warm, steps, stream, freeze=True):
-    """fresh handle, `warm` warm-up steps from the reset, `steps` timed steps -> dict"""
+def protocol_run(B, device, local_rank, seed, workload, kind, warm, steps, stream, freeze=True, stagger=False):
+    """fresh handle, `warm` warm-up steps from the reset, `steps` timed steps -> dict.  stagger: the episode counters are spread over the episode length, so a
+    few envs time out and are reset on EVERY step (what a training run looks like) instead of all together"""
     sim = make_sim(load_hip_lib(), B, local_rank, seed, workload, freeze_curriculum=freeze)
+    if stagger:
+        g_ = torch.Generator(device="cpu").manual_seed(7)
+        sim.env_set_episode_length(torch.randint(0, 1000, (B,), generator=g_, dtype=torch.int32).to(device), stream)
     act = make_actions(min(warm + steps, 600), B, device, workload=workload, kind=kind)   # sets A / C are periodic, B is i.i.d.: the tape is cycled
     buf = Buffers(B, workload, device)
     resets = 0
@@ -566,6 +571,9 @@ def main():
         envcls = go2env_class_run(B, device, local_rank, 1 + rank, W, K)
         action_sets = {k: protocol_run(B, device, local_rank, 1, "walk", k, 200, 1000, stream) for k in ("A", "B", "C")}
         action_sets["note"] = "SURVEY 8d: A zeros (standing), B 0.5*N(0,1) (falls / resets), C open-loop sine gait; 200 warm-up + 1000 timed steps each, curriculum frozen at 0.10"
+        action_sets["C_staggered_resets"] = protocol_run(B, device, local_rank, 1, "walk", "C", 200, 1000, stream, stagger=True)
+        action_sets["C_staggered_resets"]["note"] = ("set C with the episode counters spread over the 1000-step episode: about four envs time out, are re-drawn and dropped on EVERY step, "
+                                                     "as in a training run (reset path, full-batch FK refresh and a few landing robots in every launch)")
         curriculum_live = protocol_run(B, device, local_rank, 1, "walk", "C", 200, 1000, stream, freeze=False)
         workloads = {"stairs": protocol_run(B, device, local_rank, 1, "stairs", "C", 100, 300, stream),
                      "jump_dr": protocol_run(B, device, local_rank, 1, "jump_dr", "C", 100, 300, stream),
