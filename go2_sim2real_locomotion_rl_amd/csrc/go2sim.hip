@@ -476,10 +476,10 @@ DEV void tri_index(const ModelView& m, int idx, int& i, int& j) { i = m.tri_i[id
 // (team_sync = s_waitcnt vmcnt(0) + s_barrier) makes the table visible.  Source and destination are padded to whole KiB.
 constexpr int lds_dma_bytes(int nbytes) { return (nbytes + 1023) / 1024 * 1024; }
 template <int NBYTES>
-DEV void wg_dma_to_lds(void* lds_dst, const void* __restrict__ src) {
+DEV void wg_dma_to_lds(void* lds_dst, const void* __restrict__ src, int lane = (int)threadIdx.x) {   // one wavefront; `lane` = its lane index (workgroups of several wavefronts pass threadIdx.x % 64)
 #pragma unroll
   for (int k = 0; k < lds_dma_bytes(NBYTES) / 1024; ++k)
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((const char*)src + (k * 64 + (int)threadIdx.x) * 16),
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((const char*)src + (k * 64 + lane) * 16),
                                      (__attribute__((address_space(3))) void*)((char*)lds_dst + k * 1024), 16, 0, 0);
 }
 constexpr int MODELS_LDS_BYTES = lds_dma_bytes((int)sizeof(ModelS));
@@ -5381,10 +5381,41 @@ __global__ void k_env_globals(const DCfg* __restrict__ cp, Glob* gp, Acc* acc, u
 }
 
 // per-env part of reset_idx (go2_env_walk.py:1156-1240)
-DEV void env_reset_one(const Model& m, const DCfg& c, const Glob& g, const E& e, int b, uint64_t seed) {
+// The draws of a reset.  TEAM form (k_env_post_b_team): the thirteen Philox blocks of env_reset_one are independent, so lane k of the env's team forms block k
+// (uniform code: purpose, index, range and destination come from the lane index), the ten per-env DR blocks are finished by their lanes, and the three
+// blocks of the serial part (per-env global DR, pose, commands) travel to lane 0.  Same keys and the same expressions as the one-lane form below.
+struct ResetDraws { dm_u4 per_env, pose, cmd; };
+template <int T>
+DEV ResetDraws env_reset_draws_team(const DCfg& c, const Glob& g, const E& e, int b, uint64_t seed, int tl, bool was_reset) {
+  static_assert(T >= 16, "thirteen blocks side by side");
+  const uint32_t rc = g.reset_calls - 1;
+  const double ts = g.t_sample;
+  const int k = tl < 13 ? tl : 12;
+  const uint32_t purpose = k < 11 ? RNG_RESET_DR : (k == 11 ? RNG_RESET_POSE : RNG_RESET_CMD);
+  const dm_u4 r = rng4(seed, purpose, b, rc, k < 11 ? k : 0);
+  // the per-env DR blocks: kp factors 0..2, kd factors 3..5, gravity offset 6 (three values), motor strength 7..9
+  const int has = k < 3 ? GO2SIM_IC_HAS_KPF_DR : (k < 6 ? GO2SIM_IC_HAS_KDF_DR : (k == 6 ? GO2SIM_IC_HAS_GOFF_DR : GO2SIM_IC_HAS_MSTR_DR));
+  const int rng = k < 3 ? GO2SIM_FC_KPF_EASY_LO : (k < 6 ? GO2SIM_FC_KDF_EASY_LO : (k == 6 ? GO2SIM_FC_GOFF_EASY_LO : GO2SIM_FC_MSTR_EASY_LO));
+  const int off = k < 3 ? FO(kp_factors) + 4 * k : (k < 6 ? FO(kd_factors) + 4 * (k - 3) : (k == 6 ? FO(gravity_offset) : FO(motor_strength) + 4 * (k - 7)));
+  const int n = k == 6 ? 3 : 4;
+  if (was_reset && tl < 10 && c.i[has]) {
+    const double lo = lerp_lo(c, rng, ts), hi = lerp_hi(c, rng, ts);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) if (j < n) gstore(e, off, j, rand_float(lo, hi, r.v[j]));
+  }
+  ResetDraws d;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    d.per_env.v[j] = (uint32_t)__shfl((int)r.v[j], 10, T); d.pose.v[j] = (uint32_t)__shfl((int)r.v[j], 11, T); d.cmd.v[j] = (uint32_t)__shfl((int)r.v[j], 12, T);
+  }
+  return d;
+}
+// per-env part of reset_idx (go2_env_walk.py:1156-1240).  `pre` (team form): the per-env DR blocks are already stored and the three serial blocks are handed in
+DEV void env_reset_one(const Model& m, const DCfg& c, const Glob& g, const E& e, int b, uint64_t seed, const ResetDraws* pre = nullptr) {
   uint32_t rc = g.reset_calls - 1;
   double ts = g.t_sample;
   auto kp_factors = e.kp_factors(); auto kd_factors = e.kd_factors(); auto motor_strength = e.motor_strength(); auto gravity_offset = e.gravity_offset();
+  if (!pre) {
   if (c.i[GO2SIM_IC_HAS_KPF_DR])
     for (int blk = 0; blk < 3; ++blk) { dm_u4 r = rng4(seed, RNG_RESET_DR, b, rc, blk); for (int k = 0; k < 4; ++k) kp_factors[4 * blk + k] = rand_float(lerp_lo(c, GO2SIM_FC_KPF_EASY_LO, ts), lerp_hi(c, GO2SIM_FC_KPF_EASY_LO, ts), r.v[k]); }
   if (c.i[GO2SIM_IC_HAS_KDF_DR])
@@ -5395,8 +5426,9 @@ DEV void env_reset_one(const Model& m, const DCfg& c, const Glob& g, const E& e,
   }
   if (c.i[GO2SIM_IC_HAS_MSTR_DR])
     for (int blk = 0; blk < 3; ++blk) { dm_u4 r = rng4(seed, RNG_RESET_DR, b, rc, 7 + blk); for (int k = 0; k < 4; ++k) motor_strength[4 * blk + k] = rand_float(lerp_lo(c, GO2SIM_FC_MSTR_EASY_LO, ts), lerp_hi(c, GO2SIM_FC_MSTR_EASY_LO, ts), r.v[k]); }
+  }
   if (c.i[GO2SIM_IC_PER_ENV_GLOBAL_DR]) {   // extension (BASELINE configs[4], not in the reference): the friction / base-mass scalars are drawn per env
-    dm_u4 r = rng4(seed, RNG_RESET_DR, b, rc, 10);
+    dm_u4 r = pre ? pre->per_env : rng4(seed, RNG_RESET_DR, b, rc, 10);
     if (c.i[GO2SIM_IC_HAS_FRICTION_DR]) {
       float mu = rand_float(lerp_lo(c, GO2SIM_FC_FRICTION_EASY_LO, ts), lerp_hi(c, GO2SIM_FC_FRICTION_EASY_LO, ts), r.v[0]);
       auto gf = e.geom_friction();
@@ -5405,7 +5437,7 @@ DEV void env_reset_one(const Model& m, const DCfg& c, const Glob& g, const E& e,
     if (c.i[GO2SIM_IC_HAS_MASS_DR])
       e.mass_shift()[c.i[GO2SIM_IC_BASE_LINK]] = rand_float(lerp_lo(c, GO2SIM_FC_MASS_EASY_LO, ts), lerp_hi(c, GO2SIM_FC_MASS_EASY_LO, ts), r.v[1]);
   }
-  dm_u4 rp = rng4(seed, RNG_RESET_POSE, b, rc, 0);
+  dm_u4 rp = pre ? pre->pose : rng4(seed, RNG_RESET_POSE, b, rc, 0);
   {
     int max_d = imx(c.i[GO2SIM_IC_MIN_DELAY], imn(g.delay_max_cur, c.i[GO2SIM_IC_MAX_DELAY]));
     e.delay_steps()[0] = rand_int(c.i[GO2SIM_IC_MIN_DELAY], max_d, rp.v[3]);
@@ -5456,7 +5488,7 @@ DEV void env_reset_one(const Model& m, const DCfg& c, const Glob& g, const E& e,
   { auto fat = e.feet_air_time(); auto fc = e.foot_contact(); auto lfc = e.last_foot_contact(); for (int i = 0; i < 4; ++i) { fat[i] = 0.0f; fc[i] = 0; lfc[i] = 0; } }
   { auto es = e.episode_sums(); for (int k = 0; k < NREW; ++k) es[k] = 0.0f; }
   e.episode_length()[0] = 0; e.reset_buf()[0] = 1;
-  dm_u4 r = rng4(seed, RNG_RESET_CMD, b, rc, 0);
+  dm_u4 r = pre ? pre->cmd : rng4(seed, RNG_RESET_CMD, b, rc, 0);
   float cx, cy, cz;
   sample_commands(c, g, r, b, cx, cy, cz);
   auto cmd = e.commands();
@@ -5542,8 +5574,11 @@ DEV int post_b_src_off(int k) {
   off = (k >= PB_PUSH) ? FO(current_push_force) + k - PB_PUSH : off;
   return off;
 }
+// Two wavefronts per workgroup over the SAME 64 / T envs: wavefront 0 resets the flagged envs and writes the observations; wavefront 1 exists for the steps on
+// which a reset call happened (in a training run: every step) and refreshes the kinematics of the workgroup's envs WHILE wavefront 0 assembles the
+// observations -- neither reads what the other writes, so the slowest workgroup of the launch costs reset + max(observations, FK) instead of their sum.
 template <int T>
-__global__ __launch_bounds__(64) void k_env_post_b_team(Pool P, const Model* __restrict__ mp, const ModelS* __restrict__ msp, const DCfg* __restrict__ cp,
+__global__ __launch_bounds__(128) void k_env_post_b_team(Pool P, const Model* __restrict__ mp, const ModelS* __restrict__ msp, const DCfg* __restrict__ cp,
                                                         const Glob* __restrict__ gp, uint64_t seed, uint32_t step_count, float* __restrict__ obs_out,
                                                         float* __restrict__ priv_out, float* __restrict__ rew_out, uint8_t* __restrict__ reset_out,
                                                         float* __restrict__ timeout_out) {
@@ -5555,26 +5590,37 @@ __global__ __launch_bounds__(64) void k_env_post_b_team(Pool P, const Model* __r
   __shared__ KinData fk_lds[EPW];
   __shared__ alignas(16) char ms_raw[MODELS_LDS_BYTES];
   const bool fk_needed = gp->n_reset_now > 0;
-  if (fk_needed) wg_dma_to_lds<(int)sizeof(ModelS)>(ms_raw, msp);
-  const int tl = threadIdx.x % T, slot = threadIdx.x / T;
-  const int b = xcd_block() * EPW + slot;
-  if (b >= P.B) return;
-  const Model& m = *mp; const DCfg& c = *cp; const Glob& g = *gp;
-  E e(P, b);
-  auto fk_refresh = [&]() {
+  const int lane = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6;
+  if (wave == 1) {
     if (!fk_needed) return;
+    wg_dma_to_lds<(int)sizeof(ModelS)>(ms_raw, msp, lane);
+  }
+  const int tl = lane % T, slot = lane / T;
+  const int b = xcd_block() * EPW + slot;
+  if (wave == 1) {                                                     // the FK wavefront
+    __syncthreads();                                                   // wavefront 0 has reset its flagged envs and applied the global DR scalars
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    if (b >= P.B) return;
+    E e(P, b);
     KinData* ks = &fk_lds[slot];
-    team_sync();                                                       // the reset's qpos / vel / DR stores of this team are visible
     team_stage<ND, T>(tl, [&](int d) { return gload(e, FO(vel), d); }, [&](int d, float v) { ks->vel[d] = v; });
     team_stage<NQ, T>(tl, [&](int q) { return gload(e, FO(qpos), q); }, [&](int q, float v) { ks->qpos[q] = v; });
     tk_stage_links<T>(e, ks, tl);
     team_sync();
     const ModelView mv((const ModelS*)ms_raw, msp);
     tk_kinematics<T>(mv, e, ks, tl, true);
-  };
-  const int was_reset = e.reset_buf()[0];
-  if (g.n_reset_now > 0) {                                             // reset_tail, spread over the team
-    if (tl == 0 && was_reset) env_reset_one(m, c, g, e, b, seed);
+    return;
+  }
+  const bool valid = b < P.B;                                          // (lanes beyond the batch stay with their wavefront up to its ONE barrier)
+  const Model& m = *mp; const DCfg& c = *cp; const Glob& g = *gp;
+  E e(P, valid ? b : P.B - 1);
+  auto fk_refresh = [&]() {};                                          // (done by wavefront 1)
+  const int was_reset = valid ? e.reset_buf()[0] : 0;
+  if (valid && g.n_reset_now > 0) {                                    // reset_tail, spread over the team
+    {
+      const ResetDraws rd = env_reset_draws_team<T>(c, g, e, b, seed, tl, was_reset != 0);    // (all lanes of the team: the blocks are shuffled)
+      if (tl == 0 && was_reset) env_reset_one(m, c, g, e, b, seed, &rd);
+    }
     const bool per_env = c.i[GO2SIM_IC_PER_ENV_GLOBAL_DR] != 0;      // per-env draws were applied by env_reset_one
     if (c.i[GO2SIM_IC_HAS_FRICTION_DR] && !per_env) for (int i = tl; i < NG; i += T) e.geom_friction()[i] = g.friction;
     if (tl == 0) {
@@ -5585,6 +5631,8 @@ __global__ __launch_bounds__(64) void k_env_post_b_team(Pool P, const Model* __r
     }
     team_sync();
   }
+  if (fk_needed) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __syncthreads(); }   // hand the reset state over to the FK wavefront
+  if (!valid) return;
   const int na = c.i[GO2SIM_IC_NUM_ACTIONS], nobs = c.i[GO2SIM_IC_NUM_OBS], npriv = c.i[GO2SIM_IC_NUM_PRIV_OBS];
   if (c.i[GO2SIM_IC_ENV_KIND] == 1) {                                  // go2_env_base.py:165-196: rewards after the reset, 45 observations
     if (tl == 0) {
@@ -6133,7 +6181,7 @@ static bool step_graph_build(go2sim* h, const float* actions, float* obs, float*
     ok = graph_add_kernel(h, last, k_env_terrain_rows, dim3((h->B + 255) / 256), dim3(256), nullptr, nullptr, nullptr, h->P, h->dcfg, h->dglob, h->seed);
     if (!ok) return false;
   }
-  ok = graph_add_kernel(h, last, k_env_post_b_team<16>, dim3((h->B + 3) / 4), b64, &g.n_post_b, &g.p_post_b, &sl, h->P, h->dm, h->dms, h->dcfg, h->dglob, h->seed, h->step_count,
+  ok = graph_add_kernel(h, last, k_env_post_b_team<16>, dim3((h->B + 3) / 4), dim3(128), &g.n_post_b, &g.p_post_b, &sl, h->P, h->dm, h->dms, h->dcfg, h->dglob, h->seed, h->step_count,
                         obs, priv, rew, reset, timeout);
   if (!ok) return false;
   g.a_pb_step = (uint32_t*)sl[6];
@@ -6528,7 +6576,7 @@ int go2sim_env_step(go2sim_t* h, const float* actions, float* obs, float* priv, 
     ScopedTimer t(h, s, T_ENV_POST);
     hipLaunchKernelGGL(k_env_post_a, g, dim3(WG * POST_A_WAVES), 0, s, h->P, h->dm, h->hcfg, h->dglob, h->dacc, h->seed, h->step_count);
     if (h->hcfg.i[GO2SIM_IC_USE_TERRAIN]) hipLaunchKernelGGL(k_env_terrain_rows, dim3((h->B + 255) / 256), dim3(256), 0, s, h->P, h->dcfg, h->dglob, h->seed);
-    hipLaunchKernelGGL(k_env_post_b_team<16>, dim3((h->B + 3) / 4), dim3(64), 0, s, h->P, h->dm, h->dms, h->dcfg, h->dglob, h->seed, h->step_count, obs, priv, rew, reset, timeout);
+    hipLaunchKernelGGL(k_env_post_b_team<16>, dim3((h->B + 3) / 4), dim3(128), 0, s, h->P, h->dm, h->dms, h->dcfg, h->dglob, h->seed, h->step_count, obs, priv, rew, reset, timeout);
   }
   HIPCHK(hipGetLastError());
   h->action_write_idx = (h->action_write_idx + 1) % (h->hcfg.i[GO2SIM_IC_MAX_DELAY] + 1);
